@@ -1,0 +1,42 @@
+"""Closed-form (RNG-free) fills shared by the golden-vector generator and the tests, so the
+committed fixtures only need to hold OUTPUTS; every input/weight is rebuilt from a formula."""
+import math
+
+import numpy as np
+
+
+def cf(shape, scale=0.1, freq=0.37, phase=0.0, dtype=np.float32):
+    """scale * sin(freq * i + phase) over the flattened index i, reshaped."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.float64)
+    return (scale * np.sin(freq * i + phase)).reshape(shape).astype(dtype)
+
+
+def cf_adjacency(n, phase=0.0):
+    """A dense non-symmetric non-negative 'adjacency' with unit diagonal."""
+    a = np.abs(cf((n, n), scale=1.0, freq=0.61, phase=phase, dtype=np.float64))
+    np.fill_diagonal(a, 1.0)
+    return a.astype(np.float32)
+
+
+def cf_params(shapes, base_phase=0.0):
+    """Deterministic parameter dict for a {name: shape} map.  Weight scale follows the
+    reference's xavier-normal law (std = 1.414*sqrt(2/(fan_in+fan_out))) so activations stay
+    in the same regime as a real model; biases get small non-zero values so they matter."""
+    out = {}
+    for k, (name, shape) in enumerate(sorted(shapes.items())):
+        ph = base_phase + 0.71 * k
+        if len(shape) == 2 and name.endswith(".weight") and "dconv" in name:
+            std = 1.414 * math.sqrt(2.0 / (shape[0] + shape[1]))
+            out[name] = cf(shape, scale=std * math.sqrt(2.0), freq=0.913, phase=ph)
+        elif len(shape) == 2:
+            out[name] = cf(shape, scale=0.15, freq=0.913, phase=ph)
+        else:
+            out[name] = cf(shape, scale=0.05, freq=1.31, phase=ph)
+    return out
+
+
+def sample_view(a, step=97):
+    """Strided sample + summary stats: a compact fingerprint of a large gradient tensor."""
+    flat = np.asarray(a, dtype=np.float64).reshape(-1)
+    return np.concatenate([[flat.sum(), np.abs(flat).sum(), np.square(flat).sum()], flat[::step]])

@@ -1,0 +1,172 @@
+"""Pin the oracle: every oracle function vs vectors produced by the genuine reference
+(tests/golden/make_golden.py).  CPU only.  Tolerances are fp32 re-association noise
+(the reference's own fp32-vs-fp64 noise floor is ~1e-6 relative)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from closed_form import cf, sample_view
+from oracle import dcrnn_oracle as orc
+
+ATOL = 2e-6
+
+
+def close(a, b, atol=ATOL, rtol=2e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= atol * scale + rtol * 0, f"max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def close_view(arr, gold_view, step=97, tol=2e-5):
+    """compare a tensor against its stored fingerprint (sum, abs-sum, sq-sum, strided sample)."""
+    v = sample_view(arr, step)
+    assert v.shape == gold_view.shape
+    scale = max(1e-6, float(np.abs(gold_view[3:]).max()))
+    assert np.abs(v[3:] - gold_view[3:]).max() <= tol * scale
+    assert abs(v[1] - gold_view[1]) <= 1e-4 * max(1e-6, gold_view[1])
+    assert abs(v[2] - gold_view[2]) <= 1e-4 * max(1e-9, gold_view[2])
+
+
+def test_scaled_laplacian_matches_reference(golden, adj3d):
+    close(orc.scaled_laplacian(adj3d, None), golden["supports/scaled_laplacian_adj3d"], atol=2e-7)
+    close(orc.scaled_laplacian(adj3d, 2), golden["supports/scaled_laplacian_adj3d_lmax2"], atol=2e-7)
+
+
+def test_correlation_graph_pipeline(golden):
+    clip = cf((12, 19, 100), scale=1.0, freq=0.7391, phase=0.2) + cf((12, 19, 100), scale=0.5, freq=0.0137, phase=1.0)
+    adj = orc.correlation_adjacency(clip, top_k=3)
+    close(adj, golden["corr/adj"], atol=1e-6)
+    s = orc.compute_supports(adj, "dual_random_walk")
+    close(s[0].numpy(), golden["corr/s1"].astype(np.float32), atol=1e-6)
+    close(s[1].numpy(), golden["corr/s2"].astype(np.float32), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", list(cases.DCONV_CASES))
+def test_diffusion_conv(tag, golden, adj3d):
+    c = cases.dconv_inputs(tag, adj3d)
+    out = orc.diffusion_conv(c["sup"], c["x"], c["s"], c["weight"], c["biases"], 19, 2)
+    close(out.numpy(), golden[f"dconv/{tag}/out"])
+
+
+@pytest.mark.parametrize("tag", list(cases.CELL_CASES))
+def test_cell_forward_backward(tag, golden, adj3d):
+    c = cases.cell_inputs(tag, adj3d)
+    p = {k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+    x = c["x"].clone().requires_grad_(True)
+    s = c["s"].clone().requires_grad_(True)
+    out = orc.dcgru_cell(c["sup"], x, s, p["dconv_gate.weight"], p["dconv_gate.biases"],
+                         p["dconv_candidate.weight"], p["dconv_candidate.biases"], 19, c["h"], 2, c["act"])
+    (out * c["wout"]).sum().backward()
+    close(out.detach().numpy(), golden[f"cell/{tag}/out"])
+    grads = {"dx": x.grad, "dh": s.grad}
+    grads.update({"d_" + k: v.grad for k, v in p.items()})
+    for k, g in grads.items():
+        ref = golden[f"cell/{tag}/{k}"]
+        if c["full"]:
+            close(g.numpy(), ref, atol=5e-6)
+        else:
+            close_view(g.numpy(), ref)
+
+
+@pytest.mark.parametrize("tag", list(cases.CLS_CASES))
+def test_classification_model(tag, golden, adj3d):
+    c = cases.cls_inputs(tag, adj3d)
+    p = {k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+    logits = orc.classification_forward(p, c["cfg"], c["x"], c["seq"], c["sup"])
+    close(logits.detach().numpy(), golden[f"cls/{tag}/logits"])
+    loss = orc.bce_with_logits(logits, c["y"]) if c["classes"] == 1 else orc.cross_entropy(logits, c["y"])
+    loss.backward()
+    assert abs(loss.item() - float(golden[f"cls/{tag}/loss"])) < 2e-6
+    for k, v in p.items():
+        ref = golden[f"cls/{tag}/d_{k}"]
+        if c["full"]:
+            close(v.grad.numpy(), ref, atol=5e-6)
+        else:
+            close_view(v.grad.numpy(), ref)
+    with torch.no_grad():
+        b = c["x"].shape[0]
+        h0 = torch.zeros(c["cfg"].num_rnn_layers, b, 19 * c["cfg"].rnn_units)
+        fin, top = orc.encoder_forward(c["params"], c["cfg"], c["x"].transpose(0, 1), h0, c["sup"])
+    close(fin.numpy(), golden[f"cls/{tag}/enc_final"])
+    ref_top = golden[f"cls/{tag}/enc_top"]
+    if ref_top.ndim == 3:
+        close(top.numpy(), ref_top)
+    else:
+        close_view(top.numpy(), ref_top, step=7)
+
+
+@pytest.mark.parametrize("tag", list(cases.SSL_CASES))
+def test_ssl_model(tag, golden, adj3d):
+    c = cases.ssl_inputs(tag, adj3d)
+    uniq = {}
+    p = {}
+    for k, v in c["params"].items():            # shared decoder cell: one leaf, two names (Q6)
+        if id(v) not in uniq:
+            uniq[id(v)] = v.clone().requires_grad_(True)
+        p[k] = uniq[id(v)]
+    named = list(golden[f"ssl/{tag}/named_parameters"])
+    assert set(named) <= set(p.keys())
+    assert sorted(p.keys()) == list(golden[f"ssl/{tag}/state_dict_keys"])
+    for loss_name in ("MAE", "mae"):
+        for v in uniq.values():
+            v.grad = None
+        pred = orc.next_time_pred_forward(p, c["cfg"], c["x"], c["y"], c["sup"])
+        loss = orc.regression_loss(c["y"], pred, cases.SSL_MEAN, cases.SSL_STD, loss_fn=loss_name)
+        loss.backward()
+        assert abs(loss.item() - float(golden[f"ssl/{tag}/{loss_name}/loss"])) < 5e-6
+        for k in named:
+            ref = golden[f"ssl/{tag}/{loss_name}/d_{k}"]
+            if c["full"]:
+                close(p[k].grad.numpy(), ref, atol=5e-6)
+            else:
+                close_view(p[k].grad.numpy(), ref)
+    ref_pred = golden[f"ssl/{tag}/pred"]
+    if ref_pred.ndim == 4:
+        close(pred.detach().numpy(), ref_pred)
+    else:
+        close_view(pred.detach().numpy(), ref_pred, step=7)
+
+
+def test_q1_carried_x0_is_not_textbook(adj3d):
+    """the hop list with two supports is [X, S1X, (2S1^2-I)X, S2S1X, (2S2^2-I)S1X]."""
+    sup = cases.dual_supports(2)
+    x = cases.T(cf((2, 19, 5), scale=1.0, freq=0.77))
+    hops = orc.hop_stack(sup, x, 2)
+    s1, s2 = sup
+    expect3 = torch.matmul(s2, torch.matmul(s1, x))
+    textbook3 = torch.matmul(s2, x)
+    assert torch.allclose(hops[:, 3], expect3, atol=1e-6)
+    assert (hops[:, 3] - textbook3).abs().max() > 1e-2
+
+
+def test_param_shapes_match_pretrained_manifest():
+    here = os.path.join(os.path.dirname(__file__), "golden", "pretrained_manifest.json")
+    man = json.load(open(here))
+    for fn, entry in man.items():
+        filt = "dual_random_walk" if "correlation" in fn else "laplacian"
+        cfg = orc.DCRNNConfig(filter_type=filt, num_rnn_layers=3)
+        shapes = orc.param_shapes(cfg, "ssl")
+        assert entry["top_keys"] == ["model_state"]
+        assert {k: list(v) for k, v in shapes.items()} == entry["model_state"], fn
+
+
+def test_param_counts_match_survey():
+    def count(cfg, model):
+        seen, tot = set(), 0
+        for k, shp in orc.param_shapes(cfg, model).items():
+            if ".decoding_cells." in k and int(k.split(".")[2]) >= 2:
+                continue
+            tot += int(np.prod(shp))
+        return tot
+    assert count(orc.DCRNNConfig(), "classification") == 168641
+    assert count(orc.DCRNNConfig(filter_type="dual_random_walk"), "classification") == 280769
+    assert count(orc.DCRNNConfig(num_classes=4), "classification") == 168836
+    assert count(orc.DCRNNConfig(filter_type="dual_random_walk"), "ssl") == 567908
+    assert count(orc.DCRNNConfig(filter_type="dual_random_walk", num_rnn_layers=3), "ssl") == 690980
