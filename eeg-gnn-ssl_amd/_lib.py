@@ -1,0 +1,100 @@
+"""ctypes binding of libeeg_dcrnn_hip.so (C ABI: include/eeg_dcrnn.h).
+
+This is the stub a maintainer of the reference would add to call the MI355X kernels from
+Python.  The product loads ONLY the in-tree HIP library and fails loudly if it
+is missing: there is no CPU fallback.  (tests/ can construct `EegDcrnnLib(path)` on the
+emulator build of the same sources to check kernel logic without a GPU — the product never does.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip.so")
+ABI_VERSION = 1
+
+
+class LayerDims(ctypes.Structure):
+    """mirror of `eeg_layer_dims` (include/eeg_dcrnn.h)."""
+    _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Fin", c_int32),
+                ("M", c_int32), ("act", c_int32), ("p_batched", c_int32)]
+
+
+_FP = c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+_SIGNATURES = {
+    "eeg_dcrnn_last_error": (c_char_p, []),
+    "eeg_dcrnn_abi_version": (c_int, []),
+    "eeg_dcrnn_is_device_build": (c_int, []),
+    "eeg_dcrnn_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "eeg_dcrnn_hop_polys": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_pack_floats": (c_size_t, [c_int, c_int, c_int]),
+    "eeg_dcrnn_pack_cell": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_diffuse_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_diffuse_adj": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_layer_fwd_ws_floats": (c_size_t, [POINTER(LayerDims)]),
+    "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 11 + [c_void_p]),
+    "eeg_dcrnn_layer_bwd_ws_floats": (c_size_t, [POINTER(LayerDims), c_int]),
+    "eeg_dcrnn_layer_bwd": (c_int, [POINTER(LayerDims)] + [_FP] * 20 + [c_void_p]),
+    "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_cls_head_bwd": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, _FP, c_void_p]),
+}
+
+
+class EegDcrnnError(RuntimeError):
+    """Raised when a library call reports an error (shape/dtype/launch problems)."""
+
+
+class EegDcrnnLib:
+    def __init__(self, path: str = HIP_LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the MI355X HIP library is not built. Run `python -c 'import "
+                f"__graft_entry__ as g; g.build()'` (or `make -C eeg-gnn-ssl_amd/csrc`). There is no CPU fallback.")
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:
+                raise ImportError(f"{path} does not export {name} (declared in include/eeg_dcrnn.h)") from e
+            fn.restype = res
+            fn.argtypes = args
+        if self._dll.eeg_dcrnn_abi_version() != ABI_VERSION:
+            raise ImportError(f"{path}: ABI version {self._dll.eeg_dcrnn_abi_version()} != {ABI_VERSION}; rebuild")
+        self.is_device_build = bool(self._dll.eeg_dcrnn_is_device_build())
+
+    def last_error(self) -> str:
+        return self._dll.eeg_dcrnn_last_error().decode()
+
+    def call(self, name: str, *args):
+        """Invoke an int-returning entry point, raising EegDcrnnError on a non-zero status."""
+        rc = getattr(self._dll, name)(*args)
+        if rc != 0:
+            raise EegDcrnnError(f"{name}: {self.last_error()}")
+
+    def query(self, name: str, *args):
+        return getattr(self._dll, name)(*args)
+
+
+_LIB = None
+
+
+def get_lib() -> EegDcrnnLib:
+    """The product library (HIP, gfx950).  Loaded on first use; ImportError if absent."""
+    global _LIB
+    if _LIB is None:
+        lib = EegDcrnnLib(HIP_LIB_PATH)
+        if not lib.is_device_build:
+            raise ImportError(f"{HIP_LIB_PATH} is not a device build")
+        _LIB = lib
+    return _LIB
+
+
+def _set_lib_for_testing(lib) -> None:
+    """tests/ only: install an explicitly constructed library object (e.g. the emulator build)."""
+    global _LIB
+    _LIB = lib

@@ -1,0 +1,321 @@
+// C ABI of libeeg_dcrnn_hip.so (see include/eeg_dcrnn.h): argument checking + kernel orchestration.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/eeg_dcrnn.h"
+#include "kernels_diffuse.h"
+#include "kernels_gemm.h"
+#include "kernels_head.h"
+#include "kernels_pack.h"
+#include "seq_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+using namespace eeg;
+
+bool h_supported(int H) { return H == 16 || H == 32 || H == 64; }
+bool m_supported(int M) { return M == 2 || M == 3 || M == 4 || M == 5 || M == 7; }
+
+int check_dims(int N, int H, int Fin, int M) {
+    if (N < 1 || N > kMaxNodes) return fail("num_nodes=%d unsupported (1..%d)", N, kMaxNodes);
+    if (!h_supported(H)) return fail("rnn_units=%d unsupported (16, 32 or 64)", H);
+    if (Fin < 4 || Fin % 4 != 0) return fail("per-node input dim=%d unsupported (must be a positive multiple of 4)", Fin);
+    if (!m_supported(M)) return fail("num hop matrices M=%d unsupported (2,3,4,5,7)", M);
+    return 0;
+}
+
+// ---- GEMM dispatch ---------------------------------------------------------------------------
+template <int NCTW, int KC>
+int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
+           float* C, int ldc, int O, hipStream_t st) {
+    constexpr int KCS = lds_stride(KC), NB = 2 * NCTW;
+    const size_t lds = 2 * (size_t)(128 * KCS + (KC / 4) * NB * 64) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_nn_kernel<NCTW, KC>), lds);
+    dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
+    EEG_LAUNCH((gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
+    return check_launch("gemm_nn");
+}
+template <int NCTW>
+int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
+              float* C, int ldc, int O, hipStream_t st) {
+    if (F % 32 == 0) return run_nn<NCTW, 32>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    if (F % 20 == 0) return run_nn<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    if (F % 16 == 0) return run_nn<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    return run_nn<NCTW, 4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+}
+// C[R x O] = [segments] @ packed B (nct_total col tiles) + bias
+int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
+            float* C, int ldc, int O, hipStream_t st) {
+    if (nct_total <= 4) return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    return run_nn_kc<6>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+}
+
+template <int NCTW>
+int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+           float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+    constexpr int OT = 2 * NCTW * 16;
+    constexpr int YS = OT + ((16 - (OT % 32)) + 32) % 32;
+    const size_t lds = 2 * (size_t)(32 * 80 + 32 * YS) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_tn_kernel<NCTW>), lds);
+    dim3 grid(nseg * ceil_div(F, 64), nsplit);
+    EEG_LAUNCH((gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    return check_launch("gemm_tn");
+}
+int tn_split(int nseg, int F, int R, int* rows_per_split) {
+    const int blocks = nseg * ceil_div(F, 64);
+    int nsplit = ceil_div(1024, blocks);
+    int rps = round_up(ceil_div(R, nsplit), 32);
+    if (rps < 128) rps = 128;
+    nsplit = ceil_div(R, rps);
+    *rows_per_split = rps;
+    return nsplit;
+}
+// partial[nsplit][nseg*F][O] = per-split A^T dY[:, ycol0:ycol0+O]
+int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+            float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+    if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+    if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+    if (O <= 128) return run_tn<4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+    if (O <= 192) return run_tn<6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+    return fail("gemm_tn: O=%d unsupported", O);
+}
+
+int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M, float* planes,
+                hipStream_t st) {
+    const int FP = round_up(F, 16), FS = lds_stride(M * FP), NR = round_up(N, 4);
+    const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * FS) * sizeof(float);
+    if (lds > 160 * 1024) return fail("diffuse_fwd: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
+    EEG_SET_MAX_LDS(diffuse_fwd_kernel, lds);
+    const int grid = S < 2048 ? S : 2048;
+    EEG_LAUNCH(diffuse_fwd_kernel, dim3(grid), dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes);
+    return check_launch("diffuse_fwd");
+}
+int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M, float* dX,
+                hipStream_t st) {
+    const int FP = round_up(F, 16), ZS = lds_stride(M * FP), NR = round_up(N, 4);
+    const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * ZS) * sizeof(float);
+    if (lds > 160 * 1024) return fail("diffuse_adj: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
+    EEG_SET_MAX_LDS(diffuse_adj_kernel, lds);
+    const int grid = S < 2048 ? S : 2048;
+    EEG_LAUNCH(diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, dX);
+    return check_launch("diffuse_adj");
+}
+
+int seq_fwd(int H, int M, const SeqFwdArgs& a, hipStream_t st) {
+    int rc = H == 16 ? launch_seq_fwd_h16(M, a, st) : H == 32 ? launch_seq_fwd_h32(M, a, st) : launch_seq_fwd_h64(M, a, st);
+    if (rc == 1) return fail("seq_fwd: no kernel for H=%d M=%d", H, M);
+    if (rc == 2) return fail("seq_fwd: kernel launch failed (H=%d M=%d)", H, M);
+    return 0;
+}
+int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
+    int rc = H == 16 ? launch_seq_bwd_h16(M, a, st) : H == 32 ? launch_seq_bwd_h32(M, a, st) : launch_seq_bwd_h64(M, a, st);
+    if (rc == 1) return fail("seq_bwd: no kernel for H=%d M=%d", H, M);
+    if (rc == 2) return fail("seq_bwd: kernel launch failed (H=%d M=%d)", H, M);
+    return 0;
+}
+
+struct BwdWs {
+    size_t dxw, dbias, hplanes, rhplanes, partial, z, total;
+    int nsplit_x, rps_x, nsplit_h, rps_h;
+};
+BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
+    BwdWs w;
+    const size_t R = (size_t)d->T * d->B * d->N;
+    size_t o = 0;
+    w.dxw = o;      o += R * 3 * d->H;
+    w.dbias = o;    o += round_up(d->B * 3 * d->H, 64);
+    w.hplanes = o;  o += (size_t)(d->M - 1) * R * d->H;
+    w.rhplanes = o; o += (size_t)(d->M - 1) * R * d->H;
+    w.nsplit_x = tn_split(d->M, d->Fin, (int)R, &w.rps_x);
+    w.nsplit_h = tn_split(d->M, d->H, (int)R, &w.rps_h);
+    size_t px = (size_t)w.nsplit_x * d->M * d->Fin * 3 * d->H;
+    size_t ph = (size_t)w.nsplit_h * d->M * d->H * 2 * d->H;
+    w.partial = o;  o += round_up((int)(px > ph ? px : ph), 64);
+    w.z = o;        o += need_dx ? R * d->M * d->Fin : 0;
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eeg_dcrnn_last_error(void) { return g_err; }
+int eeg_dcrnn_abi_version(void) { return 1; }
+int eeg_dcrnn_is_device_build(void) {
+#if defined(EEG_SIMT_EMU)
+    return 0;
+#else
+    return 1;
+#endif
+}
+int eeg_dcrnn_supported(int N, int H, int Fin, int M) { return check_dims(N, H, Fin, M) == 0 ? 1 : 0; }
+
+int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K, float* P_out,
+                        void* stream) {
+    if (n_supports < 1 || n_supports > 4) return fail("hop_polys: n_supports=%d unsupported (1..4)", n_supports);
+    if (N < 1 || N > kMaxNodes) return fail("hop_polys: num_nodes=%d unsupported", N);
+    if (K < 1) return fail("hop_polys: max_diffusion_step=%d unsupported (>= 1)", K);
+    if (n_supports * K + 1 > kMaxM) return fail("hop_polys: %d supports x K=%d exceeds %d hop matrices", n_supports, K, kMaxM);
+    SupPtrs sp;
+    for (int i = 0; i < 4; ++i) sp.p[i] = i < n_supports ? supports[i] : nullptr;
+    const size_t lds = 4 * kMaxNodes * kMaxNodes * sizeof(float);
+    EEG_LAUNCH(hop_polys_kernel, dim3(n_graphs), dim3(round_up(N * N, 64)), lds, S_(stream), sp, n_supports, N, K, P_out);
+    return check_launch("hop_polys");
+}
+
+size_t eeg_dcrnn_pack_floats(int Fin, int H, int M) { return make_cell_pack(Fin, H, M).total; }
+
+int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const float* bc, int Fin, int H, int M,
+                        float* pack, void* stream) {
+    if (!h_supported(H)) return fail("pack_cell: rnn_units=%d unsupported", H);
+    if (Fin % 4 != 0) return fail("pack_cell: input dim %d must be a multiple of 4", Fin);
+    CellPack p = make_cell_pack(Fin, H, M);
+    EEG_LAUNCH(pack_cell_kernel, dim3(512), dim3(256), 0, S_(stream), Wg, bg, Wc, bc, pack, p);
+    return check_launch("pack_cell");
+}
+
+int eeg_dcrnn_diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M,
+                          float* planes, void* stream) {
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("diffuse_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    return diffuse_fwd(X, P, p_batched, S, B, N, F, M, planes, S_(stream));
+}
+int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M,
+                          float* dX, void* stream) {
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("diffuse_adj: bad dims N=%d F=%d M=%d", N, F, M);
+    return diffuse_adj(Z, P, p_batched, S, B, N, F, M, dX, S_(stream));
+}
+
+size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return (size_t)d->T * d->B * d->N * 3 * d->H; }
+
+int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0, const float* P, const float* pack,
+                        float* planes, float* Hext, float* Rs, float* Us, float* Cs, float* RHs, float* ws,
+                        void* stream) {
+    if (check_dims(d->N, d->H, d->Fin, d->M)) return 1;
+    if (d->T < 1 || d->B < 1) return fail("layer_fwd: empty sequence/batch (T=%d, B=%d)", d->T, d->B);
+    const bool save = Rs != nullptr;
+    if (save != (Us != nullptr) || save != (Cs != nullptr) || save != (RHs != nullptr))
+        return fail("layer_fwd: Rs/Us/Cs/RHs must be all NULL or all non-NULL");
+    hipStream_t st = S_(stream);
+    const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin;
+    const size_t state = (size_t)d->B * d->N * H;
+    CellPack p = make_cell_pack(Fin, H, M);
+    // slot 0 of Hext = initial state
+    if (h0 != nullptr) {
+        if (h0 != Hext) {
+#if defined(EEG_SIMT_EMU)
+            memcpy(Hext, h0, state * sizeof(float));
+#else
+            if (hipMemcpyAsync(Hext, h0, state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return fail("layer_fwd: h0 copy failed");
+#endif
+        }
+    } else if (hipMemsetAsync(Hext, 0, state * sizeof(float), st) != hipSuccess) {
+        return fail("layer_fwd: h0 memset failed");
+    }
+    // 1. hoisted diffusion of the layer input: planes[m-1] = P_m X
+    if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st)) return 1;
+    // 2. hoisted x-part GEMM: XW = [X | planes] @ Bx + [bg|bc]
+    SegPtrs segs;
+    for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
+    float* XW = ws;
+    if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
+    // 3. the recurrence
+    SeqFwdArgs a{XW, Hext, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs,
+                 d->T, d->B, d->N, d->act};
+    return seq_fwd(H, M, a, st);
+}
+
+size_t eeg_dcrnn_layer_bwd_ws_floats(const eeg_layer_dims* d, int need_dx) { return bwd_ws(d, need_dx).total; }
+
+int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P, const float* pack,
+                        const float* planes, const float* Hext, const float* Rs, const float* Us, const float* Cs,
+                        const float* RHs, const float* dHseq, const float* d_at_end, const float* d_at_len,
+                        const int64_t* lengths, float* dX, float* dh0, float* dWg, float* dbg, float* dWc,
+                        float* dbc, float* ws, void* stream) {
+    if (check_dims(d->N, d->H, d->Fin, d->M)) return 1;
+    hipStream_t st = S_(stream);
+    const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
+    const size_t state = (size_t)d->B * N * H;
+    CellPack p = make_cell_pack(Fin, H, M);
+    BwdWs w = bwd_ws(d, dX != nullptr);
+    float* dXW = ws + w.dxw;
+    float* dbias = ws + w.dbias;
+    // 1. BPTT through the recurrence: dXW = [dR|dU|dC] per step, dh0, per-clip bias partials
+    SeqBwdArgs a{Hext + state, Hext, Rs, Us, Cs, dHseq, d_at_end, d_at_len,
+                 reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
+                 dXW, dh0, dbias, d->T, d->B, N, d->act};
+    if (seq_bwd(H, M, a, st)) return 1;
+    EEG_LAUNCH(reduce_bias_kernel, dim3(ceil_div(3 * H, 64)), dim3(64), 0, st, dbias, d->B, H, dbg, dbc);
+    if (check_launch("reduce_bias")) return 1;
+    // 2. weight gradients (hoisted, split-K with fixed-order reduction)
+    float* part = ws + w.partial;
+    SegPtrs sx;
+    for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
+    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
+    EEG_LAUNCH(reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0, Fin, H, M, dWg, dWc);
+    if (check_launch("reduce_unpack(x)")) return 1;
+    //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
+    float* hpl = ws + w.hplanes;
+    if (diffuse_fwd(Hext, P, d->p_batched, S, d->B, N, H, M, hpl, st)) return 1;
+    SegPtrs sh;
+    for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hext : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
+    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_h, w.rps_h, st)) return 1;
+    EEG_LAUNCH(reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, 2 * H, 1, Fin, H, M, dWg, dWc);
+    if (check_launch("reduce_unpack(hg)")) return 1;
+    //   h-part of the candidate: hops(r*h_{t-1})^T dC
+    float* rpl = ws + w.rhplanes;
+    if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl, st)) return 1;
+    SegPtrs sr;
+    for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
+    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_h, w.rps_h, st)) return 1;
+    EEG_LAUNCH(reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, H, 2, Fin, H, M, dWg, dWc);
+    if (check_launch("reduce_unpack(hc)")) return 1;
+    // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
+    if (dX != nullptr) {
+        float* Z = ws + w.z;
+        SegPtrs sd;
+        for (int m = 0; m < kMaxM; ++m) sd.p[m] = m == 0 ? dXW : nullptr;
+        if (gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st)) return 1;
+        if (diffuse_adj(Z, P, d->p_batched, S, d->B, N, Fin, M, dX, st)) return 1;
+    }
+    return 0;
+}
+
+int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH, float* last, void* stream) {
+    EEG_LAUNCH(gather_last_kernel, dim3(ceil_div(B * NH, 256)), dim3(256), 0, S_(stream), Htop,
+               reinterpret_cast<const long long*>(lengths), T, B, NH, last);
+    return check_launch("gather_last");
+}
+int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H, int C,
+                           float* logits, int32_t* arg, void* stream) {
+    if (N > 64) return fail("cls_head: num_nodes=%d unsupported (<= 64)", N);
+    EEG_LAUNCH(cls_head_fwd_kernel, dim3(B), dim3(64), (size_t)N * C * sizeof(float), S_(stream), z, W, bias, B, N, H, C, logits, arg);
+    return check_launch("cls_head_fwd");
+}
+int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg, int B, int N,
+                           int H, int C, float* dz, float* dW, float* dbias, void* stream) {
+    EEG_LAUNCH(cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, dz);
+    if (check_launch("cls_head_bwd_dz")) return 1;
+    EEG_LAUNCH(cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 64)), dim3(64), 0, S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
+    return check_launch("cls_head_bwd_w");
+}
+
+}  // extern "C"

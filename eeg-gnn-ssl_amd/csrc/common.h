@@ -1,0 +1,47 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) DCRNN kernels.
+//
+// Everything here is written for wave64 + v_mfma_f32_16x16x4_f32 (exact fp32 MFMA).  Lane maps
+// (cdna_hip_programming.md §3):  A: lane l -> A[i=l&15][k=l>>4];  B: lane l -> B[k=l>>4][j=l&15];
+// C/D: lane l, reg r -> (row = 4*(l>>4)+r, col = l&15).
+//
+// EEG_SIMT_EMU is defined ONLY by tests/emu/build_emu.py, which compiles these same sources
+// against a fiber-based emulator so the kernel logic can be checked without a GPU.  The product
+// build (Makefile / __graft_entry__.build) never defines it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#if defined(EEG_SIMT_EMU)
+#include "simt_emu.h"
+#define EEG_DYN_SMEM(name) float* name = reinterpret_cast<float*>(emu::g.smem)
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define EEG_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+namespace eeg {
+
+constexpr int kWave = 64;
+constexpr int kMaxNodes = 32;   // node rows are padded to two 16-row MFMA tiles
+constexpr int kMaxM = 8;        // hop matrices incl. identity (K<=3 with two supports -> 7)
+
+__host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// LDS row stride (floats) for an MFMA A-operand tile with K logical columns: K rounded so that
+// stride % 32 == 2 -> the 16 rows of a tile land on 16 distinct even banks and the two k-lanes
+// (l>>4 = 0/1 in a 32-lane ds_read_b32 group) on even/odd banks: conflict-free fragment reads.
+__host__ __device__ constexpr int lds_stride(int k) { return k + ((2 - (k % 32)) + 32) % 32; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace eeg

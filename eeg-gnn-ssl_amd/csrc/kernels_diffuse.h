@@ -1,0 +1,107 @@
+// Graph diffusion (node mixing) on the 19-electrode graph.
+//
+//  * lds_load_polys / lds_diffuse_tiles: building blocks shared with the recurrent kernels —
+//    the (M-1) non-identity hop-polynomial matrices of one graph live in LDS zero-padded to
+//    32x32 and are applied to an LDS-resident (32 x W) feature tile with fp32 MFMA
+//    (D[n][f] = sum_n' P_m[n][n'] X[n'][f], or P_m^T for the adjoint).
+//  * diffuse_fwd_kernel: the hoisted, HBM-bound diffusion step over all T*B samples:
+//    reads X (S,N,F) once, writes the M-1 hop planes (M-1,S,N,F).  Algorithmic bytes per
+//    sample = 4*N*F*M.
+//  * diffuse_adj_kernel: dX[s] = Z_0[s] + sum_{m>=1} P_m^T Z_m[s] for Z (S,N,M*F).
+#pragma once
+#include "common.h"
+#include "lds_diffuse.h"
+
+namespace eeg {
+
+// ---- standalone forward diffusion: X (S,N,F) -> planes (M-1,S,N,F) --------------------------
+// grid-stride over samples; P shared (p_batched=0) is staged once per workgroup.
+// LDS: Pl | tile [NR][FS] with NR = round_up(N,4), FS = lds_stride(M * FP), FP = round_up(F,16):
+// slot 0 = X, slots 1..M-1 = results (staged so the global stores are full coalesced rows).
+__global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restrict__ X, const float* __restrict__ P,
+                                                          int p_batched, int S, int B, int N, int F, int M,
+                                                          float* __restrict__ planes) {
+    EEG_DYN_SMEM(sm);
+    const int FP = round_up(F, 16), FS = lds_stride(M * FP);
+    float* Pl = sm;
+    float* tile = sm + (M - 1) * kPFloats;
+    const int tid = threadIdx.x, NR = round_up(N, 4);
+    for (int e = tid; e < NR * FS; e += blockDim.x) tile[e] = 0.f;
+    if (!p_batched) lds_load_polys(Pl, P, 0, M, N);
+    const int nf4 = F / 4;                           // F % 4 == 0 (checked by the host)
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        __syncthreads();                              // previous sample's stores done with the tile
+        if (p_batched) lds_load_polys(Pl, P, s % B, M, N);
+        const float4* src = reinterpret_cast<const float4*>(X + (size_t)s * N * F);
+        for (int q = tid; q < N * nf4; q += blockDim.x) {
+            const int n = q / nf4, c4 = q % nf4;
+            const float4 v = src[q];
+            float* d = tile + n * FS + 4 * c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        lds_diffuse_tiles<false>(tile, FS, 0, FP, FP, FP, Pl, M, N, NR);
+        __syncthreads();
+        for (int m1 = 0; m1 < M - 1; ++m1) {
+            float4* dst = reinterpret_cast<float4*>(planes + ((size_t)m1 * S + s) * N * F);
+            for (int q = tid; q < N * nf4; q += blockDim.x) {
+                const int n = q / nf4, c4 = q % nf4;
+                const float* t = tile + n * FS + FP * (m1 + 1) + 4 * c4;
+                dst[q] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    }
+}
+
+// ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m -------------------
+// LDS tile [NR][ZS], NR = round_up(N,4), ZS = lds_stride(M*FP): slot m holds Z_m (cols padded to FP).
+__global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restrict__ Z, const float* __restrict__ P,
+                                                          int p_batched, int S, int B, int N, int F, int M,
+                                                          float* __restrict__ dX) {
+    EEG_DYN_SMEM(sm);
+    const int FP = round_up(F, 16), ZS = lds_stride(M * FP);
+    float* Pl = sm;
+    float* tile = sm + (M - 1) * kPFloats;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4, NR = round_up(N, 4);
+    for (int e = tid; e < NR * ZS; e += blockDim.x) tile[e] = 0.f;
+    if (!p_batched) lds_load_polys(Pl, P, 0, M, N);
+    const int nf4 = F / 4, nct = FP / 16, nks = ceil_div(N, 4);
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        __syncthreads();
+        if (p_batched) lds_load_polys(Pl, P, s % B, M, N);
+        const float4* src = reinterpret_cast<const float4*>(Z + (size_t)s * N * M * F);
+        for (int q = tid; q < N * M * nf4; q += blockDim.x) {
+            const int n = q / (M * nf4), rem = q % (M * nf4), m = rem / nf4, c4 = rem % nf4;
+            const float4 v = src[q];
+            float* d = tile + n * ZS + m * FP + 4 * c4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        // out tile (rt, ct): acc = Z_0 tile; acc += P_m^T Z_m over m >= 1
+        for (int t = wave; t < 2 * nct; t += nwaves) {
+            const int ct = t % nct, rt = t / nct;
+            f32x4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = rt * 16 + 4 * lg + r;
+                acc[r] = n < N ? tile[n * ZS + ct * 16 + lr] : 0.f;
+            }
+            for (int m1 = 0; m1 < M - 1; ++m1) {
+                const float* Pm = Pl + m1 * kPFloats;
+                for (int ks = 0; ks < nks; ++ks) {
+                    const int kk = 4 * ks + lg;
+                    acc = mfma16(Pm[kk * kPStride + rt * 16 + lr], tile[kk * ZS + (m1 + 1) * FP + ct * 16 + lr], acc);
+                }
+            }
+            const int col = ct * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = rt * 16 + 4 * lg + r;
+                if (n < N && col < F) dX[((size_t)s * N + n) * F + col] = acc[r];
+            }
+        }
+    }
+}
+
+}  // namespace eeg

@@ -1,0 +1,232 @@
+// fp32 MFMA GEMMs for the hoisted (non-recurrent) parts of the DCGRU layer.
+//
+//  gemm_nn_kernel:  C[R x O] = [A_0 | A_1 | ... ] [R x nseg*F] * B + bias     (x-part of the
+//                   diffusion convolution for all T*B samples at once; also dY * W^T for dX)
+//                   A is given as `nseg` row-major planes (R x F) = hop planes; B is the
+//                   fragment-packed weight block (kernels_pack.h).
+//  gemm_tn_kernel:  P[split][nseg*F x O] = sum over a row range of A^T dY      (weight grads;
+//                   split-K partials are reduced in fixed order by reduce_unpack_kernel).
+//
+// Both use v_mfma_f32_16x16x4_f32 on LDS-staged tiles, register-staged double buffering with one
+// barrier per K chunk.  Roofline: fp32 MFMA (157.3 TFLOP/s), see DESIGN.md.
+#pragma once
+#include "common.h"
+
+namespace eeg {
+
+struct SegPtrs { const float* p[kMaxM]; };
+
+// ---------------------------------------------------------------------------------------------
+// NN: workgroup tile = 128 rows x (2*NCTW*16) cols, 4 waves as 2 (rows) x 2 (cols); each wave
+// 4 row tiles x NCTW col tiles.  K is walked segment by segment in chunks of KC (F % KC == 0).
+// LDS per buffer: A [128][KCS] + B [KC/4][NB][64], NB = 2*NCTW col tiles of this block.
+template <int NCTW, int KC>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                      const float* __restrict__ Bp, int nct_total,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ C, int ldc, int O) {
+    constexpr int KCS = lds_stride(KC), NB = 2 * NCTW, KSC = KC / 4;
+    constexpr int A_FLOATS = 128 * KCS, B_FLOATS = KSC * NB * 64;
+    constexpr int A_LD = (128 * KC / 4 + 255) / 256;        // float4 loads per thread per chunk
+    constexpr int B_LD = (B_FLOATS / 4 + 255) / 256;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+    const int row0 = blockIdx.x * 128, ct0 = blockIdx.y * NB;
+    const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
+
+    f32x4 acc[4][NCTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int chunk) {
+        const int seg = chunk / nchunk_seg, kc0 = (chunk % nchunk_seg) * KC;
+        const float* A = segs.p[seg];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 128 * KC / 4 && row0 + row < R)
+                v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + row) * F + kc0 + 4 * c4);
+            ra[i] = v;
+        }
+        const int gks0 = (seg * F + kc0) / 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = tid + 256 * i;                 // float4 index inside [KSC][NB][64]
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < B_FLOATS / 4) {
+                const int ks = q / (NB * 16), rem = q % (NB * 16), ct = rem / 16, l4 = rem % 16;
+                if (ct0 + ct < nct_total)
+                    v = *reinterpret_cast<const float4*>(Bp + ((size_t)(gks0 + ks) * nct_total + ct0 + ct) * 64 + 4 * l4);
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
+            if (q < 128 * KC / 4) {
+                float* d = As + row * KCS + 4 * c4;
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = tid + 256 * i;
+            if (q < B_FLOATS / 4) *reinterpret_cast<float4*>(Bs + 4 * q) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) gload(ch + 1);
+        const float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        const float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            float a[4], b[NCTW];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + lr) * KCS + 4 * ks + lg];
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) b[j] = Bs[(ks * NB + wc * NCTW + j) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        if (ch + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NCTW; ++j) {
+        const int col = (ct0 + wc * NCTW + j) * 16 + lr;
+        const float bv = (bias != nullptr && col < O) ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wr * 64 + i * 16 + 4 * lg + r;
+                if (row < R && col < O) C[(size_t)row * ldc + col] = acc[i][j][r] + bv;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: workgroup output tile = 64 k-rows (one 64-wide feature block of one hop plane) x
+// (2*NCTW*16) columns of dY; 4 waves as 2 (k) x 2 (cols), each 2 k-tiles x NCTW col tiles.
+// The reduction runs over rows [split*rows_per_split, ...) in chunks of 32 rows.
+// grid = (nseg * ceil(F/64), nsplit).  partial: [nsplit][nseg*F][Ov]; Ov <= 2*NCTW*16 valid
+// columns (Ov % 4 == 0), the rest of the tile is zero-filled / not stored.
+template <int NCTW>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                      const float* __restrict__ dY, int ldy, int ycol0, int Ov,
+                                                      float* __restrict__ partial, int rows_per_split) {
+    constexpr int RC = 32, O = 2 * NCTW * 16;
+    constexpr int AS = 80;                                  // 64 + 16: stride % 32 == 16
+    constexpr int YS = O + ((16 - (O % 32)) + 32) % 32;     // stride % 32 == 16
+    constexpr int A_FLOATS = RC * AS, Y_FLOATS = RC * YS;
+    constexpr int A_LD = RC * 64 / 4 / 256;                 // = 2
+    constexpr int Y_LD = (RC * O / 4 + 255) / 256;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+    const int nfb = ceil_div(F, 64);
+    const int seg = blockIdx.x / nfb, f0 = (blockIdx.x % nfb) * 64;
+    const int rbeg = blockIdx.y * rows_per_split;
+    const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
+    const float* A = segs.p[seg];
+
+    f32x4 acc[2][NCTW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[A_LD], ry[Y_LD];
+    auto gload = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / 16, c4 = q % 16;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < rend && f0 + 4 * c4 < F)
+                v = *reinterpret_cast<const float4*>(A + (size_t)(r0 + row) * F + f0 + 4 * c4);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (O / 4), c4 = q % (O / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < RC * O / 4 && r0 + row < rend && 4 * c4 < Ov)
+                v = *reinterpret_cast<const float4*>(dY + (size_t)(r0 + row) * ldy + ycol0 + 4 * c4);
+            ry[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* At = sm + buf * (A_FLOATS + Y_FLOATS);
+        float* Ys = At + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / 16, c4 = q % 16;
+            *reinterpret_cast<float4*>(At + row * AS + 4 * c4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (O / 4), c4 = q % (O / 4);
+            if (q < RC * O / 4) *reinterpret_cast<float4*>(Ys + row * YS + 4 * c4) = ry[i];
+        }
+    };
+
+    const int nchunks = rend > rbeg ? ceil_div(rend - rbeg, RC) : 0;
+    if (nchunks > 0) {
+        gload(rbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) gload(rbeg + (ch + 1) * RC);
+        const float* At = sm + buf * (A_FLOATS + Y_FLOATS);
+        const float* Ys = At + A_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < RC / 4; ++ks) {
+            float a[2], b[NCTW];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = At[(4 * ks + lg) * AS + (wk * 2 + i) * 16 + lr];
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) b[j] = Ys[(4 * ks + lg) * YS + (wc * NCTW + j) * 16 + lr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        if (ch + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const size_t Ktot = (size_t)nseg * F;
+    float* out = partial + (size_t)blockIdx.y * Ktot * Ov;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + (wk * 2 + i) * 16 + 4 * lg + r;
+            if (f < F) {
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) {
+                    const int col = (wc * NCTW + j) * 16 + lr;
+                    if (col < Ov) out[((size_t)seg * F + f) * Ov + col] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+}  // namespace eeg

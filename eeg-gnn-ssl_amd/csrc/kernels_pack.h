@@ -1,0 +1,191 @@
+// Weight (un)packing and hop-polynomial construction.
+//
+// Reference layout (model/cell.py:40-46, 98-116): dconv weight is ((Fin+H)*M, O) row-major with
+// row = f*M + m (feature-major, hop-minor; f < Fin input features, f >= Fin hidden features);
+// gate O = 2H (first H columns r, last H columns u), candidate O = H.
+//
+// Device layout: every GEMM B-operand is stored in MFMA-fragment order for
+// v_mfma_f32_16x16x4_f32:  pack[(ks*NCT + ct)*64 + lane] = B[4*ks + (lane>>4)][16*ct + (lane&15)],
+// with the K index hop-major (k = m*F + f) so that each hop plane is a contiguous K range.
+#pragma once
+#include "common.h"
+
+namespace eeg {
+
+// Offsets (in floats) of the packs of one DCGRU cell inside a single device buffer.
+struct CellPack {
+    int Fin, H, M;
+    size_t bx;     // x-part, K = M*Fin,  O = 3H   [gate(2H) | cand(H)]          (fwd hoisted GEMM)
+    size_t bias;   // 3H                            [bg | bc]
+    size_t bhg;    // h-part gate, K = M*H,  O = 2H                               (fwd recurrence)
+    size_t bhc;    // h-part cand, K = M*H,  O = H                                (fwd recurrence)
+    size_t b1;     // bwd cand:  K = M*H  (k = m*H + o),  O = H (f)   = Wc^h transposed
+    size_t b2;     // bwd gate:  K = M*2H (k = m*2H + o), O = H (f)   = Wg^h transposed
+    size_t bxt;    // bwd dx:    K = 3H (k = o), O = round_up(M*Fin,16)  = Bx transposed
+    size_t total;
+};
+
+__host__ __device__ inline CellPack make_cell_pack(int Fin, int H, int M) {
+    CellPack p;
+    p.Fin = Fin; p.H = H; p.M = M;
+    size_t o = 0;
+    p.bx = o;   o += (size_t)M * Fin * 3 * H;
+    p.bias = o; o += (size_t)round_up(3 * H, 64);
+    p.bhg = o;  o += (size_t)M * H * 2 * H;
+    p.bhc = o;  o += (size_t)M * H * H;
+    p.b1 = o;   o += (size_t)M * H * H;
+    p.b2 = o;   o += (size_t)M * 2 * H * H;
+    p.bxt = o;  o += (size_t)3 * H * round_up(M * Fin, 16);
+    p.total = o;
+    return p;
+}
+
+// element (k, j) of each logical B matrix, read from the reference-layout tensors
+__device__ __forceinline__ float ref_wg(const float* Wg, int M, int H, int f_all, int m, int o) {
+    return Wg[((size_t)f_all * M + m) * (2 * H) + o];
+}
+__device__ __forceinline__ float ref_wc(const float* Wc, int M, int H, int f_all, int m, int o) {
+    return Wc[((size_t)f_all * M + m) * H + o];
+}
+
+__global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __restrict__ bg,
+                                 const float* __restrict__ Wc, const float* __restrict__ bc,
+                                 float* __restrict__ out, CellPack p) {
+    const int Fin = p.Fin, H = p.H, M = p.M;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < p.total; idx += stride) {
+        float v = 0.f;
+        if (idx < p.bias) {                       // bx: NCT = 3H/16
+            const size_t e = idx - p.bx;
+            const int lane = e & 63, nct = 3 * H / 16;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+            const int m = k / Fin, f = k % Fin;
+            v = j < 2 * H ? ref_wg(Wg, M, H, f, m, j) : ref_wc(Wc, M, H, f, m, j - 2 * H);
+        } else if (idx < p.bhg) {                 // bias
+            const int j = idx - p.bias;
+            v = j < 2 * H ? bg[j] : (j < 3 * H ? bc[j - 2 * H] : 0.f);
+        } else if (idx < p.bhc) {                 // bhg: NCT = 2H/16
+            const size_t e = idx - p.bhg;
+            const int lane = e & 63, nct = 2 * H / 16;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+            v = ref_wg(Wg, M, H, Fin + k % H, k / H, j);
+        } else if (idx < p.b1) {                  // bhc: NCT = H/16
+            const size_t e = idx - p.bhc;
+            const int lane = e & 63, nct = H / 16;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+            v = ref_wc(Wc, M, H, Fin + k % H, k / H, j);
+        } else if (idx < p.b2) {                  // b1[k = m*H + o][f]
+            const size_t e = idx - p.b1;
+            const int lane = e & 63, nct = H / 16;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int k = 4 * ks + (lane >> 4), f = 16 * ct + (lane & 15);
+            v = ref_wc(Wc, M, H, Fin + f, k / H, k % H);
+        } else if (idx < p.bxt) {                 // b2[k = m*2H + o][f]
+            const size_t e = idx - p.b2;
+            const int lane = e & 63, nct = H / 16;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int k = 4 * ks + (lane >> 4), f = 16 * ct + (lane & 15);
+            v = ref_wg(Wg, M, H, Fin + f, k / (2 * H), k % (2 * H));
+        } else {                                  // bxt[k = o][j = m*Fin + f]
+            const size_t e = idx - p.bxt;
+            const int lane = e & 63, nct = round_up(M * Fin, 16) / 16;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int o = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+            if (j < M * Fin) {
+                const int m = j / Fin, f = j % Fin;
+                v = o < 2 * H ? ref_wg(Wg, M, H, f, m, o) : ref_wc(Wc, M, H, f, m, o - 2 * H);
+            }
+        }
+        out[idx] = v;
+    }
+}
+
+// Sum split-K partials [nsplit][K][O] in fixed order (deterministic) and scatter into the
+// reference-layout gradient tensors.  kind 0: x-part (K = M*Fin, O = 3H); 1: h-gate (K = M*H,
+// O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f).
+__global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O, int kind,
+                                     int Fin, int H, int M, float* __restrict__ dWg, float* __restrict__ dWc) {
+    const size_t total = (size_t)K * O;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * total + idx];
+        const int k = idx / O, o = idx % O;
+        if (kind == 0) {
+            const int m = k / Fin, f = k % Fin;
+            if (o < 2 * H) dWg[((size_t)f * M + m) * (2 * H) + o] = s;
+            else dWc[((size_t)f * M + m) * H + (o - 2 * H)] = s;
+        } else if (kind == 1) {
+            const int m = k / H, f = k % H;
+            dWg[((size_t)(Fin + f) * M + m) * (2 * H) + o] = s;
+        } else {
+            const int m = k / H, f = k % H;
+            dWc[((size_t)(Fin + f) * M + m) * H + o] = s;
+        }
+    }
+}
+
+// column sums of per-sample bias-gradient partials [B][3H] -> dbg (2H), dbc (H); fixed order.
+__global__ void reduce_bias_kernel(const float* __restrict__ part, int B, int H,
+                                   float* __restrict__ dbg, float* __restrict__ dbc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 3 * H) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += part[(size_t)b * 3 * H + j];
+    if (j < 2 * H) dbg[j] = s; else dbc[j - 2 * H] = s;
+}
+
+// Hop-polynomial matrices: P_0 = I (implicit), then for every support S, in order:
+//   b = S a; emit b; repeat K-1 times { c = 2 S b - a; emit c; (b, a) <- (c, b) };
+// where `a` starts as I and is NOT reset between supports (reference quirk Q1, cell.py:83-93).
+// supports: nsup pointers, each (Bs, N, N) with Bs = B (batched) or 1.  out: (Bs, M-1, N, N).
+// One workgroup per graph; thread (i, j) owns one matrix element.
+struct SupPtrs { const float* p[4]; };
+
+__global__ void hop_polys_kernel(SupPtrs sup, int nsup, int N, int K, float* __restrict__ out) {
+    EEG_DYN_SMEM(sm);
+    float* S = sm;                       // [N*N]
+    float* a = sm + kMaxNodes * kMaxNodes;
+    float* b = a + kMaxNodes * kMaxNodes;
+    float* c = b + kMaxNodes * kMaxNodes;
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int i = tid / N, j = tid % N;
+    const bool on = tid < N * N;
+    const int M1 = nsup * K;
+    if (on) a[i * N + j] = (i == j) ? 1.f : 0.f;
+    int emitted = 0;
+    for (int s = 0; s < nsup; ++s) {
+        __syncthreads();
+        if (on) S[i * N + j] = sup.p[s][(size_t)g * N * N + i * N + j];
+        __syncthreads();
+        float v = 0.f;
+        if (on) {
+            for (int q = 0; q < N; ++q) v = fmaf(S[i * N + q], a[q * N + j], v);
+            b[i * N + j] = v;
+            out[((size_t)g * M1 + emitted) * N * N + i * N + j] = v;
+        }
+        ++emitted;
+        for (int k = 2; k <= K; ++k) {
+            __syncthreads();
+            float w = 0.f;
+            if (on) {
+                for (int q = 0; q < N; ++q) w = fmaf(S[i * N + q], b[q * N + j], w);
+                w = 2.f * w - a[i * N + j];
+                c[i * N + j] = w;
+                out[((size_t)g * M1 + emitted) * N * N + i * N + j] = w;
+            }
+            ++emitted;
+            __syncthreads();
+            if (on) {                       // (b, a) <- (c, b)
+                const float nb = c[i * N + j], na = b[i * N + j];
+                a[i * N + j] = na;
+                b[i * N + j] = nb;
+            }
+        }
+    }
+}
+
+}  // namespace eeg

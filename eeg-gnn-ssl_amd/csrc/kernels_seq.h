@@ -1,0 +1,341 @@
+// Persistent DCGRU sequence kernels (the recurrent half of model/cell.py:182-210 driven by the
+// time loop of model/model.py:90-96), one launch per layer and direction.
+//
+// Design (MI355X-first):
+//  * samples are independent, so ONE WORKGROUP OWNS ONE CLIP for the whole sequence: no
+//    inter-workgroup traffic, no grid barrier; B workgroups fill the 256 CUs at B = 256.
+//  * the recurrent weights (W^h, M*H x 3H fp32 = 147..246 kB) do not fit LDS, so every wave keeps
+//    its column slice as MFMA B-fragments IN REGISTERS for all T steps (<= 240 VGPRs of the 512
+//    available at one wave per SIMD).
+//  * the hidden state / gradient tile, its M hop-diffused copies and the (M-1) hop-polynomial
+//    matrices of the clip's graph stay in LDS; the 19-node mix is an fp32 MFMA with the padded
+//    32x32 polynomial as A operand.
+//  * the input half of the diffusion convolution (x-part, + biases) is hoisted out of the
+//    recurrence (kernels_gemm.h) and arrives as XW (T,B,N,3H) = [r | u | c] pre-activations.
+//
+// fwd per step:  hops(h) -> G = XW_g + hops(h) Wg^h -> r,u = sigmoid -> hops(r*h)
+//                -> C = XW_c + hops(r*h) Wc^h -> c = act(C) -> h' = u*h + (1-u)*c
+// bwd per step:  SURVEY.md §9 "Cell backward" with P_m^T adjoint mixes; emits dXW = [dR|dU|dC]
+//                per step (consumed afterwards by the hoisted weight-gradient / dX GEMMs).
+#pragma once
+#include "common.h"
+#include "lds_diffuse.h"
+
+namespace eeg {
+
+template <int H, int M>
+struct SeqGeom {
+    static constexpr int KA = M * H, KAP = lds_stride(KA), KS = KA / 4;        // h-wide hop tile
+    static constexpr int KG = M * 2 * H, KGP = lds_stride(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
+    static constexpr int NGT = 2 * H / 16, NCT = H / 16;                       // gate / cand col tiles
+    static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);         // per wave (4 waves)
+    static constexpr int US = H + 2;
+    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + 32 * US; }
+    static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP + 3 * H * 4; }
+};
+
+template <int H, int M>
+__global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
+    const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
+    const float* __restrict__ bhg, const float* __restrict__ bhc,
+    float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
+    float* __restrict__ RHs, int T, int B, int N, int act) {
+    using G = SeqGeom<H, M>;
+    constexpr int KAP = G::KAP, KS = G::KS, GT = G::GT, CT = G::CT, NGT = G::NGT, NCT = G::NCT, US = G::US;
+    EEG_DYN_SMEM(sm);
+    float* Pl = sm;
+    float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
+    float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
+    float* Ub = A2 + 32 * KAP;              // [32][US]   update gate
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x;
+
+    // recurrent weights -> registers (MFMA B fragments), once for all T steps
+    float wg[GT][KS], wc[CT][KS];
+#pragma unroll
+    for (int i = 0; i < GT; ++i) {
+        const int ct = wave * GT + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wg[i][ks] = ct < NGT ? bhg[((size_t)ks * NGT + ct) * 64 + lane] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int ct = wave * CT + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wc[i][ks] = ct < NCT ? bhc[((size_t)ks * NCT + ct) * 64 + lane] : 0.f;
+    }
+
+    for (int e = tid; e < 2 * 32 * KAP + 32 * US; e += 256) A[e] = 0.f;
+    lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
+    __syncthreads();
+    if (h0 != nullptr)
+        for (int e = tid; e < N * H; e += 256) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const size_t s = (size_t)t * B + b;
+        // prefetch this step's hoisted pre-activations (consumed after the diffusion phases)
+        f32x4 xg[GT][2], xc[CT][2];
+#pragma unroll
+        for (int i = 0; i < GT; ++i)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + 4 * lg + r, ct = wave * GT + i;
+                    xg[i][rt][r] = (row < N && ct < NGT) ? XW[(s * N + row) * (3 * H) + ct * 16 + lr] : 0.f;
+                }
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + 4 * lg + r, ct = wave * CT + i;
+                    xc[i][rt][r] = (row < N && ct < NCT) ? XW[(s * N + row) * (3 * H) + 2 * H + ct * 16 + lr] : 0.f;
+                }
+
+        lds_diffuse_tiles<false>(A, KAP, 0, H, H, H, Pl, M, N, 32);
+        __syncthreads();                                            // (b) hops(h) complete
+
+        // gate GEMM: (32 x M*H) @ (M*H x 2H), this wave: GT col tiles x 2 row tiles
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float a0 = A[lr * KAP + 4 * ks + lg], a1 = A[(16 + lr) * KAP + 4 * ks + lg];
+#pragma unroll
+            for (int i = 0; i < GT; ++i) {
+                xg[i][0] = mfma16(a0, wg[i][ks], xg[i][0]);
+                xg[i][1] = mfma16(a1, wg[i][ks], xg[i][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GT; ++i) {
+            const int ct = wave * GT + i;
+            if (ct < NGT) {
+                const bool is_r = ct < NCT;
+                const int col = ct * 16 + lr;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + 4 * lg + r;
+                        if (row < N) {
+                            const float g = sigmoidf_(xg[i][rt][r]);
+                            if (is_r) {
+                                const float rh = g * A[row * KAP + col];
+                                A2[row * KAP + col] = rh;
+                                if (Rs != nullptr) {
+                                    Rs[(s * N + row) * H + col] = g;
+                                    RHs[(s * N + row) * H + col] = rh;
+                                }
+                            } else {
+                                Ub[row * US + col - H] = g;
+                                if (Us != nullptr) Us[(s * N + row) * H + col - H] = g;
+                            }
+                        }
+                    }
+            }
+        }
+        __syncthreads();                                            // (c) r*h and u complete
+        lds_diffuse_tiles<false>(A2, KAP, 0, H, H, H, Pl, M, N, 32);
+        __syncthreads();                                            // (d) hops(r*h) complete
+
+        // candidate GEMM: (32 x M*H) @ (M*H x H), this wave: CT col tiles x 2 row tiles
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float a0 = A2[lr * KAP + 4 * ks + lg], a1 = A2[(16 + lr) * KAP + 4 * ks + lg];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                xc[i][0] = mfma16(a0, wc[i][ks], xc[i][0]);
+                xc[i][1] = mfma16(a1, wc[i][ks], xc[i][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int ct = wave * CT + i;
+            if (ct < NCT) {
+                const int col = ct * 16 + lr;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + 4 * lg + r;
+                        if (row < N) {
+                            const float pre = xc[i][rt][r];
+                            const float c = act == 0 ? tanhf(pre) : fmaxf(pre, 0.f);
+                            const float u = Ub[row * US + col], h = A[row * KAP + col];
+                            const float hn = u * h + (1.f - u) * c;
+                            A[row * KAP + col] = hn;
+                            Hseq[(s * N + row) * H + col] = hn;
+                            if (Cs != nullptr) Cs[(s * N + row) * H + col] = c;
+                        }
+                    }
+            }
+        }
+        __syncthreads();                                            // (a) h_t complete
+    }
+}
+
+// lengths: optional int64 (B); d_at_len is added at t = lengths[b]-1, d_at_end at t = T-1.
+template <int H, int M>
+__global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
+    const float* __restrict__ Hseq, const float* __restrict__ h0, const float* __restrict__ Rs,
+    const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
+    const float* __restrict__ d_at_end, const float* __restrict__ d_at_len, const long long* __restrict__ lengths,
+    const float* __restrict__ P, int p_batched, const float* __restrict__ b1p, const float* __restrict__ b2p,
+    float* __restrict__ dXW, float* __restrict__ dh0, float* __restrict__ dbias_part, int T, int B, int N, int act) {
+    using G = SeqGeom<H, M>;
+    constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, CT = G::CT, NCT = G::NCT;
+    EEG_DYN_SMEM(sm);
+    float* Pl = sm;
+    float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC
+    float* EG = EC + 32 * KAP;              // [32][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
+    float* red = EG + 32 * KGP;             // [3H][4]    bias-gradient reduction scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x;
+
+    float w1[CT][KS], w2[CT][KSG];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int ct = wave * CT + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w1[i][ks] = ct < NCT ? b1p[((size_t)ks * NCT + ct) * 64 + lane] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSG; ++ks) w2[i][ks] = ct < NCT ? b2p[((size_t)ks * NCT + ct) * 64 + lane] : 0.f;
+    }
+    for (int e = tid; e < 32 * KAP + 32 * KGP; e += 256) EC[e] = 0.f;
+    lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
+    const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
+
+    f32x4 dh[CT][2];
+    float sb_r[CT], sb_u[CT], sb_c[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        dh[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dh[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sb_r[i] = sb_u[i] = sb_c[i] = 0.f;
+    }
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t s = (size_t)t * B + b;
+        f32x4 hp[CT][2], rr[CT][2], dU[CT][2], dhn[CT][2];
+        // ---- E1: gate blend backward on the owned elements
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int ct = wave * CT + i, col = ct * 16 + lr;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + 4 * lg + r;
+                    float h = 0.f, rg = 0.f, du_ = 0.f, dn = 0.f;
+                    if (row < N && ct < NCT) {
+                        const size_t e = (s * N + row) * H + col, eb = ((size_t)b * N + row) * H + col;
+                        h = t > 0 ? Hseq[e - (size_t)B * N * H] : (h0 != nullptr ? h0[eb] : 0.f);
+                        rg = Rs[e];
+                        const float u = Us[e], c = Cs[e];
+                        float g = dh[i][rt][r];
+                        if (dHseq != nullptr) g += dHseq[e];
+                        if (d_at_end != nullptr && t == T - 1) g += d_at_end[eb];
+                        if (t == t_len) g += d_at_len[eb];
+                        const float dc = g * (1.f - u);
+                        const float dC = act == 0 ? dc * (1.f - c * c) : (c > 0.f ? dc : 0.f);
+                        du_ = g * (h - c) * u * (1.f - u);
+                        dn = g * u;
+                        EC[row * KAP + col] = dC;
+                        dXW[(s * N + row) * (3 * H) + 2 * H + col] = dC;
+                        dXW[(s * N + row) * (3 * H) + H + col] = du_;
+                        sb_c[i] += dC;
+                        sb_u[i] += du_;
+                    }
+                    hp[i][rt][r] = h; rr[i][rt][r] = rg; dU[i][rt][r] = du_; dhn[i][rt][r] = dn;
+                }
+        }
+        __syncthreads();                                            // #1 dC tile complete
+        lds_diffuse_tiles<true>(EC, KAP, 0, H, H, H, Pl, M, N, 32);
+        __syncthreads();                                            // #2 P_m^T dC complete
+
+        // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T (M*H x H)
+        f32x4 acc[CT][2];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float a0 = EC[lr * KAP + 4 * ks + lg], a1 = EC[(16 + lr) * KAP + 4 * ks + lg];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                acc[i][0] = mfma16(a0, w1[i][ks], acc[i][0]);
+                acc[i][1] = mfma16(a1, w1[i][ks], acc[i][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int ct = wave * CT + i, col = ct * 16 + lr;
+            if (ct < NCT) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + 4 * lg + r;
+                        if (row < N) {
+                            const float drh = acc[i][rt][r], rg = rr[i][rt][r];
+                            const float dR = drh * hp[i][rt][r] * rg * (1.f - rg);
+                            dhn[i][rt][r] += drh * rg;
+                            EG[row * KGP + col] = dR;
+                            EG[row * KGP + H + col] = dU[i][rt][r];
+                            dXW[(s * N + row) * (3 * H) + col] = dR;
+                            sb_r[i] += dR;
+                        }
+                    }
+            }
+        }
+        __syncthreads();                                            // #3 [dR|dU] tile complete
+        lds_diffuse_tiles<true>(EG, KGP, 0, 2 * H, 2 * H, 2 * H, Pl, M, N, 32);
+        __syncthreads();                                            // #4 P_m^T [dR|dU] complete
+
+        // ---- GEMM2: dh += [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
+#pragma unroll
+        for (int ks = 0; ks < KSG; ++ks) {
+            const float a0 = EG[lr * KGP + 4 * ks + lg], a1 = EG[(16 + lr) * KGP + 4 * ks + lg];
+#pragma unroll
+            for (int i = 0; i < CT; ++i) {
+                dhn[i][0] = mfma16(a0, w2[i][ks], dhn[i][0]);
+                dhn[i][1] = mfma16(a1, w2[i][ks], dhn[i][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            dh[i][0] = dhn[i][0];
+            dh[i][1] = dhn[i][1];
+        }
+    }
+
+    // ---- epilogue: dh0 and the per-clip bias-gradient partial sums
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        const int ct = wave * CT + i, col = ct * 16 + lr;
+        if (ct < NCT) {
+            if (dh0 != nullptr) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rt * 16 + 4 * lg + r;
+                        if (row < N) dh0[((size_t)b * N + row) * H + col] = dh[i][rt][r];
+                    }
+            }
+            red[(0 * H + col) * 4 + lg] = sb_r[i];
+            red[(1 * H + col) * 4 + lg] = sb_u[i];
+            red[(2 * H + col) * 4 + lg] = sb_c[i];
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < 3 * H; j += 256)
+        dbias_part[(size_t)b * 3 * H + j] = (red[j * 4] + red[j * 4 + 1]) + (red[j * 4 + 2] + red[j * 4 + 3]);
+}
+
+}  // namespace eeg

@@ -1,0 +1,56 @@
+// LDS-resident graph diffusion building blocks shared by the standalone diffusion kernels and
+// the recurrent kernels: the (M-1) non-identity hop-polynomial matrices of one graph live in LDS
+// zero-padded to 32x32 and are applied to an LDS-resident (32 x W) feature tile with fp32 MFMA
+// (D[n][f] = sum_n' P_m[n][n'] X[n'][f], or P_m^T for the adjoint).
+#pragma once
+#include "common.h"
+
+namespace eeg {
+
+constexpr int kPStride = 34;                       // lds_stride(32)
+constexpr int kPFloats = kMaxNodes * kPStride;     // one padded 32x32 matrix
+
+// P (global): (Bp, M-1, N, N); graph g.  Pl (LDS): (M-1) x [32][kPStride], zero padded.
+__device__ __forceinline__ void lds_load_polys(float* Pl, const float* __restrict__ P, int g, int M, int N) {
+    const int total = (M - 1) * kPFloats;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int m1 = e / kPFloats, r = (e % kPFloats) / kPStride, c = e % kPStride;
+        float v = 0.f;
+        if (r < N && c < N) v = P[(((size_t)g * (M - 1) + m1) * N + r) * N + c];
+        Pl[e] = v;
+    }
+}
+
+// Apply hop matrices m = 1..M-1 to the (32 x W) source block buf[:, src_off : src_off+W) and
+// write results to buf[:, dst_off + (m-1)*dst_step : +W).  Rows >= N of the source must be zero
+// (or finite); rows >= N of the result are written as exact zeros (P is zero padded).
+// Work items = (m, row tile, col tile), round-robin over the block's waves.  W % 16 == 0.
+// Result rows >= rows_limit are not stored (the standalone kernels only keep round_up(N,4) rows).
+template <bool ADJ>
+__device__ __forceinline__ void lds_diffuse_tiles(float* buf, int stride, int src_off, int dst_off,
+                                                  int dst_step, int W, const float* Pl, int M, int N,
+                                                  int rows_limit) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int nct = W / 16, nks = ceil_div(N, 4);
+    const int ntiles = (M - 1) * 2 * nct;
+    const int lr = lane & 15, lg = lane >> 4;
+    for (int t = wave; t < ntiles; t += nwaves) {
+        const int ct = t % nct, rt = (t / nct) & 1, m1 = t / (2 * nct);
+        const float* Pm = Pl + m1 * kPFloats;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nks; ++ks) {
+            const int kk = 4 * ks + lg;
+            const float a = ADJ ? Pm[kk * kPStride + rt * 16 + lr] : Pm[(rt * 16 + lr) * kPStride + kk];
+            const float b = buf[kk * stride + src_off + ct * 16 + lr];
+            acc = mfma16(a, b, acc);
+        }
+        float* d = buf + dst_off + m1 * dst_step + ct * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + 4 * lg + r;
+            if (row < rows_limit) d[row * stride] = acc[r];
+        }
+    }
+}
+
+}  // namespace eeg

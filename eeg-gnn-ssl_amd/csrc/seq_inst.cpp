@@ -1,0 +1,55 @@
+// Instantiations of the recurrent kernels for one hidden size (compile with -DEEG_SEQ_H=16|32|64).
+#include "kernels_seq.h"
+#include "seq_launch.h"
+
+#ifndef EEG_SEQ_H
+#error "compile with -DEEG_SEQ_H=<hidden units>"
+#endif
+#define EEG_CAT2(a, b) a##b
+#define EEG_CAT(a, b) EEG_CAT2(a, b)
+
+namespace eeg {
+namespace {
+
+template <int H, int M>
+int fwd_one(const SeqFwdArgs& a, hipStream_t st) {
+    const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
+    EEG_SET_MAX_LDS((seq_fwd_kernel<H, M>), lds);
+    EEG_LAUNCH((seq_fwd_kernel<H, M>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched, a.bhg,
+               a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+template <int H, int M>
+int bwd_one(const SeqBwdArgs& a, hipStream_t st) {
+    const size_t lds = SeqGeom<H, M>::bwd_lds_floats() * sizeof(float);
+    EEG_SET_MAX_LDS((seq_bwd_kernel<H, M>), lds);
+    EEG_LAUNCH((seq_bwd_kernel<H, M>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs, a.dHseq,
+               a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0, a.dbias_part,
+               a.T, a.B, a.N, a.act);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace
+
+int EEG_CAT(launch_seq_fwd_h, EEG_SEQ_H)(int M, const SeqFwdArgs& a, hipStream_t st) {
+    switch (M) {
+        case 2: return fwd_one<EEG_SEQ_H, 2>(a, st);
+        case 3: return fwd_one<EEG_SEQ_H, 3>(a, st);
+        case 4: return fwd_one<EEG_SEQ_H, 4>(a, st);
+        case 5: return fwd_one<EEG_SEQ_H, 5>(a, st);
+        case 7: return fwd_one<EEG_SEQ_H, 7>(a, st);
+        default: return 1;
+    }
+}
+int EEG_CAT(launch_seq_bwd_h, EEG_SEQ_H)(int M, const SeqBwdArgs& a, hipStream_t st) {
+    switch (M) {
+        case 2: return bwd_one<EEG_SEQ_H, 2>(a, st);
+        case 3: return bwd_one<EEG_SEQ_H, 3>(a, st);
+        case 4: return bwd_one<EEG_SEQ_H, 4>(a, st);
+        case 5: return bwd_one<EEG_SEQ_H, 5>(a, st);
+        case 7: return bwd_one<EEG_SEQ_H, 7>(a, st);
+        default: return 1;
+    }
+}
+
+}  // namespace eeg

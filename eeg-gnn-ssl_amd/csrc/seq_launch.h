@@ -1,0 +1,41 @@
+// Host-side launch interface of the templated recurrent kernels.  The (H, M) instantiations are
+// compiled in separate translation units (seq_inst.cpp, one per H) to keep build times parallel.
+#pragma once
+#include "common.h"
+
+namespace eeg {
+
+struct SeqFwdArgs {
+    const float *XW, *h0, *P;
+    int p_batched;
+    const float *bhg, *bhc;
+    float *Hseq, *Rs, *Us, *Cs, *RHs;
+    int T, B, N, act;
+};
+struct SeqBwdArgs {
+    const float *Hseq, *h0, *Rs, *Us, *Cs, *dHseq, *d_at_end, *d_at_len;
+    const long long* lengths;
+    const float* P;
+    int p_batched;
+    const float *b1, *b2;
+    float *dXW, *dh0, *dbias_part;
+    int T, B, N, act;
+};
+
+// return 0 ok, 1 unsupported M for this H, 2 launch error
+int launch_seq_fwd_h16(int M, const SeqFwdArgs& a, hipStream_t st);
+int launch_seq_fwd_h32(int M, const SeqFwdArgs& a, hipStream_t st);
+int launch_seq_fwd_h64(int M, const SeqFwdArgs& a, hipStream_t st);
+int launch_seq_bwd_h16(int M, const SeqBwdArgs& a, hipStream_t st);
+int launch_seq_bwd_h32(int M, const SeqBwdArgs& a, hipStream_t st);
+int launch_seq_bwd_h64(int M, const SeqBwdArgs& a, hipStream_t st);
+bool seq_m_supported(int M);
+
+#if defined(EEG_SIMT_EMU)
+#define EEG_SET_MAX_LDS(kern, bytes) ((void)0)
+#else
+#define EEG_SET_MAX_LDS(kern, bytes) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+#endif
+
+}  // namespace eeg

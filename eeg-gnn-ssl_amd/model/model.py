@@ -1,0 +1,178 @@
+"""DCRNN encoder / decoder / task models with the reference's signatures, attribute names and
+`state_dict` layout (tsy935/eeg-gnn-ssl model/model.py:48-360), backed by the MI355X kernels.
+
+Differences that are deliberate and invisible to callers:
+  * one persistent HIP launch per (layer, direction) replaces the Python `for t` loop of
+    model.py:93-96 (the x-part of every diffusion convolution is hoisted out of the recurrence);
+  * hop polynomials of the supports are built once per forward instead of per step;
+  * the classification model gathers h at len-1 on the device (no `lengths.cpu()` sync,
+    utils.py:347) and routes its gradient straight into the BPTT kernel.
+"""
+import random
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .. import utils
+from .cell import DCGRUCell
+
+
+class DCRNNEncoder(nn.Module):
+    """reference: model.py:48-109."""
+
+    def __init__(self, input_dim, max_diffusion_step, hid_dim, num_nodes, num_rnn_layers,
+                 dcgru_activation=None, filter_type="laplacian", device=None):
+        super().__init__()
+        self.hid_dim = hid_dim
+        self.num_rnn_layers = num_rnn_layers
+        self.num_nodes = num_nodes
+        self.max_diffusion_step = max_diffusion_step
+        self._device = device
+        cells = []
+        for layer in range(num_rnn_layers):
+            cells.append(DCGRUCell(input_dim=input_dim if layer == 0 else hid_dim, num_units=hid_dim,
+                                   max_diffusion_step=max_diffusion_step, num_nodes=num_nodes,
+                                   nonlinearity=dcgru_activation, filter_type=filter_type))
+        self.encoding_cells = nn.ModuleList(cells)
+
+    def run(self, inputs, initial_hidden_state, supports, lengths=None):
+        """Layer-major pass (model.py:90-99).  Returns (finals (L,B,N*H), top sequence (T,B,N*H),
+        top state at t = lengths-1 (B,N*H) or None)."""
+        t_len, b = inputs.shape[0], inputs.shape[1]
+        self.encoding_cells[0]._check_supports(supports)
+        p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
+        cur = inputs.reshape(t_len, b, self.num_nodes, -1)
+        finals, top_sel = [], None
+        for layer, cell in enumerate(self.encoding_cells):
+            h0 = None if initial_hidden_state is None else initial_hidden_state[layer]
+            is_top = layer == self.num_rnn_layers - 1
+            if is_top and lengths is not None:
+                hseq, top_sel = cell.run_sequence(cur, h0, p, p_batched, lengths)
+                finals.append(hseq[t_len - 1])
+            else:
+                hseq, hfin = cell.run_sequence(cur, h0, p, p_batched)
+                finals.append(hfin)
+            cur = hseq.view(t_len, b, self.num_nodes, self.hid_dim)
+        return torch.stack(finals, dim=0), cur.reshape(t_len, b, -1), top_sel
+
+    def forward(self, inputs, initial_hidden_state, supports):
+        """inputs (T,B,N,Din), initial_hidden_state (L,B,N*H) ->
+        (output_hidden (L,B,N*H), current_inputs (T,B,N*H))"""
+        finals, top, _ = self.run(inputs, initial_hidden_state, supports)
+        return finals, top
+
+    def init_hidden(self, batch_size):
+        return torch.stack([c.init_hidden(batch_size) for c in self.encoding_cells], dim=0)
+
+
+class DCGRUDecoder(nn.Module):
+    """reference: model.py:112-204.  Time-major autoregressive loop; layers >= 1 share ONE cell
+    object (model.py:126-143), so `decoding_cells.1` and `.2` alias the same parameters."""
+
+    def __init__(self, input_dim, max_diffusion_step, num_nodes, hid_dim, output_dim, num_rnn_layers,
+                 dcgru_activation=None, filter_type="laplacian", device=None, dropout=0.0):
+        super().__init__()
+        self.input_dim = input_dim
+        self.hid_dim = hid_dim
+        self.num_nodes = num_nodes
+        self.output_dim = output_dim
+        self.num_rnn_layers = num_rnn_layers
+        self.max_diffusion_step = max_diffusion_step
+        self._device = device
+        shared = DCGRUCell(input_dim=hid_dim, num_units=hid_dim, max_diffusion_step=max_diffusion_step,
+                           num_nodes=num_nodes, nonlinearity=dcgru_activation, filter_type=filter_type)
+        first = DCGRUCell(input_dim=input_dim, num_units=hid_dim, max_diffusion_step=max_diffusion_step,
+                          num_nodes=num_nodes, nonlinearity=dcgru_activation, filter_type=filter_type)
+        self.decoding_cells = nn.ModuleList([first] + [shared] * (num_rnn_layers - 1))
+        self.projection_layer = nn.Linear(hid_dim, output_dim)
+        self.dropout = nn.Dropout(p=dropout)
+
+    def forward(self, inputs, initial_hidden_state, supports, teacher_forcing_ratio=None):
+        """inputs (T,B,N,Dout) targets, initial_hidden_state (L,B,N*H) -> (T,B,N*Dout)."""
+        t_len, b = inputs.shape[0], inputs.shape[1]
+        targets = inputs.reshape(t_len, b, -1)
+        self.decoding_cells[0]._check_supports(supports)
+        p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
+        hidden = [initial_hidden_state[l] for l in range(self.num_rnn_layers)]
+        cur = torch.zeros(b, self.num_nodes * self.output_dim, device=inputs.device, dtype=inputs.dtype)  # GO symbol
+        outs = []
+        for t in range(t_len):
+            x = cur
+            for layer, cell in enumerate(self.decoding_cells):
+                xin = x.reshape(1, b, self.num_nodes, -1)
+                hseq, _ = cell.run_sequence(xin, hidden[layer], p, p_batched)
+                hidden[layer] = hseq[0]
+                x = hidden[layer]
+            proj = self.projection_layer(self.dropout(x.reshape(b, self.num_nodes, self.hid_dim)))
+            proj = proj.reshape(b, self.num_nodes * self.output_dim)
+            outs.append(proj)
+            if teacher_forcing_ratio is not None and random.random() < teacher_forcing_ratio:
+                cur = targets[t]
+            else:
+                cur = proj
+        return torch.stack(outs, dim=0)
+
+
+class DCRNNModel_classification(nn.Module):
+    """Seizure detection / classification model (reference: model.py:208-272).
+    forward(input_seq (B,T,N,Din), seq_lengths (B,), supports) -> (B, num_classes) logits."""
+
+    def __init__(self, args, num_classes, device=None):
+        super().__init__()
+        self.num_nodes = args.num_nodes
+        self.num_rnn_layers = args.num_rnn_layers
+        self.rnn_units = args.rnn_units
+        self._device = device
+        self.num_classes = num_classes
+        self.encoder = DCRNNEncoder(input_dim=args.input_dim, max_diffusion_step=args.max_diffusion_step,
+                                    hid_dim=args.rnn_units, num_nodes=args.num_nodes,
+                                    num_rnn_layers=args.num_rnn_layers,
+                                    dcgru_activation=args.dcgru_activation, filter_type=args.filter_type)
+        self.fc = nn.Linear(args.rnn_units, num_classes)
+        self.dropout = nn.Dropout(args.dropout)
+        self.relu = nn.ReLU()
+
+    def forward(self, input_seq, seq_lengths, supports):
+        b = input_seq.shape[0]
+        x = input_seq.transpose(0, 1)                         # (T,B,N,Din); made contiguous by the op
+        _, _, last = self.encoder.run(x, None, supports, lengths=seq_lengths)
+        last = self.dropout(last.view(b, self.num_nodes, self.rnn_units))
+        return ops.cls_head(last, self.fc.weight, self.fc.bias)    # relu -> fc -> max over nodes
+
+
+class DCRNNModel_nextTimePred(nn.Module):
+    """Self-supervised next-clip prediction model (reference: model.py:277-360).
+    forward(encoder_inputs (B,T,N,Din), decoder_inputs (B,T_out,N,Dout), supports, batches_seen)
+    -> (B,T_out,N,Dout)."""
+
+    def __init__(self, args, device=None):
+        super().__init__()
+        self.num_nodes = args.num_nodes
+        self.num_rnn_layers = args.num_rnn_layers
+        self.rnn_units = args.rnn_units
+        self._device = device
+        self.output_dim = args.output_dim
+        self.cl_decay_steps = args.cl_decay_steps
+        self.use_curriculum_learning = bool(args.use_curriculum_learning)
+        self.encoder = DCRNNEncoder(input_dim=args.input_dim, max_diffusion_step=args.max_diffusion_step,
+                                    hid_dim=args.rnn_units, num_nodes=args.num_nodes,
+                                    num_rnn_layers=args.num_rnn_layers,
+                                    dcgru_activation=args.dcgru_activation, filter_type=args.filter_type)
+        self.decoder = DCGRUDecoder(input_dim=args.output_dim, max_diffusion_step=args.max_diffusion_step,
+                                    num_nodes=args.num_nodes, hid_dim=args.rnn_units,
+                                    output_dim=args.output_dim, num_rnn_layers=args.num_rnn_layers,
+                                    dcgru_activation=args.dcgru_activation, filter_type=args.filter_type,
+                                    device=device, dropout=args.dropout)
+
+    def forward(self, encoder_inputs, decoder_inputs, supports, batches_seen=None):
+        b, t_out, n, _ = decoder_inputs.shape
+        enc_in = encoder_inputs.transpose(0, 1)
+        dec_in = decoder_inputs.transpose(0, 1)
+        enc_final, _, _ = self.encoder.run(enc_in, None, supports)
+        if self.training and self.use_curriculum_learning and batches_seen is not None:
+            ratio = utils.compute_sampling_threshold(self.cl_decay_steps, batches_seen)
+        else:
+            ratio = None
+        out = self.decoder(dec_in, enc_final, supports, teacher_forcing_ratio=ratio)
+        return out.reshape(t_out, b, n, -1).transpose(0, 1)

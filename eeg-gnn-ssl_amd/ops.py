@@ -1,0 +1,271 @@
+"""torch-facing operators over the C ABI (include/eeg_dcrnn.h): tensors in, tensors out, autograd.
+
+PyTorch is plumbing here — device memory, streams, autograd bookkeeping; all arithmetic of the
+DCRNN path runs in the HIP kernels of libeeg_dcrnn_hip.so.  Every function raises if its
+tensors are not on the GPU the library was built for: this package has no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import LayerDims
+
+ACT_CODES = {"tanh": 0, "relu": 1, None: 1}   # the reference maps anything but 'tanh' to relu (cell.py:146)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t: torch.Tensor):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def _check(lib, t: torch.Tensor, name: str, dtype=torch.float32):
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if lib.is_device_build and not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; eeg_gnn_ssl_amd runs only on an MI355X (HIP) device "
+                           f"and has no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+
+
+def num_matrices(filter_type: str, max_diffusion_step: int) -> int:
+    """cell.py:35,151-158."""
+    return (2 if filter_type == "dual_random_walk" else 1) * max_diffusion_step + 1
+
+
+# ---------------------------------------------------------------------------------------------
+# small memo so that per-step cell calls (decoder) do not rebuild hop polynomials / weight packs
+# ---------------------------------------------------------------------------------------------
+class _Memo:
+    def __init__(self, cap=8):
+        self.cap, self.items = cap, []
+
+    @staticmethod
+    def key(tensors, extra=()):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors) + tuple(extra)
+
+    def get(self, k):
+        for kk, v in self.items:
+            if kk == k:
+                return v
+        return None
+
+    def put(self, k, v):
+        self.items.append((k, v))
+        if len(self.items) > self.cap:
+            self.items.pop(0)
+
+
+_poly_memo = _Memo()
+_pack_memo = _Memo(16)
+
+
+def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: int) -> Tuple[torch.Tensor, int]:
+    """Hop-polynomial matrices of the clip graphs (cell.py:83-93 incl. quirk Q1).
+
+    supports: list of (N,N) or (B,N,N) tensors (torch.matmul broadcast semantics of cell.py:85).
+    Returns (P (G, M-1, N, N), p_batched) with G = B if any support is batched else 1."""
+    lib = _lib.get_lib()
+    sups = list(supports)
+    if len(sups) == 0:
+        raise RuntimeError("hop_polys: empty supports list")
+    k = _Memo.key(sups, (max_diffusion_step, batch))
+    hit = _poly_memo.get(k)
+    if hit is not None:
+        return hit[0], hit[1]
+    batched = any(s.dim() == 3 for s in sups)
+    n = sups[0].shape[-1]
+    norm = []
+    for i, s in enumerate(sups):
+        if s.shape[-1] != n or s.shape[-2] != n:
+            raise RuntimeError(f"supports[{i}] has shape {tuple(s.shape)}, expected (..., {n}, {n})")
+        if s.dim() == 3 and s.shape[0] != batch:
+            raise RuntimeError(f"supports[{i}] batch {s.shape[0]} != input batch {batch}")
+        if batched and s.dim() == 2:
+            s = s.unsqueeze(0).expand(batch, n, n)
+        s = s.to(torch.float32).contiguous()
+        _check(lib, s, f"supports[{i}]")
+        norm.append(s)
+    g = batch if batched else 1
+    m1 = len(norm) * max_diffusion_step
+    out = torch.empty((g, m1, n, n), dtype=torch.float32, device=norm[0].device)
+    arr = (ctypes.c_void_p * len(norm))(*[s.data_ptr() for s in norm])
+    lib.call("eeg_dcrnn_hop_polys", arr, len(norm), g, n, max_diffusion_step, _p(out), _stream(out))
+    flag = 1 if batched else 0
+    _poly_memo.put(k, (out, flag, norm, sups))   # keep the keyed tensors alive with the cache entry
+    return out, flag
+
+
+def pack_cell(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
+    """Reference-layout cell parameters -> MFMA-fragment-ordered device block (kernels_pack.h)."""
+    lib = _lib.get_lib()
+    tensors = [wg.detach(), bg.detach(), wc.detach(), bc.detach()]
+    k = _Memo.key(tensors, (fin, h, m))
+    hit = _pack_memo.get(k)
+    if hit is not None:
+        return hit
+    for t, nm in zip(tensors, ("dconv_gate.weight", "dconv_gate.biases", "dconv_candidate.weight", "dconv_candidate.biases")):
+        _check(lib, t, nm)
+    rows = (fin + h) * m
+    if tuple(wg.shape) != (rows, 2 * h) or tuple(wc.shape) != (rows, h) or tuple(bg.shape) != (2 * h,) or tuple(bc.shape) != (h,):
+        raise RuntimeError(f"cell parameter shapes {tuple(wg.shape)}, {tuple(bg.shape)}, {tuple(wc.shape)}, {tuple(bc.shape)} "
+                           f"do not match input_dim={fin}, num_units={h}, num_matrices={m}")
+    n = lib.query("eeg_dcrnn_pack_floats", fin, h, m)
+    pack = torch.empty(n, dtype=torch.float32, device=wg.device)
+    lib.call("eeg_dcrnn_pack_cell", _p(tensors[0]), _p(tensors[1]), _p(tensors[2]), _p(tensors[3]), fin, h, m, _p(pack), _stream(pack))
+    _pack_memo.put(k, pack)
+    return pack
+
+
+def diffusion_hops(x: torch.Tensor, p: torch.Tensor, p_batched: int, batch: int) -> torch.Tensor:
+    """The diffusion step alone: x (S,N,F) -> (M-1,S,N,F) hop planes P_m x (micro-benchmark entry;
+    north_star's HBM-bound kernel)."""
+    lib = _lib.get_lib()
+    _check(lib, x, "x")
+    _check(lib, p, "P")
+    s, n, f = x.shape
+    m = p.shape[1] + 1
+    out = torch.empty((m - 1, s, n, f), dtype=torch.float32, device=x.device)
+    lib.call("eeg_dcrnn_diffuse_fwd", _p(x), _p(p), p_batched, s, batch, n, f, m, _p(out), _stream(x))
+    return out
+
+
+class _DCGRULayerFn(torch.autograd.Function):
+    """One DCGRU layer over a whole sequence (the `for t` loop of model.py:93-96 around
+    DCGRUCell.forward, cell.py:182-210), fwd + explicit BPTT backward in HIP.
+
+    inputs : x (T,B,N,Fin), h0 (B,N*H) or None, P, wg, bg, wc, bc, lengths (int64 (B,) or None)
+    outputs: hseq (T,B,N*H), hsel (B,N*H) = h at t = lengths-1 (or T-1 when lengths is None)."""
+
+    @staticmethod
+    def forward(ctx, x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act):
+        lib = _lib.get_lib()
+        t_len, b = x.shape[0], x.shape[1]
+        fin = x.shape[3]
+        x = x.contiguous()
+        _check(lib, x, "inputs")
+        if h0 is not None:
+            h0 = h0.contiguous()
+            _check(lib, h0, "initial_hidden_state")
+        need_grad = any(ctx.needs_input_grad)
+        pack = pack_cell(wg, bg, wc, bc, fin, h, m)
+        dev = x.device
+        s = t_len * b
+        dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
+        planes = torch.empty((m - 1, s, n, fin), dtype=torch.float32, device=dev)
+        hext = torch.empty((t_len + 1, b, n * h), dtype=torch.float32, device=dev)
+        if need_grad:
+            rs, us, cs, rhs = (torch.empty((t_len, b, n * h), dtype=torch.float32, device=dev) for _ in range(4))
+        else:
+            rs = us = cs = rhs = None
+        ws = torch.empty(lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
+        lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(x), _p(h0), _p(p), _p(pack), _p(planes), _p(hext),
+                 _p(rs), _p(us), _p(cs), _p(rhs), _p(ws), _stream(x))
+        hseq = hext[1:]
+        if lengths is not None:
+            lengths = lengths.to(device=dev, dtype=torch.int64).contiguous()
+            hsel = torch.empty((b, n * h), dtype=torch.float32, device=dev)
+            lib.call("eeg_dcrnn_gather_last", _p(hseq), _p(lengths), t_len, b, n * h, _p(hsel), _stream(x))
+        else:
+            hsel = hseq[t_len - 1].clone()
+        if need_grad:
+            ctx.save_for_backward(x, p, pack, planes, hext, rs, us, cs, rhs, lengths)
+            ctx.meta = (t_len, b, n, h, fin, m, act, p_batched, h0 is not None)
+            ctx.set_materialize_grads(False)
+        return hseq, hsel
+
+    @staticmethod
+    def backward(ctx, d_hseq, d_hsel):
+        lib = _lib.get_lib()
+        x, p, pack, planes, hext, rs, us, cs, rhs, lengths = ctx.saved_tensors
+        t_len, b, n, h, fin, m, act, p_batched, has_h0 = ctx.meta
+        dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
+        dev = x.device
+        need_dx = ctx.needs_input_grad[0]
+        need_dh0 = has_h0 and ctx.needs_input_grad[1]
+        if d_hseq is not None:
+            d_hseq = d_hseq.contiguous()
+        if d_hsel is not None:
+            d_hsel = d_hsel.contiguous()
+        d_at_end = d_hsel if lengths is None else None
+        d_at_len = d_hsel if lengths is not None else None
+        dx = torch.empty_like(x) if need_dx else None
+        dh0 = torch.empty((b, n * h), dtype=torch.float32, device=dev) if need_dh0 else None
+        rows = (fin + h) * m
+        dwg = torch.empty((rows, 2 * h), dtype=torch.float32, device=dev)
+        dbg = torch.empty((2 * h,), dtype=torch.float32, device=dev)
+        dwc = torch.empty((rows, h), dtype=torch.float32, device=dev)
+        dbc = torch.empty((h,), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),
+                         dtype=torch.float32, device=dev)
+        lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), _p(x), _p(p), _p(pack), _p(planes), _p(hext), _p(rs),
+                 _p(us), _p(cs), _p(rhs), _p(d_hseq), _p(d_at_end), _p(d_at_len), _p(lengths), _p(dx), _p(dh0),
+                 _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(x))
+        return dx, dh0, None, dwg, dbg, dwc, dbc, None, None, None, None, None, None
+
+
+def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None):
+    """Run one DCGRU layer over x (T,B,N,Fin).  Returns (hseq (T,B,N*H), hsel (B,N*H))."""
+    act = ACT_CODES.get(activation, 1)
+    lib = _lib.get_lib()
+    if not lib.query("eeg_dcrnn_supported", n, h, x.shape[3], m):
+        raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
+    return _DCGRULayerFn.apply(x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act)
+
+
+class _ClsHeadFn(torch.autograd.Function):
+    """model.py:267-270 after dropout: per-node Linear(H->C) on relu(z), max over nodes."""
+
+    @staticmethod
+    def forward(ctx, z, w, bias):
+        lib = _lib.get_lib()
+        z = z.contiguous()
+        w = w.contiguous()
+        bias = bias.contiguous()
+        for t, nm in ((z, "last_out"), (w, "fc.weight"), (bias, "fc.bias")):
+            _check(lib, t, nm)
+        b, n, h = z.shape
+        c = w.shape[0]
+        logits = torch.empty((b, c), dtype=torch.float32, device=z.device)
+        arg = torch.empty((b, c), dtype=torch.int32, device=z.device)
+        lib.call("eeg_dcrnn_cls_head_fwd", _p(z), _p(w), _p(bias), b, n, h, c, _p(logits), _p(arg), _stream(z))
+        ctx.save_for_backward(z, w, arg)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.get_lib()
+        z, w, arg = ctx.saved_tensors
+        b, n, h = z.shape
+        c = w.shape[0]
+        dlogits = dlogits.contiguous()
+        dz = torch.empty_like(z)
+        dw = torch.empty_like(w)
+        db = torch.empty((c,), dtype=torch.float32, device=z.device)
+        lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, c, _p(dz), _p(dw), _p(db), _stream(z))
+        return dz, dw, db
+
+
+def cls_head(z, w, bias):
+    return _ClsHeadFn.apply(z, w, bias)
+
+
+def gather_last(htop: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    """utils.last_relevant_pytorch on a time-major (T,B,D) tensor, no host sync (forward only)."""
+    lib = _lib.get_lib()
+    htop = htop.contiguous()
+    _check(lib, htop, "output")
+    t_len, b, d = htop.shape
+    lengths = lengths.to(device=htop.device, dtype=torch.int64).contiguous()
+    out = torch.empty((b, d), dtype=torch.float32, device=htop.device)
+    lib.call("eeg_dcrnn_gather_last", _p(htop), _p(lengths), t_len, b, d, _p(out), _stream(htop))
+    return out

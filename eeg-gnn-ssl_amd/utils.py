@@ -1,0 +1,177 @@
+"""Hot-path helpers with the reference's names (tsy935/eeg-gnn-ssl utils.py / data_utils.py):
+graph supports that feed the diffusion convolution, the gather at len-1, the losses that seed
+backward, and the checkpoint transplant used by fine-tuning.  Only what the DCRNN path needs."""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ---- supports (host side, float64 like the reference's scipy path) ----------------------------
+def calculate_normalized_laplacian(adj):
+    """L = I - D^-1/2 A D^-1/2 (reference utils.py:205-217); dense ndarray in, dense out."""
+    adj = np.asarray(adj)
+    deg = adj.sum(axis=1)
+    with np.errstate(divide="ignore"):
+        dis = np.power(deg, -0.5)
+    dis[np.isinf(dis)] = 0.0
+    return np.eye(adj.shape[0]) - (adj * dis[None, :]).T * dis[None, :]
+
+
+def calculate_random_walk_matrix(adj_mx):
+    """D_o^-1 W (reference utils.py:220-230)."""
+    adj_mx = np.asarray(adj_mx)
+    deg = adj_mx.sum(axis=1)
+    with np.errstate(divide="ignore"):
+        dinv = np.power(deg, -1.0)
+    dinv[np.isinf(dinv)] = 0.0
+    return dinv[:, None] * adj_mx
+
+
+def calculate_reverse_random_walk_matrix(adj_mx):
+    """D_i^-1 W^T (reference utils.py:233-237)."""
+    return calculate_random_walk_matrix(np.transpose(adj_mx))
+
+
+def calculate_scaled_laplacian(adj_mx, lambda_max=2, undirected=True):
+    """2 L / lambda_max - I (reference utils.py:240-255); `lambda_max=None` -> spectral radius."""
+    adj_mx = np.asarray(adj_mx)
+    if undirected:
+        adj_mx = np.maximum(adj_mx, adj_mx.T)
+    lap = calculate_normalized_laplacian(adj_mx)
+    if lambda_max is None:
+        ev = np.linalg.eigvalsh((lap + lap.T) * 0.5)
+        lambda_max = ev[np.argmax(np.abs(ev))]
+    return (2.0 / lambda_max) * lap - np.eye(lap.shape[0])
+
+
+def compute_supports(adj_mat, filter_type):
+    """dataloader_detection.py:335-354 (`_compute_supports`): list of float32 (N,N) tensors."""
+    if filter_type == "laplacian":
+        mats = [calculate_scaled_laplacian(adj_mat, lambda_max=None)]
+    elif filter_type == "random_walk":
+        mats = [calculate_random_walk_matrix(adj_mat).T]
+    elif filter_type == "dual_random_walk":
+        mats = [calculate_random_walk_matrix(adj_mat).T, calculate_random_walk_matrix(np.transpose(adj_mat)).T]
+    else:
+        mats = [calculate_scaled_laplacian(adj_mat)]
+    return [torch.from_numpy(np.ascontiguousarray(m)).to(torch.float32) for m in mats]
+
+
+def keep_topk(adj_mat, top_k=3, directed=True):
+    """data_utils.py:174-200: keep each node's top-k neighbours (plus the diagonal)."""
+    work = np.array(adj_mat, copy=True)
+    np.fill_diagonal(work, 0)
+    nbr = np.argsort(-work, axis=-1)[:, :top_k]
+    keep = np.eye(work.shape[0], dtype=bool)
+    rows = np.repeat(np.arange(work.shape[0]), nbr.shape[1])
+    keep[rows, nbr.reshape(-1)] = True
+    if not directed:
+        keep[nbr.reshape(-1), rows] = True
+    return keep * adj_mat
+
+
+def correlation_graph(clip, top_k=3):
+    """Per-clip correlation adjacency (dataloader_detection.py:258-307): |cosine Gram| of the
+    (N, T*D) clip, unit diagonal, top-k directed.  clip: (T, N, D) ndarray -> (N, N) float32."""
+    n = clip.shape[1]
+    flat = np.transpose(clip, (1, 0, 2)).reshape(n, -1).astype(np.float64)
+    norm = np.sqrt((flat * flat).sum(axis=1))
+    gram = flat @ flat.T
+    denom = np.outer(norm, norm)
+    adj = np.divide(gram, denom, out=gram.copy(), where=denom != 0).astype(np.float32)
+    np.fill_diagonal(adj, 1.0)
+    return keep_topk(np.abs(adj), top_k=top_k, directed=True)
+
+
+# ---- sequence helpers -----------------------------------------------------------------------
+def last_relevant_pytorch(output, lengths, batch_first=True):
+    """Gather `output` at t = lengths-1 (reference utils.py:346-357).  Stays on the device (the
+    reference forces `lengths.cpu()`).  Differentiable through a plain torch gather; the
+    classification model uses the fused device path instead."""
+    idx = (lengths.to(device=output.device, dtype=torch.int64) - 1).view(-1, 1, 1)
+    if batch_first:
+        return output.gather(1, idx.expand(-1, 1, output.size(2))).squeeze(1)
+    return output.gather(0, idx.view(1, -1, 1).expand(1, -1, output.size(2))).squeeze(0)
+
+
+def compute_sampling_threshold(cl_decay_steps, global_step):
+    """Scheduled-sampling threshold (reference utils.py:385-390)."""
+    return cl_decay_steps / (cl_decay_steps + math.exp(global_step / cl_decay_steps))
+
+
+def count_parameters(model):
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+# ---- regression losses of the SSL task --------------------------------------------------------
+class StandardScaler:
+    """reference utils.py:393-428 with scalar (or broadcastable) mean / std."""
+
+    def __init__(self, mean, std):
+        self.mean, self.std = mean, std
+
+    def transform(self, data):
+        return (data - self.mean) / self.std
+
+    def inverse_transform(self, data, is_tensor=False, device=None, mask=None):
+        mean, std = self.mean, self.std
+        if is_tensor:
+            mean = torch.as_tensor(np.asarray(mean), dtype=torch.float32, device=data.device)
+            std = torch.as_tensor(np.asarray(std), dtype=torch.float32, device=data.device)
+        return data * std + mean
+
+
+def _masked(y_pred, y_true, mask_val, elementwise):
+    w = (y_true != mask_val).to(y_pred.dtype)
+    w = w / w.mean()
+    loss = elementwise(y_pred - y_true) * w
+    return torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)
+
+
+def masked_mae_loss(y_pred, y_true, mask_val=0.0):
+    """reference utils.py:431-442."""
+    return _masked(y_pred, y_true, mask_val, torch.abs).mean()
+
+
+def masked_mse_loss(y_pred, y_true, mask_val=0.0):
+    """reference utils.py:445-457 — despite the name this is the masked RMSE (sqrt of the mean)."""
+    return torch.sqrt(_masked(y_pred, y_true, mask_val, lambda d: d * d).mean())
+
+
+def compute_regression_loss(y_true, y_predicted, standard_scaler=None, device=None, loss_fn="mae",
+                            mask_val=0.0, is_tensor=True):
+    """reference utils.py:460-495.  Only the exact string 'mae' selects the MAE; the SSL trainer
+    passes "MAE" (train_ssl.py:168) and therefore optimises the masked RMSE — kept as is."""
+    if device is not None:
+        y_true, y_predicted = y_true.to(device), y_predicted.to(device)
+    if standard_scaler is not None:
+        y_true = standard_scaler.inverse_transform(y_true, is_tensor=is_tensor, device=device)
+        y_predicted = standard_scaler.inverse_transform(y_predicted, is_tensor=is_tensor, device=device)
+    if loss_fn == "mae":
+        return masked_mae_loss(y_predicted, y_true, mask_val=mask_val)
+    return masked_mse_loss(y_predicted, y_true, mask_val=mask_val)
+
+
+# ---- checkpoints ----------------------------------------------------------------------------------
+def load_model_checkpoint(checkpoint_file, model, optimizer=None):
+    """reference utils.py:156-163: restore `model_state` (and `optimizer_state` if asked)."""
+    ckpt = torch.load(checkpoint_file, map_location="cpu", weights_only=False)
+    model.load_state_dict(ckpt["model_state"])
+    if optimizer is not None:
+        optimizer.load_state_dict(ckpt["optimizer_state"])
+        return model, optimizer
+    return model
+
+
+def build_finetune_model(model_new, model_pretrained, num_rnn_layers, num_layers_frozen=0):
+    """reference utils.py:166-176: transplant the encoder dconv modules of the first
+    `num_rnn_layers` cells from an SSL-pretrained model."""
+    for layer in range(num_rnn_layers):
+        src = model_pretrained.encoder.encoding_cells[layer]
+        dst = model_new.encoder.encoding_cells[layer]
+        dst.dconv_gate = src.dconv_gate
+        dst.dconv_candidate = src.dconv_candidate
+    return model_new

@@ -1,0 +1,101 @@
+/*
+ * eeg_dcrnn.h — C ABI of libeeg_dcrnn_hip.so: MI355X (gfx950) kernels for the DCRNN hot path of
+ * tsy935/eeg-gnn-ssl (model/cell.py DiffusionGraphConv + DCGRUCell, and the encoder sequence
+ * loop of model/model.py).  Plain pointers and sizes only; every pointer is a DEVICE pointer to
+ * contiguous fp32 (int64 for lengths) unless stated; `stream` is a hipStream_t passed as void*.
+ * All functions enqueue work on `stream` and return without synchronising; they never allocate.
+ * Return value: 0 on success, non-zero on error (see eeg_dcrnn_last_error()).
+ *
+ * The reference has no FFI of its own (pure Python); each entry point below states
+ * the reference code it replaces.  The ctypes binding that a maintainer of the reference would
+ * add is shown in INTEGRATION.md and lives in eeg-gnn-ssl_amd/_lib.py.
+ *
+ * Layouts.  N = nodes (<= 32), H = rnn_units (16 | 32 | 64), F/Fin = per-node input features of a
+ * layer (multiple of 4), M = number of hop matrices incl. identity = n_supports*K + 1 (<= 8),
+ * S = T*B "samples" in time-major order (s = t*B + b).
+ *   supports : n_supports pointers, each (G, N, N) with G = B (per-clip graphs) or 1 (shared)
+ *   P        : (G, M-1, N, N) hop-polynomial matrices P_1..P_{M-1} (P_0 = I is implicit)
+ *   X        : (T, B, N, Fin)            planes : (M-1, S, N, Fin)  = P_m X_s, m = 1..M-1
+ *   Hext     : (T+1, B, N, H)  slot 0 = initial state h0, slot t+1 = h_t  (so the layer output
+ *              sequence is Hext + B*N*H and the "previous state" sequence is Hext itself)
+ *   Rs,Us,Cs,RHs : (T, B, N, H) saved reset gate, update gate, candidate, r*h_prev
+ *   Wg (((Fin+H)*M), 2H), bg (2H), Wc (((Fin+H)*M), H), bc (H): reference parameter layout,
+ *              row = f*M + m  (cell.py:40-46, 98-116)
+ */
+#ifndef EEG_DCRNN_H
+#define EEG_DCRNN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eeg_layer_dims {
+    int32_t T, B, N, H, Fin, M;
+    int32_t act;        /* 0 = tanh, 1 = relu  (cell.py:146 `nonlinearity`) */
+    int32_t p_batched;  /* 1: P holds one graph per clip (B graphs); 0: one shared graph */
+} eeg_layer_dims;
+
+/* Human-readable text of the last error raised on the calling thread. */
+const char* eeg_dcrnn_last_error(void);
+/* ABI version (bumped on any signature change). */
+int eeg_dcrnn_abi_version(void);
+/* 1 if the library was built for the GPU (always, for the product build), 0 for the test emulator. */
+int eeg_dcrnn_is_device_build(void);
+/* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
+int eeg_dcrnn_supported(int N, int H, int Fin, int M);
+
+/* Hop polynomials from the supports (replaces the per-step `torch.matmul(support, x)` chain of
+ * cell.py:83-93 incl. the carried-x0 quirk): P_out (G, n_supports*K, N, N). */
+int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K,
+                        float* P_out, void* stream);
+
+/* Number of floats of the packed weight block of one DCGRU cell. */
+size_t eeg_dcrnn_pack_floats(int Fin, int H, int M);
+/* Reference-layout parameters of one cell (cell.py:40-46,160-175) -> MFMA-fragment-ordered block. */
+int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const float* bc,
+                        int Fin, int H, int M, float* pack, void* stream);
+
+/* The HBM-bound diffusion step over all samples: planes[m-1][s] = P_m X_s  (cell.py:83-93 applied
+ * to the input features of every time step at once).  Algorithmic bytes: 4*S*N*F*M. */
+int eeg_dcrnn_diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F,
+                          int M, float* planes, void* stream);
+/* Adjoint: dX[s] = Z_0[s] + sum_{m>=1} P_m^T Z_m[s] for Z (S, N, M*F). */
+int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F,
+                          int M, float* dX, void* stream);
+
+/* One DCGRU layer over a whole sequence = the `for t` loop of model.py:93-96 around
+ * DCGRUCell.forward (cell.py:182-210).  h0 may be NULL (zeros).  Rs/Us/Cs/RHs may all be NULL
+ * (inference: nothing saved).  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch. */
+size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d);
+int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0, const float* P,
+                        const float* pack, float* planes, float* Hext, float* Rs, float* Us,
+                        float* Cs, float* RHs, float* ws, void* stream);
+
+/* Backward of the same layer (replaces autograd's replay of model.py:93-96 / cell.py).
+ * Incoming gradients (each may be NULL): dHseq (T,B,N,H) w.r.t. every h_t; d_at_end (B,N,H) w.r.t.
+ * h_{T-1} (the encoder's per-layer final state, model.py:97); d_at_len (B,N,H) w.r.t.
+ * h_{lengths[b]-1} (utils.last_relevant_pytorch; lengths int64 (B), NULL -> T).
+ * Outputs: dX (T,B,N,Fin) or NULL; dh0 (B,N,H) or NULL; dWg/dbg/dWc/dbc in reference layout
+ * (overwritten).  Reductions are fixed-order: results are run-to-run deterministic. */
+size_t eeg_dcrnn_layer_bwd_ws_floats(const eeg_layer_dims* d, int need_dx);
+int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P, const float* pack,
+                        const float* planes, const float* Hext, const float* Rs, const float* Us,
+                        const float* Cs, const float* RHs, const float* dHseq, const float* d_at_end,
+                        const float* d_at_len, const int64_t* lengths, float* dX, float* dh0,
+                        float* dWg, float* dbg, float* dWc, float* dbc, float* ws, void* stream);
+
+/* utils.last_relevant_pytorch (utils.py:346-357): last[b] = Htop[lengths[b]-1, b]. Htop (T,B,NH). */
+int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH,
+                          float* last, void* stream);
+/* model.py:267-270: logits[b][c] = max_n fc(relu(z[b][n])); arg[b][c] = maximising node. */
+int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H,
+                           int C, float* logits, int32_t* arg, void* stream);
+int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg,
+                           int B, int N, int H, int C, float* dz, float* dW, float* dbias, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEG_DCRNN_H */

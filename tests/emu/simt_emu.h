@@ -1,0 +1,188 @@
+// TEST INFRASTRUCTURE ONLY — a tiny single-OS-thread SIMT emulator used by tests/ to execute the
+// HIP kernel SOURCES of eeg-gnn-ssl_amd/csrc on the CPU (no GPU in the build container; GPU
+// minutes are scarce).  It is NOT a CPU fallback: the product library never includes this file
+// (it is only reachable with -DEEG_SIMT_EMU, which only tests/emu/build_emu.py passes).
+//
+// Model: one fiber (ucontext) per HIP thread, run-to-barrier scheduling inside one workgroup at a
+// time; __syncthreads() and the wave-collective v_mfma_f32_16x16x4_f32 are rendezvous points.
+// MFMA lane layout as documented for gfx950 (cdna_hip_programming.md §3):
+//   A: lane l supplies A[i = l&15][k = l>>4];  B: lane l supplies B[k = l>>4][j = l&15];
+//   C/D: lane l, reg r holds element (row = 4*(l>>4) + r, col = l&15);  D = C + sum_k A.B as an
+//   fmaf chain in k order.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct alignas(16) float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+namespace emu {
+struct dim3 {
+    unsigned x = 1, y = 1, z = 1;
+    dim3() {}
+    dim3(unsigned a, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    State st = RUNNABLE;
+    unsigned tid = 0;
+    float ma = 0, mb = 0;
+    f32x4 mc, md;
+};
+struct Ctx {
+    dim3 tIdx, bIdx, bDim, gDim;
+    char* smem = nullptr;
+};
+extern Ctx g;
+extern Fiber* cur;
+extern ucontext_t sched_ctx;
+inline void yield_to_sched() { swapcontext(&cur->ctx, &sched_ctx); }
+inline void sync_block() {
+    cur->st = WAIT_BLOCK;
+    yield_to_sched();
+}
+inline f32x4 mfma16(float a, float b, f32x4 c) {
+    cur->ma = a;
+    cur->mb = b;
+    cur->mc = c;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    return cur->md;
+}
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+}  // namespace emu
+
+#define threadIdx (emu::g.tIdx)
+#define blockIdx (emu::g.bIdx)
+#define blockDim (emu::g.bDim)
+#define gridDim (emu::g.gDim)
+using emu::dim3;
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+inline void __syncthreads() { emu::sync_block(); }
+
+// hip runtime surface used by the host side of the library (device memory == host memory here)
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+    memset(p, v, n);
+    return 0;
+}
+inline hipError_t hipMemcpyAsyncD2D(void* d, const void* s, size_t n, hipStream_t) {
+    memcpy(d, s, n);
+    return 0;
+}
+
+#ifdef EEG_SIMT_EMU_IMPL
+namespace emu {
+Ctx g;
+Fiber* cur = nullptr;
+ucontext_t sched_ctx;
+static const std::function<void()>* body_ptr = nullptr;
+static void trampoline() {
+    (*body_ptr)();
+    cur->st = DONE;
+    swapcontext(&cur->ctx, &sched_ctx);
+}
+static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
+    float A[16][4], B[4][16];
+    for (unsigned l = 0; l < 64; ++l) {
+        A[l & 15][l >> 4] = f[w0 + l].ma;
+        B[l >> 4][l & 15] = f[w0 + l].mb;
+    }
+    for (unsigned l = 0; l < 64; ++l) {
+        Fiber& x = f[w0 + l];
+        for (int r = 0; r < 4; ++r) {
+            int row = 4 * (l >> 4) + r, col = l & 15;
+            float acc = x.mc[r];
+            for (int k = 0; k < 4; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+            x.md[r] = acc;
+        }
+        x.st = RUNNABLE;
+    }
+}
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
+    const unsigned nt = block.x * block.y * block.z;
+    if (nt % 64 != 0) {
+        fprintf(stderr, "emu: block size %u not a multiple of 64\n", nt);
+        abort();
+    }
+    const size_t STACK = 256 * 1024;
+    std::vector<Fiber> fibers(nt);
+    std::vector<char> stacks((size_t)nt * STACK);
+    std::vector<char> smem(smem_bytes + 64);
+    body_ptr = &body;
+    g.bDim = block;
+    g.gDim = grid;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                // poison LDS so reads of never-written shared memory are visible as NaNs
+                memset(smem.data(), 0xFF, smem.size());
+                g.smem = smem.data();
+                for (unsigned t = 0; t < nt; ++t) {
+                    Fiber& f = fibers[t];
+                    f.st = RUNNABLE;
+                    f.tid = t;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = stacks.data() + (size_t)t * STACK;
+                    f.ctx.uc_stack.ss_size = STACK;
+                    f.ctx.uc_link = &sched_ctx;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                }
+                unsigned done = 0;
+                while (done < nt) {
+                    bool progressed = false;
+                    for (unsigned t = 0; t < nt; ++t) {
+                        Fiber& f = fibers[t];
+                        if (f.st != RUNNABLE) continue;
+                        cur = &f;
+                        g.bIdx = dim3(bx, by, bz);
+                        g.tIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                        swapcontext(&sched_ctx, &f.ctx);
+                        progressed = true;
+                        if (f.st == DONE) ++done;
+                    }
+                    // wave collectives
+                    for (unsigned w0 = 0; w0 < nt; w0 += 64) {
+                        unsigned waiting = 0;
+                        for (unsigned l = 0; l < 64; ++l) waiting += fibers[w0 + l].st == WAIT_WAVE;
+                        if (waiting == 64) {
+                            run_mfma(fibers, w0);
+                            progressed = true;
+                        }
+                    }
+                    // block barrier: every not-finished thread must be waiting at it
+                    unsigned wb = 0;
+                    for (unsigned t = 0; t < nt; ++t) wb += fibers[t].st == WAIT_BLOCK;
+                    if (wb && wb + done == nt) {
+                        for (unsigned t = 0; t < nt; ++t)
+                            if (fibers[t].st == WAIT_BLOCK) fibers[t].st = RUNNABLE;
+                        progressed = true;
+                    }
+                    if (!progressed) {
+                        fprintf(stderr, "emu: deadlock (divergent barrier / partial-wave MFMA) in block %u,%u\n", bx, by);
+                        abort();
+                    }
+                }
+            }
+}
+}  // namespace emu
+#endif
