@@ -8,7 +8,43 @@
 #include "kernels_gemm.h"
 #include "kernels_head.h"
 #include "kernels_pack.h"
+#include "prof.h"
 #include "seq_launch.h"
+
+#include <string>
+#include <vector>
+
+#if !defined(EEG_SIMT_EMU)
+namespace eeg {
+namespace {
+struct ProfRec { const char* name; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_open = nullptr;
+const char* g_open_name = nullptr;
+hipEvent_t prof_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+void prof_begin(const char* name, hipStream_t st) {
+    if (!g_prof_on) return;
+    g_open = prof_event();
+    g_open_name = name;
+    (void)hipEventRecord(g_open, st);
+}
+void prof_end(hipStream_t st) {
+    if (!g_prof_on || g_open == nullptr) return;
+    hipEvent_t b = prof_event();
+    (void)hipEventRecord(b, st);
+    g_recs.push_back({g_open_name, g_open, b});
+    g_open = nullptr;
+}
+}  // namespace eeg
+#endif
 
 namespace {
 
@@ -49,7 +85,7 @@ int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct
     const size_t lds = 2 * (size_t)(128 * KCS + (KC / 4) * NB * 64) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_nn_kernel<NCTW, KC>), lds);
     dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
-    EEG_LAUNCH((gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
+    EEG_LAUNCH_P("gemm_nn", (gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn");
 }
 template <int NCTW>
@@ -75,7 +111,7 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     const size_t lds = 2 * (size_t)(32 * 80 + 32 * YS) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_tn_kernel<NCTW>), lds);
     dim3 grid(nseg * ceil_div(F, 64), nsplit);
-    EEG_LAUNCH((gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
     return check_launch("gemm_tn");
 }
 int tn_split(int nseg, int F, int R, int* rows_per_split) {
@@ -104,7 +140,7 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
     if (lds > 160 * 1024) return fail("diffuse_fwd: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
     EEG_SET_MAX_LDS(diffuse_fwd_kernel, lds);
     const int grid = S < 2048 ? S : 2048;
-    EEG_LAUNCH(diffuse_fwd_kernel, dim3(grid), dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes);
+    EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, dim3(grid), dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes);
     return check_launch("diffuse_fwd");
 }
 int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M, float* dX,
@@ -114,7 +150,7 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
     if (lds > 160 * 1024) return fail("diffuse_adj: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
     EEG_SET_MAX_LDS(diffuse_adj_kernel, lds);
     const int grid = S < 2048 ? S : 2048;
-    EEG_LAUNCH(diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, dX);
+    EEG_LAUNCH_P("diffuse_adj", diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, dX);
     return check_launch("diffuse_adj");
 }
 
@@ -166,6 +202,41 @@ int eeg_dcrnn_is_device_build(void) {
     return 1;
 #endif
 }
+int eeg_dcrnn_prof_enable(int on) {
+#if !defined(EEG_SIMT_EMU)
+    eeg::g_prof_on = on != 0;
+#endif
+    return 0;
+}
+int eeg_dcrnn_prof_report(char* buf, size_t cap) {
+    if (buf == nullptr || cap == 0) return fail("prof_report: empty buffer");
+    buf[0] = 0;
+#if !defined(EEG_SIMT_EMU)
+    struct Agg { const char* name; int count; double ms; };
+    std::vector<Agg> agg;
+    for (auto& r : eeg::g_recs) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        bool found = false;
+        for (auto& a : agg)
+            if (strcmp(a.name, r.name) == 0) { a.count++; a.ms += ms; found = true; break; }
+        if (!found) agg.push_back({r.name, 1, (double)ms});
+        eeg::g_pool.push_back(r.a);
+        eeg::g_pool.push_back(r.b);
+    }
+    eeg::g_recs.clear();
+    std::string out;
+    char line[160];
+    for (auto& a : agg) {
+        snprintf(line, sizeof(line), "%s %d %.6f\n", a.name, a.count, a.ms);
+        out += line;
+    }
+    if (out.size() + 1 > cap) return fail("prof_report: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+#endif
+    return 0;
+}
 int eeg_dcrnn_supported(int N, int H, int Fin, int M) { return check_dims(N, H, Fin, M) == 0 ? 1 : 0; }
 
 int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K, float* P_out,
@@ -177,7 +248,7 @@ int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_grap
     SupPtrs sp;
     for (int i = 0; i < 4; ++i) sp.p[i] = i < n_supports ? supports[i] : nullptr;
     const size_t lds = 4 * kMaxNodes * kMaxNodes * sizeof(float);
-    EEG_LAUNCH(hop_polys_kernel, dim3(n_graphs), dim3(round_up(N * N, 64)), lds, S_(stream), sp, n_supports, N, K, P_out);
+    EEG_LAUNCH_P("hop_polys", hop_polys_kernel, dim3(n_graphs), dim3(round_up(N * N, 64)), lds, S_(stream), sp, n_supports, N, K, P_out);
     return check_launch("hop_polys");
 }
 
@@ -188,7 +259,7 @@ int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const
     if (!h_supported(H)) return fail("pack_cell: rnn_units=%d unsupported", H);
     if (Fin % 4 != 0) return fail("pack_cell: input dim %d must be a multiple of 4", Fin);
     CellPack p = make_cell_pack(Fin, H, M);
-    EEG_LAUNCH(pack_cell_kernel, dim3(512), dim3(256), 0, S_(stream), Wg, bg, Wc, bc, pack, p);
+    EEG_LAUNCH_P("pack_cell", pack_cell_kernel, dim3(512), dim3(256), 0, S_(stream), Wg, bg, Wc, bc, pack, p);
     return check_launch("pack_cell");
 }
 
@@ -263,14 +334,14 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
                  dXW, dh0, dbias, d->T, d->B, N, d->act};
     if (seq_bwd(H, M, a, st)) return 1;
-    EEG_LAUNCH(reduce_bias_kernel, dim3(ceil_div(3 * H, 64)), dim3(64), 0, st, dbias, d->B, H, dbg, dbc);
+    EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 64)), dim3(64), 0, st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction)
     float* part = ws + w.partial;
     SegPtrs sx;
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
     if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
-    EEG_LAUNCH(reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0, Fin, H, M, dWg, dWc);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(x)")) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     float* hpl = ws + w.hplanes;
@@ -278,7 +349,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hext : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
     if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_h, w.rps_h, st)) return 1;
-    EEG_LAUNCH(reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, 2 * H, 1, Fin, H, M, dWg, dWc);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, 2 * H, 1, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hg)")) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     float* rpl = ws + w.rhplanes;
@@ -286,7 +357,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
     if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_h, w.rps_h, st)) return 1;
-    EEG_LAUNCH(reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, H, 2, Fin, H, M, dWg, dWc);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, H, 2, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hc)")) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {
@@ -300,21 +371,21 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
 }
 
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH, float* last, void* stream) {
-    EEG_LAUNCH(gather_last_kernel, dim3(ceil_div(B * NH, 256)), dim3(256), 0, S_(stream), Htop,
+    EEG_LAUNCH_P("gather_last", gather_last_kernel, dim3(ceil_div(B * NH, 256)), dim3(256), 0, S_(stream), Htop,
                reinterpret_cast<const long long*>(lengths), T, B, NH, last);
     return check_launch("gather_last");
 }
 int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H, int C,
                            float* logits, int32_t* arg, void* stream) {
     if (N > 64) return fail("cls_head: num_nodes=%d unsupported (<= 64)", N);
-    EEG_LAUNCH(cls_head_fwd_kernel, dim3(B), dim3(64), (size_t)N * C * sizeof(float), S_(stream), z, W, bias, B, N, H, C, logits, arg);
+    EEG_LAUNCH_P("cls_head_fwd", cls_head_fwd_kernel, dim3(B), dim3(64), (size_t)N * C * sizeof(float), S_(stream), z, W, bias, B, N, H, C, logits, arg);
     return check_launch("cls_head_fwd");
 }
 int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg, int B, int N,
                            int H, int C, float* dz, float* dW, float* dbias, void* stream) {
-    EEG_LAUNCH(cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, dz);
+    EEG_LAUNCH_P("cls_head_bwd_dz", cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, dz);
     if (check_launch("cls_head_bwd_dz")) return 1;
-    EEG_LAUNCH(cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 64)), dim3(64), 0, S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
+    EEG_LAUNCH_P("cls_head_bwd_w", cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 64)), dim3(64), 0, S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
     return check_launch("cls_head_bwd_w");
 }
 

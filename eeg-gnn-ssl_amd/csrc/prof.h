@@ -1,0 +1,22 @@
+// Optional per-kernel timing with HIP events on the launch stream (used by bench.py to report the
+// roofline fraction of each kernel "live").  Disabled by default: zero overhead unless
+// eeg_dcrnn_prof_enable(1) was called.
+#pragma once
+#include "common.h"
+
+namespace eeg {
+#if defined(EEG_SIMT_EMU)
+inline void prof_begin(const char*, hipStream_t) {}
+inline void prof_end(hipStream_t) {}
+#else
+void prof_begin(const char* name, hipStream_t st);
+void prof_end(hipStream_t st);
+#endif
+}  // namespace eeg
+
+#define EEG_LAUNCH_P(name, kern, grid, block, smem, stream, ...) \
+    do {                                                           \
+        eeg::prof_begin(name, stream);                             \
+        EEG_LAUNCH(kern, grid, block, smem, stream, __VA_ARGS__);  \
+        eeg::prof_end(stream);                                     \
+    } while (0)

@@ -41,6 +41,7 @@ class DCRNNEncoder(nn.Module):
         top state at t = lengths-1 (B,N*H) or None)."""
         t_len, b = inputs.shape[0], inputs.shape[1]
         self.encoding_cells[0]._check_supports(supports)
+        ops.new_forward_scope()
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
         cur = inputs.reshape(t_len, b, self.num_nodes, -1)
         finals, top_sel = [], None
@@ -93,6 +94,7 @@ class DCGRUDecoder(nn.Module):
         t_len, b = inputs.shape[0], inputs.shape[1]
         targets = inputs.reshape(t_len, b, -1)
         self.decoding_cells[0]._check_supports(supports)
+        ops.new_forward_scope()
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
         hidden = [initial_hidden_state[l] for l in range(self.num_rnn_layers)]
         cur = torch.zeros(b, self.num_nodes * self.output_dim, device=inputs.device, dtype=inputs.dtype)  # GO symbol

@@ -69,6 +69,15 @@ _poly_memo = _Memo()
 _pack_memo = _Memo(16)
 
 
+def new_forward_scope():
+    """Drop the memoised hop polynomials / weight packs.  Called at the start of every encoder /
+    decoder forward, so the memo only ever serves repeated cell calls INSIDE one forward (the
+    decoder's time loop) and can never hand out packs of stale weights (e.g. after an optimiser
+    that updates parameters through an aliased flat buffer, which does not bump `_version`)."""
+    _poly_memo.items.clear()
+    _pack_memo.items.clear()
+
+
 def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: int) -> Tuple[torch.Tensor, int]:
     """Hop-polynomial matrices of the clip graphs (cell.py:83-93 incl. quirk Q1).
 

@@ -1,0 +1,97 @@
+"""The reference's supervised/SSL optimisation step (train.py:222-224,253-275; train_ssl.py:147-178)
+re-hosted for one-process-per-GPU data parallelism over RCCL.
+
+Recipe per step:  zero_grad -> forward -> loss -> backward -> [all-reduce of ONE flat fp32
+gradient bucket, mean over ranks] -> clip_grad_norm_(5.0) -> Adam(lr, weight_decay = coupled L2).
+
+MI355X notes: the whole model is <= 2.8 MB, so parameters and gradients live in two flat
+buffers (every `p` / `p.grad` is a view): the exchange is a single latency-bound all-reduce over
+xGMI, the norm is one reduction, Adam runs over one tensor, and nothing in the step synchronises
+with the host (the reference calls `loss.item()` and `lengths.cpu()` every step)."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class FlatParameters:
+    """Re-home a module's parameters (and their .grad) into two contiguous fp32 buffers.
+    Shared parameters (the decoder's shared cell, model.py:126-143) appear once."""
+
+    def __init__(self, module: torch.nn.Module):
+        params, seen = [], set()
+        for p in module.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        self.params = params
+        total = sum(p.numel() for p in params)
+        dev, dt = params[0].device, params[0].dtype
+        self.flat = torch.empty(total, device=dev, dtype=dt)
+        self.flat_grad = torch.zeros(total, device=dev, dtype=dt)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+                off += n
+        self.flat_param = torch.nn.Parameter(self.flat, requires_grad=True)
+        self.flat_param.grad = self.flat_grad
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+
+class TrainStep:
+    """One optimisation step of the reference recipe on the local shard of the global batch."""
+
+    def __init__(self, model: torch.nn.Module, task: str = "detection", lr: float = 3e-4,
+                 weight_decay: float = 5e-4, max_grad_norm: float = 5.0,
+                 scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None):
+        assert task in ("detection", "classification", "ssl")
+        self.model, self.task, self.max_grad_norm = model, task, max_grad_norm
+        self.fp = FlatParameters(model)
+        self.opt = torch.optim.Adam([self.fp.flat_param], lr=lr, weight_decay=weight_decay)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
+
+    def loss(self, out, y):
+        if self.task == "detection":        # train.py:203-204,266-267
+            return torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), y)
+        if self.task == "classification":   # train.py:205-206,268
+            return torch.nn.functional.cross_entropy(out, y)
+        from . import utils                 # train_ssl.py:165-170 ("MAE" -> masked RMSE, Q9)
+        sc = None if self.scaler_mean is None else utils.StandardScaler(self.scaler_mean, self.scaler_std)
+        return utils.compute_regression_loss(y_true=y, y_predicted=out, standard_scaler=sc, loss_fn="MAE")
+
+    def forward_backward(self, x, y, seq_lengths, supports):
+        self.fp.zero_grad()
+        if self.task == "ssl":
+            out = self.model(x, y, supports)
+        else:
+            out = self.model(x, seq_lengths, supports)
+        loss = self.loss(out, y)
+        loss.backward()
+        return loss.detach()
+
+    def reduce_and_update(self):
+        g = self.fp.flat_grad
+        if self.world > 1:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)        # RCCL over xGMI: one flat bucket
+            g.div_(self.world)
+        norm = torch.linalg.vector_norm(g)
+        g.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))   # == clip_grad_norm_
+        self.opt.step()
+        ops.new_forward_scope()          # parameters changed through the flat alias: drop weight packs
+        return norm
+
+    def step(self, x, y, seq_lengths, supports):
+        loss = self.forward_backward(x, y, seq_lengths, supports)
+        self.reduce_and_update()
+        return loss

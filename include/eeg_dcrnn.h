@@ -43,6 +43,11 @@ const char* eeg_dcrnn_last_error(void);
 int eeg_dcrnn_abi_version(void);
 /* 1 if the library was built for the GPU (always, for the product build), 0 for the test emulator. */
 int eeg_dcrnn_is_device_build(void);
+/* Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline):
+ * enable(1) starts recording, report() synchronises and writes "name launches total_ms" lines
+ * into buf (and clears the records). */
+int eeg_dcrnn_prof_enable(int on);
+int eeg_dcrnn_prof_report(char* buf, size_t cap);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
 int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 

@@ -1,0 +1,40 @@
+"""CPU leg: the kernel SOURCES compiled against the SIMT emulator (tests/emu), driven through the
+same C ABI + Python host layer as the product, checked against the reference's golden vectors.
+This validates kernel logic / index maps / orchestration without a GPU; the `-m gpu` tests in
+test_gpu_parity.py run the identical checks on the real MI355X library."""
+import pytest
+
+import cases
+import parity_suite as ps
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator():
+    import emu_support
+    lib = emu_support.install_emulator()
+    yield lib
+    emu_support.uninstall()
+
+
+@pytest.mark.parametrize("tag", list(cases.CELL_CASES))
+def test_cell(tag, golden, adj3d):
+    ps.check_cell_case(tag, golden, adj3d, "cpu")
+
+
+@pytest.mark.parametrize("tag", list(cases.DCONV_CASES))
+def test_dconv(tag, golden, adj3d):
+    ps.check_dconv_case(tag, golden, adj3d, "cpu")
+
+
+@pytest.mark.parametrize("tag", list(cases.CLS_CASES))
+def test_classification_model(tag, golden, adj3d):
+    ps.check_cls_case(tag, golden, adj3d, "cpu")
+
+
+@pytest.mark.parametrize("tag", list(cases.SSL_CASES))
+def test_ssl_model(tag, golden, adj3d):
+    ps.check_ssl_case(tag, golden, adj3d, "cpu")
+
+
+def test_random_vs_oracle_h32_relu_varlen(adj3d):
+    ps.check_vs_oracle_random("cpu", "dual_random_walk", 12, 32, 2, 4, 3, 4, adj3d, seed=3, lengths=[4, 2, 1], act="relu")

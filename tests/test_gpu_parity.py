@@ -1,0 +1,178 @@
+"""`-m gpu`: parity of the MI355X library (libeeg_dcrnn_hip.so, through the C ABI and the Python
+host layer) against the reference's golden vectors and the oracle, plus size-independent
+properties at BASELINE.json's full sizes.  Nothing here reads /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import parity_suite as ps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_library():
+    from eeg_gnn_ssl_amd import _lib
+    _lib._set_lib_for_testing(None)
+    lib = _lib.get_lib()                  # ImportError if the HIP library is missing: no fallback
+    assert lib.is_device_build and os.path.basename(lib.path) == "libeeg_dcrnn_hip.so"
+    assert torch.cuda.is_available()
+    yield lib
+
+
+@pytest.mark.parametrize("tag", list(cases.CELL_CASES))
+def test_cell(tag, golden, adj3d):
+    ps.check_cell_case(tag, golden, adj3d, DEV)
+
+
+@pytest.mark.parametrize("tag", list(cases.DCONV_CASES))
+def test_dconv(tag, golden, adj3d):
+    ps.check_dconv_case(tag, golden, adj3d, DEV)
+
+
+@pytest.mark.parametrize("tag", list(cases.CLS_CASES))
+def test_classification_model(tag, golden, adj3d):
+    ps.check_cls_case(tag, golden, adj3d, DEV)
+
+
+@pytest.mark.parametrize("tag", list(cases.SSL_CASES))
+def test_ssl_model(tag, golden, adj3d):
+    ps.check_ssl_case(tag, golden, adj3d, DEV)
+
+
+@pytest.mark.parametrize("filt,din,h,layers,t_len,b,classes,lengths,act", [
+    ("laplacian", 100, 64, 2, 12, 4, 1, None, "tanh"),                  # BASELINE cfg1
+    ("dual_random_walk", 100, 64, 2, 7, 5, 4, [7, 3, 1, 6, 2], "tanh"),
+    ("dual_random_walk", 12, 32, 3, 5, 3, 4, [5, 2, 4], "relu"),
+    ("laplacian", 20, 16, 1, 9, 6, 1, None, "tanh"),
+])
+def test_random_vs_oracle(filt, din, h, layers, t_len, b, classes, lengths, act, adj3d):
+    ps.check_vs_oracle_random(DEV, filt, din, h, layers, t_len, b, classes, adj3d, seed=11, lengths=lengths, act=act)
+
+
+def _full_size_model(filt, classes):
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    torch.manual_seed(5)
+    model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("biases"):
+                p.normal_(0, 0.1)
+    return model.train()
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_full_size_slice_vs_oracle_and_determinism(workload, adj3d):
+    """BASELINE cfg2 / cfg3 at full size (B=256, T=60): (i) clips are independent, so the first
+    clips of the batch must equal the oracle run on just those clips (1e-4); (ii) two runs are
+    bit-identical (fixed-order reductions); (iii) parameter gradients of the full batch equal the
+    sum of the gradients of its two halves (linearity of the batch reduction)."""
+    import bench
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS[workload]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123)
+    model = _full_size_model(filt, classes)
+    xd, yd, ld = x.to(DEV), y.to(DEV), lengths.to(DEV)
+    supd = [s.to(DEV) for s in sup]
+
+    def run(sl):
+        model.zero_grad()
+        lg = model(xd[sl], ld[sl], [s[sl] for s in supd])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), yd[sl], reduction="sum")
+        loss.backward()
+        return lg.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    full = slice(0, batch)
+    lg1, g1 = run(full)
+    lg2, g2 = run(full)
+    assert torch.equal(lg1, lg2), "forward is not run-to-run deterministic"
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), f"gradient {k} is not run-to-run deterministic"
+    # halves
+    _, ga = run(slice(0, batch // 2))
+    _, gb = run(slice(batch // 2, batch))
+    for k in g1:
+        ref = g1[k]
+        err = ((ga[k] + gb[k]) - ref).abs().max() / ref.abs().max().clamp_min(1e-6)
+        assert err < 5e-5, f"{k}: full-batch gradient != sum of half-batch gradients ({err:.2e})"
+    # oracle on the first clips
+    nb = 2
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    lo = orc.classification_forward(params, cfg, x[:nb], lengths[:nb], [s[:nb] for s in sup])
+    err = (lg1[:nb].cpu() - lo).abs().max().item()
+    assert err < 1e-4, f"{workload}: logits of the first clips differ from the oracle by {err:.2e}"
+
+
+def test_full_size_hidden_sequence_vs_oracle(adj3d):
+    """cfg2 shape: the top-layer hidden sequence (all 60 steps) of the first clips vs the oracle."""
+    import bench
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS["cfg2"]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=321)
+    model = _full_size_model(filt, classes)
+    with torch.no_grad():
+        fin, top = model.encoder(x.to(DEV).transpose(0, 1), model.encoder.init_hidden(batch).to(DEV), [s.to(DEV) for s in sup])
+    nb = 2
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    h0 = torch.zeros(2, nb, 19 * 64)
+    fo, to = orc.encoder_forward(params, cfg, x[:nb].transpose(0, 1), h0, [s[:nb] for s in sup])
+    assert (top[:, :nb].cpu() - to).abs().max().item() < 1e-4
+    assert (fin[:, :nb].cpu() - fo).abs().max().item() < 1e-4
+
+
+def test_diffusion_step_linearity_full_size(adj3d):
+    """The HBM-bound diffusion kernel at cfg3 size (S = 60*256 samples, per-clip graphs):
+    linear in x, and equal to the dense P_m x product on a sample."""
+    from eeg_gnn_ssl_amd import ops
+    b, t_len = 256, 60
+    sup = cases.dual_supports(4)
+    sup = [s.repeat(b // 4, 1, 1).to(DEV) for s in sup]
+    p, pb = ops.hop_polys(sup, 2, b)
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn(t_len * b, 19, 100, generator=g).to(DEV)
+    x2 = torch.randn(t_len * b, 19, 100, generator=g).to(DEV)
+    a = ops.diffusion_hops(x1, p, pb, b)
+    c = ops.diffusion_hops(x2, p, pb, b)
+    s = ops.diffusion_hops(x1 + 2 * x2, p, pb, b)
+    assert (s - (a + 2 * c)).abs().max().item() < 2e-5
+    ref = torch.einsum("gmij,tgjf->mtgif", p, x1.view(t_len, b, 19, 100)).reshape(a.shape)
+    assert (a - ref).abs().max().item() < 2e-5
+
+
+def test_errors_are_loud():
+    from eeg_gnn_ssl_amd import DCGRUCell
+    cell = DCGRUCell(100, 64, 2, 19, filter_type="laplacian").to(DEV)
+    sup = [torch.eye(19, device=DEV)]
+    with pytest.raises(RuntimeError):                       # CPU tensors: no CPU path
+        DCGRUCell(100, 64, 2, 19)( [torch.eye(19)], torch.zeros(2, 1900), torch.zeros(2, 19 * 64))
+    with pytest.raises(RuntimeError):                       # wrong number of supports
+        cell(sup + sup, torch.zeros(2, 1900, device=DEV), torch.zeros(2, 19 * 64, device=DEV))
+    with pytest.raises(RuntimeError):                       # unsupported hidden size
+        DCGRUCell(100, 48, 2, 19).to(DEV)(sup, torch.zeros(2, 1900, device=DEV), torch.zeros(2, 19 * 48, device=DEV))
+
+
+def test_training_reduces_loss_and_auroc_on_synthetic_labels():
+    """Parity AUROC on synthetic labels (north_star): a few optimisation steps of the reference
+    recipe on the synthetic detection task must reduce the loss and lift AUROC above chance."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    from sklearn.metrics import roc_auc_score
+    torch.manual_seed(0)
+    task, filt, classes = "detection", "laplacian", 1
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, 12, 128, classes, seed=7)
+    model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV).train()
+    step = TrainStep(model, task=task, lr=2e-3, weight_decay=5e-4)
+    xd, yd, ld, supd = x.to(DEV), y.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup]
+    losses = [step.step(xd, yd, ld, supd).item() for _ in range(30)]
+    with torch.no_grad():
+        prob = torch.sigmoid(model(xd, ld, supd)).view(-1).cpu().numpy()
+    auc = roc_auc_score(y.numpy(), prob)
+    assert losses[-1] < losses[0] and auc > 0.7, (losses[0], losses[-1], auc)
