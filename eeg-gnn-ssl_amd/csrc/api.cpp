@@ -138,9 +138,18 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
     const int FP = round_up(F, 16), FS = lds_stride(M * FP), NR = round_up(N, 4);
     const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * FS) * sizeof(float);
     if (lds > 160 * 1024) return fail("diffuse_fwd: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
+    if (N * (F / 4) > 256 * kDiffPrefetch) return fail("diffuse_fwd: N*F=%d exceeds %d floats per sample", N * F, 1024 * kDiffPrefetch);
     EEG_SET_MAX_LDS(diffuse_fwd_kernel, lds);
-    const int grid = S < 2048 ? S : 2048;
-    EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, dim3(grid), dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes);
+    dim3 grid;
+    if (p_batched) {
+        const int T = S / B;
+        int tg = ceil_div(2048, B);
+        if (tg > T) tg = T;
+        grid = dim3(B, tg < 1 ? 1 : tg);
+    } else {
+        grid = dim3(S < 2048 ? S : 2048, 1);
+    }
+    EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, grid, dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes);
     return check_launch("diffuse_fwd");
 }
 int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M, float* dX,
@@ -334,7 +343,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
                  dXW, dh0, dbias, d->T, d->B, N, d->act};
     if (seq_bwd(H, M, a, st)) return 1;
-    EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 64)), dim3(64), 0, st, dbias, d->B, H, dbg, dbc);
+    EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction)
     float* part = ws + w.partial;
@@ -385,7 +394,7 @@ int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits,
                            int H, int C, float* dz, float* dW, float* dbias, void* stream) {
     EEG_LAUNCH_P("cls_head_bwd_dz", cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, dz);
     if (check_launch("cls_head_bwd_dz")) return 1;
-    EEG_LAUNCH_P("cls_head_bwd_w", cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 64)), dim3(64), 0, S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
+    EEG_LAUNCH_P("cls_head_bwd_w", cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 16)), dim3(256), 256 * sizeof(float), S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
     return check_launch("cls_head_bwd_w");
 }
 

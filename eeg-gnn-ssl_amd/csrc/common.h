@@ -17,6 +17,7 @@
 #define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+#define EEG_SCHED_FENCE() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -26,6 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// pins the instruction order at this point (keeps hand-placed LDS prefetches ahead of the MFMAs)
+#define EEG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace eeg {
@@ -42,6 +45,26 @@ __host__ __device__ constexpr int round_up(int a, int b) { return ceil_div(a, b)
 // (l>>4 = 0/1 in a 32-lane ds_read_b32 group) on even/odd banks: conflict-free fragment reads.
 __host__ __device__ constexpr int lds_stride(int k) { return k + ((2 - (k % 32)) + 32) % 32; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// LDS row stride for MFMA A-operand tiles read with ds_read_b128 (4 consecutive k per lane):
+// stride % 64 == 4 -> the 16 rows x 4 dwords of a lane group tile the 64 banks (one residual
+// 2-way overlap per group); rows stay 16-byte aligned.
+__host__ __device__ constexpr int lds_stride_q(int k) { return k + ((4 - (k % 64)) + 64) % 64; }
+
+// Quad-permuted K order of the recurrent-kernel weight packs: MFMA number `ks` consumes, on lane
+// group g = lane>>4, the logical k index 16*(ks/4) + 4*g + (ks%4), so that one ds_read_b128 of
+// A[row][16q + 4g .. +3] feeds four consecutive MFMAs.
+__host__ __device__ constexpr int kperm(int ks, int g) { return 16 * (ks / 4) + 4 * g + (ks % 4); }
+
+// Fast activations for the recurrent epilogues: v_exp_f32 / v_rcp_f32 (1 ulp each); absolute
+// error of sigmoid/tanh ~2e-7, far inside the 1e-4 parity budget (tests assert 2e-5).
+#if defined(EEG_SIMT_EMU)
+__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+#else
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
 
 }  // namespace eeg

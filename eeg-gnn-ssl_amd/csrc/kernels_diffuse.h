@@ -15,9 +15,14 @@
 namespace eeg {
 
 // ---- standalone forward diffusion: X (S,N,F) -> planes (M-1,S,N,F) --------------------------
-// grid-stride over samples; P shared (p_batched=0) is staged once per workgroup.
+// grid = (G, TG): workgroup (g, tg) owns graph g (g = clip b when P is per-clip, else a slice of
+// the sample range) so its polynomials are staged in LDS once; it walks its samples with the next
+// sample's rows prefetched into registers while the current one is diffused (HBM latency hidden
+// inside the workgroup, 3-4 workgroups per CU hide the rest).
 // LDS: Pl | tile [NR][FS] with NR = round_up(N,4), FS = lds_stride(M * FP), FP = round_up(F,16):
 // slot 0 = X, slots 1..M-1 = results (staged so the global stores are full coalesced rows).
+constexpr int kDiffPrefetch = 4;        // float4 per thread per sample: covers N*F <= 4096 floats
+
 __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restrict__ X, const float* __restrict__ P,
                                                           int p_batched, int S, int B, int N, int F, int M,
                                                           float* __restrict__ planes) {
@@ -26,27 +31,49 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
     float* Pl = sm;
     float* tile = sm + (M - 1) * kPFloats;
     const int tid = threadIdx.x, NR = round_up(N, 4);
-    for (int e = tid; e < NR * FS; e += blockDim.x) tile[e] = 0.f;
-    if (!p_batched) lds_load_polys(Pl, P, 0, M, N);
-    const int nf4 = F / 4;                           // F % 4 == 0 (checked by the host)
-    for (int s = blockIdx.x; s < S; s += gridDim.x) {
-        __syncthreads();                              // previous sample's stores done with the tile
-        if (p_batched) lds_load_polys(Pl, P, s % B, M, N);
+    const int nf4 = F / 4, nq = N * nf4;            // F % 4 == 0, nq <= 1024 (checked by the host)
+    // sample walk: per-clip graphs -> s = t*B + g for t = tg, tg+TG, ...; shared graph -> s = wg, wg+nwg, ...
+    int s_first, s_step, g;
+    if (p_batched) {
+        g = blockIdx.x;
+        s_first = blockIdx.y * B + g;
+        s_step = gridDim.y * B;
+    } else {
+        g = 0;
+        s_first = blockIdx.y * gridDim.x + blockIdx.x;
+        s_step = gridDim.x * gridDim.y;
+    }
+    for (int e = tid; e < NR * FS; e += 256) tile[e] = 0.f;
+    lds_load_polys(Pl, P, g, M, N);
+
+    float4 pre[kDiffPrefetch];
+    auto fetch = [&](int s) {
         const float4* src = reinterpret_cast<const float4*>(X + (size_t)s * N * F);
-        for (int q = tid; q < N * nf4; q += blockDim.x) {
-            const int n = q / nf4, c4 = q % nf4;
-            const float4 v = src[q];
-            float* d = tile + n * FS + 4 * c4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+#pragma unroll
+        for (int i = 0; i < kDiffPrefetch; ++i) {
+            const int q = tid + 256 * i;
+            pre[i] = (s < S && q < nq) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    fetch(s_first);
+    for (int s = s_first; s < S; s += s_step) {
+        __syncthreads();                              // tile free: previous stores have read it
+#pragma unroll
+        for (int i = 0; i < kDiffPrefetch; ++i) {
+            const int q = tid + 256 * i;
+            if (q < nq) {
+                float* d = tile + (q / nf4) * FS + 4 * (q % nf4);
+                d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z; d[3] = pre[i].w;
+            }
+        }
+        fetch(s + s_step);                            // next sample's rows fly during the MFMAs
         __syncthreads();
         lds_diffuse_tiles<false>(tile, FS, 0, FP, FP, FP, Pl, M, N, NR);
         __syncthreads();
         for (int m1 = 0; m1 < M - 1; ++m1) {
             float4* dst = reinterpret_cast<float4*>(planes + ((size_t)m1 * S + s) * N * F);
-            for (int q = tid; q < N * nf4; q += blockDim.x) {
-                const int n = q / nf4, c4 = q % nf4;
-                const float* t = tile + n * FS + FP * (m1 + 1) + 4 * c4;
+            for (int q = tid; q < nq; q += 256) {
+                const float* t = tile + (q / nf4) * FS + FP * (m1 + 1) + 4 * (q % nf4);
                 dst[q] = make_float4(t[0], t[1], t[2], t[3]);
             }
         }

@@ -58,24 +58,30 @@ __global__ void cls_head_bwd_dz_kernel(const float* __restrict__ z, const float*
 }
 
 // dW[c][h] = sum_b dlogits[b][c] relu(z[b][arg[b][c]][h]);  dbias[c] = sum_b dlogits[b][c]
-// (fixed summation order over b: deterministic)
+// block = 16 outputs x 16 batch slices, LDS combine in a fixed order (deterministic).
 __global__ void cls_head_bwd_w_kernel(const float* __restrict__ z, const float* __restrict__ dlogits,
                                       const int* __restrict__ arg, int B, int N, int H, int C,
                                       float* __restrict__ dW, float* __restrict__ dbias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    EEG_DYN_SMEM(sm);                                 // [16][16]
+    const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    float s = 0.f;
     if (i < C * H) {
         const int c = i / H, h = i % H;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) {
+        for (int b = q; b < B; b += 16) {
             const int n = arg[(size_t)b * C + c];
             s = fmaf(dlogits[(size_t)b * C + c], fmaxf(z[((size_t)b * N + n) * H + h], 0.f), s);
         }
-        dW[i] = s;
     } else if (i < C * H + C) {
         const int c = i - C * H;
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dlogits[(size_t)b * C + c];
-        dbias[c] = s;
+        for (int b = q; b < B; b += 16) s += dlogits[(size_t)b * C + c];
+    }
+    sm[q * 16 + o] = s;
+    __syncthreads();
+    if (q == 0 && i < C * H + C) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += sm[k * 16 + o];
+        if (i < C * H) dW[i] = t; else dbias[i - C * H] = t;
     }
 }
 

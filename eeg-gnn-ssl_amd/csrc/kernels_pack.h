@@ -7,6 +7,8 @@
 // Device layout: every GEMM B-operand is stored in MFMA-fragment order for
 // v_mfma_f32_16x16x4_f32:  pack[(ks*NCT + ct)*64 + lane] = B[4*ks + (lane>>4)][16*ct + (lane&15)],
 // with the K index hop-major (k = m*F + f) so that each hop plane is a contiguous K range.
+// The four recurrent-kernel packs (bhg, bhc, b1, b2) use the quad-permuted K order `kperm`
+// (common.h) instead of 4*ks + (lane>>4), matching their ds_read_b128 A-fragment reads.
 #pragma once
 #include "common.h"
 
@@ -69,25 +71,25 @@ __global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __re
             const size_t e = idx - p.bhg;
             const int lane = e & 63, nct = 2 * H / 16;
             const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
-            const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+            const int k = kperm(ks, lane >> 4), j = 16 * ct + (lane & 15);
             v = ref_wg(Wg, M, H, Fin + k % H, k / H, j);
         } else if (idx < p.b1) {                  // bhc: NCT = H/16
             const size_t e = idx - p.bhc;
             const int lane = e & 63, nct = H / 16;
             const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
-            const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+            const int k = kperm(ks, lane >> 4), j = 16 * ct + (lane & 15);
             v = ref_wc(Wc, M, H, Fin + k % H, k / H, j);
         } else if (idx < p.b2) {                  // b1[k = m*H + o][f]
             const size_t e = idx - p.b1;
             const int lane = e & 63, nct = H / 16;
             const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
-            const int k = 4 * ks + (lane >> 4), f = 16 * ct + (lane & 15);
+            const int k = kperm(ks, lane >> 4), f = 16 * ct + (lane & 15);
             v = ref_wc(Wc, M, H, Fin + f, k / H, k % H);
         } else if (idx < p.bxt) {                 // b2[k = m*2H + o][f]
             const size_t e = idx - p.b2;
             const int lane = e & 63, nct = H / 16;
             const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
-            const int k = 4 * ks + (lane >> 4), f = 16 * ct + (lane & 15);
+            const int k = kperm(ks, lane >> 4), f = 16 * ct + (lane & 15);
             v = ref_wg(Wg, M, H, Fin + f, k / (2 * H), k % (2 * H));
         } else {                                  // bxt[k = o][j = m*Fin + f]
             const size_t e = idx - p.bxt;
@@ -111,8 +113,15 @@ __global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit,
     const size_t total = (size_t)K * O;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * total + idx];
+        // 8 independent partial sums keep 8 loads in flight; combined in a fixed order
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(sp + u) * total + idx];
+        }
+        for (int u = 0; sp + u < nsplit; ++u) acc[u] += part[(size_t)(sp + u) * total + idx];
+        const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         const int k = idx / O, o = idx % O;
         if (kind == 0) {
             const int m = k / Fin, f = k % Fin;
@@ -129,13 +138,22 @@ __global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit,
 }
 
 // column sums of per-sample bias-gradient partials [B][3H] -> dbg (2H), dbc (H); fixed order.
+// block = 256 threads = 16 columns x 16 row-slices; LDS combine in a fixed order.
 __global__ void reduce_bias_kernel(const float* __restrict__ part, int B, int H,
                                    float* __restrict__ dbg, float* __restrict__ dbc) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= 3 * H) return;
+    EEG_DYN_SMEM(sm);                                 // [16][16]
+    const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + c;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += part[(size_t)b * 3 * H + j];
-    if (j < 2 * H) dbg[j] = s; else dbc[j - 2 * H] = s;
+    if (j < 3 * H)
+        for (int b = q; b < B; b += 16) s += part[(size_t)b * 3 * H + j];
+    sm[q * 16 + c] = s;
+    __syncthreads();
+    if (q == 0 && j < 3 * H) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += sm[i * 16 + c];
+        if (j < 2 * H) dbg[j] = t; else dbc[j - 2 * H] = t;
+    }
 }
 
 // Hop-polynomial matrices: P_0 = I (implicit), then for every support S, in order:

@@ -10,6 +10,8 @@
 //  * the hidden state / gradient tile, its M hop-diffused copies and the (M-1) hop-polynomial
 //    matrices of the clip's graph stay in LDS; the 19-node mix is an fp32 MFMA with the padded
 //    32x32 polynomial as A operand.
+//  * A fragments come from LDS as ds_read_b128 (four k per lane, K order permuted to match:
+//    common.h kperm) and are fetched one quad ahead of the MFMAs that consume them.
 //  * the input half of the diffusion convolution (x-part, + biases) is hoisted out of the
 //    recurrence (kernels_gemm.h) and arrives as XW (T,B,N,3H) = [r | u | c] pre-activations.
 //
@@ -17,6 +19,11 @@
 //                -> C = XW_c + hops(r*h) Wc^h -> c = act(C) -> h' = u*h + (1-u)*c
 // bwd per step:  SURVEY.md §9 "Cell backward" with P_m^T adjoint mixes; emits dXW = [dR|dU|dC]
 //                per step (consumed afterwards by the hoisted weight-gradient / dX GEMMs).
+//
+// Element ownership: a lane owns, for each of its column tiles, the C-layout elements
+// (row = 16*rt + 4*(lane>>4) + r, col = 16*ct + (lane&15)), rt in {0,1}, r in 0..3.  Rows >= N are
+// padding: they are computed (finite garbage stays confined to padding rows) but written to LDS as
+// zeros and never stored to HBM.
 #pragma once
 #include "common.h"
 #include "lds_diffuse.h"
@@ -25,14 +32,46 @@ namespace eeg {
 
 template <int H, int M>
 struct SeqGeom {
-    static constexpr int KA = M * H, KAP = lds_stride(KA), KS = KA / 4;        // h-wide hop tile
-    static constexpr int KG = M * 2 * H, KGP = lds_stride(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
-    static constexpr int NGT = 2 * H / 16, NCT = H / 16;                       // gate / cand col tiles
-    static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);         // per wave (4 waves)
-    static constexpr int US = H + 2;
+    static constexpr int KA = M * H, KAP = lds_stride_q(KA), KS = KA / 4;        // h-wide hop tile
+    static constexpr int KG = M * 2 * H, KGP = lds_stride_q(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
+    static constexpr int NGT = 2 * H / 16, NCT = H / 16;                         // gate / cand col tiles
+    static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
+    static constexpr int US = H + 4;
     static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + 32 * US; }
     static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP + 3 * H * 4; }
 };
+
+// acc[i][rt] += A(32 x 4*NKS, LDS, stride) @ Wfrag[i][.]  for NT column tiles; A fragments are read
+// as float4 (k = 16q + 4*(lane>>4) + j) one quad ahead of their use.
+template <int NT, int NKS>
+__device__ __forceinline__ void mfma_rows32(const float* __restrict__ A, int stride, int lr, int lg,
+                                            const float (&w)[NT][NKS], f32x4 (&acc)[NT][2]) {
+    static_assert(NKS % 4 == 0, "K must be a multiple of 16");
+    const float* p0 = A + lr * stride + 4 * lg;
+    const float* p1 = p0 + 16 * stride;
+    float4 a0 = *reinterpret_cast<const float4*>(p0);
+    float4 a1 = *reinterpret_cast<const float4*>(p1);
+#pragma unroll
+    for (int q = 0; q < NKS / 4; ++q) {
+        float4 n0 = a0, n1 = a1;
+        if (q + 1 < NKS / 4) {
+            n0 = *reinterpret_cast<const float4*>(p0 + 16 * (q + 1));
+            n1 = *reinterpret_cast<const float4*>(p1 + 16 * (q + 1));
+        }
+        EEG_SCHED_FENCE();      // next quad's fragments are in flight while this quad's MFMAs issue
+        const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                acc[i][0] = mfma16(x0[j], w[i][4 * q + j], acc[i][0]);
+                acc[i][1] = mfma16(x1[j], w[i][4 * q + j], acc[i][1]);
+            }
+        EEG_SCHED_FENCE();
+        a0 = n0;
+        a1 = n1;
+    }
+}
 
 template <int H, int M>
 __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
@@ -49,20 +88,21 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* Ub = A2 + 32 * KAP;              // [32][US]   update gate
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x;
+    const bool save = Rs != nullptr;
 
     // recurrent weights -> registers (MFMA B fragments), once for all T steps
     float wg[GT][KS], wc[CT][KS];
 #pragma unroll
     for (int i = 0; i < GT; ++i) {
-        const int ct = wave * GT + i;
+        const int ct = wave * GT + i < NGT ? wave * GT + i : 0;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wg[i][ks] = ct < NGT ? bhg[((size_t)ks * NGT + ct) * 64 + lane] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) wg[i][ks] = bhg[((size_t)ks * NGT + ct) * 64 + lane];
     }
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ct = wave * CT + i;
+        const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wc[i][ks] = ct < NCT ? bhc[((size_t)ks * NCT + ct) * 64 + lane] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) wc[i][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
     }
 
     for (int e = tid; e < 2 * 32 * KAP + 32 * US; e += 256) A[e] = 0.f;
@@ -72,66 +112,68 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         for (int e = tid; e < N * H; e += 256) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
     __syncthreads();
 
+    // per-lane row bookkeeping: rows of the owned elements, clamped copies for safe loads
+    int rowv[2][4], rowc[2][4];
+    bool valid[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rowv[rt][r] = rt * 16 + 4 * lg + r;
+            valid[rt][r] = rowv[rt][r] < N;
+            rowc[rt][r] = valid[rt][r] ? rowv[rt][r] : N - 1;
+        }
+
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
-        // prefetch this step's hoisted pre-activations (consumed after the diffusion phases)
+        const float* xw = XW + s * N * (3 * H);
+        // prefetch this step's hoisted pre-activations (consumed after the diffusion phase);
+        // padding rows read a valid row instead of branching
         f32x4 xg[GT][2], xc[CT][2];
 #pragma unroll
-        for (int i = 0; i < GT; ++i)
+        for (int i = 0; i < GT; ++i) {
+            const int ct = wave * GT + i < NGT ? wave * GT + i : 0;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rt * 16 + 4 * lg + r, ct = wave * GT + i;
-                    xg[i][rt][r] = (row < N && ct < NGT) ? XW[(s * N + row) * (3 * H) + ct * 16 + lr] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) xg[i][rt][r] = xw[rowc[rt][r] * (3 * H) + ct * 16 + lr];
+        }
 #pragma unroll
-        for (int i = 0; i < CT; ++i)
+        for (int i = 0; i < CT; ++i) {
+            const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rt * 16 + 4 * lg + r, ct = wave * CT + i;
-                    xc[i][rt][r] = (row < N && ct < NCT) ? XW[(s * N + row) * (3 * H) + 2 * H + ct * 16 + lr] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) xc[i][rt][r] = xw[rowc[rt][r] * (3 * H) + 2 * H + ct * 16 + lr];
+        }
 
         lds_diffuse_tiles<false>(A, KAP, 0, H, H, H, Pl, M, N, 32);
         __syncthreads();                                            // (b) hops(h) complete
 
         // gate GEMM: (32 x M*H) @ (M*H x 2H), this wave: GT col tiles x 2 row tiles
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float a0 = A[lr * KAP + 4 * ks + lg], a1 = A[(16 + lr) * KAP + 4 * ks + lg];
-#pragma unroll
-            for (int i = 0; i < GT; ++i) {
-                xg[i][0] = mfma16(a0, wg[i][ks], xg[i][0]);
-                xg[i][1] = mfma16(a1, wg[i][ks], xg[i][1]);
-            }
-        }
+        mfma_rows32<GT, KS>(A, KAP, lr, lg, wg, xg);
 #pragma unroll
         for (int i = 0; i < GT; ++i) {
             const int ct = wave * GT + i;
-            if (ct < NGT) {
+            if (ct < NGT) {                                          // wave-uniform
                 const bool is_r = ct < NCT;
                 const int col = ct * 16 + lr;
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = rt * 16 + 4 * lg + r;
-                        if (row < N) {
-                            const float g = sigmoidf_(xg[i][rt][r]);
-                            if (is_r) {
-                                const float rh = g * A[row * KAP + col];
-                                A2[row * KAP + col] = rh;
-                                if (Rs != nullptr) {
-                                    Rs[(s * N + row) * H + col] = g;
-                                    RHs[(s * N + row) * H + col] = rh;
-                                }
-                            } else {
-                                Ub[row * US + col - H] = g;
-                                if (Us != nullptr) Us[(s * N + row) * H + col - H] = g;
+                        const int row = rowv[rt][r];
+                        const float g = sigmoidf_(xg[i][rt][r]);
+                        if (is_r) {
+                            const float rh = valid[rt][r] ? g * A[row * KAP + col] : 0.f;
+                            A2[row * KAP + col] = rh;
+                            if (save && valid[rt][r]) {
+                                Rs[(s * N + row) * H + col] = g;
+                                RHs[(s * N + row) * H + col] = rh;
                             }
+                        } else {
+                            Ub[row * US + col - H] = g;
+                            if (save && valid[rt][r]) Us[(s * N + row) * H + col - H] = g;
                         }
                     }
             }
@@ -141,15 +183,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         __syncthreads();                                            // (d) hops(r*h) complete
 
         // candidate GEMM: (32 x M*H) @ (M*H x H), this wave: CT col tiles x 2 row tiles
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float a0 = A2[lr * KAP + 4 * ks + lg], a1 = A2[(16 + lr) * KAP + 4 * ks + lg];
-#pragma unroll
-            for (int i = 0; i < CT; ++i) {
-                xc[i][0] = mfma16(a0, wc[i][ks], xc[i][0]);
-                xc[i][1] = mfma16(a1, wc[i][ks], xc[i][1]);
-            }
-        }
+        mfma_rows32<CT, KS>(A2, KAP, lr, lg, wc, xc);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i;
@@ -159,15 +193,15 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = rt * 16 + 4 * lg + r;
-                        if (row < N) {
-                            const float pre = xc[i][rt][r];
-                            const float c = act == 0 ? tanhf(pre) : fmaxf(pre, 0.f);
-                            const float u = Ub[row * US + col], h = A[row * KAP + col];
-                            const float hn = u * h + (1.f - u) * c;
-                            A[row * KAP + col] = hn;
+                        const int row = rowv[rt][r];
+                        const float pre = xc[i][rt][r];
+                        const float c = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
+                        const float u = Ub[row * US + col], h = A[row * KAP + col];
+                        const float hn = valid[rt][r] ? u * h + (1.f - u) * c : 0.f;
+                        A[row * KAP + col] = hn;
+                        if (valid[rt][r]) {
                             Hseq[(s * N + row) * H + col] = hn;
-                            if (Cs != nullptr) Cs[(s * N + row) * H + col] = c;
+                            if (save) Cs[(s * N + row) * H + col] = c;
                         }
                     }
             }
@@ -197,15 +231,26 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float w1[CT][KS], w2[CT][KSG];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ct = wave * CT + i;
+        const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) w1[i][ks] = ct < NCT ? b1p[((size_t)ks * NCT + ct) * 64 + lane] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) w1[i][ks] = b1p[((size_t)ks * NCT + ct) * 64 + lane];
 #pragma unroll
-        for (int ks = 0; ks < KSG; ++ks) w2[i][ks] = ct < NCT ? b2p[((size_t)ks * NCT + ct) * 64 + lane] : 0.f;
+        for (int ks = 0; ks < KSG; ++ks) w2[i][ks] = b2p[((size_t)ks * NCT + ct) * 64 + lane];
     }
     for (int e = tid; e < 32 * KAP + 32 * KGP; e += 256) EC[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
+
+    int rowv[2][4], rowc[2][4];
+    bool valid[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rowv[rt][r] = rt * 16 + 4 * lg + r;
+            valid[rt][r] = rowv[rt][r] < N;
+            rowc[rt][r] = valid[rt][r] ? rowv[rt][r] : N - 1;
+        }
 
     f32x4 dh[CT][2];
     float sb_r[CT], sb_u[CT], sb_c[CT];
@@ -217,39 +262,39 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     }
     __syncthreads();
 
+    const size_t tstride = (size_t)B * N * H;
     for (int t = T - 1; t >= 0; --t) {
         const size_t s = (size_t)t * B + b;
         f32x4 hp[CT][2], rr[CT][2], dU[CT][2], dhn[CT][2];
-        // ---- E1: gate blend backward on the owned elements
+        // ---- E1: gate blend backward on the owned elements (padding rows: clamped loads, zeroed)
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ct = wave * CT + i, col = ct * 16 + lr;
+            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + lr;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rt * 16 + 4 * lg + r;
-                    float h = 0.f, rg = 0.f, du_ = 0.f, dn = 0.f;
-                    if (row < N && ct < NCT) {
-                        const size_t e = (s * N + row) * H + col, eb = ((size_t)b * N + row) * H + col;
-                        h = t > 0 ? Hseq[e - (size_t)B * N * H] : (h0 != nullptr ? h0[eb] : 0.f);
-                        rg = Rs[e];
-                        const float u = Us[e], c = Cs[e];
-                        float g = dh[i][rt][r];
-                        if (dHseq != nullptr) g += dHseq[e];
-                        if (d_at_end != nullptr && t == T - 1) g += d_at_end[eb];
-                        if (t == t_len) g += d_at_len[eb];
-                        const float dc = g * (1.f - u);
-                        const float dC = act == 0 ? dc * (1.f - c * c) : (c > 0.f ? dc : 0.f);
-                        du_ = g * (h - c) * u * (1.f - u);
-                        dn = g * u;
-                        EC[row * KAP + col] = dC;
-                        dXW[(s * N + row) * (3 * H) + 2 * H + col] = dC;
-                        dXW[(s * N + row) * (3 * H) + H + col] = du_;
-                        sb_c[i] += dC;
-                        sb_u[i] += du_;
+                    const bool ok = valid[rt][r] && ctv < NCT;
+                    const size_t e = (s * N + rowc[rt][r]) * H + col, eb = ((size_t)b * N + rowc[rt][r]) * H + col;
+                    float h = t > 0 ? Hseq[e - tstride] : (h0 != nullptr ? h0[eb] : 0.f);
+                    float rg = Rs[e];
+                    const float u = Us[e], c = Cs[e];
+                    float g = dh[i][rt][r];
+                    if (dHseq != nullptr) g += dHseq[e];
+                    if (d_at_end != nullptr && t == T - 1) g += d_at_end[eb];
+                    if (t == t_len) g += d_at_len[eb];
+                    g = ok ? g : 0.f;
+                    const float dc = g * (1.f - u);
+                    const float dC = act == 0 ? dc * (1.f - c * c) : (c > 0.f ? dc : 0.f);
+                    const float du_ = g * (h - c) * u * (1.f - u);
+                    if (ctv < NCT) EC[rowv[rt][r] * KAP + col] = dC;        // zeros on padding rows
+                    if (ok) {
+                        dXW[(s * N + rowv[rt][r]) * (3 * H) + 2 * H + col] = dC;
+                        dXW[(s * N + rowv[rt][r]) * (3 * H) + H + col] = du_;
                     }
-                    hp[i][rt][r] = h; rr[i][rt][r] = rg; dU[i][rt][r] = du_; dhn[i][rt][r] = dn;
+                    sb_c[i] += dC;
+                    sb_u[i] += du_;
+                    hp[i][rt][r] = h; rr[i][rt][r] = rg; dU[i][rt][r] = du_; dhn[i][rt][r] = g * u;
                 }
         }
         __syncthreads();                                            // #1 dC tile complete
@@ -263,33 +308,23 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float a0 = EC[lr * KAP + 4 * ks + lg], a1 = EC[(16 + lr) * KAP + 4 * ks + lg];
-#pragma unroll
-            for (int i = 0; i < CT; ++i) {
-                acc[i][0] = mfma16(a0, w1[i][ks], acc[i][0]);
-                acc[i][1] = mfma16(a1, w1[i][ks], acc[i][1]);
-            }
-        }
+        mfma_rows32<CT, KS>(EC, KAP, lr, lg, w1, acc);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i, col = ct * 16 + lr;
-            if (ct < NCT) {
+            if (ct < NCT) {                                          // wave-uniform
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = rt * 16 + 4 * lg + r;
-                        if (row < N) {
-                            const float drh = acc[i][rt][r], rg = rr[i][rt][r];
-                            const float dR = drh * hp[i][rt][r] * rg * (1.f - rg);
-                            dhn[i][rt][r] += drh * rg;
-                            EG[row * KGP + col] = dR;
-                            EG[row * KGP + H + col] = dU[i][rt][r];
-                            dXW[(s * N + row) * (3 * H) + col] = dR;
-                            sb_r[i] += dR;
-                        }
+                        const int row = rowv[rt][r];
+                        const float drh = acc[i][rt][r], rg = rr[i][rt][r];   // exact 0 on padding rows
+                        const float dR = drh * hp[i][rt][r] * rg * (1.f - rg);
+                        dhn[i][rt][r] += drh * rg;
+                        EG[row * KGP + col] = dR;
+                        EG[row * KGP + H + col] = dU[i][rt][r];
+                        if (valid[rt][r]) dXW[(s * N + row) * (3 * H) + col] = dR;
+                        sb_r[i] += dR;
                     }
             }
         }
@@ -297,16 +332,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         lds_diffuse_tiles<true>(EG, KGP, 0, 2 * H, 2 * H, 2 * H, Pl, M, N, 32);
         __syncthreads();                                            // #4 P_m^T [dR|dU] complete
 
-        // ---- GEMM2: dh += [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
-#pragma unroll
-        for (int ks = 0; ks < KSG; ++ks) {
-            const float a0 = EG[lr * KGP + 4 * ks + lg], a1 = EG[(16 + lr) * KGP + 4 * ks + lg];
-#pragma unroll
-            for (int i = 0; i < CT; ++i) {
-                dhn[i][0] = mfma16(a0, w2[i][ks], dhn[i][0]);
-                dhn[i][1] = mfma16(a1, w2[i][ks], dhn[i][1]);
-            }
-        }
+        // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
+        mfma_rows32<CT, KSG>(EG, KGP, lr, lg, w2, dhn);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             dh[i][0] = dhn[i][0];
@@ -323,10 +350,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rt * 16 + 4 * lg + r;
-                        if (row < N) dh0[((size_t)b * N + row) * H + col] = dh[i][rt][r];
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (valid[rt][r]) dh0[((size_t)b * N + rowv[rt][r]) * H + col] = dh[i][rt][r];
             }
             red[(0 * H + col) * 4 + lg] = sb_r[i];
             red[(1 * H + col) * 4 + lg] = sb_u[i];

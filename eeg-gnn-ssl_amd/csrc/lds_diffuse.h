@@ -24,9 +24,10 @@ __device__ __forceinline__ void lds_load_polys(float* Pl, const float* __restric
 // Apply hop matrices m = 1..M-1 to the (32 x W) source block buf[:, src_off : src_off+W) and
 // write results to buf[:, dst_off + (m-1)*dst_step : +W).  Rows >= N of the source must be zero
 // (or finite); rows >= N of the result are written as exact zeros (P is zero padded).
-// Work items = (m, row tile, col tile), round-robin over the block's waves.  W % 16 == 0.
-// Result rows >= rows_limit are not stored (the standalone kernels only keep round_up(N,4) rows).
-template <bool ADJ>
+// Work items = (m, row tile, col tile), dealt round-robin to the block's waves; each wave works on
+// UNR tiles at once (independent accumulators: the 16x16x4 MFMA has a 40-cycle dependent latency).
+// W % 16 == 0.  Result rows >= rows_limit are not stored.
+template <bool ADJ, int UNR = 4>
 __device__ __forceinline__ void lds_diffuse_tiles(float* buf, int stride, int src_off, int dst_off,
                                                   int dst_step, int W, const float* Pl, int M, int N,
                                                   int rows_limit) {
@@ -34,21 +35,37 @@ __device__ __forceinline__ void lds_diffuse_tiles(float* buf, int stride, int sr
     const int nct = W / 16, nks = ceil_div(N, 4);
     const int ntiles = (M - 1) * 2 * nct;
     const int lr = lane & 15, lg = lane >> 4;
-    for (int t = wave; t < ntiles; t += nwaves) {
-        const int ct = t % nct, rt = (t / nct) & 1, m1 = t / (2 * nct);
-        const float* Pm = Pl + m1 * kPFloats;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < nks; ++ks) {
-            const int kk = 4 * ks + lg;
-            const float a = ADJ ? Pm[kk * kPStride + rt * 16 + lr] : Pm[(rt * 16 + lr) * kPStride + kk];
-            const float b = buf[kk * stride + src_off + ct * 16 + lr];
-            acc = mfma16(a, b, acc);
-        }
-        float* d = buf + dst_off + m1 * dst_step + ct * 16 + lr;
+    for (int t0 = wave; t0 < ntiles; t0 += nwaves * UNR) {
+        f32x4 acc[UNR];
+        int aoff[UNR], boff[UNR], doff[UNR], row0[UNR];
+        bool ok[UNR];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rt * 16 + 4 * lg + r;
-            if (row < rows_limit) d[row * stride] = acc[r];
+        for (int u = 0; u < UNR; ++u) {
+            const int t = t0 + u * nwaves;
+            ok[u] = t < ntiles;
+            const int tt = ok[u] ? t : t0;
+            const int ct = tt % nct, rt = (tt / nct) & 1, m1 = tt / (2 * nct);
+            aoff[u] = m1 * kPFloats + (ADJ ? (lg * kPStride + rt * 16 + lr) : ((rt * 16 + lr) * kPStride + lg));
+            boff[u] = lg * stride + src_off + ct * 16 + lr;
+            row0[u] = rt * 16 + 4 * lg;
+            doff[u] = row0[u] * stride + dst_off + m1 * dst_step + ct * 16 + lr;
+            acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const float a = Pl[aoff[u] + (ADJ ? 4 * ks * kPStride : 4 * ks)];
+                const float b = buf[boff[u] + 4 * ks * stride];
+                acc[u] = mfma16(a, b, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (ok[u]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0[u] + r < rows_limit) buf[doff[u] + r * stride] = acc[u][r];
+            }
         }
     }
 }

@@ -57,7 +57,9 @@ class TrainStep:
         assert task in ("detection", "classification", "ssl")
         self.model, self.task, self.max_grad_norm = model, task, max_grad_norm
         self.fp = FlatParameters(model)
-        self.opt = torch.optim.Adam([self.fp.flat_param], lr=lr, weight_decay=weight_decay)
+        # one flat tensor -> one fused Adam kernel on the GPU (foreach would launch ~8 tiny kernels)
+        fused = self.fp.flat.is_cuda
+        self.opt = torch.optim.Adam([self.fp.flat_param], lr=lr, weight_decay=weight_decay, fused=fused)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
 
