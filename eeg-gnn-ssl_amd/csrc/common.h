@@ -18,6 +18,7 @@
     emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 #define EEG_SCHED_FENCE() ((void)0)
+__device__ __forceinline__ long long cycle_now() { return 0; }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,6 +30,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 // pins the instruction order at this point (keeps hand-placed LDS prefetches ahead of the MFMAs)
 #define EEG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 
 namespace eeg {

@@ -73,14 +73,44 @@ __device__ __forceinline__ void mfma_rows32(const float* __restrict__ A, int str
     }
 }
 
+// Optional in-kernel phase timer (development aid, enabled through eeg_dcrnn_set_seq_probe):
+// lane 0 of every wave accumulates shader-clock cycles per phase and stores them at the end.
+struct PhaseProbe {
+    long long acc[6];
+    long long last;
+    bool on;
+    __device__ __forceinline__ void start(const long long* p) {
+        on = p != nullptr;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i] = 0;
+        last = on ? cycle_now() : 0;
+    }
+    __device__ __forceinline__ void mark(int k) {
+        if (on) {
+            const long long t = cycle_now();
+            acc[k] += t - last;
+            last = t;
+        }
+    }
+    __device__ __forceinline__ void dump(long long* p, int slot0) {
+        if (on && (threadIdx.x & 63) == 0) {
+            long long* d = p + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + slot0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = acc[i];
+        }
+    }
+};
+
 template <int H, int M>
 __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
     float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
-    float* __restrict__ RHs, int T, int B, int N, int act) {
+    float* __restrict__ RHs, int T, int B, int N, int act, long long* probe) {
     using G = SeqGeom<H, M>;
     constexpr int KAP = G::KAP, KS = G::KS, GT = G::GT, CT = G::CT, NGT = G::NGT, NCT = G::NCT, US = G::US;
+    PhaseProbe pp;
+    pp.start(probe);
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
     float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
@@ -129,29 +159,36 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         const float* xw = XW + s * N * (3 * H);
         // prefetch this step's hoisted pre-activations (consumed after the diffusion phase);
         // padding rows read a valid row instead of branching
-        f32x4 xg[GT][2], xc[CT][2];
+        // (added in the epilogues, so the loads have a whole GEMM to land)
+        f32x4 xg[GT][2], xc[CT][2], ag[GT][2], ac[CT][2];
 #pragma unroll
         for (int i = 0; i < GT; ++i) {
             const int ct = wave * GT + i < NGT ? wave * GT + i : 0;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < 2; ++rt) {
+                ag[i][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xg[i][rt][r] = xw[rowc[rt][r] * (3 * H) + ct * 16 + lr];
+            }
         }
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < 2; ++rt) {
+                ac[i][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xc[i][rt][r] = xw[rowc[rt][r] * (3 * H) + 2 * H + ct * 16 + lr];
+            }
         }
 
         lds_diffuse_tiles<false>(A, KAP, 0, H, H, H, Pl, M, N, 32);
         __syncthreads();                                            // (b) hops(h) complete
+        pp.mark(0);
 
         // gate GEMM: (32 x M*H) @ (M*H x 2H), this wave: GT col tiles x 2 row tiles
-        mfma_rows32<GT, KS>(A, KAP, lr, lg, wg, xg);
+        mfma_rows32<GT, KS>(A, KAP, lr, lg, wg, ag);
+        pp.mark(1);
 #pragma unroll
         for (int i = 0; i < GT; ++i) {
             const int ct = wave * GT + i;
@@ -163,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = rowv[rt][r];
-                        const float g = sigmoidf_(xg[i][rt][r]);
+                        const float g = sigmoidf_(ag[i][rt][r] + xg[i][rt][r]);
                         if (is_r) {
                             const float rh = valid[rt][r] ? g * A[row * KAP + col] : 0.f;
                             A2[row * KAP + col] = rh;
@@ -179,11 +216,14 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
             }
         }
         __syncthreads();                                            // (c) r*h and u complete
+        pp.mark(2);
         lds_diffuse_tiles<false>(A2, KAP, 0, H, H, H, Pl, M, N, 32);
         __syncthreads();                                            // (d) hops(r*h) complete
+        pp.mark(3);
 
         // candidate GEMM: (32 x M*H) @ (M*H x H), this wave: CT col tiles x 2 row tiles
-        mfma_rows32<CT, KS>(A2, KAP, lr, lg, wc, xc);
+        mfma_rows32<CT, KS>(A2, KAP, lr, lg, wc, ac);
+        pp.mark(4);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i;
@@ -194,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = rowv[rt][r];
-                        const float pre = xc[i][rt][r];
+                        const float pre = ac[i][rt][r] + xc[i][rt][r];
                         const float c = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
                         const float u = Ub[row * US + col], h = A[row * KAP + col];
                         const float hn = valid[rt][r] ? u * h + (1.f - u) * c : 0.f;
@@ -207,7 +247,9 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
             }
         }
         __syncthreads();                                            // (a) h_t complete
+        pp.mark(5);
     }
+    pp.dump(probe, 0);
 }
 
 // lengths: optional int64 (B); d_at_len is added at t = lengths[b]-1, d_at_end at t = T-1.
@@ -217,9 +259,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
     const float* __restrict__ d_at_end, const float* __restrict__ d_at_len, const long long* __restrict__ lengths,
     const float* __restrict__ P, int p_batched, const float* __restrict__ b1p, const float* __restrict__ b2p,
-    float* __restrict__ dXW, float* __restrict__ dh0, float* __restrict__ dbias_part, int T, int B, int N, int act) {
+    float* __restrict__ dXW, float* __restrict__ dh0, float* __restrict__ dbias_part, int T, int B, int N, int act,
+    long long* probe) {
     using G = SeqGeom<H, M>;
     constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, CT = G::CT, NCT = G::NCT;
+    PhaseProbe pp;
+    pp.start(probe);
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
     float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC
@@ -263,10 +308,42 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     __syncthreads();
 
     const size_t tstride = (size_t)B * N * H;
+    // operands of step t are fetched during step t+1 (one step ahead): h_{t-1}, r, u, c and the
+    // external gradient of h_t (dHseq + d_at_end + d_at_len); padding rows read a valid row.
+    f32x4 nh[CT][2], nr[CT][2], nu[CT][2], nc[CT][2], ng[CT][2];
+    auto fetch = [&](int t) {
+        const size_t s = (size_t)t * B + b;
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + lr;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t e = (s * N + rowc[rt][r]) * H + col, eb = ((size_t)b * N + rowc[rt][r]) * H + col;
+                    nh[i][rt][r] = t > 0 ? Hseq[e - tstride] : (h0 != nullptr ? h0[eb] : 0.f);
+                    nr[i][rt][r] = Rs[e];
+                    nu[i][rt][r] = Us[e];
+                    nc[i][rt][r] = Cs[e];
+                    float g = dHseq != nullptr ? dHseq[e] : 0.f;
+                    if (d_at_end != nullptr && t == T - 1) g += d_at_end[eb];
+                    if (t == t_len) g += d_at_len[eb];
+                    ng[i][rt][r] = g;
+                }
+        }
+    };
+    fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const size_t s = (size_t)t * B + b;
-        f32x4 hp[CT][2], rr[CT][2], dU[CT][2], dhn[CT][2];
-        // ---- E1: gate blend backward on the owned elements (padding rows: clamped loads, zeroed)
+        f32x4 hp[CT][2], rr[CT][2], dU[CT][2], dhn[CT][2], uu[CT][2], cc[CT][2], gg[CT][2];
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                hp[i][rt] = nh[i][rt]; rr[i][rt] = nr[i][rt]; uu[i][rt] = nu[i][rt]; cc[i][rt] = nc[i][rt]; gg[i][rt] = ng[i][rt];
+            }
+        if (t > 0) fetch(t - 1);
+        // ---- E1: gate blend backward on the owned elements (padding rows zeroed)
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + lr;
@@ -275,15 +352,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = valid[rt][r] && ctv < NCT;
-                    const size_t e = (s * N + rowc[rt][r]) * H + col, eb = ((size_t)b * N + rowc[rt][r]) * H + col;
-                    float h = t > 0 ? Hseq[e - tstride] : (h0 != nullptr ? h0[eb] : 0.f);
-                    float rg = Rs[e];
-                    const float u = Us[e], c = Cs[e];
-                    float g = dh[i][rt][r];
-                    if (dHseq != nullptr) g += dHseq[e];
-                    if (d_at_end != nullptr && t == T - 1) g += d_at_end[eb];
-                    if (t == t_len) g += d_at_len[eb];
-                    g = ok ? g : 0.f;
+                    const float h = hp[i][rt][r], u = uu[i][rt][r], c = cc[i][rt][r];
+                    const float g = ok ? dh[i][rt][r] + gg[i][rt][r] : 0.f;
                     const float dc = g * (1.f - u);
                     const float dC = act == 0 ? dc * (1.f - c * c) : (c > 0.f ? dc : 0.f);
                     const float du_ = g * (h - c) * u * (1.f - u);
@@ -294,12 +364,14 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     }
                     sb_c[i] += dC;
                     sb_u[i] += du_;
-                    hp[i][rt][r] = h; rr[i][rt][r] = rg; dU[i][rt][r] = du_; dhn[i][rt][r] = g * u;
+                    dU[i][rt][r] = du_; dhn[i][rt][r] = g * u;
                 }
         }
         __syncthreads();                                            // #1 dC tile complete
+        pp.mark(0);
         lds_diffuse_tiles<true>(EC, KAP, 0, H, H, H, Pl, M, N, 32);
         __syncthreads();                                            // #2 P_m^T dC complete
+        pp.mark(1);
 
         // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T (M*H x H)
         f32x4 acc[CT][2];
@@ -309,6 +381,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         mfma_rows32<CT, KS>(EC, KAP, lr, lg, w1, acc);
+        pp.mark(2);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i, col = ct * 16 + lr;
@@ -329,11 +402,14 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             }
         }
         __syncthreads();                                            // #3 [dR|dU] tile complete
+        pp.mark(3);
         lds_diffuse_tiles<true>(EG, KGP, 0, 2 * H, 2 * H, 2 * H, Pl, M, N, 32);
         __syncthreads();                                            // #4 P_m^T [dR|dU] complete
+        pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
         mfma_rows32<CT, KSG>(EG, KGP, lr, lg, w2, dhn);
+        pp.mark(5);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             dh[i][0] = dhn[i][0];
@@ -361,6 +437,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     __syncthreads();
     for (int j = tid; j < 3 * H; j += 256)
         dbias_part[(size_t)b * 3 * H + j] = (red[j * 4] + red[j * 4 + 1]) + (red[j * 4 + 2] + red[j * 4 + 3]);
+    pp.dump(probe, 8);
 }
 
 }  // namespace eeg

@@ -11,6 +11,7 @@ struct SeqFwdArgs {
     const float *bhg, *bhc;
     float *Hseq, *Rs, *Us, *Cs, *RHs;
     int T, B, N, act;
+    long long* probe;
 };
 struct SeqBwdArgs {
     const float *Hseq, *h0, *Rs, *Us, *Cs, *dHseq, *d_at_end, *d_at_len;
@@ -20,6 +21,7 @@ struct SeqBwdArgs {
     const float *b1, *b2;
     float *dXW, *dh0, *dbias_part;
     int T, B, N, act;
+    long long* probe;
 };
 
 // return 0 ok, 1 unsupported M for this H, 2 launch error

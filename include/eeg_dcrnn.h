@@ -48,6 +48,9 @@ int eeg_dcrnn_is_device_build(void);
  * into buf (and clears the records). */
 int eeg_dcrnn_prof_enable(int on);
 int eeg_dcrnn_prof_report(char* buf, size_t cap);
+/* Development aid: when set to a device buffer of B*4*16 int64, the recurrent kernels store the
+ * shader-clock cycles each wave spent per phase (slots 0-5 forward, 8-13 backward); NULL disables. */
+int eeg_dcrnn_set_seq_probe(int64_t* probe);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
 int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 

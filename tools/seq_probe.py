@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Development aid (GPU box): per-phase shader-clock cycles of the recurrent kernels at cfg2 size.
+usage: python tools/seq_probe.py [workload]"""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+task, filt, t_len, batch, classes = bench.WORKLOADS[wl]
+dev = torch.device("cuda", 0)
+x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123)
+model = DCRNNModel_classification(bench.make_args(filt), classes, device=dev).to(dev).train()
+x, y, lengths, sup = x.to(dev), y.to(dev), lengths.to(dev), [s.to(dev) for s in sup]
+lib = _lib.get_lib()
+
+
+def run():
+    model.zero_grad()
+    lg = model(x, lengths, sup)
+    loss = (torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), y) if classes == 1
+            else torch.nn.functional.cross_entropy(lg, y))
+    loss.backward()
+    torch.cuda.synchronize()
+
+
+run()
+probe = torch.zeros(batch * 4 * 16, dtype=torch.int64, device=dev)
+lib.query("eeg_dcrnn_set_seq_probe", ctypes.c_void_p(probe.data_ptr()))
+run()          # last launches of each direction (layer 0 bwd, layer 1 fwd) leave their counters
+lib.query("eeg_dcrnn_set_seq_probe", None)
+p = probe.view(batch, 4, 16).double().cpu()
+names_f = ["diffuse(h)+bar", "gate GEMM", "gate epilogue+bar", "diffuse(rh)+bar", "cand GEMM", "cand epilogue+bar"]
+names_b = ["E1+bar", "adj diffuse dC+bar", "GEMM1", "epi1+bar", "adj diffuse dG+bar", "GEMM2"]
+for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
+    tot = p[:, :, off:off + 6].sum(-1).mean().item() / t_len
+    print(f"{title}: {tot:9.0f} cycles/step/wave (mean over {batch} WGs x 4 waves)")
+    for k, nm in enumerate(names):
+        v = p[:, :, off + k] / t_len
+        print(f"   {nm:22s} mean {v.mean().item():8.0f}  min {v.min().item():8.0f}  max {v.max().item():8.0f}   per-wave means "
+              + " ".join(f"{v[:, w].mean().item():7.0f}" for w in range(4)))
