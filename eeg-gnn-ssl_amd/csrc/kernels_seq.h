@@ -5,13 +5,16 @@
 //  * samples are independent, so ONE WORKGROUP OWNS ONE CLIP for the whole sequence: no
 //    inter-workgroup traffic, no grid barrier; B workgroups fill the 256 CUs at B = 256.
 //  * the recurrent weights (W^h, M*H x 3H fp32 = 147..246 kB) do not fit LDS, so every wave keeps
-//    its column slice as MFMA B-fragments IN REGISTERS for all T steps (<= 240 VGPRs of the 512
-//    available at one wave per SIMD).
-//  * the hidden state / gradient tile, its M hop-diffused copies and the (M-1) hop-polynomial
-//    matrices of the clip's graph stay in LDS; the 19-node mix is an fp32 MFMA with the padded
-//    32x32 polynomial as A operand.
-//  * A fragments come from LDS as ds_read_b128 (four k per lane, K order permuted to match:
-//    common.h kperm) and are fetched one quad ahead of the MFMAs that consume them.
+//    its column slice as MFMA fragments IN REGISTERS for all T steps, next to the fragments of the
+//    clip's (M-1) hop-polynomial matrices (they are constant over the sequence too).
+//  * the hidden state / gradient tile and its M hop-diffused copies stay in LDS.
+//  * every MFMA is issued "transposed": D^T(16 cols x 16 nodes) = W^T-frag (A operand) x
+//    X^T-frag (B operand).  The fragment lane maps are identical to the untransposed product, but
+//    the result lands as lane (node = lane&15, 4 CONSECUTIVE columns 4*(lane>>4)..+3), so every
+//    epilogue access — XW / saved-gate loads, r,u,c,h stores, LDS tile updates — is one 16-byte
+//    vector op per (lane, tile) with a single validity guard (node < N).
+//  * node-feature fragments come from LDS as ds_read_b128 (four k per lane, K order permuted to
+//    match: common.h kperm), fetched one quad ahead of the MFMAs that consume them.
 //  * the input half of the diffusion convolution (x-part, + biases) is hoisted out of the
 //    recurrence (kernels_gemm.h) and arrives as XW (T,B,N,3H) = [r | u | c] pre-activations.
 //
@@ -20,10 +23,9 @@
 // bwd per step:  SURVEY.md §9 "Cell backward" with P_m^T adjoint mixes; emits dXW = [dR|dU|dC]
 //                per step (consumed afterwards by the hoisted weight-gradient / dX GEMMs).
 //
-// Element ownership: a lane owns, for each of its column tiles, the C-layout elements
-// (row = 16*rt + 4*(lane>>4) + r, col = 16*ct + (lane&15)), rt in {0,1}, r in 0..3.  Rows >= N are
-// padding: they are computed (finite garbage stays confined to padding rows) but written to LDS as
-// zeros and never stored to HBM.
+// Ownership: for column tile ct and node tile nt in {0,1} a lane owns node n = 16*nt + (lane&15)
+// and columns 16*ct + 4*(lane>>4) + 0..3.  Nodes >= N are padding: computed (finite values that
+// never leave padding rows), written to LDS as zeros, never stored to HBM.
 #pragma once
 #include "common.h"
 #include "lds_diffuse.h"
@@ -38,16 +40,22 @@ struct SeqGeom {
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
     static constexpr int US = H + 4;
     static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + 32 * US; }
-    static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP + 3 * H * 4; }
+    static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP; }
 };
 
-// acc[i][rt] += A(32 x 4*NKS, LDS, stride) @ Wfrag[i][.]  for NT column tiles; A fragments are read
-// as float4 (k = 16q + 4*(lane>>4) + j) one quad ahead of their use.
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return (f32x4){v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+// acc[i][nt] += W-frag[i][.] x X(32 nodes x 4*NKS, LDS, stride)^T for NT column tiles; the node
+// fragments are read as float4 (k = 16q + 4*(lane>>4) + j) one quad ahead of their use.
 template <int NT, int NKS>
-__device__ __forceinline__ void mfma_rows32(const float* __restrict__ A, int stride, int lr, int lg,
-                                            const float (&w)[NT][NKS], f32x4 (&acc)[NT][2]) {
+__device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lr, int lg,
+                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2]) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
-    const float* p0 = A + lr * stride + 4 * lg;
+    const float* p0 = X + lr * stride + 4 * lg;
     const float* p1 = p0 + 16 * stride;
     float4 a0 = *reinterpret_cast<const float4*>(p0);
     float4 a1 = *reinterpret_cast<const float4*>(p1);
@@ -64,8 +72,8 @@ __device__ __forceinline__ void mfma_rows32(const float* __restrict__ A, int str
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                acc[i][0] = mfma16(x0[j], w[i][4 * q + j], acc[i][0]);
-                acc[i][1] = mfma16(x1[j], w[i][4 * q + j], acc[i][1]);
+                acc[i][0] = mfma16(w[i][4 * q + j], x0[j], acc[i][0]);
+                acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
             }
         EEG_SCHED_FENCE();
         a0 = n0;
@@ -101,7 +109,7 @@ struct PhaseProbe {
     }
 };
 
-template <int H, int M>
+template <int H, int M, int NKS>
 __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const int b = blockIdx.x;
     const bool save = Rs != nullptr;
 
-    // recurrent weights -> registers (MFMA B fragments), once for all T steps
+    // recurrent weights -> registers (MFMA fragments), once for all T steps
     float wg[GT][KS], wc[CT][KS];
 #pragma unroll
     for (int i = 0; i < GT; ++i) {
@@ -138,112 +146,111 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     for (int e = tid; e < 2 * 32 * KAP + 32 * US; e += 256) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
+    float pf[(M - 1) * 2][NKS];
+    load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
     if (h0 != nullptr)
         for (int e = tid; e < N * H; e += 256) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
     __syncthreads();
 
-    // per-lane row bookkeeping: rows of the owned elements, clamped copies for safe loads
-    int rowv[2][4], rowc[2][4];
-    bool valid[2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rowv[rt][r] = rt * 16 + 4 * lg + r;
-            valid[rt][r] = rowv[rt][r] < N;
-            rowc[rt][r] = valid[rt][r] ? rowv[rt][r] : N - 1;
-        }
+    // nodes owned by this lane (per node tile), clamped copies for branch-free loads
+    const int node[2] = {lr, 16 + lr};
+    const bool valid[2] = {lr < N, 16 + lr < N};
+    const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
         const float* xw = XW + s * N * (3 * H);
-        // prefetch this step's hoisted pre-activations (consumed after the diffusion phase);
-        // padding rows read a valid row instead of branching
-        // (added in the epilogues, so the loads have a whole GEMM to land)
+        // this step's hoisted pre-activations (added in the epilogues: a whole GEMM to land)
         f32x4 xg[GT][2], xc[CT][2], ag[GT][2], ac[CT][2];
 #pragma unroll
         for (int i = 0; i < GT; ++i) {
             const int ct = wave * GT + i < NGT ? wave * GT + i : 0;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                ag[i][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xg[i][rt][r] = xw[rowc[rt][r] * (3 * H) + ct * 16 + lr];
+            for (int nt = 0; nt < 2; ++nt) {
+                ag[i][nt] = zero4;
+                xg[i][nt] = ld4(xw + nodec[nt] * (3 * H) + ct * 16 + 4 * lg);
             }
         }
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                ac[i][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xc[i][rt][r] = xw[rowc[rt][r] * (3 * H) + 2 * H + ct * 16 + lr];
+            for (int nt = 0; nt < 2; ++nt) {
+                ac[i][nt] = zero4;
+                xc[i][nt] = ld4(xw + nodec[nt] * (3 * H) + 2 * H + ct * 16 + 4 * lg);
             }
         }
 
-        lds_diffuse_tiles<false>(A, KAP, 0, H, H, H, Pl, M, N, 32);
+        lds_diffuse_regs<M, NKS, H>(A, KAP, pf, wave, lr, lg);
         __syncthreads();                                            // (b) hops(h) complete
         pp.mark(0);
 
-        // gate GEMM: (32 x M*H) @ (M*H x 2H), this wave: GT col tiles x 2 row tiles
-        mfma_rows32<GT, KS>(A, KAP, lr, lg, wg, ag);
+        // gate GEMM: (2H cols) x (32 nodes), K = M*H; this wave: GT col tiles x 2 node tiles
+        mfma_nodes32<GT, KS>(A, KAP, lr, lg, wg, ag);
         pp.mark(1);
+        float* r_t = Rs + s * N * H;
+        float* rh_t = RHs + s * N * H;
+        float* u_t = Us + s * N * H;
 #pragma unroll
         for (int i = 0; i < GT; ++i) {
             const int ct = wave * GT + i;
             if (ct < NGT) {                                          // wave-uniform
                 const bool is_r = ct < NCT;
-                const int col = ct * 16 + lr;
+                const int col = (is_r ? ct : ct - NCT) * 16 + 4 * lg;
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4 g;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rowv[rt][r];
-                        const float g = sigmoidf_(ag[i][rt][r] + xg[i][rt][r]);
-                        if (is_r) {
-                            const float rh = valid[rt][r] ? g * A[row * KAP + col] : 0.f;
-                            A2[row * KAP + col] = rh;
-                            if (save && valid[rt][r]) {
-                                Rs[(s * N + row) * H + col] = g;
-                                RHs[(s * N + row) * H + col] = rh;
-                            }
-                        } else {
-                            Ub[row * US + col - H] = g;
-                            if (save && valid[rt][r]) Us[(s * N + row) * H + col - H] = g;
+                    for (int r = 0; r < 4; ++r) g[r] = sigmoidf_(ag[i][nt][r] + xg[i][nt][r]);
+                    if (is_r) {
+                        f32x4 rh = g * ld4(A + node[nt] * KAP + col);
+                        rh = valid[nt] ? rh : zero4;
+                        st4(A2 + node[nt] * KAP + col, rh);
+                        if (save && valid[nt]) {
+                            st4(r_t + node[nt] * H + col, g);
+                            st4(rh_t + node[nt] * H + col, rh);
                         }
+                    } else {
+                        st4(Ub + node[nt] * US + col, g);
+                        if (save && valid[nt]) st4(u_t + node[nt] * H + col, g);
                     }
+                }
             }
         }
         __syncthreads();                                            // (c) r*h and u complete
         pp.mark(2);
-        lds_diffuse_tiles<false>(A2, KAP, 0, H, H, H, Pl, M, N, 32);
+        lds_diffuse_regs<M, NKS, H>(A2, KAP, pf, wave, lr, lg);
         __syncthreads();                                            // (d) hops(r*h) complete
         pp.mark(3);
 
-        // candidate GEMM: (32 x M*H) @ (M*H x H), this wave: CT col tiles x 2 row tiles
-        mfma_rows32<CT, KS>(A2, KAP, lr, lg, wc, ac);
+        // candidate GEMM: (H cols) x (32 nodes), K = M*H; this wave: CT col tiles x 2 node tiles
+        mfma_nodes32<CT, KS>(A2, KAP, lr, lg, wc, ac);
         pp.mark(4);
+        float* h_t = Hseq + s * N * H;
+        float* c_t = Cs + s * N * H;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave * CT + i;
             if (ct < NCT) {
-                const int col = ct * 16 + lr;
+                const int col = ct * 16 + 4 * lg;
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 u = ld4(Ub + node[nt] * US + col), h = ld4(A + node[nt] * KAP + col);
+                    f32x4 c, hn;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = rowv[rt][r];
-                        const float pre = ac[i][rt][r] + xc[i][rt][r];
-                        const float c = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
-                        const float u = Ub[row * US + col], h = A[row * KAP + col];
-                        const float hn = valid[rt][r] ? u * h + (1.f - u) * c : 0.f;
-                        A[row * KAP + col] = hn;
-                        if (valid[rt][r]) {
-                            Hseq[(s * N + row) * H + col] = hn;
-                            if (save) Cs[(s * N + row) * H + col] = c;
-                        }
+                        const float pre = ac[i][nt][r] + xc[i][nt][r];
+                        c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
+                        hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                     }
+                    hn = valid[nt] ? hn : zero4;
+                    st4(A + node[nt] * KAP + col, hn);
+                    if (valid[nt]) {
+                        st4(h_t + node[nt] * H + col, hn);
+                        if (save) st4(c_t + node[nt] * H + col, c);
+                    }
+                }
             }
         }
         __syncthreads();                                            // (a) h_t complete
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 }
 
 // lengths: optional int64 (B); d_at_len is added at t = lengths[b]-1, d_at_end at t = T-1.
-template <int H, int M>
+template <int H, int M, int NKS>
 __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     const float* __restrict__ Hseq, const float* __restrict__ h0, const float* __restrict__ Rs,
     const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
@@ -269,7 +276,6 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float* Pl = sm;
     float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC
     float* EG = EC + 32 * KAP;              // [32][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
-    float* red = EG + 32 * KGP;             // [3H][4]    bias-gradient reduction scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x;
 
@@ -285,91 +291,88 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     for (int e = tid; e < 32 * KAP + 32 * KGP; e += 256) EC[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
+    __syncthreads();
+    float pf[(M - 1) * 2][NKS];
+    load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
 
-    int rowv[2][4], rowc[2][4];
-    bool valid[2][4];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rowv[rt][r] = rt * 16 + 4 * lg + r;
-            valid[rt][r] = rowv[rt][r] < N;
-            rowc[rt][r] = valid[rt][r] ? rowv[rt][r] : N - 1;
-        }
+    const int node[2] = {lr, 16 + lr};
+    const bool valid[2] = {lr < N, 16 + lr < N};
+    const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 dh[CT][2];
-    float sb_r[CT], sb_u[CT], sb_c[CT];
+    f32x4 dh[CT][2], sb_r[CT], sb_u[CT], sb_c[CT];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        dh[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dh[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        sb_r[i] = sb_u[i] = sb_c[i] = 0.f;
+        dh[i][0] = zero4;
+        dh[i][1] = zero4;
+        sb_r[i] = sb_u[i] = sb_c[i] = zero4;
     }
-    __syncthreads();
 
     const size_t tstride = (size_t)B * N * H;
     // operands of step t are fetched during step t+1 (one step ahead): h_{t-1}, r, u, c and the
-    // external gradient of h_t (dHseq + d_at_end + d_at_len); padding rows read a valid row.
+    // external gradient of h_t (dHseq + d_at_end + d_at_len); padding nodes read a valid row.
     f32x4 nh[CT][2], nr[CT][2], nu[CT][2], nc[CT][2], ng[CT][2];
     auto fetch = [&](int t) {
         const size_t s = (size_t)t * B + b;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + lr;
+            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + 4 * lg;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t e = (s * N + rowc[rt][r]) * H + col, eb = ((size_t)b * N + rowc[rt][r]) * H + col;
-                    nh[i][rt][r] = t > 0 ? Hseq[e - tstride] : (h0 != nullptr ? h0[eb] : 0.f);
-                    nr[i][rt][r] = Rs[e];
-                    nu[i][rt][r] = Us[e];
-                    nc[i][rt][r] = Cs[e];
-                    float g = dHseq != nullptr ? dHseq[e] : 0.f;
-                    if (d_at_end != nullptr && t == T - 1) g += d_at_end[eb];
-                    if (t == t_len) g += d_at_len[eb];
-                    ng[i][rt][r] = g;
-                }
+            for (int nt = 0; nt < 2; ++nt) {
+                const size_t e = (s * N + nodec[nt]) * H + col, eb = ((size_t)b * N + nodec[nt]) * H + col;
+                nh[i][nt] = t > 0 ? ld4(Hseq + e - tstride) : (h0 != nullptr ? ld4(h0 + eb) : zero4);
+                nr[i][nt] = ld4(Rs + e);
+                nu[i][nt] = ld4(Us + e);
+                nc[i][nt] = ld4(Cs + e);
+                f32x4 g = dHseq != nullptr ? ld4(dHseq + e) : zero4;
+                if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + eb);
+                if (t == t_len) g += ld4(d_at_len + eb);
+                ng[i][nt] = g;
+            }
         }
     };
     fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
         const size_t s = (size_t)t * B + b;
+        float* dxw = dXW + s * N * (3 * H);
         f32x4 hp[CT][2], rr[CT][2], dU[CT][2], dhn[CT][2], uu[CT][2], cc[CT][2], gg[CT][2];
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                hp[i][rt] = nh[i][rt]; rr[i][rt] = nr[i][rt]; uu[i][rt] = nu[i][rt]; cc[i][rt] = nc[i][rt]; gg[i][rt] = ng[i][rt];
+            for (int nt = 0; nt < 2; ++nt) {
+                hp[i][nt] = nh[i][nt]; rr[i][nt] = nr[i][nt]; uu[i][nt] = nu[i][nt]; cc[i][nt] = nc[i][nt]; gg[i][nt] = ng[i][nt];
             }
         if (t > 0) fetch(t - 1);
-        // ---- E1: gate blend backward on the owned elements (padding rows zeroed)
+        // ---- E1: gate blend backward on the owned elements (padding nodes zeroed)
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + lr;
+            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + 4 * lg;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int nt = 0; nt < 2; ++nt) {
+                const bool ok = valid[nt] && ctv < NCT;
+                const f32x4 h = hp[i][nt], u = uu[i][nt], c = cc[i][nt];
+                const f32x4 g = ok ? dh[i][nt] + gg[i][nt] : zero4;
+                f32x4 dC, du_;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const bool ok = valid[rt][r] && ctv < NCT;
-                    const float h = hp[i][rt][r], u = uu[i][rt][r], c = cc[i][rt][r];
-                    const float g = ok ? dh[i][rt][r] + gg[i][rt][r] : 0.f;
-                    const float dc = g * (1.f - u);
-                    const float dC = act == 0 ? dc * (1.f - c * c) : (c > 0.f ? dc : 0.f);
-                    const float du_ = g * (h - c) * u * (1.f - u);
-                    if (ctv < NCT) EC[rowv[rt][r] * KAP + col] = dC;        // zeros on padding rows
-                    if (ok) {
-                        dXW[(s * N + rowv[rt][r]) * (3 * H) + 2 * H + col] = dC;
-                        dXW[(s * N + rowv[rt][r]) * (3 * H) + H + col] = du_;
-                    }
-                    sb_c[i] += dC;
-                    sb_u[i] += du_;
-                    dU[i][rt][r] = du_; dhn[i][rt][r] = g * u;
+                    const float dc = g[r] * (1.f - u[r]);
+                    dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
+                    du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
                 }
+                if (ctv < NCT) st4(EC + node[nt] * KAP + col, dC);            // zeros on padding nodes
+                if (ok) {
+                    st4(dxw + node[nt] * (3 * H) + 2 * H + col, dC);
+                    st4(dxw + node[nt] * (3 * H) + H + col, du_);
+                }
+                sb_c[i] += dC;
+                sb_u[i] += du_;
+                dU[i][nt] = du_;
+                dhn[i][nt] = g * u;
+            }
         }
         __syncthreads();                                            // #1 dC tile complete
         pp.mark(0);
-        lds_diffuse_tiles<true>(EC, KAP, 0, H, H, H, Pl, M, N, 32);
+        lds_diffuse_regs<M, NKS, H>(EC, KAP, pf, wave, lr, lg);
         __syncthreads();                                            // #2 P_m^T dC complete
         pp.mark(1);
 
@@ -377,38 +380,35 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         f32x4 acc[CT][2];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[i][0] = zero4;
+            acc[i][1] = zero4;
         }
-        mfma_rows32<CT, KS>(EC, KAP, lr, lg, w1, acc);
+        mfma_nodes32<CT, KS>(EC, KAP, lr, lg, w1, acc);
         pp.mark(2);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ct = wave * CT + i, col = ct * 16 + lr;
+            const int ct = wave * CT + i, col = ct * 16 + 4 * lg;
             if (ct < NCT) {                                          // wave-uniform
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rowv[rt][r];
-                        const float drh = acc[i][rt][r], rg = rr[i][rt][r];   // exact 0 on padding rows
-                        const float dR = drh * hp[i][rt][r] * rg * (1.f - rg);
-                        dhn[i][rt][r] += drh * rg;
-                        EG[row * KGP + col] = dR;
-                        EG[row * KGP + H + col] = dU[i][rt][r];
-                        if (valid[rt][r]) dXW[(s * N + row) * (3 * H) + col] = dR;
-                        sb_r[i] += dR;
-                    }
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 drh = acc[i][nt], rg = rr[i][nt];    // exact 0 on padding nodes
+                    const f32x4 dR = drh * hp[i][nt] * rg * (1.f - rg);
+                    dhn[i][nt] += drh * rg;
+                    st4(EG + node[nt] * KGP + col, dR);
+                    st4(EG + node[nt] * KGP + H + col, dU[i][nt]);
+                    if (valid[nt]) st4(dxw + node[nt] * (3 * H) + col, dR);
+                    sb_r[i] += dR;
+                }
             }
         }
         __syncthreads();                                            // #3 [dR|dU] tile complete
         pp.mark(3);
-        lds_diffuse_tiles<true>(EG, KGP, 0, 2 * H, 2 * H, 2 * H, Pl, M, N, 32);
+        lds_diffuse_regs<M, NKS, 2 * H>(EG, KGP, pf, wave, lr, lg);
         __syncthreads();                                            // #4 P_m^T [dR|dU] complete
         pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
-        mfma_rows32<CT, KSG>(EG, KGP, lr, lg, w2, dhn);
+        mfma_nodes32<CT, KSG>(EG, KGP, lr, lg, w2, dhn);
         pp.mark(5);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -417,26 +417,33 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         }
     }
 
-    // ---- epilogue: dh0 and the per-clip bias-gradient partial sums
+    // ---- epilogue: dh0 and the per-clip bias-gradient partial sums (fixed-order node reduction)
+    __syncthreads();                                                // all waves done with EG
+    float* red = EG;                                                // [3H][16]
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ct = wave * CT + i, col = ct * 16 + lr;
+        const int ct = wave * CT + i, col = ct * 16 + 4 * lg;
         if (ct < NCT) {
             if (dh0 != nullptr) {
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (valid[rt][r]) dh0[((size_t)b * N + rowv[rt][r]) * H + col] = dh[i][rt][r];
+                for (int nt = 0; nt < 2; ++nt)
+                    if (valid[nt]) st4(dh0 + ((size_t)b * N + node[nt]) * H + col, dh[i][nt]);
             }
-            red[(0 * H + col) * 4 + lg] = sb_r[i];
-            red[(1 * H + col) * 4 + lg] = sb_u[i];
-            red[(2 * H + col) * 4 + lg] = sb_c[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(0 * H + col + r) * 16 + lr] = sb_r[i][r];
+                red[(1 * H + col + r) * 16 + lr] = sb_u[i][r];
+                red[(2 * H + col + r) * 16 + lr] = sb_c[i][r];
+            }
         }
     }
     __syncthreads();
-    for (int j = tid; j < 3 * H; j += 256)
-        dbias_part[(size_t)b * 3 * H + j] = (red[j * 4] + red[j * 4 + 1]) + (red[j * 4 + 2] + red[j * 4 + 3]);
+    for (int j = tid; j < 3 * H; j += 256) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
+        dbias_part[(size_t)b * 3 * H + j] = sacc;
+    }
     pp.dump(probe, 8);
 }
 

@@ -70,4 +70,52 @@ __device__ __forceinline__ void lds_diffuse_tiles(float* buf, int stride, int sr
     }
 }
 
+// ---- register-resident variant used by the persistent recurrent kernels -----------------------
+// The hop polynomials never change during a sequence, so each lane keeps its MFMA A-fragments of
+// all (m, row-tile) pairs in registers: pf[(m-1)*2 + rt][ks].  NKS = ceil(N/4) k-steps (5 for the
+// 19-electrode graph).
+template <int M, int NKS, bool ADJ>
+__device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[(M - 1) * 2][NKS], int lr, int lg) {
+#pragma unroll
+    for (int c = 0; c < (M - 1) * 2; ++c) {
+        const int m1 = c >> 1, rt = c & 1;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            pf[c][ks] = ADJ ? Pl[m1 * kPFloats + (4 * ks + lg) * kPStride + rt * 16 + lr]
+                            : Pl[m1 * kPFloats + (rt * 16 + lr) * kPStride + 4 * ks + lg];
+    }
+}
+
+// Diffuse the W-wide source block buf[:, 0:W) (rows = nodes) into slots m = 1..M-1 at column
+// offsets m*W.  Wave w owns column tiles ct = w, w+4, ...: it reads the NKS feature fragments of a
+// tile once and runs the (M-1)*2 independent MFMA chains (all hops x both node tiles) on them.
+// Issued transposed (features as A operand, polynomial as B operand) so that a lane ends up with
+// 4 consecutive columns of one node row: one ds_write_b128 per chain.
+template <int M, int NKS, int W>
+__device__ __forceinline__ void lds_diffuse_regs(float* buf, int stride, const float (&pf)[(M - 1) * 2][NKS],
+                                                 int wave, int lr, int lg) {
+    constexpr int NCT = W / 16, NC = (M - 1) * 2;
+#pragma unroll
+    for (int j = 0; j < (NCT + 3) / 4; ++j) {
+        const int ct = wave + 4 * j;
+        if (ct < NCT) {                                     // wave-uniform
+            float b[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + ct * 16 + lr];
+            f32x4 acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = mfma16(b[ks], pf[c][ks], acc[c]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float* d = buf + ((c & 1) * 16 + lr) * stride + ((c >> 1) + 1) * W + ct * 16 + 4 * lg;
+                *reinterpret_cast<float4*>(d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+            }
+        }
+    }
+}
+
 }  // namespace eeg

@@ -12,22 +12,31 @@
 namespace eeg {
 namespace {
 
+// NKS = k-steps of the node mix: 5 covers N <= 20 (the 19-electrode graph), 8 covers N <= 32.
+template <int H, int M, int NKS>
+int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
+    const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
+    EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS>), lds);
+    EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched,
+                 a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 template <int H, int M>
 int fwd_one(const SeqFwdArgs& a, hipStream_t st) {
-    const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
-    EEG_SET_MAX_LDS((seq_fwd_kernel<H, M>), lds);
-    EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched, a.bhg,
-               a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+    return a.N <= 20 ? fwd_nks<H, M, 5>(a, st) : fwd_nks<H, M, 8>(a, st);
+}
+template <int H, int M, int NKS>
+int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
+    const size_t lds = SeqGeom<H, M>::bwd_lds_floats() * sizeof(float);
+    EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS>), lds);
+    EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
+                 a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
+                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 template <int H, int M>
 int bwd_one(const SeqBwdArgs& a, hipStream_t st) {
-    const size_t lds = SeqGeom<H, M>::bwd_lds_floats() * sizeof(float);
-    EEG_SET_MAX_LDS((seq_bwd_kernel<H, M>), lds);
-    EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs, a.dHseq,
-               a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0, a.dbias_part,
-               a.T, a.B, a.N, a.act, a.probe);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    return a.N <= 20 ? bwd_nks<H, M, 5>(a, st) : bwd_nks<H, M, 8>(a, st);
 }
 
 }  // namespace
