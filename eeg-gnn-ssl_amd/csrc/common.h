@@ -18,6 +18,7 @@
     emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 #define EEG_SCHED_FENCE() ((void)0)
+#define EEG_WAVE_SYNC() emu::wave_sync()
 __device__ __forceinline__ long long cycle_now() { return 0; }
 #else
 #include <hip/hip_runtime.h>
@@ -30,6 +31,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 // pins the instruction order at this point (keeps hand-placed LDS prefetches ahead of the MFMAs)
 #define EEG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A wave executes in lockstep and its LDS operations complete in order, so data a wave wrote to LDS
+// is visible to its own later LDS reads; this only stops the compiler from reordering across it.
+#define EEG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 __device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 

@@ -38,8 +38,7 @@ struct SeqGeom {
     static constexpr int KG = M * 2 * H, KGP = lds_stride_q(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
     static constexpr int NGT = 2 * H / 16, NCT = H / 16;                         // gate / cand col tiles
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
-    static constexpr int US = H + 4;
-    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + 32 * US; }
+    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP; }
     static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP; }
 };
 
@@ -116,34 +115,33 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
     float* __restrict__ RHs, int T, int B, int N, int act, long long* probe) {
     using G = SeqGeom<H, M>;
-    constexpr int KAP = G::KAP, KS = G::KS, GT = G::GT, CT = G::CT, NGT = G::NGT, NCT = G::NCT, US = G::US;
+    constexpr int KAP = G::KAP, KS = G::KS, CT = G::CT, NGT = G::NGT, NCT = G::NCT;
     PhaseProbe pp;
     pp.start(probe);
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
     float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
-    float* Ub = A2 + 32 * KAP;              // [32][US]   update gate
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x;
     const bool save = Rs != nullptr;
 
+    // Wave w owns column tiles ct = w + 4*i of r, u, c and h (so gate tiles ct and NCT+ct): the
+    // epilogue -> diffusion hand-offs are wave-local and u never leaves registers.
     // recurrent weights -> registers (MFMA fragments), once for all T steps
-    float wg[GT][KS], wc[CT][KS];
-#pragma unroll
-    for (int i = 0; i < GT; ++i) {
-        const int ct = wave * GT + i < NGT ? wave * GT + i : 0;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wg[i][ks] = bhg[((size_t)ks * NGT + ct) * 64 + lane];
-    }
+    float wr[CT][KS], wu[CT][KS], wc[CT][KS];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
+        const int ct = wave + 4 * i < NCT ? wave + 4 * i : 0;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) wc[i][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) {
+            wr[i][ks] = bhg[((size_t)ks * NGT + ct) * 64 + lane];
+            wu[i][ks] = bhg[((size_t)ks * NGT + NCT + ct) * 64 + lane];
+            wc[i][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
+        }
     }
 
-    for (int e = tid; e < 2 * 32 * KAP + 32 * US; e += 256) A[e] = 0.f;
+    for (int e = tid; e < 2 * 32 * KAP; e += 256) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
     float pf[(M - 1) * 2][NKS];
@@ -157,86 +155,90 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const bool valid[2] = {lr < N, 16 + lr < N};
     const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int oxw[CT][2], oh[CT][2];              // 32-bit element offsets inside one time step
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ct = wave + 4 * i < NCT ? wave + 4 * i : 0;
+            oxw[i][nt] = nodec[nt] * (3 * H) + ct * 16 + 4 * lg;
+            oh[i][nt] = nodec[nt] * H + ct * 16 + 4 * lg;
+        }
 
+    auto diffuse_own = [&](float* buf) {       // hop-diffuse this wave's own column tiles of buf
+        EEG_WAVE_SYNC();
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+            if (wave + 4 * i < NCT) lds_diffuse_tile<M, NKS>(buf, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
+    };
+    diffuse_own(A);                                                 // hops(h_0)
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
         const float* xw = XW + s * N * (3 * H);
         // this step's hoisted pre-activations (added in the epilogues: a whole GEMM to land)
-        f32x4 xg[GT][2], xc[CT][2], ag[GT][2], ac[CT][2];
+        f32x4 xr[CT][2], xu[CT][2], xc[CT][2], ar[CT][2], au[CT][2], ac[CT][2], ug[CT][2];
 #pragma unroll
-        for (int i = 0; i < GT; ++i) {
-            const int ct = wave * GT + i < NGT ? wave * GT + i : 0;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                ag[i][nt] = zero4;
-                xg[i][nt] = ld4(xw + nodec[nt] * (3 * H) + ct * 16 + 4 * lg);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
+        for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                ac[i][nt] = zero4;
-                xc[i][nt] = ld4(xw + nodec[nt] * (3 * H) + 2 * H + ct * 16 + 4 * lg);
+                ar[i][nt] = zero4; au[i][nt] = zero4; ac[i][nt] = zero4;
+                xr[i][nt] = ld4(xw + oxw[i][nt]);
+                xu[i][nt] = ld4(xw + oxw[i][nt] + H);
+                xc[i][nt] = ld4(xw + oxw[i][nt] + 2 * H);
             }
-        }
-
-        lds_diffuse_regs<M, NKS, H>(A, KAP, pf, wave, lr, lg);
-        __syncthreads();                                            // (b) hops(h) complete
+        __syncthreads();                                            // (1) hops(h) complete
         pp.mark(0);
 
-        // gate GEMM: (2H cols) x (32 nodes), K = M*H; this wave: GT col tiles x 2 node tiles
-        mfma_nodes32<GT, KS>(A, KAP, lr, lg, wg, ag);
+        // gate GEMM: (2H cols) x (32 nodes), K = M*H
+        mfma_nodes32<CT, KS>(A, KAP, lr, lg, wr, ar);
+        mfma_nodes32<CT, KS>(A, KAP, lr, lg, wu, au);
         pp.mark(1);
         float* r_t = Rs + s * N * H;
         float* rh_t = RHs + s * N * H;
         float* u_t = Us + s * N * H;
 #pragma unroll
-        for (int i = 0; i < GT; ++i) {
-            const int ct = wave * GT + i;
-            if (ct < NGT) {                                          // wave-uniform
-                const bool is_r = ct < NCT;
-                const int col = (is_r ? ct : ct - NCT) * 16 + 4 * lg;
+        for (int i = 0; i < CT; ++i) {
+            const int ct = wave + 4 * i;
+            if (ct < NCT) {                                          // wave-uniform
+                const int col = ct * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 g;
+                    f32x4 rg, u;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) g[r] = sigmoidf_(ag[i][nt][r] + xg[i][nt][r]);
-                    if (is_r) {
-                        f32x4 rh = g * ld4(A + node[nt] * KAP + col);
-                        rh = valid[nt] ? rh : zero4;
-                        st4(A2 + node[nt] * KAP + col, rh);
-                        if (save && valid[nt]) {
-                            st4(r_t + node[nt] * H + col, g);
-                            st4(rh_t + node[nt] * H + col, rh);
-                        }
-                    } else {
-                        st4(Ub + node[nt] * US + col, g);
-                        if (save && valid[nt]) st4(u_t + node[nt] * H + col, g);
+                    for (int r = 0; r < 4; ++r) {
+                        rg[r] = sigmoidf_(ar[i][nt][r] + xr[i][nt][r]);
+                        u[r] = sigmoidf_(au[i][nt][r] + xu[i][nt][r]);
+                    }
+                    ug[i][nt] = u;
+                    f32x4 rh = rg * ld4(A + node[nt] * KAP + col);
+                    rh = valid[nt] ? rh : zero4;
+                    st4(A2 + node[nt] * KAP + col, rh);
+                    if (save && valid[nt]) {
+                        st4(r_t + oh[i][nt], rg);
+                        st4(rh_t + oh[i][nt], rh);
+                        st4(u_t + oh[i][nt], u);
                     }
                 }
             }
         }
-        __syncthreads();                                            // (c) r*h and u complete
         pp.mark(2);
-        lds_diffuse_regs<M, NKS, H>(A2, KAP, pf, wave, lr, lg);
-        __syncthreads();                                            // (d) hops(r*h) complete
+        diffuse_own(A2);                                            // own column tiles: no barrier needed
+        __syncthreads();                                            // (2) hops(r*h) complete
         pp.mark(3);
 
-        // candidate GEMM: (H cols) x (32 nodes), K = M*H; this wave: CT col tiles x 2 node tiles
+        // candidate GEMM: (H cols) x (32 nodes), K = M*H
         mfma_nodes32<CT, KS>(A2, KAP, lr, lg, wc, ac);
         pp.mark(4);
         float* h_t = Hseq + s * N * H;
         float* c_t = Cs + s * N * H;
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ct = wave * CT + i;
+            const int ct = wave + 4 * i;
             if (ct < NCT) {
                 const int col = ct * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 u = ld4(Ub + node[nt] * US + col), h = ld4(A + node[nt] * KAP + col);
+                    const f32x4 u = ug[i][nt], h = ld4(A + node[nt] * KAP + col);
                     f32x4 c, hn;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -247,14 +249,16 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                     hn = valid[nt] ? hn : zero4;
                     st4(A + node[nt] * KAP + col, hn);
                     if (valid[nt]) {
-                        st4(h_t + node[nt] * H + col, hn);
-                        if (save) st4(c_t + node[nt] * H + col, c);
+                        st4(h_t + oh[i][nt], hn);
+                        if (save) st4(c_t + oh[i][nt], c);
                     }
                 }
             }
         }
-        __syncthreads();                                            // (a) h_t complete
         pp.mark(5);
+        // hops(h_t) of the own column tiles for the next step (their slot-0 source was just written by
+        // this wave; other waves only read A2 until barrier (1) of the next step)
+        if (t + 1 < T) diffuse_own(A);
     }
     pp.dump(probe, 0);
 }
@@ -279,10 +283,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     const int b = blockIdx.x;
 
+    // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
+    // the 2H-wide gate gradient): all elementwise -> diffusion hand-offs are wave-local.
     float w1[CT][KS], w2[CT][KSG];
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ct = wave * CT + i < NCT ? wave * CT + i : 0;
+        const int ct = wave + 4 * i < NCT ? wave + 4 * i : 0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) w1[i][ks] = b1p[((size_t)ks * NCT + ct) * 64 + lane];
 #pragma unroll
@@ -299,6 +305,18 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     const bool valid[2] = {lr < N, 16 + lr < N};
     const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int oh[CT][2], oxw[CT][2];              // 32-bit element offsets inside one time step
+    bool own[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+        own[i] = wave + 4 * i < NCT;
+        const int ct = own[i] ? wave + 4 * i : 0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            oh[i][nt] = nodec[nt] * H + ct * 16 + 4 * lg;
+            oxw[i][nt] = node[nt] * (3 * H) + ct * 16 + 4 * lg;
+        }
+    }
 
     f32x4 dh[CT][2], sb_r[CT], sb_u[CT], sb_c[CT];
 #pragma unroll
@@ -309,32 +327,31 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     }
 
     const size_t tstride = (size_t)B * N * H;
+    const size_t boff = (size_t)b * N * H;
     // operands of step t are fetched during step t+1 (one step ahead): h_{t-1}, r, u, c and the
     // external gradient of h_t (dHseq + d_at_end + d_at_len); padding nodes read a valid row.
     f32x4 nh[CT][2], nr[CT][2], nu[CT][2], nc[CT][2], ng[CT][2];
     auto fetch = [&](int t) {
-        const size_t s = (size_t)t * B + b;
+        const size_t so = (size_t)t * tstride + boff;            // wave-uniform element offset of step t
+        const float* hs = t > 0 ? Hseq + (so - tstride) : (h0 != nullptr ? h0 + boff : nullptr);
 #pragma unroll
-        for (int i = 0; i < CT; ++i) {
-            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + 4 * lg;
+        for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const size_t e = (s * N + nodec[nt]) * H + col, eb = ((size_t)b * N + nodec[nt]) * H + col;
-                nh[i][nt] = t > 0 ? ld4(Hseq + e - tstride) : (h0 != nullptr ? ld4(h0 + eb) : zero4);
-                nr[i][nt] = ld4(Rs + e);
-                nu[i][nt] = ld4(Us + e);
-                nc[i][nt] = ld4(Cs + e);
-                f32x4 g = dHseq != nullptr ? ld4(dHseq + e) : zero4;
-                if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + eb);
-                if (t == t_len) g += ld4(d_at_len + eb);
+                const int o = oh[i][nt];
+                nh[i][nt] = hs != nullptr ? ld4(hs + o) : zero4;
+                nr[i][nt] = ld4(Rs + so + o);
+                nu[i][nt] = ld4(Us + so + o);
+                nc[i][nt] = ld4(Cs + so + o);
+                f32x4 g = dHseq != nullptr ? ld4(dHseq + so + o) : zero4;
+                if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + boff + o);
+                if (t == t_len) g += ld4(d_at_len + boff + o);
                 ng[i][nt] = g;
             }
-        }
     };
     fetch(T - 1);
     for (int t = T - 1; t >= 0; --t) {
-        const size_t s = (size_t)t * B + b;
-        float* dxw = dXW + s * N * (3 * H);
+        float* dxw = dXW + ((size_t)t * B + b) * N * (3 * H);
         f32x4 hp[CT][2], rr[CT][2], dU[CT][2], dhn[CT][2], uu[CT][2], cc[CT][2], gg[CT][2];
 #pragma unroll
         for (int i = 0; i < CT; ++i)
@@ -346,10 +363,10 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         // ---- E1: gate blend backward on the owned elements (padding nodes zeroed)
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ctv = wave * CT + i, ct = ctv < NCT ? ctv : 0, col = ct * 16 + 4 * lg;
+            const int col = (own[i] ? wave + 4 * i : 0) * 16 + 4 * lg;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const bool ok = valid[nt] && ctv < NCT;
+                const bool ok = valid[nt] && own[i];
                 const f32x4 h = hp[i][nt], u = uu[i][nt], c = cc[i][nt];
                 const f32x4 g = ok ? dh[i][nt] + gg[i][nt] : zero4;
                 f32x4 dC, du_;
@@ -359,10 +376,10 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
                     du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
                 }
-                if (ctv < NCT) st4(EC + node[nt] * KAP + col, dC);            // zeros on padding nodes
+                if (own[i]) st4(EC + node[nt] * KAP + col, dC);              // zeros on padding nodes
                 if (ok) {
-                    st4(dxw + node[nt] * (3 * H) + 2 * H + col, dC);
-                    st4(dxw + node[nt] * (3 * H) + H + col, du_);
+                    st4(dxw + oxw[i][nt] + 2 * H, dC);
+                    st4(dxw + oxw[i][nt] + H, du_);
                 }
                 sb_c[i] += dC;
                 sb_u[i] += du_;
@@ -370,10 +387,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                 dhn[i][nt] = g * u;
             }
         }
-        __syncthreads();                                            // #1 dC tile complete
         pp.mark(0);
-        lds_diffuse_regs<M, NKS, H>(EC, KAP, pf, wave, lr, lg);
-        __syncthreads();                                            // #2 P_m^T dC complete
+        EEG_WAVE_SYNC();
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+            if (own[i]) lds_diffuse_tile<M, NKS>(EC, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
+        __syncthreads();                                            // (1) P_m^T dC complete
         pp.mark(1);
 
         // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T (M*H x H)
@@ -387,8 +406,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         pp.mark(2);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
-            const int ct = wave * CT + i, col = ct * 16 + 4 * lg;
-            if (ct < NCT) {                                          // wave-uniform
+            if (own[i]) {                                            // wave-uniform
+                const int col = (wave + 4 * i) * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const f32x4 drh = acc[i][nt], rg = rr[i][nt];    // exact 0 on padding nodes
@@ -396,15 +415,20 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     dhn[i][nt] += drh * rg;
                     st4(EG + node[nt] * KGP + col, dR);
                     st4(EG + node[nt] * KGP + H + col, dU[i][nt]);
-                    if (valid[nt]) st4(dxw + node[nt] * (3 * H) + col, dR);
+                    if (valid[nt]) st4(dxw + oxw[i][nt], dR);
                     sb_r[i] += dR;
                 }
             }
         }
-        __syncthreads();                                            // #3 [dR|dU] tile complete
         pp.mark(3);
-        lds_diffuse_regs<M, NKS, 2 * H>(EG, KGP, pf, wave, lr, lg);
-        __syncthreads();                                            // #4 P_m^T [dR|dU] complete
+        EEG_WAVE_SYNC();
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+            if (own[i]) {
+                lds_diffuse_tile<M, NKS>(EG, KGP, (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
+                lds_diffuse_tile<M, NKS>(EG, KGP, H + (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
+            }
+        __syncthreads();                                            // (2) P_m^T [dR|dU] complete
         pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
@@ -422,12 +446,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float* red = EG;                                                // [3H][16]
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-        const int ct = wave * CT + i, col = ct * 16 + 4 * lg;
-        if (ct < NCT) {
+        if (own[i]) {
+            const int col = (wave + 4 * i) * 16 + 4 * lg;
             if (dh0 != nullptr) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    if (valid[nt]) st4(dh0 + ((size_t)b * N + node[nt]) * H + col, dh[i][nt]);
+                    if (valid[nt]) st4(dh0 + boff + node[nt] * H + col, dh[i][nt]);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -86,35 +86,31 @@ __device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[(M 
     }
 }
 
-// Diffuse the W-wide source block buf[:, 0:W) (rows = nodes) into slots m = 1..M-1 at column
-// offsets m*W.  Wave w owns column tiles ct = w, w+4, ...: it reads the NKS feature fragments of a
-// tile once and runs the (M-1)*2 independent MFMA chains (all hops x both node tiles) on them.
-// Issued transposed (features as A operand, polynomial as B operand) so that a lane ends up with
-// 4 consecutive columns of one node row: one ds_write_b128 per chain.
-template <int M, int NKS, int W>
-__device__ __forceinline__ void lds_diffuse_regs(float* buf, int stride, const float (&pf)[(M - 1) * 2][NKS],
-                                                 int wave, int lr, int lg) {
-    constexpr int NCT = W / 16, NC = (M - 1) * 2;
+// Diffuse ONE 16-column tile: source buf[:, src_col : src_col+16) (rows = nodes) -> slots
+// m = 1..M-1 at columns src_col + m*slot_w.  The wave reads the NKS feature fragments once and runs
+// the (M-1)*2 independent MFMA chains (all hops x both node tiles) on them.  Issued transposed
+// (features as A operand, polynomial as B operand) so that a lane ends up with 4 consecutive
+// columns of one node row: one ds_write_b128 per chain.
+// Wave-local use: when the source tile was written by this same wave, only EEG_WAVE_SYNC() (no
+// workgroup barrier) is needed before the call.
+template <int M, int NKS>
+__device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src_col, int slot_w,
+                                                 const float (&pf)[(M - 1) * 2][NKS], int lr, int lg) {
+    constexpr int NC = (M - 1) * 2;
+    float b[NKS];
 #pragma unroll
-    for (int j = 0; j < (NCT + 3) / 4; ++j) {
-        const int ct = wave + 4 * j;
-        if (ct < NCT) {                                     // wave-uniform
-            float b[NKS];
+    for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + src_col + lr];
+    f32x4 acc[NC];
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + ct * 16 + lr];
-            f32x4 acc[NC];
+    for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(b[ks], pf[c][ks], acc[c]);
 #pragma unroll
-                for (int c = 0; c < NC; ++c) acc[c] = mfma16(b[ks], pf[c][ks], acc[c]);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                float* d = buf + ((c & 1) * 16 + lr) * stride + ((c >> 1) + 1) * W + ct * 16 + 4 * lg;
-                *reinterpret_cast<float4*>(d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
-            }
-        }
+    for (int c = 0; c < NC; ++c) {
+        float* d = buf + ((c & 1) * 16 + lr) * stride + ((c >> 1) + 1) * slot_w + src_col + 4 * lg;
+        *reinterpret_cast<float4*>(d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
     }
 }
 

@@ -38,6 +38,7 @@ struct Fiber {
     unsigned tid = 0;
     float ma = 0, mb = 0;
     f32x4 mc, md;
+    bool sync_only = false;
 };
 struct Ctx {
     dim3 tIdx, bIdx, bDim, gDim;
@@ -58,6 +59,14 @@ inline f32x4 mfma16(float a, float b, f32x4 c) {
     cur->st = WAIT_WAVE;
     yield_to_sched();
     return cur->md;
+}
+// rendezvous of the 64 lanes of a wave: stands for the lockstep execution of real hardware where
+// a wave's LDS writes are visible to its own later LDS reads without a workgroup barrier
+inline void wave_sync() {
+    cur->sync_only = true;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    cur->sync_only = false;
 }
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 }  // namespace emu
@@ -102,6 +111,16 @@ static void trampoline() {
     swapcontext(&cur->ctx, &sched_ctx);
 }
 static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
+    unsigned nsync = 0;
+    for (unsigned l = 0; l < 64; ++l) nsync += f[w0 + l].sync_only;
+    if (nsync == 64) {
+        for (unsigned l = 0; l < 64; ++l) f[w0 + l].st = RUNNABLE;
+        return;
+    }
+    if (nsync != 0) {
+        fprintf(stderr, "emu: wave mixes wave_sync() and mfma at one rendezvous\n");
+        abort();
+    }
     float A[16][4], B[4][16];
     for (unsigned l = 0; l < 64; ++l) {
         A[l & 15][l >> 4] = f[w0 + l].ma;
