@@ -136,6 +136,15 @@ int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
 
 int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M, float* planes,
                 hipStream_t st) {
+    if (N == 19 && F / 4 <= 128) {                // the EEG montage: streaming kernel (no LDS)
+        const int F4 = F / 4, SPW = 256 / F4, sB = p_batched ? B : 1, T = S / sB;
+        int ny = ceil_div(T, SPW);
+        const int want = ceil_div(4096, sB);     // ~16 workgroups per CU in total
+        if (ny > want) ny = want;
+        if (ny < 1) ny = 1;
+        EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(256), 0, st, X, P, p_batched, S, B, F, M, planes);
+        return check_launch("diffuse_fwd");
+    }
     const int FP = round_up(F, 16), FS = lds_stride(M * FP), NR = round_up(N, 4);
     const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * FS) * sizeof(float);
     if (lds > 160 * 1024) return fail("diffuse_fwd: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);

@@ -80,6 +80,51 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
     }
 }
 
+// ---- streaming forward diffusion (the HBM-roofline kernel) ------------------------------------
+// One thread = one 16-byte feature column (4 features) of one sample: it loads the N node rows of
+// that column into registers (N independent 16-byte loads in flight per thread), applies the
+// (M-1) hop polynomials with VALU FMAs and streams the results out.  All threads of a workgroup
+// work on samples of ONE graph (g = blockIdx.x), so the polynomial coefficients are wave-uniform:
+// the compiler keeps them in SGPRs (scalar loads), there is no LDS and no barrier.
+// Algorithmic bytes per sample: 4*N*F*M; VALU work 2*(M-1)*N*N*F flop is ~4x below the HBM time.
+template <int N>
+__global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __restrict__ X,
+                                                                 const float* __restrict__ P, int p_batched,
+                                                                 int S, int B, int F, int M,
+                                                                 float* __restrict__ planes) {
+    const int F4 = F / 4, SPW = 256 / F4;            // float4 columns per sample, samples per pass
+    const int tl = threadIdx.x / F4, c4 = threadIdx.x % F4;
+    const int sB = p_batched ? B : 1, g = p_batched ? blockIdx.x : 0;
+    const int T = S / sB;
+    const float* __restrict__ Pg = P + (size_t)g * (M - 1) * N * N;
+    if (tl >= SPW) return;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    float4* O4 = reinterpret_cast<float4*>(planes);
+    for (int t = blockIdx.y * SPW + tl; t < T; t += gridDim.y * SPW) {
+        const size_t s = (size_t)t * sB + g;
+        float4 x[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) x[n] = X4[(s * N + n) * F4 + c4];
+        for (int m1 = 0; m1 < M - 1; ++m1) {
+            const float* __restrict__ Pm = Pg + m1 * N * N;
+            float4* out = O4 + (((size_t)m1 * S + s) * N) * F4 + c4;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < N; ++q) {
+                    const float p = Pm[n * N + q];
+                    a.x = fmaf(p, x[q].x, a.x);
+                    a.y = fmaf(p, x[q].y, a.y);
+                    a.z = fmaf(p, x[q].z, a.z);
+                    a.w = fmaf(p, x[q].w, a.w);
+                }
+                out[(size_t)n * F4] = a;
+            }
+        }
+    }
+}
+
 // ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m -------------------
 // LDS tile [NR][ZS], NR = round_up(N,4), ZS = lds_stride(M*FP): slot m holds Z_m (cols padded to FP).
 __global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restrict__ Z, const float* __restrict__ P,
