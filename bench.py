@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the live per-kernel HIP-event timing")
+    ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning)")
     args = ap.parse_args()
 
     t_boot = time.perf_counter()
@@ -181,6 +182,9 @@ def main():
     from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib
     from eeg_gnn_ssl_amd.train_step import TrainStep
 
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.get_lib().call("eeg_dcrnn_set_tuning", int(k), int(v))
     task, filt, t_len, batch, classes = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch

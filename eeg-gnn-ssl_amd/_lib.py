@@ -30,6 +30,7 @@ _SIGNATURES = {
     "eeg_dcrnn_is_device_build": (c_int, []),
     "eeg_dcrnn_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "eeg_dcrnn_set_seq_probe": (c_int, [_FP]),
+    "eeg_dcrnn_set_tuning": (c_int, [c_int, c_int]),
     "eeg_dcrnn_prof_enable": (c_int, [c_int]),
     "eeg_dcrnn_prof_report": (c_int, [ctypes.c_char_p, c_size_t]),
     "eeg_dcrnn_hop_polys": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, _FP, c_void_p]),

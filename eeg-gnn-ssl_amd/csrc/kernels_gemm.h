@@ -122,6 +122,121 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(SegPtrs segs, int nseg, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// NN v2: same tiling, but (i) MFMAs issued transposed (weights as A operand) so a lane owns 4
+// consecutive output columns of one row -> 16-byte bias loads / C stores; (ii) register budget
+// capped so two workgroups share a CU (one hides the other's barrier / staging stalls).
+template <int NCTW, int KC>
+__global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                          const float* __restrict__ Bp, int nct_total,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ C, int ldc, int O) {
+    constexpr int KCS = lds_stride(KC), NB = 2 * NCTW, KSC = KC / 4;
+    constexpr int A_FLOATS = 128 * KCS, B_FLOATS = KSC * NB * 64;
+    constexpr int A_LD = (128 * KC / 4 + 255) / 256;
+    constexpr int B_LD = (B_FLOATS / 4 + 255) / 256;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+    const int row0 = blockIdx.x * 128, ct0 = blockIdx.y * NB;
+    const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
+
+    f32x4 acc[4][NCTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int chunk) {
+        const int seg = chunk / nchunk_seg, kc0 = (chunk % nchunk_seg) * KC;
+        const float* A = segs.p[seg];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 128 * KC / 4 && row0 + row < R)
+                v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + row) * F + kc0 + 4 * c4);
+            ra[i] = v;
+        }
+        const int gks0 = (seg * F + kc0) / 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < B_FLOATS / 4) {
+                const int ks = q / (NB * 16), rem = q % (NB * 16), ct = rem / 16, l4 = rem % 16;
+                if (ct0 + ct < nct_total)
+                    v = *reinterpret_cast<const float4*>(Bp + ((size_t)(gks0 + ks) * nct_total + ct0 + ct) * 64 + 4 * l4);
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
+            if (q < 128 * KC / 4) {
+                float* d = As + row * KCS + 4 * c4;
+                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = tid + 256 * i;
+            if (q < B_FLOATS / 4) *reinterpret_cast<float4*>(Bs + 4 * q) = rb[i];
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) gload(ch + 1);
+        const float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        const float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            float a[4], b[NCTW];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + lr) * KCS + 4 * ks + lg];
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) b[j] = Bs[(ks * NB + wc * NCTW + j) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // transposed
+        }
+        if (ch + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // lane owns row (row0 + wr*64 + i*16 + lr), columns (ct*16 + 4*lg .. +3)
+#pragma unroll
+    for (int j = 0; j < NCTW; ++j) {
+        const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr && col + 3 < O) bv = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + wr * 64 + i * 16 + lr;
+            if (row < R) {
+                float* c = C + (size_t)row * ldc + col;
+                if (col + 3 < O) {
+                    *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y,
+                                                                acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < O) c[r] = acc[i][j][r] + (bias != nullptr ? bias[col + r] : 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN: workgroup output tile = 64 k-rows (one 64-wide feature block of one hop plane) x
 // (2*NCTW*16) columns of dY; 4 waves as 2 (k) x 2 (cols), each 2 k-tiles x NCTW col tiles.
 // The reduction runs over rows [split*rows_per_split, ...) in chunks of 32 rows.

@@ -51,6 +51,9 @@ int eeg_dcrnn_prof_report(char* buf, size_t cap);
 /* Development aid: when set to a device buffer of B*4*16 int64, the recurrent kernels store the
  * shader-clock cycles each wave spent per phase (slots 0-5 forward, 8-13 backward); NULL disables. */
 int eeg_dcrnn_set_seq_probe(int64_t* probe);
+/* Development aid: integer knobs selecting kernel variants for A/B timing (key 0: 1 = first-
+ * generation NN GEMM).  Defaults (all 0) are the shipped configuration. */
+int eeg_dcrnn_set_tuning(int key, int value);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
 int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 
