@@ -130,7 +130,28 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
     return check_launch("gemm_tn");
 }
-int tn_split(int nseg, int F, int R, int* rows_per_split) {
+template <int KTW, int NCTW>
+int run_tn2(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+            float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+    constexpr int KP = KTW * 64, OT = 2 * NCTW * 16;
+    constexpr int AS = KP + ((16 - (KP % 32)) + 32) % 32, YS = OT + ((16 - (OT % 32)) + 32) % 32;
+    const size_t lds = 2 * (size_t)(32 * AS + 32 * YS) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_tn2_kernel<KTW, NCTW>), lds);
+    EEG_LAUNCH_P("gemm_tn", (gemm_tn2_kernel<KTW, NCTW>), dim3(nsplit), dim3(512), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    return check_launch("gemm_tn2");
+}
+// v2 applies when the whole K fits 4 wave-rows of KTW tiles and O % 4 == 0, H-sized columns
+bool tn2_ok(int nseg, int F, int O) {
+    const int kt = ceil_div(nseg * F, 16);
+    return g_tune[1] == 0 && F % 4 == 0 && (O == 64 || O == 128 || O == 192) && (kt <= 20 || (kt <= 32 && O <= 128));   // (8,6) would spill
+}
+int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
+    if (tn2_ok(nseg, F, O)) {                         // one workgroup per CU, equal row slices
+        int rps = round_up(ceil_div(R, 256), 32);
+        if (rps < 32) rps = 32;
+        *rows_per_split = rps;
+        return ceil_div(R, rps);
+    }
     const int blocks = nseg * ceil_div(F, 64);
     int nsplit = ceil_div(1024, blocks);
     int rps = round_up(ceil_div(R, nsplit), 32);
@@ -142,6 +163,17 @@ int tn_split(int nseg, int F, int R, int* rows_per_split) {
 // partial[nsplit][nseg*F][O] = per-split A^T dY[:, ycol0:ycol0+O]
 int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
             float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+    if (tn2_ok(nseg, F, O)) {
+        const int kt = ceil_div(nseg * F, 16);
+#define EEG_TN2(KTW)                                                                                              \
+    (O == 192 ? run_tn2<KTW, 6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st)        \
+     : O == 128 ? run_tn2<KTW, 4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st)     \
+                : run_tn2<KTW, 2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st))
+        if (kt <= 12) return EEG_TN2(3);
+        if (kt <= 20) return EEG_TN2(5);
+        return EEG_TN2(8);
+#undef EEG_TN2
+    }
     if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     if (O <= 128) return run_tn<4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
@@ -203,7 +235,7 @@ int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
 
 struct BwdWs {
     size_t dxw, dbias, hplanes, rhplanes, partial, z, total;
-    int nsplit_x, rps_x, nsplit_h, rps_h;
+    int nsplit_x, rps_x, nsplit_hg, rps_hg, nsplit_hc, rps_hc;
 };
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     BwdWs w;
@@ -213,11 +245,15 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     w.dbias = o;    o += round_up(d->B * 3 * d->H, 64);
     w.hplanes = o;  o += (size_t)(d->M - 1) * R * d->H;
     w.rhplanes = o; o += (size_t)(d->M - 1) * R * d->H;
-    w.nsplit_x = tn_split(d->M, d->Fin, (int)R, &w.rps_x);
-    w.nsplit_h = tn_split(d->M, d->H, (int)R, &w.rps_h);
+    w.nsplit_x = tn_split(d->M, d->Fin, (int)R, 3 * d->H, &w.rps_x);
+    w.nsplit_hg = tn_split(d->M, d->H, (int)R, 2 * d->H, &w.rps_hg);
+    w.nsplit_hc = tn_split(d->M, d->H, (int)R, d->H, &w.rps_hc);
     size_t px = (size_t)w.nsplit_x * d->M * d->Fin * 3 * d->H;
-    size_t ph = (size_t)w.nsplit_h * d->M * d->H * 2 * d->H;
-    w.partial = o;  o += round_up((int)(px > ph ? px : ph), 64);
+    size_t pg = (size_t)w.nsplit_hg * d->M * d->H * 2 * d->H;
+    size_t pc = (size_t)w.nsplit_hc * d->M * d->H * d->H;
+    size_t pm = px > pg ? px : pg;
+    pm = pm > pc ? pm : pc;
+    w.partial = o;  o += (pm + 63) / 64 * 64;
     w.z = o;        o += need_dx ? R * d->M * d->Fin : 0;
     w.total = o;
     return w;
@@ -391,16 +427,16 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     if (diffuse_fwd(Hext, P, d->p_batched, S, d->B, N, H, M, hpl, st)) return 1;
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hext : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
-    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_h, w.rps_h, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, 2 * H, 1, Fin, H, M, dWg, dWc);
+    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hg, M * H, 2 * H, 1, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hg)")) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     float* rpl = ws + w.rhplanes;
     if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl, st)) return 1;
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
-    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_h, w.rps_h, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_h, M * H, H, 2, Fin, H, M, dWg, dWc);
+    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hc, M * H, H, 2, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hc)")) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {

@@ -344,4 +344,113 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TN v2: ONE 8-wave workgroup accumulates the whole (nseg*F) x Ov gradient block for its row slice,
+// so every A plane row and every dY row is read from HBM exactly once per launch.
+// Waves: 4 (k) x 2 (cols); each wave KTW k-tiles x NCTW col tiles (KTW*4*16 >= nseg*F,
+// 2*NCTW*16 >= Ov).  MFMAs are issued transposed (dY fragment as A operand) so a lane owns 4
+// consecutive output columns of one k row -> 16-byte partial stores.
+// grid = nsplit; partial: [nsplit][nseg*F][Ov].
+template <int KTW, int NCTW>
+__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                          const float* __restrict__ dY, int ldy, int ycol0, int Ov,
+                                                          float* __restrict__ partial, int rows_per_split) {
+    constexpr int RC = 32, KP = KTW * 64, OT = 2 * NCTW * 16;
+    constexpr int AS = KP + ((16 - (KP % 32)) + 32) % 32;      // stride % 32 == 16
+    constexpr int YS = OT + ((16 - (OT % 32)) + 32) % 32;
+    constexpr int A_FLOATS = RC * AS, Y_FLOATS = RC * YS;
+    constexpr int A_LD = (RC * KP / 4 + 511) / 512;
+    constexpr int Y_LD = (RC * OT / 4 + 511) / 512;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wk = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+    const int Ktot = nseg * F, F4 = F / 4;
+    const int rbeg = blockIdx.x * rows_per_split;
+    const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
+
+    f32x4 acc[KTW][NCTW];
+#pragma unroll
+    for (int i = 0; i < KTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[A_LD], ry[Y_LD];
+    auto gload = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 512 * i, row = q / (KP / 4), k4 = q % (KP / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < RC * KP / 4 && r0 + row < rend && 4 * k4 < Ktot) {
+                const int seg = k4 / F4, c4 = k4 % F4;
+                v = *reinterpret_cast<const float4*>(segs.p[seg] + (size_t)(r0 + row) * F + 4 * c4);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            const int q = tid + 512 * i, row = q / (OT / 4), c4 = q % (OT / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < RC * OT / 4 && r0 + row < rend && 4 * c4 < Ov)
+                v = *reinterpret_cast<const float4*>(dY + (size_t)(r0 + row) * ldy + ycol0 + 4 * c4);
+            ry[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* At = sm + buf * (A_FLOATS + Y_FLOATS);
+        float* Ys = At + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 512 * i, row = q / (KP / 4), k4 = q % (KP / 4);
+            if (q < RC * KP / 4) *reinterpret_cast<float4*>(At + row * AS + 4 * k4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < Y_LD; ++i) {
+            const int q = tid + 512 * i, row = q / (OT / 4), c4 = q % (OT / 4);
+            if (q < RC * OT / 4) *reinterpret_cast<float4*>(Ys + row * YS + 4 * c4) = ry[i];
+        }
+    };
+
+    const int nchunks = rend > rbeg ? ceil_div(rend - rbeg, RC) : 0;
+    if (nchunks > 0) {
+        gload(rbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) gload(rbeg + (ch + 1) * RC);
+        const float* At = sm + buf * (A_FLOATS + Y_FLOATS);
+        const float* Ys = At + A_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < RC / 4; ++ks) {
+            float a[KTW], b[NCTW];
+#pragma unroll
+            for (int i = 0; i < KTW; ++i) a[i] = At[(4 * ks + lg) * AS + (wk * KTW + i) * 16 + lr];
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) b[j] = Ys[(4 * ks + lg) * YS + (wc * NCTW + j) * 16 + lr];
+#pragma unroll
+            for (int i = 0; i < KTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // D[o][k]
+        }
+        if (ch + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // lane owns k = (wk*KTW + i)*16 + lr, columns (wc*NCTW + j)*16 + 4*lg .. +3
+    float* out = partial + (size_t)blockIdx.x * Ktot * Ov;
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+        const int k = (wk * KTW + i) * 16 + lr;
+        if (k < Ktot) {
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) {
+                const int col = (wc * NCTW + j) * 16 + 4 * lg;
+                if (col < Ov)
+                    *reinterpret_cast<float4*>(out + (size_t)k * Ov + col) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    }
+}
+
 }  // namespace eeg
