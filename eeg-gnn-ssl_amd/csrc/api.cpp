@@ -90,20 +90,23 @@ int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct
     EEG_LAUNCH_P("gemm_nn", (gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn");
 }
-template <int NCTW, int KC>
+template <int NCTW, int KC, int MINB = 2, int PD = 1>
 int run_nn2(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
             float* C, int ldc, int O, hipStream_t st) {
     constexpr int KCS = lds_stride(KC), NB = 2 * NCTW;
     const size_t lds = 2 * (size_t)(128 * KCS + (KC / 4) * NB * 64) * sizeof(float);
-    EEG_SET_MAX_LDS((gemm_nn2_kernel<NCTW, KC>), lds);
+    EEG_SET_MAX_LDS((gemm_nn2_kernel<NCTW, KC, MINB, PD>), lds);
     dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
-    EEG_LAUNCH_P("gemm_nn", (gemm_nn2_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
+    EEG_LAUNCH_P("gemm_nn", (gemm_nn2_kernel<NCTW, KC, MINB, PD>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn2");
 }
 template <int NCTW>
 int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
               float* C, int ldc, int O, hipStream_t st) {
     if (g_tune[0] == 0 && ldc % 4 == 0) {            // v2 kernels (default)
+        if (g_tune[2] == 1 && F % 16 == 0) return run_nn2<NCTW, 16, 3, 1>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+        if (g_tune[2] == 2 && F % 16 == 0) return run_nn2<NCTW, 16, 2, 2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+        if (g_tune[2] == 2 && F % 20 == 0) return run_nn2<NCTW, 20, 2, 2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
         if (F % 16 == 0) return run_nn2<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
         if (F % 20 == 0) return run_nn2<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
     }
@@ -143,7 +146,7 @@ int run_tn2(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
 // v2 applies when the whole K fits 4 wave-rows of KTW tiles and O % 4 == 0, H-sized columns
 bool tn2_ok(int nseg, int F, int O) {
     const int kt = ceil_div(nseg * F, 16);
-    return g_tune[1] == 0 && F % 4 == 0 && (O == 64 || O == 128 || O == 192) && (kt <= 20 || (kt <= 32 && O <= 128));   // (8,6) would spill
+    return g_tune[1] == 0 && F % 4 == 0 && (O == 64 || O == 128 || O == 192) && kt > 12 && (kt <= 20 || (kt <= 32 && O <= 128));   // small K: v1 is faster; (8,6) would spill
 }
 int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
     if (tn2_ok(nseg, F, O)) {                         // one workgroup per CU, equal row slices

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(SegPtrs segs, int nseg, in
 // NN v2: same tiling, but (i) MFMAs issued transposed (weights as A operand) so a lane owns 4
 // consecutive output columns of one row -> 16-byte bias loads / C stores; (ii) register budget
 // capped so two workgroups share a CU (one hides the other's barrier / staging stalls).
-template <int NCTW, int KC>
-__global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg, int F, int R,
+template <int NCTW, int KC, int MINB = 2, int PD = 1>
+__global__ __launch_bounds__(256, MINB) void gemm_nn2_kernel(SegPtrs segs, int nseg, int F, int R,
                                                           const float* __restrict__ Bp, int nct_total,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ C, int ldc, int O) {
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg
 #pragma unroll
         for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[A_LD], rb[B_LD];
-    auto gload = [&](int chunk) {
+    float4 ra[PD][A_LD], rb[PD][B_LD];       // PD register sets: chunk c+1 (and c+2) in flight
+    auto gload = [&](int chunk, int set) {
         const int seg = chunk / nchunk_seg, kc0 = (chunk % nchunk_seg) * KC;
         const float* A = segs.p[seg];
 #pragma unroll
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < 128 * KC / 4 && row0 + row < R)
                 v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + row) * F + kc0 + 4 * c4);
-            ra[i] = v;
+            ra[set][i] = v;
         }
         const int gks0 = (seg * F + kc0) / 4;
 #pragma unroll
@@ -168,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg
                 if (ct0 + ct < nct_total)
                     v = *reinterpret_cast<const float4*>(Bp + ((size_t)(gks0 + ks) * nct_total + ct0 + ct) * 64 + 4 * l4);
             }
-            rb[i] = v;
+            rb[set][i] = v;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int set) {
         float* As = sm + buf * (A_FLOATS + B_FLOATS);
         float* Bs = As + A_FLOATS;
 #pragma unroll
@@ -179,22 +179,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg
             const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
             if (q < 128 * KC / 4) {
                 float* d = As + row * KCS + 4 * c4;
-                d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+                d[0] = ra[set][i].x; d[1] = ra[set][i].y; d[2] = ra[set][i].z; d[3] = ra[set][i].w;
             }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int q = tid + 256 * i;
-            if (q < B_FLOATS / 4) *reinterpret_cast<float4*>(Bs + 4 * q) = rb[i];
+            if (q < B_FLOATS / 4) *reinterpret_cast<float4*>(Bs + 4 * q) = rb[set][i];
         }
     };
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunks) gload(ch + 1);
+    auto compute = [&](int buf) {
         const float* As = sm + buf * (A_FLOATS + B_FLOATS);
         const float* Bs = As + A_FLOATS;
 #pragma unroll
@@ -209,8 +204,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nn2_kernel(SegPtrs segs, int nseg
 #pragma unroll
                 for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // transposed
         }
-        if (ch + 1 < nchunks) lstore(buf ^ 1);
-        __syncthreads();
+    };
+    gload(0, 0);
+    lstore(0, 0);
+    __syncthreads();
+    if (PD == 1) {
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int buf = ch & 1;
+            if (ch + 1 < nchunks) gload(ch + 1, 0);
+            compute(buf);
+            if (ch + 1 < nchunks) lstore(buf ^ 1, 0);
+            __syncthreads();
+        }
+    } else {
+        // distance-2 prefetch: chunk c+1 sits in register set (c+1)&1 (issued one iteration ago),
+        // chunk c+2 is issued now; a load has two MFMA phases to land before it is stored to LDS.
+        if (nchunks > 1) gload(1, PD - 1);
+        for (int ch = 0; ch < nchunks; ch += 2) {
+            if (ch + 2 < nchunks) gload(ch + 2, 0);
+            compute(0);
+            if (ch + 1 < nchunks) lstore(1, PD - 1);
+            __syncthreads();
+            if (ch + 1 < nchunks) {
+                if (ch + 3 < nchunks) gload(ch + 3, PD - 1);
+                compute(1);
+                if (ch + 2 < nchunks) lstore(0, 0);
+                __syncthreads();
+            }
+        }
     }
     // lane owns row (row0 + wr*64 + i*16 + lr), columns (ct*16 + 4*lg .. +3)
 #pragma unroll
