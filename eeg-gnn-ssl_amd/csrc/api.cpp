@@ -392,7 +392,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0
     if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
     // 3. the recurrence
     SeqFwdArgs a{XW, Hext, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs,
-                 d->T, d->B, d->N, d->act, g_seq_probe};
+                 d->T, d->B, d->N, d->act, g_seq_probe, g_tune[3]};
     return seq_fwd(H, M, a, st);
 }
 
@@ -414,7 +414,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     // 1. BPTT through the recurrence: dXW = [dR|dU|dC] per step, dh0, per-clip bias partials
     SeqBwdArgs a{Hext + state, Hext, Rs, Us, Cs, dHseq, d_at_end, d_at_len,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
-                 dXW, dh0, dbias, d->T, d->B, N, d->act, g_seq_probe};
+                 dXW, dh0, dbias, d->T, d->B, N, d->act, g_seq_probe, g_tune[3]};
     if (seq_bwd(H, M, a, st)) return 1;
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;

@@ -12,6 +12,7 @@ struct SeqFwdArgs {
     float *Hseq, *Rs, *Us, *Cs, *RHs;
     int T, B, N, act;
     long long* probe;
+    int force_generic;      // development knob: use the two-tile (padded) kernels even for N == 19
 };
 struct SeqBwdArgs {
     const float *Hseq, *h0, *Rs, *Us, *Cs, *dHseq, *d_at_end, *d_at_len;
@@ -22,6 +23,7 @@ struct SeqBwdArgs {
     float *dXW, *dh0, *dbias_part;
     int T, B, N, act;
     long long* probe;
+    int force_generic;
 };
 
 // return 0 ok, 1 unsupported M for this H, 2 launch error

@@ -39,6 +39,8 @@ struct Fiber {
     float ma = 0, mb = 0;
     f32x4 mc, md;
     bool sync_only = false;
+    int shfl_mask = -1;          // >= 0: this rendezvous is a __shfl_xor with that lane mask
+    float shfl_val = 0.f;
 };
 struct Ctx {
     dim3 tIdx, bIdx, bDim, gDim;
@@ -68,6 +70,15 @@ inline void wave_sync() {
     yield_to_sched();
     cur->sync_only = false;
 }
+// wave-collective butterfly shuffle (all 64 lanes must call it with the same mask)
+inline float shfl_xor(float v, int mask) {
+    cur->shfl_mask = mask;
+    cur->shfl_val = v;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    cur->shfl_mask = -1;
+    return cur->shfl_val;
+}
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 }  // namespace emu
 
@@ -83,6 +94,7 @@ using emu::dim3;
 #define __launch_bounds__(...)
 #define __restrict__
 inline void __syncthreads() { emu::sync_block(); }
+inline float __shfl_xor(float v, int mask) { return emu::shfl_xor(v, mask); }
 
 // hip runtime surface used by the host side of the library (device memory == host memory here)
 typedef void* hipStream_t;
@@ -119,6 +131,25 @@ static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
     }
     if (nsync != 0) {
         fprintf(stderr, "emu: wave mixes wave_sync() and mfma at one rendezvous\n");
+        abort();
+    }
+    unsigned nshfl = 0;
+    for (unsigned l = 0; l < 64; ++l) nshfl += f[w0 + l].shfl_mask >= 0;
+    if (nshfl == 64) {
+        const int mask = f[w0].shfl_mask;
+        float tmp[64];
+        for (unsigned l = 0; l < 64; ++l) {
+            if (f[w0 + l].shfl_mask != mask) { fprintf(stderr, "emu: divergent shfl masks\n"); abort(); }
+            tmp[l] = f[w0 + l].shfl_val;
+        }
+        for (unsigned l = 0; l < 64; ++l) {
+            f[w0 + l].shfl_val = tmp[(l ^ (unsigned)mask) & 63];
+            f[w0 + l].st = RUNNABLE;
+        }
+        return;
+    }
+    if (nshfl != 0) {
+        fprintf(stderr, "emu: wave mixes shfl and mfma at one rendezvous\n");
         abort();
     }
     float A[16][4], B[4][16];
