@@ -80,35 +80,41 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     }
 }
 
-// Optional in-kernel phase timer (development aid, enabled through eeg_dcrnn_set_seq_probe):
-// lane 0 of every wave accumulates shader-clock cycles per phase and stores them at the end.
+// Optional in-kernel phase timer (development aid, eeg_dcrnn_set_seq_probe): lane 0 of every wave
+// accumulates shader-clock cycles per phase.  COMPILE-TIME switch: a run-time "probe != nullptr"
+// branch directly behind an MFMA chain lets the compiler sink the first VALU read of the MFMA
+// result below the branch, where its hazard recognizer no longer pads the XDL-write -> VALU-read
+// wait states (observed on gfx950 / ROCm 7.2: components 2,3 of the accumulator read stale).
+template <bool ON>
 struct PhaseProbe {
     long long acc[6];
     long long last;
-    bool on;
-    __device__ __forceinline__ void start(const long long* p) {
-        on = p != nullptr;
+    __device__ __forceinline__ void start() {
+        if (ON) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[i] = 0;
-        last = on ? cycle_now() : 0;
+            for (int i = 0; i < 6; ++i) acc[i] = 0;
+            last = cycle_now();
+        }
     }
     __device__ __forceinline__ void mark(int k) {
-        if (on) {
+        if (ON) {
             const long long t = cycle_now();
             acc[k] += t - last;
             last = t;
         }
     }
     __device__ __forceinline__ void dump(long long* p, int slot0) {
-        if (on && (threadIdx.x & 63) == 0) {
-            long long* d = p + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + slot0;
+        if (ON) {
+            if (p != nullptr && (threadIdx.x & 63) == 0) {
+                long long* d = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 16 + slot0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) d[i] = acc[i];
+                for (int i = 0; i < 6; ++i) d[i] = acc[i];
+            }
         }
     }
 };
 
-template <int H, int M, int NKS>
+template <int H, int M, int NKS, bool PROBE = false>
 __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
@@ -116,8 +122,8 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* __restrict__ RHs, int T, int B, int N, int act, long long* probe) {
     using G = SeqGeom<H, M>;
     constexpr int KAP = G::KAP, KS = G::KS, CT = G::CT, NGT = G::NGT, NCT = G::NCT;
-    PhaseProbe pp;
-    pp.start(probe);
+    PhaseProbe<PROBE> pp;
+    pp.start();
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
     float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 }
 
 // lengths: optional int64 (B); d_at_len is added at t = lengths[b]-1, d_at_end at t = T-1.
-template <int H, int M, int NKS>
+template <int H, int M, int NKS, bool PROBE = false>
 __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     const float* __restrict__ Hseq, const float* __restrict__ h0, const float* __restrict__ Rs,
     const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     long long* probe) {
     using G = SeqGeom<H, M>;
     constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, CT = G::CT, NCT = G::NCT;
-    PhaseProbe pp;
-    pp.start(probe);
+    PhaseProbe<PROBE> pp;
+    pp.start();
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
     float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC

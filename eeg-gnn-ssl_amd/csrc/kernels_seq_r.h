@@ -119,24 +119,35 @@ __device__ __forceinline__ void mfma_nodes16(const float* __restrict__ X, int st
 template <int M, int NR, bool ADJ>
 __device__ __forceinline__ void diffuse_rem(float* buf, int stride, int src_col, int slot_w,
                                             const float* __restrict__ Pl, int lr, int lg) {
-    float b[kRNKS];
+    float b[kRNKS], v[M - 1][NR];
 #pragma unroll
     for (int ks = 0; ks < kRNKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + src_col + lr];
+    // all partial sums first (independent), then all butterflies, then the stores: nothing in
+    // between aliases the LDS tile, so the reads / shuffles pipeline instead of serialising
 #pragma unroll
-    for (int m1 = 0; m1 < M - 1; ++m1) {
-        float rem[NR];
+    for (int m1 = 0; m1 < M - 1; ++m1)
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            float v = 0.f;
+            float a = 0.f;
 #pragma unroll
             for (int ks = 0; ks < kRNKS; ++ks) {
                 const int q = 4 * ks + lg;
                 const float p = ADJ ? Pl[m1 * kPFloats + q * kPStride + 16 + j] : Pl[m1 * kPFloats + (16 + j) * kPStride + q];
-                v = fmaf(p, b[ks], v);
+                a = fmaf(p, b[ks], a);
             }
-            rem[j] = lg_allreduce(v);
+            v[m1][j] = a;
         }
-        if (lg < NR) buf[(16 + lg) * stride + (m1 + 1) * slot_w + src_col + lr] = pick<NR>(rem, lg);
+#pragma unroll
+    for (int m1 = 0; m1 < M - 1; ++m1)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[m1][j] += __shfl_xor(v[m1][j], 16);
+#pragma unroll
+    for (int m1 = 0; m1 < M - 1; ++m1)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) v[m1][j] += __shfl_xor(v[m1][j], 32);
+    if (lg < NR) {
+#pragma unroll
+        for (int m1 = 0; m1 < M - 1; ++m1) buf[(16 + lg) * stride + (m1 + 1) * slot_w + src_col + lr] = pick<NR>(v[m1], lg);
     }
 }
 // out[i] = (sum over all k) W[k][col lr of tile i] * X[node 16+lg][k]  for the lane's own node
@@ -149,30 +160,43 @@ __device__ __forceinline__ void valu_nodes_rem(const float* __restrict__ X, int 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j) rem[i][j] = 0.f;
+    f32x4 xr[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) xr[j] = ld4(pr + j * stride);
 #pragma unroll
     for (int q = 0; q < NKS / 4; ++q) {
-        f32x4 xr[NR];
+        f32x4 nx[NR];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) xr[j] = ld4(pr + j * stride + 16 * q);
+        for (int j = 0; j < NR; ++j) nx[j] = xr[j];
+        if (q + 1 < NKS / 4) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) nx[j] = ld4(pr + j * stride + 16 * (q + 1));
+        }
+        EEG_SCHED_FENCE();          // exactly one quad of node rows in flight
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < NR; ++j) rem[i][j] = fmaf(w[i][4 * q + j4], xr[j][j4], rem[i][j]);
-        EEG_SCHED_FENCE();          // one quad of node rows at a time (register budget, not speed)
+        EEG_SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < NR; ++j) xr[j] = nx[j];
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        float t[NR];
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) t[j] = lg_allreduce(rem[i][j]);
-        out[i] = pick<NR>(t, lg);
-    }
+        for (int j = 0; j < NR; ++j) rem[i][j] += __shfl_xor(rem[i][j], 16);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) rem[i][j] += __shfl_xor(rem[i][j], 32);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) out[i] = pick<NR>(rem[i], lg);
 }
 
 // ================================================================================================
-template <int H, int M, int NR>
+template <int H, int M, int NR, bool PROBE = false>
 __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
@@ -216,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
 
     if (is_tile) {
         // ===================================== TILE waves =====================================
-        PhaseProbe pp;
-        pp.start(probe);
+        PhaseProbe<PROBE> pp;
+        pp.start();
         float pf0[M - 1][kRNKS];
         load_poly_tile<M, false>(Pl, pf0, lr, lg);
         int oxw[CT], oh[CT], lt[CT];
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
 }
 
 // ================================================================================================
-template <int H, int M, int NR>
+template <int H, int M, int NR, bool PROBE = false>
 __global__ __launch_bounds__(512, 2) void seq_bwd_r_kernel(
     const float* __restrict__ Hseq, const float* __restrict__ h0, const float* __restrict__ Rs,
     const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
@@ -413,8 +437,8 @@ __global__ __launch_bounds__(512, 2) void seq_bwd_r_kernel(
 
     if (is_tile) {
         // ===================================== TILE waves =====================================
-        PhaseProbe pp;
-        pp.start(probe);
+        PhaseProbe<PROBE> pp;
+        pp.start();
         float pf0[M - 1][kRNKS];
         load_poly_tile<M, true>(Pl, pf0, lr, lg);
         int oh[CT], oxw[CT], lc[CT], lgt[CT];

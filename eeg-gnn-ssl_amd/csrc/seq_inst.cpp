@@ -17,6 +17,14 @@ namespace {
 template <int H, int M, int NKS>
 int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
+    if constexpr (H == 64 && M == 3 && NKS == 5) {
+        if (a.probe != nullptr) {
+            EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS, true>), lds);
+            EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS, true>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P,
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS>), lds);
     EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched,
                  a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
@@ -26,6 +34,14 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
 template <int H, int M, int NR>
 int fwd_r(const SeqFwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeomR<H, M>::fwd_lds_floats() * sizeof(float);
+    if constexpr (H == 64 && M == 3) {
+        if (a.probe != nullptr) {
+            EEG_SET_MAX_LDS((seq_fwd_r_kernel<H, M, NR, true>), lds);
+            EEG_LAUNCH_P("seq_fwd", (seq_fwd_r_kernel<H, M, NR, true>), dim3(a.B), dim3(512), lds, st, a.XW, a.h0, a.P,
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     EEG_SET_MAX_LDS((seq_fwd_r_kernel<H, M, NR>), lds);
     EEG_LAUNCH_P("seq_fwd", (seq_fwd_r_kernel<H, M, NR>), dim3(a.B), dim3(512), lds, st, a.XW, a.h0, a.P, a.p_batched,
                  a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
@@ -40,6 +56,15 @@ int fwd_one(const SeqFwdArgs& a, hipStream_t st) {
 template <int H, int M, int NKS>
 int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeom<H, M>::bwd_lds_floats() * sizeof(float);
+    if constexpr (H == 64 && M == 3 && NKS == 5) {
+        if (a.probe != nullptr) {
+            EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS, true>), lds);
+            EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS, true>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us,
+                         a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
+                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS>), lds);
     EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                  a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
@@ -49,6 +74,15 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
 template <int H, int M, int NR>
 int bwd_r(const SeqBwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeomR<H, M>::bwd_lds_floats() * sizeof(float);
+    if constexpr (H == 64 && M == 3) {
+        if (a.probe != nullptr) {
+            EEG_SET_MAX_LDS((seq_bwd_r_kernel<H, M, NR, true>), lds);
+            EEG_LAUNCH_P("seq_bwd", (seq_bwd_r_kernel<H, M, NR, true>), dim3(a.B), dim3(512), lds, st, a.Hseq, a.h0, a.Rs, a.Us,
+                         a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
+                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     EEG_SET_MAX_LDS((seq_bwd_r_kernel<H, M, NR>), lds);
     EEG_LAUNCH_P("seq_bwd", (seq_bwd_r_kernel<H, M, NR>), dim3(a.B), dim3(512), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                  a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
