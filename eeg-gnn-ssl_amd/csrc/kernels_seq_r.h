@@ -39,10 +39,23 @@ struct SeqGeomR {
     }
 };
 
-__device__ __forceinline__ float lg_allreduce(float v) {      // sum over the 4 lane groups
+// Sum over the 4 lane groups (lanes l, l^16, l^32, l^48); every lane gets the total.
+// gfx950: v_permlane16_swap(x, x) leaves [x0 x0 x2 x2] / [x1 x1 x3 x3] (rows of 16 lanes), so the
+// sum of the two results is the xor-16 butterfly; v_permlane32_swap likewise for xor-32: four VALU
+// instructions, no LDS crossbar round trips (ds_bpermute) on the latency-critical remainder path.
+__device__ __forceinline__ float lg_allreduce(float v) {
+#if defined(EEG_SIMT_EMU)
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     return v;
+#else
+    const unsigned x = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const float s1 = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned y = __builtin_bit_cast(unsigned, s1);
+    auto b = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+#endif
 }
 template <int NR>
 __device__ __forceinline__ float pick(const float (&v)[NR], int lg) {   // v[lg] without dynamic indexing
@@ -140,11 +153,7 @@ __device__ __forceinline__ void diffuse_rem(float* buf, int stride, int src_col,
 #pragma unroll
     for (int m1 = 0; m1 < M - 1; ++m1)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) v[m1][j] += __shfl_xor(v[m1][j], 16);
-#pragma unroll
-    for (int m1 = 0; m1 < M - 1; ++m1)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) v[m1][j] += __shfl_xor(v[m1][j], 32);
+        for (int j = 0; j < NR; ++j) v[m1][j] = lg_allreduce(v[m1][j]);
     if (lg < NR) {
 #pragma unroll
         for (int m1 = 0; m1 < M - 1; ++m1) buf[(16 + lg) * stride + (m1 + 1) * slot_w + src_col + lr] = pick<NR>(v[m1], lg);
@@ -160,19 +169,23 @@ __device__ __forceinline__ void valu_nodes_rem(const float* __restrict__ X, int 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j) rem[i][j] = 0.f;
-    f32x4 xr[NR];
+    // LDS latency (not FMA throughput) bounds this loop: keep PD quads of node rows in flight
+    constexpr int NQ = NKS / 4, PD = NQ < 3 ? NQ : 3;
+    f32x4 ring[PD][NR];
 #pragma unroll
-    for (int j = 0; j < NR; ++j) xr[j] = ld4(pr + j * stride);
+    for (int d = 0; d < PD; ++d)
 #pragma unroll
-    for (int q = 0; q < NKS / 4; ++q) {
-        f32x4 nx[NR];
+        for (int j = 0; j < NR; ++j) ring[d][j] = ld4(pr + j * stride + 16 * d);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) nx[j] = xr[j];
-        if (q + 1 < NKS / 4) {
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 xr[NR];
 #pragma unroll
-            for (int j = 0; j < NR; ++j) nx[j] = ld4(pr + j * stride + 16 * (q + 1));
+        for (int j = 0; j < NR; ++j) xr[j] = ring[q % PD][j];
+        if (q + PD < NQ) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) ring[q % PD][j] = ld4(pr + j * stride + 16 * (q + PD));
         }
-        EEG_SCHED_FENCE();          // exactly one quad of node rows in flight
+        EEG_SCHED_FENCE();
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
@@ -180,17 +193,11 @@ __device__ __forceinline__ void valu_nodes_rem(const float* __restrict__ X, int 
 #pragma unroll
                 for (int j = 0; j < NR; ++j) rem[i][j] = fmaf(w[i][4 * q + j4], xr[j][j4], rem[i][j]);
         EEG_SCHED_FENCE();
-#pragma unroll
-        for (int j = 0; j < NR; ++j) xr[j] = nx[j];
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < NR; ++j) rem[i][j] += __shfl_xor(rem[i][j], 16);
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) rem[i][j] += __shfl_xor(rem[i][j], 32);
+        for (int j = 0; j < NR; ++j) rem[i][j] = lg_allreduce(rem[i][j]);
 #pragma unroll
     for (int i = 0; i < NT; ++i) out[i] = pick<NR>(rem[i], lg);
 }
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
         pp.dump(probe, 0);
     } else {
         // ====================================== REM waves ======================================
+        EEG_SETPRIO(2);      // the younger half of the workgroup: give its VALU stream priority
         int oxw[CT], oh[CT], lt[CT];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -552,6 +560,7 @@ __global__ __launch_bounds__(512, 2) void seq_bwd_r_kernel(
         pp.dump(probe, 8);
     } else {
         // ====================================== REM waves ======================================
+        EEG_SETPRIO(2);
         int oh[CT], oxw[CT], lc[CT], lgt[CT];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
