@@ -106,7 +106,7 @@ struct PhaseProbe {
     __device__ __forceinline__ void dump(long long* p, int slot0) {
         if (ON) {
             if (p != nullptr && (threadIdx.x & 63) == 0) {
-                long long* d = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 16 + slot0;
+                long long* d = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 32 + slot0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) d[i] = acc[i];
             }

@@ -334,6 +334,8 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
     } else {
         // ====================================== REM waves ======================================
         EEG_SETPRIO(2);      // the younger half of the workgroup: give its VALU stream priority
+        PhaseProbe<PROBE> pp;
+        pp.start();
         int oxw[CT], oh[CT], lt[CT];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -354,7 +356,9 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
                 xr[i] = xw[oxw[i]]; xu[i] = xw[oxw[i] + H]; xc[i] = xw[oxw[i] + 2 * H];
             }
             __syncthreads();                                        // (1)
+            pp.mark(0);
             valu_nodes_rem<2 * CT, KS, NR>(A, KAP, lr, lg, wg, g2);
+            pp.mark(1);
             float* r_t = Rs + s * N * H;
             float* rh_t = RHs + s * N * H;
             float* u_t = Us + s * N * H;
@@ -373,11 +377,14 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
                 }
             }
             __syncthreads();                                        // (1b)
+            pp.mark(2);
 #pragma unroll
             for (int i = 0; i < CT; ++i)
                 if (own[i]) diffuse_rem<M, NR, false>(A2, KAP, (wave + 4 * i) * 16, H, Pl, lr, lg);
             __syncthreads();                                        // (2)
+            pp.mark(3);
             valu_nodes_rem<CT, KS, NR>(A2, KAP, lr, lg, wc, c1);
+            pp.mark(4);
             float* h_t = Hseq + s * N * H;
             float* c_t = Cs + s * N * H;
 #pragma unroll
@@ -392,12 +399,14 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
                 }
             }
             __syncthreads();                                        // (2b)
+            pp.mark(5);
             if (t + 1 < T) {
 #pragma unroll
                 for (int i = 0; i < CT; ++i)
                     if (own[i]) diffuse_rem<M, NR, false>(A, KAP, (wave + 4 * i) * 16, H, Pl, lr, lg);
             }
         }
+        pp.dump(probe, 16);
     }
 }
 

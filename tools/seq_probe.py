@@ -31,14 +31,15 @@ def run():
 
 
 run()
-probe = torch.zeros(batch * 4 * 16, dtype=torch.int64, device=dev)
+probe = torch.zeros(batch * 4 * 32, dtype=torch.int64, device=dev)
 lib.query("eeg_dcrnn_set_seq_probe", ctypes.c_void_p(probe.data_ptr()))
 run()          # last launches of each direction (layer 0 bwd, layer 1 fwd) leave their counters
 lib.query("eeg_dcrnn_set_seq_probe", None)
-p = probe.view(batch, 4, 16).double().cpu()
+p = probe.view(batch, 4, 32).double().cpu()
 names_f = ["diffuse(h)+bar", "gate GEMM", "gate epilogue+bar", "diffuse(rh)+bar", "cand GEMM", "cand epilogue+bar"]
 names_b = ["E1+bar", "adj diffuse dC+bar", "GEMM1", "epi1+bar", "adj diffuse dG+bar", "GEMM2"]
-for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
+names_rf = ["diffuse+loads+bar(1)", "gate VALU", "gate epi+bar(1b)", "diffuse+bar(2)", "cand VALU", "cand epi+bar(2b)"]
+for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b), ("seq_fwd REM waves", 16, names_rf)):
     tot = p[:, :, off:off + 6].sum(-1).mean().item() / t_len
     print(f"{title}: {tot:9.0f} cycles/step/wave (mean over {batch} WGs x 4 waves)")
     for k, nm in enumerate(names):
