@@ -176,7 +176,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # RCCL on ROCm
+        dist.init_process_group(backend="nccl")                     # "nccl" IS RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib
@@ -257,8 +257,15 @@ def main():
     if timed:
         dom = max(timed, key=lambda k: timed[k]["ms_per_step"])
         d = timed[dom]
+        traffic = None            # HBM bytes per launch from the committed PMC passes (same command, cfg2)
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+        for name, tb in (traffic or {}).items():
+            if name in kernels:
+                kernels[name]["traffic_bytes_per_launch_pmc"] = tb
         roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": None, "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
+                    "frac": d["frac"], "traffic": (traffic or {}).get(dom), "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
                     "kernels": kernels,
                     "kernel_ms_per_step_total": round(sum(v["ms_per_step"] for v in kernels.values()), 3),
                     "whole_step_flops": round(sum(v for k, v in work.items() if not k.startswith("diffuse")) / 1e9, 1),

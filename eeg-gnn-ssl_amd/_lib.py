@@ -38,6 +38,8 @@ _SIGNATURES = {
     "eeg_dcrnn_pack_cell": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_diffuse_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_diffuse_adj": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_dconv_fwd_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "eeg_dcrnn_dconv_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, _FP, _FP, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_layer_fwd_ws_floats": (c_size_t, [POINTER(LayerDims)]),
     "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 11 + [c_void_p]),
     "eeg_dcrnn_layer_bwd_ws_floats": (c_size_t, [POINTER(LayerDims), c_int]),
@@ -45,6 +47,11 @@ _SIGNATURES = {
     "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_bwd": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_bce_logits": (c_int, [_FP, _FP, c_int, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_ce_logits": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_clip_adam_ws_floats": (c_size_t, []),
+    "eeg_dcrnn_clip_adam": (c_int, [_FP, _FP, _FP, _FP, c_size_t, c_float, c_float, c_float, c_float, c_float, c_float,
+                                    c_int, c_float, _FP, _FP, c_void_p]),
 }
 
 

@@ -1,4 +1,5 @@
 // C ABI of libeeg_dcrnn_hip.so (see include/eeg_dcrnn.h): argument checking + kernel orchestration.
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -8,6 +9,7 @@
 #include "kernels_gemm.h"
 #include "kernels_head.h"
 #include "kernels_pack.h"
+#include "kernels_tail.h"
 #include "prof.h"
 #include "seq_launch.h"
 
@@ -469,6 +471,51 @@ int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits,
     if (check_launch("cls_head_bwd_dz")) return 1;
     EEG_LAUNCH_P("cls_head_bwd_w", cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 16)), dim3(256), 256 * sizeof(float), S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
     return check_launch("cls_head_bwd_w");
+}
+
+size_t eeg_dcrnn_dconv_fwd_ws_floats(int B, int N, int F, int M, int O) {
+    return (size_t)(M - 1) * B * N * F + (size_t)F * M * O;
+}
+int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M,
+                        const float* W, const float* bias, int O, float* out, float* ws, void* stream) {
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("dconv_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (O % 16 != 0) return fail("dconv_fwd: output_dim=%d must be a multiple of 16", O);
+    hipStream_t st = S_(stream);
+    float* planes = ws;
+    float* pack = ws + (size_t)(M - 1) * B * N * F;
+    if (diffuse_fwd(X, P, p_batched, B, B, N, F, M, planes, st)) return 1;
+    EEG_LAUNCH_P("pack_dense", pack_dense_kernel, dim3(256), dim3(256), 0, st, W, F, M, O, pack);
+    if (check_launch("pack_dense")) return 1;
+    SegPtrs segs;
+    for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * B * N * F : nullptr);
+    return gemm_nn(segs, M, F, B * N, pack, O / 16, bias, out, O, O, st);
+}
+int eeg_dcrnn_bce_logits(const float* logits, const float* y, int B, float* loss, float* dlogits, void* stream) {
+    if (B < 1) return fail("bce_logits: empty batch");
+    EEG_LAUNCH_P("loss_bce", bce_logits_kernel, dim3(1), dim3(256), 256 * sizeof(float), S_(stream), logits, y, B, loss, dlogits);
+    return check_launch("bce_logits");
+}
+int eeg_dcrnn_ce_logits(const float* logits, const int64_t* y, int B, int C, float* loss, float* dlogits, void* stream) {
+    if (B < 1 || C < 1) return fail("ce_logits: empty batch");
+    EEG_LAUNCH_P("loss_ce", ce_logits_kernel, dim3(1), dim3(256), 256 * sizeof(float), S_(stream), logits,
+                 reinterpret_cast<const long long*>(y), B, C, loss, dlogits);
+    return check_launch("ce_logits");
+}
+size_t eeg_dcrnn_clip_adam_ws_floats(void) { return 64; }
+int eeg_dcrnn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                        float grad_scale, float* ws, float* norm_out, void* stream) {
+    if (step < 1) return fail("clip_adam: step must be >= 1");
+    const int nparts = 64;
+    EEG_LAUNCH_P("grad_sqnorm", sqnorm_partial_kernel, dim3(nparts), dim3(256), 256 * sizeof(float), S_(stream), grads, n, ws);
+    if (check_launch("grad_sqnorm")) return 1;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    EEG_LAUNCH_P("clip_adam", clip_adam_kernel, dim3(blocks), dim3(256), 0, S_(stream), params, grads, exp_avg, exp_avg_sq, n,
+                 ws, nparts, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, norm_out);
+    return check_launch("clip_adam");
 }
 
 }  // extern "C"

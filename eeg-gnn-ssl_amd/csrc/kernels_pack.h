@@ -105,6 +105,19 @@ __global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __re
     }
 }
 
+// One reference-layout dconv weight ((F*M), O) row = f*M+m  ->  fragment pack with hop-major K
+// (k = m*F + f), NCT = O/16 column tiles (used by the stand-alone DiffusionGraphConv.forward).
+__global__ void pack_dense_kernel(const float* __restrict__ W, int F, int M, int O, float* __restrict__ out) {
+    const size_t total = (size_t)F * M * O;
+    const int nct = O / 16;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = e & 63, ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+        const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+        const int m = k / F, f = k % F;
+        out[e] = W[((size_t)f * M + m) * O + j];
+    }
+}
+
 // Sum split-K partials [nsplit][K][O] in fixed order (deterministic) and scatter into the
 // reference-layout gradient tensors.  kind 0: x-part (K = M*Fin, O = 3H); 1: h-gate (K = M*H,
 // O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f).

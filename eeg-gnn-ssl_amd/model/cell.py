@@ -39,19 +39,16 @@ class DiffusionGraphConv(nn.Module):
     def forward(self, supports, inputs, state, output_size, bias_start=0.0):
         """(B, N*Din), (B, N*H) -> (B, N*output_size); reference cell.py:66-118.
 
-        Forward-only convenience (no autograd): the training path never calls it.  Implemented
-        with the same HIP diffusion kernel + the reference's weight layout."""
+        Forward-only convenience (no autograd): the training path never calls it.  HIP diffusion
+        kernel + fp32-MFMA GEMM on the reference's weight layout (eeg_dcrnn_dconv_fwd)."""
         b = inputs.shape[0]
-        n, f, m = self._num_nodes, self._input_size, self._num_matrices
-        x = torch.cat([inputs.reshape(b, n, -1), state.reshape(b, n, -1)], dim=2).contiguous()
+        n, f = self._num_nodes, self._input_size
+        if f % 4 != 0:
+            raise RuntimeError(f"DiffusionGraphConv: input_dim + hid_dim = {f} must be a multiple of 4")
+        x = torch.cat([inputs.reshape(b, n, -1), state.reshape(b, n, -1)], dim=2)
         with torch.no_grad():
             p, p_batched = ops.hop_polys(supports, self._max_diffusion_step, b)
-            if f % 4 != 0:
-                raise RuntimeError(f"DiffusionGraphConv: input_dim + hid_dim = {f} must be a multiple of 4")
-            planes = ops.diffusion_hops(x, p, p_batched, b)                      # (M-1, B, N, F)
-            hops = torch.cat([x.unsqueeze(0), planes], dim=0)                    # (M, B, N, F)
-            flat = hops.permute(1, 2, 3, 0).reshape(b * n, f * m)                # row order f*M + m
-            out = torch.addmm(self.biases, flat, self.weight)
+            out = ops.dconv_forward(x, p, p_batched, self.weight, self.biases)
         return out.reshape(b, n * output_size)
 
 

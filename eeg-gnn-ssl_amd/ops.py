@@ -148,6 +148,25 @@ def diffusion_hops(x: torch.Tensor, p: torch.Tensor, p_batched: int, batch: int)
     return out
 
 
+def dconv_forward(x, p, p_batched, weight, biases):
+    """DiffusionGraphConv.forward (cell.py:66-118) on x (B,N,F): HIP diffusion + fp32-MFMA GEMM with
+    the reference-layout weight ((F*M), O).  Forward only."""
+    lib = _lib.get_lib()
+    x = x.contiguous()
+    w = weight.detach().contiguous()
+    bvec = biases.detach().contiguous()
+    for t, nm in ((x, "inputs_and_state"), (p, "P"), (w, "weight"), (bvec, "biases")):
+        _check(lib, t, nm)
+    b, n, f = x.shape
+    m, o = p.shape[1] + 1, w.shape[1]
+    if w.shape[0] != f * m:
+        raise RuntimeError(f"weight has {w.shape[0]} rows, expected (input_dim+hid_dim)*num_matrices = {f * m}")
+    out = torch.empty((b, n, o), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.query("eeg_dcrnn_dconv_fwd_ws_floats", b, n, f, m, o), dtype=torch.float32, device=x.device)
+    lib.call("eeg_dcrnn_dconv_fwd", _p(x), _p(p), p_batched, b, n, f, m, _p(w), _p(bvec), o, _p(out), _p(ws), _stream(x))
+    return out
+
+
 class _DCGRULayerFn(torch.autograd.Function):
     """One DCGRU layer over a whole sequence (the `for t` loop of model.py:93-96 around
     DCGRUCell.forward, cell.py:182-210), fwd + explicit BPTT backward in HIP.
@@ -278,3 +297,67 @@ def gather_last(htop: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
     out = torch.empty((b, d), dtype=torch.float32, device=htop.device)
     lib.call("eeg_dcrnn_gather_last", _p(htop), _p(lengths), t_len, b, d, _p(out), _stream(htop))
     return out
+
+
+class _BCELogitsFn(torch.autograd.Function):
+    """nn.BCEWithLogitsLoss() (mean): value and dlogits from one HIP launch (train.py:203-204)."""
+
+    @staticmethod
+    def forward(ctx, logits, y):
+        lib = _lib.get_lib()
+        x = logits.contiguous().view(-1)
+        yy = y.to(torch.float32).contiguous().view(-1)
+        _check(lib, x, "logits")
+        _check(lib, yy, "targets")
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        lib.call("eeg_dcrnn_bce_logits", _p(x), _p(yy), x.numel(), _p(loss), _p(dx), _stream(x))
+        ctx.save_for_backward(dx)
+        ctx.shape = logits.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dx,) = ctx.saved_tensors
+        return (dx * dloss).view(ctx.shape), None
+
+
+class _CELogitsFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) on (B,C) logits and int64 class targets (train.py:205-206)."""
+
+    @staticmethod
+    def forward(ctx, logits, y):
+        lib = _lib.get_lib()
+        x = logits.contiguous()
+        yy = y.to(torch.int64).contiguous()
+        _check(lib, x, "logits")
+        _check(lib, yy, "targets", torch.int64)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        lib.call("eeg_dcrnn_ce_logits", _p(x), _p(yy), x.shape[0], x.shape[1], _p(loss), _p(dx), _stream(x))
+        ctx.save_for_backward(dx)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dx,) = ctx.saved_tensors
+        return dx * dloss, None
+
+
+def bce_with_logits(logits, y):
+    return _BCELogitsFn.apply(logits, y)
+
+
+def cross_entropy(logits, y):
+    return _CELogitsFn.apply(logits, y)
+
+
+def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, max_norm, grad_scale, ws,
+                   norm_out=None):
+    """Fused clip_grad_norm_ + Adam (coupled L2) over flat fp32 buffers (train.py:273-275)."""
+    lib = _lib.get_lib()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _check(lib, t, nm)
+    lib.call("eeg_dcrnn_clip_adam", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), float(max_norm),
+             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale),
+             _p(ws), _p(norm_out), _stream(params))

@@ -57,17 +57,21 @@ class TrainStep:
         assert task in ("detection", "classification", "ssl")
         self.model, self.task, self.max_grad_norm = model, task, max_grad_norm
         self.fp = FlatParameters(model)
-        # one flat tensor -> one fused Adam kernel on the GPU (foreach would launch ~8 tiny kernels)
-        fused = self.fp.flat.is_cuda
-        self.opt = torch.optim.Adam([self.fp.flat_param], lr=lr, weight_decay=weight_decay, fused=fused)
+        # optimiser state lives in flat buffers; the update is ONE fused HIP kernel (clip + Adam)
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, (0.9, 0.999), 1e-8
+        self.exp_avg = torch.zeros_like(self.fp.flat)
+        self.exp_avg_sq = torch.zeros_like(self.fp.flat)
+        self.ws = torch.zeros(64, device=self.fp.flat.device, dtype=torch.float32)
+        self.grad_norm = torch.zeros(1, device=self.fp.flat.device, dtype=torch.float32)
+        self.step_count = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
 
     def loss(self, out, y):
         if self.task == "detection":        # train.py:203-204,266-267
-            return torch.nn.functional.binary_cross_entropy_with_logits(out.view(-1), y)
+            return ops.bce_with_logits(out.view(-1), y)
         if self.task == "classification":   # train.py:205-206,268
-            return torch.nn.functional.cross_entropy(out, y)
+            return ops.cross_entropy(out, y)
         from . import utils                 # train_ssl.py:165-170 ("MAE" -> masked RMSE, Q9)
         sc = None if self.scaler_mean is None else utils.StandardScaler(self.scaler_mean, self.scaler_std)
         return utils.compute_regression_loss(y_true=y, y_predicted=out, standard_scaler=sc, loss_fn="MAE")
@@ -86,12 +90,12 @@ class TrainStep:
         g = self.fp.flat_grad
         if self.world > 1:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)        # RCCL over xGMI: one flat bucket
-            g.div_(self.world)
-        norm = torch.linalg.vector_norm(g)
-        g.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))   # == clip_grad_norm_
-        self.opt.step()
+        self.step_count += 1
+        # mean over ranks (grad_scale), clip_grad_norm_(max_norm) and Adam in one pass over the buffers
+        ops.clip_adam_step(self.fp.flat, g, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas,
+                           self.eps, self.weight_decay, self.max_grad_norm, 1.0 / self.world, self.ws, self.grad_norm)
         ops.new_forward_scope()          # parameters changed through the flat alias: drop weight packs
-        return norm
+        return self.grad_norm
 
     def step(self, x, y, seq_lengths, supports):
         loss = self.forward_backward(x, y, seq_lengths, supports)

@@ -77,6 +77,12 @@ int eeg_dcrnn_diffuse_fwd(const float* X, const float* P, int p_batched, int S, 
 int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F,
                           int M, float* dX, void* stream);
 
+/* DiffusionGraphConv.forward (cell.py:66-118) on its own: X (B,N,F) = [inputs | state] per node,
+ * W ((F*M), O) and bias (O) in reference layout, out (B,N,O).  Forward only. */
+size_t eeg_dcrnn_dconv_fwd_ws_floats(int B, int N, int F, int M, int O);
+int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M,
+                        const float* W, const float* bias, int O, float* out, float* ws, void* stream);
+
 /* One DCGRU layer over a whole sequence = the `for t` loop of model.py:93-96 around
  * DCGRUCell.forward (cell.py:182-210).  h0 may be NULL (zeros).  Rs/Us/Cs/RHs may all be NULL
  * (inference: nothing saved).  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch. */
@@ -106,6 +112,20 @@ int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, in
                            int C, float* logits, int32_t* arg, void* stream);
 int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg,
                            int B, int N, int H, int C, float* dz, float* dW, float* dbias, void* stream);
+
+/* Losses that seed backward (train.py:203-206,266-268), value + gradient in one launch:
+ * nn.BCEWithLogitsLoss() on logits (B,) / nn.CrossEntropyLoss() on logits (B,C); loss[0] = mean. */
+int eeg_dcrnn_bce_logits(const float* logits, const float* y, int B, float* loss, float* dlogits, void* stream);
+int eeg_dcrnn_ce_logits(const float* logits, const int64_t* y, int B, int C, float* loss, float* dlogits,
+                        void* stream);
+/* clip_grad_norm_(max_norm) + torch.optim.Adam(lr, betas, eps, weight_decay = coupled L2) step
+ * `step` (1-based) over flat fp32 buffers of n elements (train.py:222-223,273-275).  grads are
+ * first multiplied by grad_scale (1/world_size after a summed all-reduce).  ws: 64 floats scratch;
+ * norm_out (nullable) receives the pre-clip gradient norm.  Deterministic (fixed-order sums). */
+size_t eeg_dcrnn_clip_adam_ws_floats(void);
+int eeg_dcrnn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                        int step, float grad_scale, float* ws, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

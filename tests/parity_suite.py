@@ -189,3 +189,49 @@ def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3
     assert_close(lg.detach().cpu().numpy(), lo.detach().numpy(), "logits vs oracle")
     for k, p in model.named_parameters():
         assert_close_scaled(p.grad.cpu().numpy(), po[k].grad.numpy(), f"d_{k} vs oracle", tol=5e-5)
+
+
+def check_training_tail(device):
+    """HIP loss kernels and the fused clip+Adam step vs their torch definitions
+    (train.py:203-206,273-275: BCEWithLogits / CrossEntropy, clip_grad_norm_(5), Adam + coupled L2)."""
+    from eeg_gnn_ssl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, generator=g)
+    y = (torch.rand(37, generator=g) > 0.5).float()
+    xd = x.to(device).requires_grad_(True)
+    loss = ops.bce_with_logits(xd, y.to(device))
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, y)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert_close_scaled(xd.grad.cpu().numpy(), xr.grad.numpy(), "bce dlogits", tol=1e-5)
+    x = torch.randn(21, 4, generator=g)
+    yc = torch.randint(0, 4, (21,), generator=g)
+    xd = x.to(device).requires_grad_(True)
+    loss = ops.cross_entropy(xd, yc.to(device))
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, yc)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert_close_scaled(xd.grad.cpu().numpy(), xr.grad.numpy(), "ce dlogits", tol=1e-5)
+    n = 70001
+    p0 = torch.randn(n, generator=g)
+    pd = p0.to(device).clone()
+    m = torch.zeros(n, device=device)
+    v = torch.zeros(n, device=device)
+    ws = torch.zeros(64, device=device)
+    norm = torch.zeros(1, device=device)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=3e-3, weight_decay=5e-4)
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=g) * (0.001 if step == 3 else 0.05)      # step 3: no clipping
+        gd = gr.to(device).clone()
+        ops.clip_adam_step(pd, gd, m, v, step, 3e-3, (0.9, 0.999), 1e-8, 5e-4, 5.0, 1.0, ws, norm)
+        pr.grad = gr.clone()
+        nr = torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        opt.step()
+        assert abs(norm.item() - nr.item()) <= 1e-4 * max(1.0, nr.item())
+        assert_close_scaled(gd.cpu().numpy(), pr.grad.numpy(), f"clipped grad step {step}", tol=1e-5)
+        assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6, step

@@ -38,3 +38,7 @@ def test_ssl_model(tag, golden, adj3d):
 
 def test_random_vs_oracle_h32_relu_varlen(adj3d):
     ps.check_vs_oracle_random("cpu", "dual_random_walk", 12, 32, 2, 4, 3, 4, adj3d, seed=3, lengths=[4, 2, 1], act="relu")
+
+
+def test_training_tail_kernels():
+    ps.check_training_tail("cpu")

@@ -176,3 +176,7 @@ def test_training_reduces_loss_and_auroc_on_synthetic_labels():
         prob = torch.sigmoid(model(xd, ld, supd)).view(-1).cpu().numpy()
     auc = roc_auc_score(y.numpy(), prob)
     assert losses[-1] < losses[0] and auc > 0.7, (losses[0], losses[-1], auc)
+
+
+def test_training_tail_kernels():
+    ps.check_training_tail(DEV)
