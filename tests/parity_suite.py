@@ -198,20 +198,20 @@ def check_training_tail(device):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(37, generator=g)
     y = (torch.rand(37, generator=g) > 0.5).float()
-    xd = x.to(device).requires_grad_(True)
+    xd = x.clone().to(device).requires_grad_(True)
     loss = ops.bce_with_logits(xd, y.to(device))
     loss.backward()
-    xr = x.clone().requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
     ref = torch.nn.functional.binary_cross_entropy_with_logits(xr, y)
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-6
     assert_close_scaled(xd.grad.cpu().numpy(), xr.grad.numpy(), "bce dlogits", tol=1e-5)
     x = torch.randn(21, 4, generator=g)
     yc = torch.randint(0, 4, (21,), generator=g)
-    xd = x.to(device).requires_grad_(True)
+    xd = x.clone().to(device).requires_grad_(True)
     loss = ops.cross_entropy(xd, yc.to(device))
     loss.backward()
-    xr = x.clone().requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
     ref = torch.nn.functional.cross_entropy(xr, yc)
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-6
