@@ -37,12 +37,15 @@ WORKLOADS = {
     "cfg3": ("detection", "dual_random_walk", 60, 256, 1),
     "cfg4": ("classification", "laplacian", 60, 256, 4),
     "cfg1": ("detection", "laplacian", 12, 4, 1),
+    "cfg5": ("ssl", "dual_random_walk", 60, 512, 0),
 }
+T_OUT = 12        # SSL prediction horizon (args.py:52-56)
 DESCR = {
     "cfg2": "BASELINE cfg2: DCRNN detection, distance graph, clip_len=60, batch=256/GPU, K=2, 2x64, synthetic FFT inputs",
     "cfg3": "BASELINE cfg3: DCRNN detection, correlation graph (per-clip adj), clip_len=60, batch=256/GPU",
     "cfg4": "BASELINE cfg4: DCRNN 4-class classification, distance graph, clip_len=60, batch=256/GPU (2048 over 8)",
     "cfg1": "BASELINE cfg1: DCRNN detection, distance graph, clip_len=12, batch=4 (plumbing)",
+    "cfg5": "BASELINE cfg5: SSL seq2seq pretrain (encoder 60 s + decoder 12 s), correlation graph, batch=512/GPU (4096 over 8)",
 }
 
 
@@ -68,7 +71,9 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed):
     else:
         lengths = torch.full((batch,), t_len, dtype=torch.int64)
     stat = x[:, :, :, :10].mean(dim=(1, 2, 3))
-    if classes == 1:
+    if task == "ssl":
+        y = torch.randn(batch, T_OUT, N_NODES, D_IN, generator=g)     # independent next clip (loss parity only)
+    elif classes == 1:
         y = (stat > 0).float()
     else:
         q = torch.quantile(stat, torch.tensor([0.25, 0.5, 0.75]))
@@ -89,7 +94,7 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed):
     return x, y, lengths, supports
 
 
-def algorithmic_work(filter_type, t_len, batch):
+def algorithmic_work(filter_type, t_len, batch, task="detection"):
     """Per-step algorithmic FLOPs / bytes of every kernel class."""
     m = (2 if filter_type == "dual_random_walk" else 1) * K_DIFF + 1
     n, h = N_NODES, H_UNITS
@@ -106,6 +111,20 @@ def algorithmic_work(filter_type, t_len, batch):
         if l > 0:
             w["gemm_nn"] += 2.0 * r * 3 * h * (m * fin)
             w["diffuse_adj"] += 4.0 * s * n * fin * (m + 1)
+    if task == "ssl":       # decoder: T_OUT autoregressive steps; every layer's dx is needed (feedback / layer below)
+        sd = T_OUT * batch
+        rd = sd * n
+        for k in list(w):
+            w["dec_" + k] = 0.0
+        for fin in fins:
+            w["dec_seq_fwd"] += sd * (2 * (m - 1) * 2 * n * n * h + 2 * n * (h * m) * 3 * h)
+            w["dec_seq_bwd"] += sd * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
+            w["dec_gemm_nn"] += 2.0 * rd * (m * fin) * 3 * h * 2
+            w["dec_gemm_tn"] += 2.0 * rd * (m * fin) * 3 * h + 2.0 * rd * (m * h) * 3 * h
+            w["dec_diffuse_fwd"] += 4.0 * sd * n * fin * m + 2 * 4.0 * sd * n * h * m
+            w["dec_diffuse_adj"] += 4.0 * sd * n * fin * (m + 1)
+        w["dec_gemm_nn"] += 2 * 2.0 * rd * h * D_IN          # projection forward + d h_top
+        w["dec_gemm_tn"] += 2.0 * rd * h * D_IN              # projection weight gradient
     return w
 
 
@@ -116,16 +135,21 @@ def cpu_baseline(workload, sample_clips=32, budget_s=60.0):
     small sample and the best one is used (and reported as `cores`)."""
     from oracle import dcrnn_oracle as orc
     task, filt, t_len, _, classes = WORKLOADS[workload]
-    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
-    params = {k: v.requires_grad_(True) for k, v in orc.init_params(cfg, "classification", seed=0).items()}
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=max(classes, 1))
+    kind = "nextTimePred" if task == "ssl" else "classification"
+    params = {k: v.requires_grad_(True) for k, v in orc.init_params(cfg, kind, seed=0).items()}
     x, y, lengths, sup = synthetic_batch(task, filt, t_len, sample_clips, classes, seed=123)
 
     def one(nclips):
         for p in params.values():
             p.grad = None
         t0 = time.perf_counter()
-        logits = orc.classification_forward(params, cfg, x[:nclips], lengths[:nclips], [s[:nclips] for s in sup])
-        loss = orc.bce_with_logits(logits, y[:nclips]) if classes == 1 else orc.cross_entropy(logits, y[:nclips])
+        if task == "ssl":
+            pred = orc.next_time_pred_forward(params, cfg, x[:nclips], y[:nclips], [s[:nclips] for s in sup])
+            loss = orc.regression_loss(y[:nclips], pred, loss_fn="MAE")
+        else:
+            logits = orc.classification_forward(params, cfg, x[:nclips], lengths[:nclips], [s[:nclips] for s in sup])
+            loss = orc.bce_with_logits(logits, y[:nclips]) if classes == 1 else orc.cross_entropy(logits, y[:nclips])
         loss.backward()
         return time.perf_counter() - t0
 
@@ -163,6 +187,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the live per-kernel HIP-event timing")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the "
+                    "captured HIP graph of forward+loss+backward")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning)")
     args = ap.parse_args()
 
@@ -189,7 +215,11 @@ def main():
     if args.batch:
         batch = args.batch
     torch.manual_seed(123)                                   # identical replicas on every rank
-    model = DCRNNModel_classification(make_args(filt), classes, device=dev).to(dev)
+    if task == "ssl":
+        from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
+        model = DCRNNModel_nextTimePred(make_args(filt), device=dev).to(dev)
+    else:
+        model = DCRNNModel_classification(make_args(filt), classes, device=dev).to(dev)
     model.train()
     stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0)
     x, y, lengths, supports = synthetic_batch(task, filt, t_len, batch, classes, seed=123 + rank)
@@ -206,20 +236,35 @@ def main():
             print(f"[bench +{time.perf_counter() - t_boot:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     log(f"inputs on device, {args.warmup} warm-up steps")
-    for _ in range(args.warmup):
-        stepper.step(x, y, lengths, supports)
     lib = _lib.get_lib()
+    graphed = False
+    if not args.no_graph:
+        # forward + loss + backward replayed as ONE HIP graph; all-reduce + fused clip/Adam stay eager
+        try:
+            stepper.capture(x, y, lengths, supports)
+            graphed = True
+        except Exception as e:                                   # noqa: BLE001 -- fall back to eager launches
+            log(f"HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly")
+            torch.cuda.synchronize()
+    one_step = stepper.replay_step if graphed else (lambda: stepper.step(x, y, lengths, supports))
+    for _ in range(args.warmup):
+        one_step()
     sync_all()
-    if not args.no_prof:
-        lib.query("eeg_dcrnn_prof_enable", 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = stepper.step(x, y, lengths, supports)
+        loss = one_step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    log(f"timed {args.steps} steps: {elapsed / args.steps * 1e3:.3f} ms/step")
+    log(f"timed {args.steps} steps ({'graph replay' if graphed else 'eager'}): {elapsed / args.steps * 1e3:.3f} ms/step")
     prof = {}
     if not args.no_prof:
+        # per-kernel durations: the SAME K steps once more, launched eagerly with a HIP-event pair
+        # around every launch on the launch stream (events cannot be read back from a graph replay;
+        # the pairs themselves cost ~0.2 ms/step, which is why they are kept out of the timed region)
+        lib.query("eeg_dcrnn_prof_enable", 1)
+        for _ in range(args.steps):
+            stepper.step(x, y, lengths, supports)
+        torch.cuda.synchronize()
         lib.query("eeg_dcrnn_prof_enable", 0)
         buf = ctypes.create_string_buffer(1 << 16)
         lib.call("eeg_dcrnn_prof_report", buf, len(buf))
@@ -238,13 +283,13 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     clips_per_s = batch * world / (elapsed / args.steps)
-    work = algorithmic_work(filt, t_len, batch)
+    work = algorithmic_work(filt, t_len, batch, task)
     kernels = {}
     for name, (cnt, ms) in prof.items():
         per_step_ms = ms / args.steps
         ent = {"launches_per_step": cnt / args.steps, "ms_per_step": round(per_step_ms, 4)}
         if name in work and work[name] > 0 and per_step_ms > 0:
-            if name.startswith("diffuse"):
+            if "diffuse" in name:
                 gbs = work[name] / (per_step_ms * 1e-3) / 1e9
                 ent.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
             else:
@@ -268,8 +313,8 @@ def main():
                     "frac": d["frac"], "traffic": (traffic or {}).get(dom), "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
                     "kernels": kernels,
                     "kernel_ms_per_step_total": round(sum(v["ms_per_step"] for v in kernels.values()), 3),
-                    "whole_step_flops": round(sum(v for k, v in work.items() if not k.startswith("diffuse")) / 1e9, 1),
-                    "whole_step_mfma_frac": round(sum(v for k, v in work.items() if not k.startswith("diffuse"))
+                    "whole_step_flops": round(sum(v for k, v in work.items() if "diffuse" not in k) / 1e9, 1),
+                    "whole_step_mfma_frac": round(sum(v for k, v in work.items() if "diffuse" not in k)
                                                   / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)}
     out = {
         "metric": "EEG clips/sec (60s, 19ch, K=2, 2-layer x64) fwd+bwd",
@@ -278,6 +323,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": DESCR[args.workload], "per_gpu_batch": batch, "global_batch": batch * world,
                    "clip_len": t_len, "parallelism": f"dp{world}", "optimizer_step_included": True,
+                   "launch": "hip-graph replay (fwd+loss+bwd) + eager all-reduce/clip+Adam" if graphed else "eager",
                    "final_loss": round(loss_val, 5)},
         "roofline": roofline,
     }

@@ -22,6 +22,12 @@ class LayerDims(ctypes.Structure):
                 ("M", c_int32), ("act", c_int32), ("p_batched", c_int32)]
 
 
+class DecoderDims(ctypes.Structure):
+    """mirror of `eeg_decoder_dims` (include/eeg_dcrnn.h)."""
+    _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Dout", c_int32),
+                ("M", c_int32), ("L", c_int32), ("act", c_int32), ("p_batched", c_int32)]
+
+
 _FP = c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 _SIGNATURES = {
@@ -44,6 +50,14 @@ _SIGNATURES = {
     "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 11 + [c_void_p]),
     "eeg_dcrnn_layer_bwd_ws_floats": (c_size_t, [POINTER(LayerDims), c_int]),
     "eeg_dcrnn_layer_bwd": (c_int, [POINTER(LayerDims)] + [_FP] * 20 + [c_void_p]),
+    "eeg_dcrnn_decoder_saved_floats": (c_size_t, [POINTER(DecoderDims)]),
+    "eeg_dcrnn_decoder_fwd_ws_floats": (c_size_t, [POINTER(DecoderDims)]),
+    "eeg_dcrnn_decoder_bwd_ws_floats": (c_size_t, [POINTER(DecoderDims)]),
+    "eeg_dcrnn_decoder_fwd": (c_int, [POINTER(DecoderDims), _FP, POINTER(c_int32), _FP, _FP, POINTER(c_void_p), _FP, _FP,
+                                      _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_decoder_bwd": (c_int, [POINTER(DecoderDims), POINTER(c_int32), _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP,
+                                      POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                      _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_bwd": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, _FP, c_void_p]),

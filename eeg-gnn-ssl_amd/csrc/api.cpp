@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstring>
 
+#include <string>
+#include <vector>
+
 #include "../../include/eeg_dcrnn.h"
 #include "kernels_diffuse.h"
 #include "kernels_gemm.h"
@@ -25,6 +28,8 @@ std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open = nullptr;
 const char* g_open_name = nullptr;
+const char* g_prefix = nullptr;
+std::vector<std::string*> g_names;
 hipEvent_t prof_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e;
@@ -32,9 +37,18 @@ hipEvent_t prof_event() {
     return e;
 }
 }  // namespace
+void prof_set_prefix(const char* prefix) { g_prefix = prefix; }
 void prof_begin(const char* name, hipStream_t st) {
     if (!g_prof_on) return;
     g_open = prof_event();
+    if (g_prefix != nullptr) {                       // interned so that records can keep a plain pointer
+        std::string full = std::string(g_prefix) + name;
+        const std::string* hit = nullptr;
+        for (auto& n : g_names)
+            if (*n == full) { hit = n; break; }
+        if (hit == nullptr) { g_names.push_back(new std::string(full)); hit = g_names.back(); }
+        name = hit->c_str();
+    }
     g_open_name = name;
     (void)hipEventRecord(g_open, st);
 }
@@ -120,7 +134,9 @@ int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int 
 // C[R x O] = [segments] @ packed B (nct_total col tiles) + bias
 int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
             float* C, int ldc, int O, hipStream_t st) {
-    if (nct_total <= 4) return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    // few row blocks (per-step decoder GEMMs): narrower column blocks fill more CUs
+    if (nct_total <= 4 || ceil_div(R, 128) * ceil_div(nct_total, 12) < 160)
+        return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
     return run_nn_kc<6>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
 }
 
@@ -187,14 +203,18 @@ int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
 }
 
 int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M, float* planes,
-                hipStream_t st) {
+                hipStream_t st, size_t plane_stride = 0) {
+    if (plane_stride == 0) plane_stride = (size_t)S * N * F;
     if (N == 19 && F / 4 <= 128) {                // the EEG montage: streaming kernel (no LDS)
-        const int F4 = F / 4, SPW = 256 / F4, sB = p_batched ? B : 1, T = S / sB;
+        const int F4 = F / 4, sB = p_batched ? B : 1, T = S / sB;
+        int threads = 256;                        // few samples per graph (decoder steps): narrower workgroups
+        while (threads > 64 && (threads / 2) / F4 >= T && (threads / 2) >= F4) threads /= 2;
+        const int SPW = threads / F4;
         int ny = ceil_div(T, SPW);
         const int want = ceil_div(4096, sB);     // ~16 workgroups per CU in total
         if (ny > want) ny = want;
         if (ny < 1) ny = 1;
-        EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(256), 0, st, X, P, p_batched, S, B, F, M, planes);
+        EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, X, P, p_batched, S, B, F, M, planes, plane_stride);
         return check_launch("diffuse_fwd");
     }
     const int FP = round_up(F, 16), FS = lds_stride(M * FP), NR = round_up(N, 4);
@@ -211,17 +231,17 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
     } else {
         grid = dim3(S < 2048 ? S : 2048, 1);
     }
-    EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, grid, dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes);
+    EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, grid, dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes, plane_stride);
     return check_launch("diffuse_fwd");
 }
 int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M, float* dX,
-                hipStream_t st) {
+                hipStream_t st, const float* add = nullptr) {
     const int FP = round_up(F, 16), ZS = lds_stride(M * FP), NR = round_up(N, 4);
     const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * ZS) * sizeof(float);
     if (lds > 160 * 1024) return fail("diffuse_adj: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
     EEG_SET_MAX_LDS(diffuse_adj_kernel, lds);
     const int grid = S < 2048 ? S : 2048;
-    EEG_LAUNCH_P("diffuse_adj", diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, dX);
+    EEG_LAUNCH_P("diffuse_adj", diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, add, dX);
     return check_launch("diffuse_adj");
 }
 
@@ -262,6 +282,119 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     w.z = o;        o += need_dx ? R * d->M * d->Fin : 0;
     w.total = o;
     return w;
+}
+
+
+// Hoisted weight gradients of one cell over all R = T*B*N rows (split-K GEMMs with fixed-order
+// reduction): x-part [X | P_m X]^T [dR|dU|dC], h-part of the gate hops(h_{t-1})^T [dR|dU] and of the
+// candidate hops(r*h_{t-1})^T dC.  accumulate = add into dWg/dWc (a cell shared by several layers).
+int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* planes, const float* Hprev,
+                      const float* RHs, const float* dXW, const float* P, float* hpl, float* rpl, float* part,
+                      const BwdWs& w, bool accumulate, float* dWg, float* dWc, hipStream_t st) {
+    const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
+    const int acc = accumulate ? 8 : 0;
+    SegPtrs sx;
+    for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
+    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0 | acc, Fin, H, M, dWg, dWc);
+    if (check_launch("reduce_unpack(x)")) return 1;
+    //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
+    if (diffuse_fwd(Hprev, P, d->p_batched, S, d->B, N, H, M, hpl, st)) return 1;
+    SegPtrs sh;
+    for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
+    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hg, M * H, 2 * H, 1 | acc, Fin, H, M, dWg, dWc);
+    if (check_launch("reduce_unpack(hg)")) return 1;
+    //   h-part of the candidate: hops(r*h_{t-1})^T dC
+    if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl, st)) return 1;
+    SegPtrs sr;
+    for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
+    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hc, M * H, H, 2 | acc, Fin, H, M, dWg, dWc);
+    return check_launch("reduce_unpack(hc)");
+}
+
+// out0[c] (c < split) / out1[c - split] = sum_r A[r][c]: two fixed-order stages.
+int colsum_rows_per_chunk(int R) { int rpc = ceil_div(R, 512); return rpc < 64 ? 64 : rpc; }
+size_t colsum_ws(int R, int C) { return (size_t)ceil_div(R, colsum_rows_per_chunk(R)) * C; }
+int colsum(const float* A, int R, int C, int split, float* ws, float* out0, float* out1, hipStream_t st) {
+    const int rpc = colsum_rows_per_chunk(R), nchunk = ceil_div(R, rpc);
+    EEG_LAUNCH_P("reduce_bias", colsum_partial_kernel, dim3(nchunk, ceil_div(C, 128)), dim3(256), 256 * sizeof(float), st, A, R, C, rpc, ws);
+    if (check_launch("colsum_partial")) return 1;
+    EEG_LAUNCH_P("reduce_bias", colsum_final_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, ws, nchunk, C, split, out0, out1);
+    return check_launch("colsum_final");
+}
+
+// ---- decoder (model.py:112-204): buffer carving shared by forward and backward -------------------
+struct DecLayout {
+    // saved (forward -> backward)
+    size_t xin, proj_pack, proj_bias, saved_total;
+    size_t planes[8], hext[8], rs[8], us[8], cs[8], rhs[8];
+    // backward workspace
+    size_t dxw[8], dbias[8], dotot, da, dhn, z, hpl, rpl, partial, projt_pack, colsum, bwd_total;
+    int nsplit_p, rps_p;
+    BwdWs lw[8];
+    eeg_layer_dims ld[8];
+};
+size_t align64(size_t v) { return (v + 63) / 64 * 64; }
+DecLayout dec_layout(const eeg_decoder_dims* d) {
+    DecLayout y;
+    const size_t state = (size_t)d->B * d->N * d->H, R = (size_t)d->T * d->B * d->N;
+    const int nct_o = ceil_div(d->Dout, 16), nct_h = ceil_div(d->H, 16);
+    size_t o = 0;
+    y.xin = o;       o += align64(R * d->Dout);
+    y.proj_pack = o; o += align64((size_t)(d->H / 4) * nct_o * 64);
+    y.proj_bias = o; o += align64((size_t)nct_o * 16);
+    for (int l = 0; l < d->L; ++l) {
+        const int fin = l == 0 ? d->Dout : d->H;
+        y.ld[l] = eeg_layer_dims{d->T, d->B, d->N, d->H, fin, d->M, d->act, d->p_batched};
+        y.planes[l] = o; o += align64((size_t)(d->M - 1) * R * fin);
+        y.hext[l] = o;   o += align64((size_t)(d->T + 1) * state);
+        y.rs[l] = o;     o += align64((size_t)d->T * state);
+        y.us[l] = o;     o += align64((size_t)d->T * state);
+        y.cs[l] = o;     o += align64((size_t)d->T * state);
+        y.rhs[l] = o;    o += align64((size_t)d->T * state);
+    }
+    y.saved_total = o;
+    o = 0;
+    size_t part = 0;
+    for (int l = 0; l < d->L; ++l) {
+        y.lw[l] = bwd_ws(&y.ld[l], 0);
+        y.dxw[l] = o; o += align64(R * 3 * d->H);
+        const size_t pl = y.lw[l].total - y.lw[l].partial;      // partial is the last region when need_dx = 0
+        part = pl > part ? pl : part;
+    }
+    for (int l = 0; l < d->L; ++l) { y.dbias[l] = o; o += (size_t)d->T * d->B * 3 * d->H; }   // contiguous: shared layers reduce at once
+    o = align64(o);
+    y.dotot = o;  o += align64(R * d->Dout);
+    y.da = o;     o += align64(state);
+    y.dhn = o;    o += align64(2 * (size_t)d->L * state);
+    y.z = o;      o += align64((size_t)d->B * d->N * d->M * (d->Dout > d->H ? d->Dout : d->H));
+    y.hpl = o;    o += align64((size_t)(d->M - 1) * R * d->H);
+    y.rpl = o;    o += align64((size_t)(d->M - 1) * R * d->H);
+    y.nsplit_p = tn_split(1, d->Dout, (int)R, d->H, &y.rps_p);
+    const size_t pp = (size_t)y.nsplit_p * d->Dout * d->H;
+    part = pp > part ? pp : part;
+    y.partial = o; o += align64(part);
+    y.projt_pack = o; o += align64((size_t)(d->Dout / 4) * nct_h * 64);
+    const size_t c1 = colsum_ws((int)R, d->Dout), c2 = colsum_ws(d->L * d->T * d->B, 3 * d->H);
+    y.colsum = o; o += align64(c1 > c2 ? c1 : c2);
+    y.bwd_total = o;
+    return y;
+}
+int check_decoder_dims(const eeg_decoder_dims* d) {
+    if (d->L < 1 || d->L > 8) return fail("decoder: num_rnn_layers=%d unsupported (1..8)", d->L);
+    if (d->T < 1 || d->B < 1) return fail("decoder: empty sequence/batch (T=%d, B=%d)", d->T, d->B);
+    if (check_dims(d->N, d->H, d->Dout, d->M)) return 1;
+    return check_dims(d->N, d->H, d->H, d->M);
+}
+int copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
+#if defined(EEG_SIMT_EMU)
+    memcpy(dst, src, n * sizeof(float));
+    return 0;
+#else
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : fail("device copy failed");
+#endif
 }
 
 }  // namespace
@@ -421,28 +554,8 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction)
-    float* part = ws + w.partial;
-    SegPtrs sx;
-    for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
-    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0, Fin, H, M, dWg, dWc);
-    if (check_launch("reduce_unpack(x)")) return 1;
-    //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
-    float* hpl = ws + w.hplanes;
-    if (diffuse_fwd(Hext, P, d->p_batched, S, d->B, N, H, M, hpl, st)) return 1;
-    SegPtrs sh;
-    for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hext : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
-    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hg, M * H, 2 * H, 1, Fin, H, M, dWg, dWc);
-    if (check_launch("reduce_unpack(hg)")) return 1;
-    //   h-part of the candidate: hops(r*h_{t-1})^T dC
-    float* rpl = ws + w.rhplanes;
-    if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl, st)) return 1;
-    SegPtrs sr;
-    for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
-    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hc, M * H, H, 2, Fin, H, M, dWg, dWc);
-    if (check_launch("reduce_unpack(hc)")) return 1;
+    if (cell_weight_grads(d, X, planes, Hext, RHs, dXW, P, ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false,
+                          dWg, dWc, st)) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {
         float* Z = ws + w.z;
@@ -452,6 +565,136 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         if (diffuse_adj(Z, P, d->p_batched, S, d->B, N, Fin, M, dX, st)) return 1;
     }
     return 0;
+}
+
+
+/* ---- decoder ---------------------------------------------------------------------------------- */
+size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d) { return dec_layout(d).saved_total; }
+size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d) { return (size_t)d->B * d->N * 3 * d->H; }
+size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d) { return dec_layout(d).bwd_total; }
+
+int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const int32_t* teacher, const float* h0,
+                          const float* P, const float* const* packs, const float* Wp, const float* bp, float* out,
+                          float* saved, float* ws, void* stream) {
+    if (check_decoder_dims(d)) return 1;
+    ProfPrefix tag("dec_");
+    hipStream_t st = S_(stream);
+    const DecLayout y = dec_layout(d);
+    const int B = d->B, N = d->N, H = d->H, M = d->M, Dout = d->Dout, L = d->L, RB = B * N;
+    const size_t state = (size_t)RB * H, xstep = (size_t)RB * Dout;
+    const int nct_o = ceil_div(Dout, 16);
+    float* xin = saved + y.xin;
+    float* ppack = saved + y.proj_pack;
+    float* pbias = saved + y.proj_bias;
+    EEG_LAUNCH_P("pack_cell", pack_linear_kernel, dim3(64), dim3(256), 0, st, Wp, Dout, H, 1, ppack);
+    if (check_launch("pack_linear")) return 1;
+    if (hipMemsetAsync(pbias, 0, (size_t)nct_o * 16 * sizeof(float), st) != hipSuccess) return fail("decoder_fwd: memset failed");
+    if (copy_floats(pbias, bp, Dout, st)) return 1;
+    if (hipMemsetAsync(xin, 0, xstep * sizeof(float), st) != hipSuccess) return fail("decoder_fwd: memset failed");   // GO symbol
+    for (int l = 0; l < L; ++l)
+        if (copy_floats(saved + y.hext[l], h0 + (size_t)l * state, state, st)) return 1;
+    float* XW = ws;
+    for (int t = 0; t < d->T; ++t) {
+        for (int l = 0; l < L; ++l) {
+            const int Fin = l == 0 ? Dout : H;
+            const size_t Rall = (size_t)d->T * RB;
+            const float* X = l == 0 ? xin + (size_t)t * xstep : saved + y.hext[l - 1] + (size_t)(t + 1) * state;
+            float* planes = saved + y.planes[l] + (size_t)t * RB * Fin;     // plane m at + (m-1)*Rall*Fin
+            const CellPack p = make_cell_pack(Fin, H, M);
+            const float* pack = packs[l];
+            if (diffuse_fwd(X, P, d->p_batched, B, B, N, Fin, M, planes, st, Rall * Fin)) return 1;
+            SegPtrs segs;
+            for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * Rall * Fin : nullptr);
+            if (gemm_nn(segs, M, Fin, RB, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
+            float* Hext = saved + y.hext[l];
+            SeqFwdArgs a{XW, Hext + (size_t)t * state, P, d->p_batched, pack + p.bhg, pack + p.bhc,
+                         Hext + (size_t)(t + 1) * state, saved + y.rs[l] + (size_t)t * state,
+                         saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state,
+                         saved + y.rhs[l] + (size_t)t * state, 1, B, N, d->act, nullptr, g_tune[3]};
+            if (seq_fwd(H, M, a, st)) return 1;
+        }
+        // projection (model.py:188-190): out_t = h_top W_p^T + b_p
+        SegPtrs sp;
+        for (int m = 0; m < kMaxM; ++m) sp.p[m] = m == 0 ? saved + y.hext[L - 1] + (size_t)(t + 1) * state : nullptr;
+        if (gemm_nn(sp, 1, H, RB, ppack, nct_o, pbias, out + (size_t)t * xstep, Dout, Dout, st)) return 1;
+        if (t + 1 < d->T) {   // next decoder input: the projection, or the target under teacher forcing (model.py:194-200)
+            const bool tf = teacher != nullptr && teacher[t] != 0;
+            if (copy_floats(xin + (size_t)(t + 1) * xstep, tf ? targets + (size_t)t * xstep : out + (size_t)t * xstep, xstep, st)) return 1;
+        }
+    }
+    return 0;
+}
+
+int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, const float* P, const float* const* packs,
+                          const float* Wp, const float* saved, const float* dOut, float* dh0, float* const* dWg,
+                          float* const* dbg, float* const* dWc, float* const* dbc, float* dWp, float* dbp, float* ws,
+                          void* stream) {
+    if (check_decoder_dims(d)) return 1;
+    ProfPrefix tag("dec_");
+    hipStream_t st = S_(stream);
+    const DecLayout y = dec_layout(d);
+    const int B = d->B, N = d->N, H = d->H, M = d->M, Dout = d->Dout, L = d->L, RB = B * N, T = d->T;
+    const size_t state = (size_t)RB * H, xstep = (size_t)RB * Dout, Rall = (size_t)T * RB;
+    const int nct_h = ceil_div(H, 16);
+    float* tpack = ws + y.projt_pack;
+    EEG_LAUNCH_P("pack_cell", pack_linear_kernel, dim3(64), dim3(256), 0, st, Wp, Dout, H, 0, tpack);
+    if (check_launch("pack_linear")) return 1;
+    float* dOtot = ws + y.dotot;
+    float* dA = ws + y.da;
+    float* Z = ws + y.z;
+    auto feeds_back = [&](int t) { return t + 1 < T && !(teacher != nullptr && teacher[t] != 0); };   // out_t is step t+1's input
+    for (int t = T - 1; t >= 0; --t) {
+        // total gradient of out_t: the loss term, plus (autoregressive feedback) dx of layer 0 at step t+1, which
+        // the adjoint diffusion of that step has already added into dOtot[t]
+        const float* dO = feeds_back(t) ? dOtot + (size_t)t * xstep : dOut + (size_t)t * xstep;
+        if (!feeds_back(t) && copy_floats(dOtot + (size_t)t * xstep, dO, xstep, st)) return 1;   // dense copy for the hoisted GEMM
+        SegPtrs sp;
+        for (int m = 0; m < kMaxM; ++m) sp.p[m] = m == 0 ? dOtot + (size_t)t * xstep : nullptr;
+        if (gemm_nn(sp, 1, Dout, RB, tpack, nct_h, nullptr, dA, H, H, st)) return 1;               // d h_top = dO W_p
+        for (int l = L - 1; l >= 0; --l) {
+            const int Fin = l == 0 ? Dout : H;
+            const CellPack p = make_cell_pack(Fin, H, M);
+            const float* pack = packs[l];
+            const float* Hext = saved + y.hext[l];
+            float* dXW = ws + y.dxw[l] + (size_t)t * RB * 3 * H;
+            float* dhn_in = ws + y.dhn + ((size_t)((t + 1) & 1) * L + l) * state;
+            float* dhn_out = ws + y.dhn + ((size_t)(t & 1) * L + l) * state;
+            SeqBwdArgs a{Hext + (size_t)(t + 1) * state, Hext + (size_t)t * state, saved + y.rs[l] + (size_t)t * state,
+                         saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state, dA,
+                         t == T - 1 ? nullptr : dhn_in, nullptr, nullptr, P, d->p_batched, pack + p.b1, pack + p.b2,
+                         dXW, t == 0 ? dh0 + (size_t)l * state : dhn_out, ws + y.dbias[l] + (size_t)t * B * 3 * H,
+                         1, B, N, d->act, nullptr, g_tune[3]};
+            if (seq_bwd(H, M, a, st)) return 1;
+            const bool need_dx = l > 0 || (t > 0 && feeds_back(t - 1));
+            if (need_dx) {
+                SegPtrs sd;
+                for (int m = 0; m < kMaxM; ++m) sd.p[m] = m == 0 ? dXW : nullptr;
+                if (gemm_nn(sd, 1, 3 * H, RB, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st)) return 1;
+                if (l > 0) {
+                    if (diffuse_adj(Z, P, d->p_batched, B, B, N, Fin, M, dA, st)) return 1;         // -> layer below's h_t
+                } else {
+                    if (diffuse_adj(Z, P, d->p_batched, B, B, N, Fin, M, dOtot + (size_t)(t - 1) * xstep, st,
+                                    dOut + (size_t)(t - 1) * xstep)) return 1;
+                }
+            }
+        }
+    }
+    // hoisted parameter gradients over all T steps
+    for (int l = 0; l < L; ++l) {
+        const bool first_use = l <= 1;                    // layers >= 1 share one cell (model.py:126-143)
+        const float* X = l == 0 ? saved + y.xin : saved + y.hext[l - 1] + state;
+        if (cell_weight_grads(&y.ld[l], X, saved + y.planes[l], saved + y.hext[l], saved + y.rhs[l], ws + y.dxw[l], P,
+                              ws + y.hpl, ws + y.rpl, ws + y.partial, y.lw[l], !first_use, dWg[l], dWc[l], st)) return 1;
+    }
+    if (colsum(ws + y.dbias[0], T * B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
+    if (L > 1 && colsum(ws + y.dbias[1], (L - 1) * T * B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
+    // projection: dW_p (Dout x H) = sum_rows dOtot^T h_top ;  db_p = column sums of dOtot
+    SegPtrs so;
+    for (int m = 0; m < kMaxM; ++m) so.p[m] = m == 0 ? dOtot : nullptr;
+    if (gemm_tn(so, 1, Dout, (int)Rall, saved + y.hext[L - 1] + state, H, 0, H, ws + y.partial, y.nsplit_p, y.rps_p, st)) return 1;
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(64), dim3(256), 0, st, ws + y.partial, y.nsplit_p, Dout, H, 3, Dout, H, 1, dWp, dWp);
+    if (check_launch("reduce_unpack(proj)")) return 1;
+    return colsum(dOtot, (int)Rall, Dout, Dout, ws + y.colsum, dbp, nullptr, st);
 }
 
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH, float* last, void* stream) {

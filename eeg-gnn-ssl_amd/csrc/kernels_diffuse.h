@@ -25,7 +25,7 @@ constexpr int kDiffPrefetch = 4;        // float4 per thread per sample: covers 
 
 __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restrict__ X, const float* __restrict__ P,
                                                           int p_batched, int S, int B, int N, int F, int M,
-                                                          float* __restrict__ planes) {
+                                                          float* __restrict__ planes, size_t plane_stride) {
     EEG_DYN_SMEM(sm);
     const int FP = round_up(F, 16), FS = lds_stride(M * FP);
     float* Pl = sm;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
         lds_diffuse_tiles<false>(tile, FS, 0, FP, FP, FP, Pl, M, N, NR);
         __syncthreads();
         for (int m1 = 0; m1 < M - 1; ++m1) {
-            float4* dst = reinterpret_cast<float4*>(planes + ((size_t)m1 * S + s) * N * F);
+            float4* dst = reinterpret_cast<float4*>(planes + (size_t)m1 * plane_stride + (size_t)s * N * F);
             for (int q = tid; q < nq; q += 256) {
                 const float* t = tile + (q / nf4) * FS + FP * (m1 + 1) + 4 * (q % nf4);
                 dst[q] = make_float4(t[0], t[1], t[2], t[3]);
@@ -91,8 +91,8 @@ template <int N>
 __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __restrict__ X,
                                                                  const float* __restrict__ P, int p_batched,
                                                                  int S, int B, int F, int M,
-                                                                 float* __restrict__ planes) {
-    const int F4 = F / 4, SPW = 256 / F4;            // float4 columns per sample, samples per pass
+                                                                 float* __restrict__ planes, size_t plane_stride) {
+    const int F4 = F / 4, SPW = blockDim.x / F4;     // float4 columns per sample, samples per pass
     const int tl = threadIdx.x / F4, c4 = threadIdx.x % F4;
     const int sB = p_batched ? B : 1, g = p_batched ? blockIdx.x : 0;
     const int T = S / sB;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __
         for (int n = 0; n < N; ++n) x[n] = X4[(s * N + n) * F4 + c4];
         for (int m1 = 0; m1 < M - 1; ++m1) {
             const float* __restrict__ Pm = Pg + m1 * N * N;
-            float4* out = O4 + (((size_t)m1 * S + s) * N) * F4 + c4;
+            float4* out = O4 + (size_t)m1 * (plane_stride / 4) + (s * N) * F4 + c4;
 #pragma unroll
             for (int n = 0; n < N; ++n) {
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -125,11 +125,11 @@ __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __
     }
 }
 
-// ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m -------------------
+// ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m [+ add] -----------
 // LDS tile [NR][ZS], NR = round_up(N,4), ZS = lds_stride(M*FP): slot m holds Z_m (cols padded to FP).
 __global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restrict__ Z, const float* __restrict__ P,
                                                           int p_batched, int S, int B, int N, int F, int M,
-                                                          float* __restrict__ dX) {
+                                                          const float* __restrict__ add, float* __restrict__ dX) {
     EEG_DYN_SMEM(sm);
     const int FP = round_up(F, 16), ZS = lds_stride(M * FP);
     float* Pl = sm;
@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = rt * 16 + 4 * lg + r;
-                if (n < N && col < F) dX[((size_t)s * N + n) * F + col] = acc[r];
+                if (n < N && col < F) {
+                    const size_t o = ((size_t)s * N + n) * F + col;
+                    dX[o] = add != nullptr ? acc[r] + add[o] : acc[r];
+                }
             }
         }
     }

@@ -118,10 +118,25 @@ __global__ void pack_dense_kernel(const float* __restrict__ W, int F, int M, int
     }
 }
 
+// nn.Linear weight W (Out x In) -> fragment pack of a (K x O) right-hand side with zero-padded
+// column tiles: transposed = 1: K = In, O = Out (y = x W^T);  transposed = 0: K = Out, O = In (dx = dy W).
+__global__ void pack_linear_kernel(const float* __restrict__ W, int Out, int In, int transposed, float* __restrict__ out) {
+    const int K = transposed ? In : Out, O = transposed ? Out : In;
+    const int nct = (O + 15) / 16;
+    const size_t total = (size_t)(K / 4) * nct * 64;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = e & 63, ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+        const int k = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+        float v = 0.f;
+        if (j < O) v = transposed ? W[(size_t)j * In + k] : W[(size_t)k * In + j];
+        out[e] = v;
+    }
+}
+
 // Sum split-K partials [nsplit][K][O] in fixed order (deterministic) and scatter into the
 // reference-layout gradient tensors.  kind 0: x-part (K = M*Fin, O = 3H); 1: h-gate (K = M*H,
-// O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f).
-__global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O, int kind,
+// O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f); 3: dWg = plain (K x O).
+__global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O, int kind_flags,
                                      int Fin, int H, int M, float* __restrict__ dWg, float* __restrict__ dWc) {
     const size_t total = (size_t)K * O;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -134,8 +149,25 @@ __global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit,
             for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(sp + u) * total + idx];
         }
         for (int u = 0; sp + u < nsplit; ++u) acc[u] += part[(size_t)(sp + u) * total + idx];
-        const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         const int k = idx / O, o = idx % O;
+        const bool accumulate = (kind_flags & 8) != 0;   // += into the gradient (shared decoder cell, model.py:126-143)
+        const int kind = kind_flags & 7;
+        if (accumulate) {
+            float* dst;
+            if (kind == 0) {
+                const int m = k / Fin, f = k % Fin;
+                dst = o < 2 * H ? &dWg[((size_t)f * M + m) * (2 * H) + o] : &dWc[((size_t)f * M + m) * H + (o - 2 * H)];
+            } else if (kind == 1) {
+                dst = &dWg[((size_t)(Fin + k % H) * M + k / H) * (2 * H) + o];
+            } else if (kind == 3) {
+                dst = &dWg[idx];
+            } else {
+                dst = &dWc[((size_t)(Fin + k % H) * M + k / H) * H + o];
+            }
+            *dst += s;
+            continue;
+        }
         if (kind == 0) {
             const int m = k / Fin, f = k % Fin;
             if (o < 2 * H) dWg[((size_t)f * M + m) * (2 * H) + o] = s;
@@ -143,11 +175,52 @@ __global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit,
         } else if (kind == 1) {
             const int m = k / H, f = k % H;
             dWg[((size_t)(Fin + f) * M + m) * (2 * H) + o] = s;
+        } else if (kind == 3) {                       // plain (K x O) matrix
+            dWg[idx] = s;
         } else {
             const int m = k / H, f = k % H;
             dWc[((size_t)(Fin + f) * M + m) * H + o] = s;
         }
     }
+}
+
+// Column sums of a dense (R x C) matrix in two fixed-order stages (projection bias gradient):
+// stage 1: partial[chunk][C] over `rpc` rows per chunk (block = 2 row slices x 128 columns).
+__global__ void colsum_partial_kernel(const float* __restrict__ A, int R, int C, int rpc, float* __restrict__ partial) {
+    EEG_DYN_SMEM(sm);                                 // [2][128]
+    const int c = threadIdx.x & 127, q = threadIdx.x >> 7;
+    const int col = blockIdx.y * 128 + c;
+    const int r0 = blockIdx.x * rpc, r1 = (r0 + rpc < R) ? r0 + rpc : R;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < C) {
+        int r = r0 + q;
+        for (; r + 6 < r1; r += 8) {
+            a0 += A[(size_t)r * C + col];
+            a1 += A[(size_t)(r + 2) * C + col];
+            a2 += A[(size_t)(r + 4) * C + col];
+            a3 += A[(size_t)(r + 6) * C + col];
+        }
+        for (; r < r1; r += 2) a0 += A[(size_t)r * C + col];
+    }
+    sm[q * 128 + c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && col < C) partial[(size_t)blockIdx.x * C + col] = sm[c] + sm[128 + c];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nchunk, int C, int split,
+                                    float* __restrict__ out0, float* __restrict__ out1) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= C) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= nchunk; i += 4) {
+        a0 += partial[(size_t)i * C + col];
+        a1 += partial[(size_t)(i + 1) * C + col];
+        a2 += partial[(size_t)(i + 2) * C + col];
+        a3 += partial[(size_t)(i + 3) * C + col];
+    }
+    for (; i < nchunk; ++i) a0 += partial[(size_t)i * C + col];
+    const float s = (a0 + a1) + (a2 + a3);
+    if (col < split) out0[col] = s; else out1[col - split] = s;
 }
 
 // column sums of per-sample bias-gradient partials [B][3H] -> dbg (2H), dbc (H); fixed order.

@@ -8,10 +8,16 @@ namespace eeg {
 #if defined(EEG_SIMT_EMU)
 inline void prof_begin(const char*, hipStream_t) {}
 inline void prof_end(hipStream_t) {}
+inline void prof_set_prefix(const char*) {}
 #else
 void prof_begin(const char* name, hipStream_t st);
 void prof_end(hipStream_t st);
+void prof_set_prefix(const char* prefix);      // records made while set are named prefix+name
 #endif
+struct ProfPrefix {                             // RAII: tag the launches of one API call (e.g. "dec_")
+    explicit ProfPrefix(const char* p) { prof_set_prefix(p); }
+    ~ProfPrefix() { prof_set_prefix(nullptr); }
+};
 }  // namespace eeg
 
 #define EEG_LAUNCH_P(name, kern, grid, block, smem, stream, ...) \

@@ -90,12 +90,34 @@ class DCGRUDecoder(nn.Module):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, inputs, initial_hidden_state, supports, teacher_forcing_ratio=None):
-        """inputs (T,B,N,Dout) targets, initial_hidden_state (L,B,N*H) -> (T,B,N*Dout)."""
+        """inputs (T,B,N,Dout) targets, initial_hidden_state (L,B,N*H) -> (T,B,N*Dout).
+
+        One native operator (eeg_dcrnn_decoder_fwd/bwd) runs the T autoregressive steps, the cells of
+        all layers and the projection; the teacher-forcing coin flips (model.py:194-200: one
+        `random.random()` per step) are drawn here, in the reference's order."""
         t_len, b = inputs.shape[0], inputs.shape[1]
-        targets = inputs.reshape(t_len, b, -1)
         self.decoding_cells[0]._check_supports(supports)
         ops.new_forward_scope()
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
+        if self.training and self.dropout.p > 0:
+            return self._forward_stepwise(inputs, initial_hidden_state, p, p_batched, teacher_forcing_ratio)
+        teacher = None
+        if teacher_forcing_ratio is not None:
+            teacher = tuple(random.random() < teacher_forcing_ratio for _ in range(t_len))
+        first = self.decoding_cells[0]
+        shared = self.decoding_cells[1] if self.num_rnn_layers > 1 else None
+        cell_params = lambda c: (c.dconv_gate.weight, c.dconv_gate.biases, c.dconv_candidate.weight,   # noqa: E731
+                                 c.dconv_candidate.biases)
+        return ops.dcgru_decoder(inputs.reshape(t_len, b, -1), initial_hidden_state, p, p_batched, cell_params(first),
+                                 None if shared is None else cell_params(shared), self.projection_layer.weight,
+                                 self.projection_layer.bias, self.num_nodes, self.hid_dim, self.output_dim,
+                                 first.num_matrices, self.num_rnn_layers, first._activation_name, teacher)
+
+    def _forward_stepwise(self, inputs, initial_hidden_state, p, p_batched, teacher_forcing_ratio):
+        """Per-step composition (one T=1 layer operator per cell and step); only used when dropout is
+        active on the projection input during training (torch generates the dropout mask)."""
+        t_len, b = inputs.shape[0], inputs.shape[1]
+        targets = inputs.reshape(t_len, b, -1)
         hidden = [initial_hidden_state[l] for l in range(self.num_rnn_layers)]
         cur = torch.zeros(b, self.num_nodes * self.output_dim, device=inputs.device, dtype=inputs.dtype)  # GO symbol
         outs = []

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import LayerDims
+from ._lib import DecoderDims, LayerDims
 
 ACT_CODES = {"tanh": 0, "relu": 1, None: 1}   # the reference maps anything but 'tanh' to relu (cell.py:146)
 
@@ -248,6 +248,85 @@ def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh",
     if not lib.query("eeg_dcrnn_supported", n, h, x.shape[3], m):
         raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
     return _DCGRULayerFn.apply(x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act)
+
+
+class _DecoderFn(torch.autograd.Function):
+    """DCGRUDecoder.forward (model.py:160-204) as one operator: T autoregressive steps through L cells
+    and the projection; explicit BPTT backward with all parameter gradients hoisted over the T steps.
+
+    inputs : targets (T,B,N*Dout) or None, h0 (L,B,N*H), P, teacher (tuple of T bools or None),
+             first cell (wg,bg,wc,bc), shared cell (wg,bg,wc,bc) or Nones when L == 1, Wp (Dout,H), bp (Dout)
+    output : (T,B,N*Dout)"""
+
+    @staticmethod
+    def forward(ctx, targets, h0, p, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, meta):
+        lib = _lib.get_lib()
+        t_len, b, n, h, dout, m, n_layers, act, p_batched = meta
+        dev = h0.device
+        h0 = h0.contiguous()
+        wp, bp = wp.detach().contiguous(), bp.detach().contiguous()
+        for t, nm in ((h0, "initial_hidden_state"), (p, "P"), (wp, "projection_layer.weight"), (bp, "projection_layer.bias")):
+            _check(lib, t, nm)
+        if tuple(wp.shape) != (dout, h) or tuple(bp.shape) != (dout,):
+            raise RuntimeError(f"projection_layer shapes {tuple(wp.shape)}, {tuple(bp.shape)} do not match ({dout}, {h})")
+        use_tf = teacher is not None and any(teacher)
+        if use_tf:
+            targets = targets.contiguous()
+            _check(lib, targets, "inputs (teacher-forcing targets)")
+        packs = [pack_cell(wg0, bg0, wc0, bc0, dout, h, m)]
+        if n_layers > 1:
+            packs += [pack_cell(wg1, bg1, wc1, bc1, h, h, m)] * (n_layers - 1)
+        dims = DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched)
+        out = torch.empty((t_len, b, n * dout), dtype=torch.float32, device=dev)
+        saved = torch.empty(lib.query("eeg_dcrnn_decoder_saved_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.query("eeg_dcrnn_decoder_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
+        tf_arr = (ctypes.c_int32 * t_len)(*[1 if (use_tf and teacher[i]) else 0 for i in range(t_len)]) if use_tf else None
+        pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
+        lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_arr, _p(h0), _p(p), pk_arr,
+                 _p(wp), _p(bp), _p(out), _p(saved), _p(ws), _stream(h0))
+        ctx.save_for_backward(p, saved, wp, *packs[:2])
+        ctx.meta, ctx.teacher = meta, (tuple(bool(v) for v in teacher) if use_tf else None)
+        ctx.shapes = (wg0.shape, bg0.shape, wc0.shape, bc0.shape,
+                      None if wg1 is None else (wg1.shape, bg1.shape, wc1.shape, bc1.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        lib = _lib.get_lib()
+        p, saved, wp, *packs = ctx.saved_tensors
+        t_len, b, n, h, dout, m, n_layers, act, p_batched = ctx.meta
+        dev = saved.device
+        d_out = d_out.contiguous()
+        dims = DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched)
+        packs = [packs[0]] + ([packs[1]] * (n_layers - 1) if n_layers > 1 else [])
+        new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)   # noqa: E731
+        s0 = ctx.shapes
+        g0 = [new(s0[0]), new(s0[1]), new(s0[2]), new(s0[3])]
+        g1 = [new(sh) for sh in s0[4]] if n_layers > 1 else [None] * 4
+        dh0 = new((n_layers, b, n * h))
+        dwp, dbp = new((dout, h)), new((dout,))
+        ws = new((lib.query("eeg_dcrnn_decoder_bwd_ws_floats", ctypes.byref(dims)),))
+        teacher = ctx.teacher
+        tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if teacher else None
+        arr = lambda k: (ctypes.c_void_p * n_layers)(*[(g0 if l == 0 else g1)[k].data_ptr() for l in range(n_layers)])  # noqa: E731
+        pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
+        lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_arr, _p(p), pk_arr, _p(wp), _p(saved), _p(d_out), _p(dh0),
+                 arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
+        return (None, dh0, None, g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3], dwp, dbp, None, None)
+
+
+def dcgru_decoder(targets, h0, p, p_batched, first_cell, shared_cell, wp, bp, n, h, dout, m, n_layers,
+                  activation="tanh", teacher=None):
+    """Run the whole decoder: returns (T,B,N*Dout).  first_cell / shared_cell = (wg, bg, wc, bc)."""
+    lib = _lib.get_lib()
+    act = ACT_CODES.get(activation, 1)
+    for fin in (dout, h):
+        if not lib.query("eeg_dcrnn_supported", n, h, fin, m):
+            raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
+    t_len, b = targets.shape[0], targets.shape[1]
+    meta = (t_len, b, n, h, dout, m, n_layers, act, p_batched)
+    sc = shared_cell if shared_cell is not None else (None, None, None, None)
+    return _DecoderFn.apply(targets, h0, p, *first_cell, *sc, wp, bp, teacher, meta)
 
 
 class _ClsHeadFn(torch.autograd.Function):

@@ -86,6 +86,33 @@ class TrainStep:
         loss.backward()
         return loss.detach()
 
+    # -- HIP-graph replay of forward + loss + backward -------------------------------------------
+    def capture(self, x, y, seq_lengths, supports, warmup: int = 2):
+        """Capture zero_grad -> forward -> loss -> backward on the given (static) input tensors into
+        one HIP graph (torch.cuda.CUDAGraph: the library launches on torch's current stream, never
+        synchronises and allocates only through torch, so the ~60 launches of a step replay as one
+        graph launch).  The exchange + optimiser tail stay outside the graph: the RCCL all-reduce is
+        issued eagerly between the replay and the fused clip+Adam kernel.  New data is fed by
+        copying into the captured tensors (`x.copy_(batch)`)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                       # populate the allocator before capture
+                self.forward_backward(x, y, seq_lengths, supports)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.forward_backward(x, y, seq_lengths, supports)
+        self._graph, self._graph_loss = graph, loss
+        self._graph_inputs = (x, y, seq_lengths, supports)
+        return graph
+
+    def replay_step(self):
+        """One optimisation step on the captured tensors: graph replay + all-reduce + clip/Adam."""
+        self._graph.replay()
+        self.reduce_and_update()
+        return self._graph_loss
+
     def reduce_and_update(self):
         g = self.fp.flat_grad
         if self.world > 1:

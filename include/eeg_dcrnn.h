@@ -37,6 +37,13 @@ typedef struct eeg_layer_dims {
     int32_t p_batched;  /* 1: P holds one graph per clip (B graphs); 0: one shared graph */
 } eeg_layer_dims;
 
+typedef struct eeg_decoder_dims {
+    int32_t T, B, N, H;  /* T = output horizon (decoder steps) */
+    int32_t Dout;        /* output_dim = input_dim of the first decoding cell (model.py:131-143) */
+    int32_t M, L;        /* hop matrices; num_rnn_layers (layers >= 1 share ONE cell, model.py:126-143) */
+    int32_t act, p_batched;
+} eeg_decoder_dims;
+
 /* Human-readable text of the last error raised on the calling thread. */
 const char* eeg_dcrnn_last_error(void);
 /* ABI version (bumped on any signature change). */
@@ -103,6 +110,28 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                         const float* Cs, const float* RHs, const float* dHseq, const float* d_at_end,
                         const float* d_at_len, const int64_t* lengths, float* dX, float* dh0,
                         float* dWg, float* dbg, float* dWc, float* dbc, float* ws, void* stream);
+
+/* DCGRUDecoder.forward (model.py:160-204): T autoregressive steps through L cells + the projection
+ * Linear(H -> Dout), GO symbol = zeros, next input = the projection of step t or, where the HOST
+ * array teacher[t] != 0 (curriculum learning, model.py:194-200; NULL = never), targets[t].
+ *   targets (T,B,N,Dout) (only read under teacher forcing, may be NULL when teacher is NULL);
+ *   h0 (L,B,N,H) encoder finals; packs: HOST array of L device pointers to cell packs
+ *   (packs[1..L-1] = the shared cell); Wp (Dout,H), bp (Dout): nn.Linear layout; out (T,B,N,Dout).
+ *   saved: eeg_dcrnn_decoder_saved_floats() floats kept for the backward; ws: scratch.
+ * The recurrence cannot be hoisted (the input of step t+1 is the output of step t), so the forward
+ * launches per step; the backward runs BPTT per step and ALL parameter gradients as GEMMs hoisted
+ * over the T steps.  dWg/dbg/dWc/dbc: HOST arrays of L device pointers (entries 1..L-1 equal:
+ * gradients of the shared cell are summed); dh0 (L,B,N,H); dWp (Dout,H); dbp (Dout). */
+size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d);
+size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d);
+size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d);
+int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const int32_t* teacher,
+                          const float* h0, const float* P, const float* const* packs, const float* Wp,
+                          const float* bp, float* out, float* saved, float* ws, void* stream);
+int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, const float* P,
+                          const float* const* packs, const float* Wp, const float* saved, const float* dOut,
+                          float* dh0, float* const* dWg, float* const* dbg, float* const* dWc,
+                          float* const* dbc, float* dWp, float* dbp, float* ws, void* stream);
 
 /* utils.last_relevant_pytorch (utils.py:346-357): last[b] = Htop[lengths[b]-1, b]. Htop (T,B,NH). */
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH,

@@ -235,3 +235,50 @@ def check_training_tail(device):
         assert abs(norm.item() - nr.item()) <= 1e-4 * max(1.0, nr.item())
         assert_close_scaled(gd.cpu().numpy(), pr.grad.numpy(), f"clipped grad step {step}", tol=1e-5)
         assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6, step
+
+
+def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed=0, ratio=None, act="tanh"):
+    """DCGRUDecoder (the native decoder operator) vs the oracle on random inputs: outputs, gradient
+    w.r.t. the initial hidden states and all parameter gradients (shared cell for layers >= 1),
+    with the teacher-forcing coin flips (model.py:194-200) replayed from the same `random` seed."""
+    import random
+    from eeg_gnn_ssl_amd import DCGRUDecoder
+    g = torch.Generator().manual_seed(seed)
+    cfg = orc.DCRNNConfig(filter_type=filt, input_dim=dout, output_dim=dout, rnn_units=h, num_rnn_layers=layers,
+                          dcgru_activation=act)
+    params = {k: v for k, v in orc.init_params(cfg, "ssl", seed=seed).items() if k.startswith("decoder.")}
+    for k in params:
+        if k.endswith("biases") and not any(params[k] is params[q] for q in params if q < k):
+            params[k].copy_(0.1 * torch.randn(params[k].shape, generator=g))
+    sup = cases.supports_for(filt, adj3d, b)
+    targets = torch.randn(t_out, b, 19, dout, generator=g)
+    h0 = 0.5 * torch.randn(layers, b, 19 * h, generator=g)
+    wout = torch.randn(t_out, b, 19 * dout, generator=g)
+    mask = None
+    if ratio is not None:
+        random.seed(seed)
+        mask = [random.random() < ratio for _ in range(t_out)]
+        assert any(mask) and not all(mask[:-1]), mask
+    uniq = {}
+    po = {}
+    for k, v in params.items():                       # shared tensors stay shared in the autograd graph
+        key = v.data_ptr()
+        if key not in uniq:
+            uniq[key] = v.clone().requires_grad_(True)
+        po[k] = uniq[key]
+    h0o = h0.clone().requires_grad_(True)
+    oo = orc.decoder_forward(po, cfg, targets, h0o, sup, mask)
+    (oo * wout).sum().backward()
+    dec = DCGRUDecoder(input_dim=dout, max_diffusion_step=2, num_nodes=19, hid_dim=h, output_dim=dout,
+                       num_rnn_layers=layers, dcgru_activation=act, filter_type=filt)
+    load(dec, {k[len("decoder."):]: v for k, v in params.items()}, device)
+    dec.train()
+    h0d = h0.clone().to(device).requires_grad_(True)
+    if ratio is not None:
+        random.seed(seed)
+    out = dec(targets.to(device), h0d, [s.to(device) for s in sup], teacher_forcing_ratio=ratio)
+    (out * wout.to(device)).sum().backward()
+    assert_close(out.detach().cpu().numpy(), oo.detach().numpy(), "decoder outputs vs oracle")
+    assert_close_scaled(h0d.grad.cpu().numpy(), h0o.grad.numpy(), "d_initial_hidden_state vs oracle", tol=5e-5)
+    for k, p in dec.named_parameters():
+        assert_close_scaled(p.grad.cpu().numpy(), po["decoder." + k].grad.numpy(), f"d_{k} vs oracle", tol=5e-5)

@@ -180,3 +180,39 @@ def test_training_reduces_loss_and_auroc_on_synthetic_labels():
 
 def test_training_tail_kernels():
     ps.check_training_tail(DEV)
+
+
+def test_hip_graph_replay_equals_eager_steps():
+    """TrainStep.capture/replay_step (one HIP graph for zero_grad+fwd+loss+bwd) must produce the
+    same parameters, bit for bit, as the eagerly launched steps (all reductions are fixed-order)."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, classes = "classification", "dual_random_walk", 4
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, 9, 6, classes, seed=3)
+    xd, yd, ld, supd = x.to(DEV), y.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup]
+    finals, losses = [], []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3)
+        if graphed:
+            st.capture(xd, yd, ld, supd)
+        ls = []
+        for _ in range(4):
+            ls.append(float((st.replay_step() if graphed else st.step(xd, yd, ld, supd)).item()))
+        torch.cuda.synchronize()
+        finals.append(st.fp.flat.detach().clone())
+        losses.append(ls)
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1])
+
+
+@pytest.mark.parametrize("filt,dout,h,layers,t_out,b,ratio,act", [
+    ("laplacian", 8, 16, 2, 5, 3, 0.5, "tanh"),            # teacher forcing on some steps
+    ("dual_random_walk", 12, 32, 3, 4, 2, 0.6, "relu"),    # shared cell used by two layers + teacher forcing
+    ("laplacian", 20, 16, 1, 3, 2, None, "tanh"),          # single layer, fully autoregressive
+    ("dual_random_walk", 100, 64, 2, 12, 6, None, "tanh"),
+])
+def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
+    ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
