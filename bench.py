@@ -102,6 +102,8 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
     r = s * n
     fins = [D_IN] + [h] * (LAYERS - 1)
     w = {"seq_fwd": 0.0, "seq_bwd": 0.0, "gemm_nn": 0.0, "gemm_tn": 0.0, "diffuse_fwd": 0.0, "diffuse_adj": 0.0}
+    if filter_type == "dual_random_walk":
+        w["corr_gram"] = 4.0 * s * n * D_IN          # per-clip correlation graph: every clip read once
     for l, fin in enumerate(fins):
         w["seq_fwd"] += s * (2 * (m - 1) * 2 * n * n * h + 2 * n * (h * m) * 3 * h)
         w["seq_bwd"] += s * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
@@ -187,6 +189,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the live per-kernel HIP-event timing")
+    ap.add_argument("--host-supports", action="store_true", help="correlation-graph workloads: use supports prepared "
+                    "on the host (the reference's DataLoader path) instead of building them on the GPU every step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the "
                     "captured HIP graph of forward+loss+backward")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning)")
@@ -205,7 +209,7 @@ def main():
         dist.init_process_group(backend="nccl")                     # "nccl" IS RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib, ops
     from eeg_gnn_ssl_amd.train_step import TrainStep
 
     for kv in args.tune:
@@ -225,6 +229,15 @@ def main():
     x, y, lengths, supports = synthetic_batch(task, filt, t_len, batch, classes, seed=123 + rank)
     x, y, lengths = x.to(dev), y.to(dev), lengths.to(dev)
     supports = [s.to(dev) for s in supports]
+    device_graph = filt == "dual_random_walk" and not args.host_supports
+    if device_graph:
+        # per-clip correlation graph + supports are rebuilt from the clips on the GPU inside every step
+        # (eeg_dcrnn_corr_graph); they must match what the host pipeline prepared for the same clips
+        chk = ops.correlation_supports(x, top_k=3)
+        bad = sum((a - b_).abs().amax(dim=(1, 2)) > 1e-5 for a, b_ in zip(chk, supports)).clamp(max=1).sum().item()
+        if bad > max(1, batch // 100):       # a rare top-3 near-tie (fp32 vs the host's fp64 Gram) may flip one edge
+            raise SystemExit(f"device correlation-graph supports differ from the host pipeline on {bad} clips")
+        supports = None
 
     def sync_all():
         if world > 1:
@@ -289,7 +302,7 @@ def main():
         per_step_ms = ms / args.steps
         ent = {"launches_per_step": cnt / args.steps, "ms_per_step": round(per_step_ms, 4)}
         if name in work and work[name] > 0 and per_step_ms > 0:
-            if "diffuse" in name:
+            if "diffuse" in name or name == "corr_gram":
                 gbs = work[name] / (per_step_ms * 1e-3) / 1e9
                 ent.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
             else:
@@ -313,8 +326,8 @@ def main():
                     "frac": d["frac"], "traffic": (traffic or {}).get(dom), "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
                     "kernels": kernels,
                     "kernel_ms_per_step_total": round(sum(v["ms_per_step"] for v in kernels.values()), 3),
-                    "whole_step_flops": round(sum(v for k, v in work.items() if "diffuse" not in k) / 1e9, 1),
-                    "whole_step_mfma_frac": round(sum(v for k, v in work.items() if "diffuse" not in k)
+                    "whole_step_flops": round(sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram") / 1e9, 1),
+                    "whole_step_mfma_frac": round(sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram")
                                                   / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)}
     out = {
         "metric": "EEG clips/sec (60s, 19ch, K=2, 2-layer x64) fwd+bwd",
@@ -323,6 +336,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": DESCR[args.workload], "per_gpu_batch": batch, "global_batch": batch * world,
                    "clip_len": t_len, "parallelism": f"dp{world}", "optimizer_step_included": True,
+                   "supports": ("per-clip correlation graph + dual random-walk supports built on the GPU inside the step"
+                                if device_graph else "prepared on the host (distance graph is fixed)"
+                                if filt == "laplacian" else "prepared on the host"),
                    "launch": "hip-graph replay (fwd+loss+bwd) + eager all-reduce/clip+Adam" if graphed else "eager",
                    "final_loss": round(loss_val, 5)},
         "roofline": roofline,

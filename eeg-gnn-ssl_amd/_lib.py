@@ -40,6 +40,8 @@ _SIGNATURES = {
     "eeg_dcrnn_prof_enable": (c_int, [c_int]),
     "eeg_dcrnn_prof_report": (c_int, [ctypes.c_char_p, c_size_t]),
     "eeg_dcrnn_hop_polys": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_corr_graph_ws_floats": (c_size_t, [c_int, c_int]),
+    "eeg_dcrnn_corr_graph": (c_int, [_FP, c_int, c_int, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_pack_floats": (c_size_t, [c_int, c_int, c_int]),
     "eeg_dcrnn_pack_cell": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_diffuse_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
@@ -63,6 +65,8 @@ _SIGNATURES = {
     "eeg_dcrnn_cls_head_bwd": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_bce_logits": (c_int, [_FP, _FP, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_ce_logits": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_masked_loss_ws_floats": (c_size_t, []),
+    "eeg_dcrnn_masked_loss": (c_int, [_FP, _FP, c_size_t, c_int, c_float, c_float, c_float, c_int, _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_clip_adam_ws_floats": (c_size_t, []),
     "eeg_dcrnn_clip_adam": (c_int, [_FP, _FP, _FP, _FP, c_size_t, c_float, c_float, c_float, c_float, c_float, c_float,
                                     c_int, c_float, _FP, _FP, c_void_p]),

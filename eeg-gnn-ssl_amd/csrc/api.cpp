@@ -10,6 +10,7 @@
 #include "../../include/eeg_dcrnn.h"
 #include "kernels_diffuse.h"
 #include "kernels_gemm.h"
+#include "kernels_graph.h"
 #include "kernels_head.h"
 #include "kernels_pack.h"
 #include "kernels_tail.h"
@@ -568,6 +569,34 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
 }
 
 
+/* ---- per-clip correlation graph -> supports --------------------------------------------------- */
+static int corr_nsplit(int B, int T) {
+    int ns = ceil_div(1024, B);
+    const int cap = ceil_div(T, 4);
+    if (ns > cap) ns = cap;
+    return ns < 1 ? 1 : ns;
+}
+size_t eeg_dcrnn_corr_graph_ws_floats(int B, int T) { return (size_t)B * corr_nsplit(B, T) * kGramFloats; }
+int eeg_dcrnn_corr_graph(const float* X, int B, int T, int N, int D, int top_k, float* adj, float* S1, float* S2,
+                         float* ws, void* stream) {
+    if (N < 1 || N > kMaxNodes) return fail("corr_graph: num_nodes=%d unsupported (1..%d)", N, kMaxNodes);
+    if (D < 4 || D % 4 != 0) return fail("corr_graph: feature dim=%d unsupported (positive multiple of 4)", D);
+    if (B < 1 || T < 1) return fail("corr_graph: empty batch/clip (B=%d, T=%d)", B, T);
+    if (top_k < 0 || top_k >= N) return fail("corr_graph: top_k=%d unsupported (0..%d)", top_k, N - 1);
+    hipStream_t st = S_(stream);
+    const int ns = corr_nsplit(B, T);
+    const size_t lds = 4 * kGramFloats * sizeof(float);
+    switch (ceil_div(D, 16)) {
+#define EEG_GRAM(NQ) case NQ: EEG_LAUNCH_P("corr_gram", corr_gram_kernel<NQ>, dim3(B, ns), dim3(256), lds, st, X, T, N, D, ws); break;
+        EEG_GRAM(1) EEG_GRAM(2) EEG_GRAM(3) EEG_GRAM(4) EEG_GRAM(5) EEG_GRAM(6) EEG_GRAM(7) EEG_GRAM(8)
+#undef EEG_GRAM
+        default: return fail("corr_graph: feature dim=%d unsupported (<= 128)", D);
+    }
+    if (check_launch("corr_gram")) return 1;
+    EEG_LAUNCH_P("corr_finish", corr_finish_kernel, dim3(B), dim3(256), (2 * 32 * 33 + 64) * sizeof(float), st, ws, ns, N, top_k, adj, S1, S2);
+    return check_launch("corr_finish");
+}
+
 /* ---- decoder ---------------------------------------------------------------------------------- */
 size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d) { return dec_layout(d).saved_total; }
 size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d) { return (size_t)d->B * d->N * 3 * d->H; }
@@ -743,6 +772,24 @@ int eeg_dcrnn_ce_logits(const float* logits, const int64_t* y, int B, int C, flo
     EEG_LAUNCH_P("loss_ce", ce_logits_kernel, dim3(1), dim3(256), 256 * sizeof(float), S_(stream), logits,
                  reinterpret_cast<const long long*>(y), B, C, loss, dlogits);
     return check_launch("ce_logits");
+}
+size_t eeg_dcrnn_masked_loss_ws_floats(void) { return 2 * kLossBlocks + 64; }
+int eeg_dcrnn_masked_loss(const float* pred, const float* y, size_t n, int use_scaler, float mean, float std_,
+                          float mask_val, int kind, float* loss, float* dpred, float* ws, void* stream) {
+    if (n < 1) return fail("masked_loss: empty tensors");
+    if (kind != 0 && kind != 1) return fail("masked_loss: kind=%d unsupported (0 = MAE, 1 = RMSE)", kind);
+    hipStream_t st = S_(stream);
+    int nblk = (int)((n + 256 * 8 - 1) / (256 * 8));
+    if (nblk > kLossBlocks) nblk = kLossBlocks;
+    EEG_LAUNCH_P("loss_masked", masked_loss_partial_kernel, dim3(nblk), dim3(256), 512 * sizeof(float), st, pred, y, n, mean, std_, use_scaler, mask_val, kind, ws);
+    if (check_launch("masked_loss_partial")) return 1;
+    EEG_LAUNCH_P("loss_masked", masked_loss_finish_kernel, dim3(1), dim3(64), 0, st, ws, nblk, kind, loss);
+    if (check_launch("masked_loss_finish")) return 1;
+    if (dpred != nullptr) {
+        EEG_LAUNCH_P("loss_masked", masked_loss_grad_kernel, dim3(nblk * 4), dim3(256), 0, st, pred, y, n, mean, std_, use_scaler, mask_val, kind, ws, dpred);
+        if (check_launch("masked_loss_grad")) return 1;
+    }
+    return 0;
 }
 size_t eeg_dcrnn_clip_adam_ws_floats(void) { return 64; }
 int eeg_dcrnn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm,

@@ -72,6 +72,12 @@ __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
+// a*b + c with the product rounded first (what two separate framework kernels compute)
+#if defined(EEG_SIMT_EMU)
+__device__ __forceinline__ float unfused_mul_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
+#else
+__device__ __forceinline__ float unfused_mul_add(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
+#endif
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
 

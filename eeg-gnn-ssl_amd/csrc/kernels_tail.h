@@ -52,6 +52,65 @@ __global__ void ce_logits_kernel(const float* __restrict__ x, const long long* _
     if (threadIdx.x == 0) loss[0] = sm[0] / (float)B;
 }
 
+// utils.compute_regression_loss (utils.py:431-495): optional scalar StandardScaler inverse transform
+// (v*std + mean), mask = (y_true != mask_val), loss = sum(e * mask) / count(mask) with e = |d| (kind 0,
+// masked MAE) or d^2 followed by sqrt (kind 1: `masked_mse_loss`, really a masked RMSE).
+// stage 1: per-block partial sums [sum | count]; stage 2 (one block): loss value + gradient scale;
+// stage 3: dpred.  Fixed-order reductions.
+constexpr int kLossBlocks = 256;
+__device__ __forceinline__ void masked_terms(float p, float y, float mean, float std_, int scaled, float mask_val,
+                                             float& d, float& mk) {
+    // two roundings like the reference's `data * std + mean` (no FMA contraction: the mask tests ys against mask_val)
+    const float ps = scaled ? unfused_mul_add(p, std_, mean) : p, ys = scaled ? unfused_mul_add(y, std_, mean) : y;
+    d = ps - ys;
+    mk = ys != mask_val ? 1.f : 0.f;
+}
+__global__ void masked_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ y, size_t n,
+                                           float mean, float std_, int scaled, float mask_val, int kind,
+                                           float* __restrict__ part) {
+    EEG_DYN_SMEM(sm);                                   // [2][256]
+    float s = 0.f, c = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float d, mk;
+        masked_terms(pred[i], y[i], mean, std_, scaled, mask_val, d, mk);
+        s += (kind == 0 ? fabsf(d) : d * d) * mk;
+        c += mk;
+    }
+    sm[threadIdx.x] = s;
+    sm[256 + threadIdx.x] = c;
+    __syncthreads();
+    for (int k = blockDim.x / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { sm[threadIdx.x] += sm[threadIdx.x + k]; sm[256 + threadIdx.x] += sm[256 + threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x] = sm[0]; part[kLossBlocks + blockIdx.x] = sm[256]; }
+}
+// part[2*kLossBlocks] = loss, [+1] = gradient scale (MAE: 1/count; RMSE: 1/(count*loss)); 0 when count == 0
+__global__ void masked_loss_finish_kernel(float* __restrict__ part, int nblk, int kind, float* __restrict__ loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f, c = 0.f;
+    for (int i = 0; i < nblk; ++i) { s += part[i]; c += part[kLossBlocks + i]; }
+    float l = 0.f, sc = 0.f;
+    if (c > 0.f) {
+        l = kind == 0 ? s / c : sqrtf(s / c);
+        sc = kind == 0 ? 1.f / c : (l > 0.f ? 1.f / (c * l) : 0.f);
+    }
+    loss[0] = l;
+    part[2 * kLossBlocks] = l;
+    part[2 * kLossBlocks + 1] = sc;
+}
+__global__ void masked_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ y, size_t n,
+                                        float mean, float std_, int scaled, float mask_val, int kind,
+                                        const float* __restrict__ part, float* __restrict__ dpred) {
+    const float sc = part[2 * kLossBlocks + 1] * (scaled ? std_ : 1.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float d, mk;
+        masked_terms(pred[i], y[i], mean, std_, scaled, mask_val, d, mk);
+        const float e = kind == 0 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d;
+        dpred[i] = e * mk * sc;
+    }
+}
+
 // stage 1: per-block partial sums of g^2 (fixed assignment of elements to blocks/threads)
 __global__ void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     EEG_DYN_SMEM(sm);

@@ -114,6 +114,26 @@ def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: 
     return out, flag
 
 
+def correlation_supports(x: torch.Tensor, top_k: int = 3, return_adj: bool = False):
+    """Per-clip correlation graph -> [S1, S2] dual random-walk supports, on the device.
+
+    x (B,T,N,D) clips (the model input).  Replaces the DataLoader-side `_get_indiv_graphs` +
+    `keep_topk` + `_compute_supports('dual_random_walk')` (dataloader_detection.py:258-307,335-354).
+    Returns [S1 (B,N,N), S2 (B,N,N)] (and the sparsified adjacency (B,N,N) if return_adj)."""
+    lib = _lib.get_lib()
+    x = x.contiguous()
+    _check(lib, x, "clips")
+    if x.dim() != 4:
+        raise RuntimeError(f"clips must be (B,T,N,D), got {tuple(x.shape)}")
+    b, t_len, n, d = x.shape
+    s1 = torch.empty((b, n, n), dtype=torch.float32, device=x.device)
+    s2 = torch.empty_like(s1)
+    adj = torch.empty_like(s1) if return_adj else None
+    ws = torch.empty(lib.query("eeg_dcrnn_corr_graph_ws_floats", b, t_len), dtype=torch.float32, device=x.device)
+    lib.call("eeg_dcrnn_corr_graph", _p(x), b, t_len, n, d, int(top_k), _p(adj), _p(s1), _p(s2), _p(ws), _stream(x))
+    return ([s1, s2], adj) if return_adj else [s1, s2]
+
+
 def pack_cell(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
     """Reference-layout cell parameters -> MFMA-fragment-ordered device block (kernels_pack.h)."""
     lib = _lib.get_lib()
@@ -421,6 +441,39 @@ class _CELogitsFn(torch.autograd.Function):
     def backward(ctx, dloss):
         (dx,) = ctx.saved_tensors
         return dx * dloss, None
+
+
+class _MaskedLossFn(torch.autograd.Function):
+    """utils.compute_regression_loss (utils.py:431-495): masked MAE / masked RMSE with an optional
+    scalar StandardScaler inverse transform; value and gradient from three small HIP launches."""
+
+    @staticmethod
+    def forward(ctx, pred, y, mean, std, mask_val, kind):
+        lib = _lib.get_lib()
+        p = pred.contiguous()
+        t = y.to(torch.float32).contiguous()
+        _check(lib, p, "y_predicted")
+        _check(lib, t, "y_true")
+        if p.shape != t.shape:
+            raise RuntimeError(f"y_predicted {tuple(p.shape)} and y_true {tuple(t.shape)} differ in shape")
+        loss = torch.empty(1, dtype=torch.float32, device=p.device)
+        dp = torch.empty_like(p)
+        ws = torch.empty(lib.query("eeg_dcrnn_masked_loss_ws_floats"), dtype=torch.float32, device=p.device)
+        scaled = mean is not None
+        lib.call("eeg_dcrnn_masked_loss", _p(p), _p(t), p.numel(), 1 if scaled else 0, float(mean) if scaled else 0.0,
+                 float(std) if scaled else 1.0, float(mask_val), int(kind), _p(loss), _p(dp), _p(ws), _stream(p))
+        ctx.save_for_backward(dp)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dp,) = ctx.saved_tensors
+        return dp * dloss, None, None, None, None, None
+
+
+def masked_regression_loss(y_predicted, y_true, mean=None, std=None, loss_fn="mae", mask_val=0.0):
+    """Only the exact string 'mae' selects the MAE (utils.py:489-495); anything else is the masked RMSE."""
+    return _MaskedLossFn.apply(y_predicted, y_true, mean, std, mask_val, 0 if loss_fn == "mae" else 1)
 
 
 def bce_with_logits(logits, y):

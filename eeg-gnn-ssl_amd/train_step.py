@@ -67,6 +67,14 @@ class TrainStep:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
 
+    def set_epoch(self, epoch: int, num_epochs: int, eta_min: float = 0.0):
+        """Cosine learning-rate schedule of the reference, stepped per epoch (train.py:224,329)."""
+        from . import utils
+        if not hasattr(self, "base_lr"):
+            self.base_lr = self.lr
+        self.lr = utils.cosine_annealing_lr(self.base_lr, epoch, num_epochs, eta_min)
+        return self.lr
+
     def loss(self, out, y):
         if self.task == "detection":        # train.py:203-204,266-267
             return ops.bce_with_logits(out.view(-1), y)
@@ -77,7 +85,11 @@ class TrainStep:
         return utils.compute_regression_loss(y_true=y, y_predicted=out, standard_scaler=sc, loss_fn="MAE")
 
     def forward_backward(self, x, y, seq_lengths, supports):
+        """supports=None: build the per-clip correlation graph and its dual random-walk supports from
+        the clips on the device (the DataLoader-side `_get_indiv_graphs` of the reference)."""
         self.fp.zero_grad()
+        if supports is None:
+            supports = ops.correlation_supports(x, top_k=3)
         if self.task == "ssl":
             out = self.model(x, y, supports)
         else:

@@ -144,15 +144,31 @@ def masked_mse_loss(y_pred, y_true, mask_val=0.0):
 def compute_regression_loss(y_true, y_predicted, standard_scaler=None, device=None, loss_fn="mae",
                             mask_val=0.0, is_tensor=True):
     """reference utils.py:460-495.  Only the exact string 'mae' selects the MAE; the SSL trainer
-    passes "MAE" (train_ssl.py:168) and therefore optimises the masked RMSE — kept as is."""
+    passes "MAE" (train_ssl.py:168) and therefore optimises the masked RMSE — kept as is.
+
+    Tensor inputs with a scalar scaler (the reference's case: utils.py:402-403 pickled scalars) run
+    in the HIP loss kernels (value + gradient, eeg_dcrnn_masked_loss); numpy inputs
+    (`is_tensor=False`) are host-side evaluation utilities."""
     if device is not None:
         y_true, y_predicted = y_true.to(device), y_predicted.to(device)
+    scalar_scaler = standard_scaler is None or (np.ndim(standard_scaler.mean) == 0 and np.ndim(standard_scaler.std) == 0)
+    if is_tensor and scalar_scaler and torch.is_tensor(y_predicted):
+        from . import ops
+        mean = None if standard_scaler is None else float(standard_scaler.mean)
+        std = None if standard_scaler is None else float(standard_scaler.std)
+        return ops.masked_regression_loss(y_predicted, y_true, mean, std, loss_fn, mask_val)
     if standard_scaler is not None:
         y_true = standard_scaler.inverse_transform(y_true, is_tensor=is_tensor, device=device)
         y_predicted = standard_scaler.inverse_transform(y_predicted, is_tensor=is_tensor, device=device)
     if loss_fn == "mae":
         return masked_mae_loss(y_predicted, y_true, mask_val=mask_val)
     return masked_mse_loss(y_predicted, y_true, mask_val=mask_val)
+
+
+def cosine_annealing_lr(base_lr, epoch, num_epochs, eta_min=0.0):
+    """Closed form of torch.optim.lr_scheduler.CosineAnnealingLR(T_max=num_epochs) stepped once per
+    epoch (train.py:224,329; train_ssl.py:151,233): lr after `epoch` scheduler steps."""
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * epoch / num_epochs)) / 2.0
 
 
 # ---- checkpoints ----------------------------------------------------------------------------------

@@ -70,6 +70,16 @@ int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K,
                         float* P_out, void* stream);
 
+/* Per-clip correlation graph and its dual random-walk supports, from the clips themselves
+ * (replaces the DataLoader-side CPU code: dataloader_detection.py:258-307 `_get_indiv_graphs`
+ * = |normalised lag-0 cross-correlation| of every electrode pair of the (N, T*D) clip, diag 1;
+ * data_utils.py:174-200 keep_topk(top_k, directed=True); dataloader_detection.py:346-349 +
+ * utils.py:220-230: S1 = (D^-1 A)^T, S2 = (D_in^-1 A^T)^T).  X (B,T,N,D) batch-major clips;
+ * adj (B,N,N) may be NULL; S1, S2 (B,N,N).  HBM-bound: algorithmic bytes 4*B*T*N*D. */
+size_t eeg_dcrnn_corr_graph_ws_floats(int B, int T);
+int eeg_dcrnn_corr_graph(const float* X, int B, int T, int N, int D, int top_k, float* adj, float* S1,
+                         float* S2, float* ws, void* stream);
+
 /* Number of floats of the packed weight block of one DCGRU cell. */
 size_t eeg_dcrnn_pack_floats(int Fin, int H, int M);
 /* Reference-layout parameters of one cell (cell.py:40-46,160-175) -> MFMA-fragment-ordered block. */
@@ -147,6 +157,14 @@ int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits,
 int eeg_dcrnn_bce_logits(const float* logits, const float* y, int B, float* loss, float* dlogits, void* stream);
 int eeg_dcrnn_ce_logits(const float* logits, const int64_t* y, int B, int C, float* loss, float* dlogits,
                         void* stream);
+/* utils.compute_regression_loss (utils.py:431-495; train_ssl.py:165-170) on n elements: optional
+ * scalar StandardScaler inverse transform v*std + mean of both tensors, mask = (y_true != mask_val),
+ * kind 0: masked MAE (loss_fn == 'mae'); kind 1: `masked_mse_loss`, which returns the masked RMSE
+ * (what train_ssl.py's "MAE" string actually selects).  loss[0] = value; dpred (nullable) = gradient
+ * w.r.t. pred.  ws: eeg_dcrnn_masked_loss_ws_floats() floats. */
+size_t eeg_dcrnn_masked_loss_ws_floats(void);
+int eeg_dcrnn_masked_loss(const float* pred, const float* y, size_t n, int use_scaler, float mean, float std_,
+                          float mask_val, int kind, float* loss, float* dpred, float* ws, void* stream);
 /* clip_grad_norm_(max_norm) + torch.optim.Adam(lr, betas, eps, weight_decay = coupled L2) step
  * `step` (1-based) over flat fp32 buffers of n elements (train.py:222-223,273-275).  grads are
  * first multiplied by grad_scale (1/world_size after a summed all-reduce).  ws: 64 floats scratch;

@@ -216,6 +216,21 @@ def check_training_tail(device):
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-6
     assert_close_scaled(xd.grad.cpu().numpy(), xr.grad.numpy(), "ce dlogits", tol=1e-5)
+    # masked MAE / RMSE (utils.py:431-495) with and without the scalar scaler; exact zeros of y_true are masked
+    for shape, scaler in (((3, 4, 19, 10), (3.924, 1.56)), ((7001,), None), ((5, 12, 19, 100), (0.0, 1.0))):
+        pr = torch.randn(shape, generator=g)
+        yt = torch.randn(shape, generator=g)
+        yt[torch.rand(shape, generator=g) < 0.2] = 0.0 if scaler is None else -scaler[0] / scaler[1]
+        for name in ("mae", "MAE"):
+            pd = pr.clone().to(device).requires_grad_(True)
+            loss = ops.masked_regression_loss(pd, yt.to(device), None if scaler is None else scaler[0],
+                                              None if scaler is None else scaler[1], name)
+            loss.backward()
+            po = pr.clone().requires_grad_(True)
+            ref = orc.regression_loss(yt, po, None if scaler is None else scaler[0], None if scaler is None else scaler[1], name)
+            ref.backward()
+            assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item())), (shape, name, loss.item(), ref.item())
+            assert_close_scaled(pd.grad.cpu().numpy(), po.grad.numpy(), f"masked {name} dpred", tol=1e-5)
     n = 70001
     p0 = torch.randn(n, generator=g)
     pd = p0.to(device).clone()
@@ -282,3 +297,32 @@ def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed
     assert_close_scaled(h0d.grad.cpu().numpy(), h0o.grad.numpy(), "d_initial_hidden_state vs oracle", tol=5e-5)
     for k, p in dec.named_parameters():
         assert_close_scaled(p.grad.cpu().numpy(), po["decoder." + k].grad.numpy(), f"d_{k} vs oracle", tol=5e-5)
+
+
+def check_correlation_supports(device, golden):
+    """On-device per-clip correlation graph -> dual random-walk supports vs (i) the golden of the
+    genuine reference pipeline on the closed-form clip and (ii) the oracle on random clips,
+    including a silent electrode (zero norm), a short clip and ragged sizes."""
+    from closed_form import cf
+    from eeg_gnn_ssl_amd import ops
+    clip = cf((12, 19, 100), scale=1.0, freq=0.7391, phase=0.2) + cf((12, 19, 100), scale=0.5, freq=0.0137, phase=1.0)
+    x = torch.from_numpy(np.ascontiguousarray(clip, dtype=np.float32)).unsqueeze(0).to(device)
+    (s1, s2), adj = ops.correlation_supports(x, top_k=3, return_adj=True)
+    assert np.abs(adj[0].cpu().numpy() - golden["corr/adj"]).max() <= 2e-6
+    assert np.abs(s1[0].cpu().numpy() - golden["corr/s1"]).max() <= 2e-6
+    assert np.abs(s2[0].cpu().numpy() - golden["corr/s2"]).max() <= 2e-6
+    g = torch.Generator().manual_seed(9)
+    for (b, t_len, n, d, top_k) in ((5, 7, 19, 100, 3), (3, 60, 19, 100, 3), (2, 1, 19, 8, 2), (4, 9, 12, 20, 4)):
+        xs = torch.randn(b, t_len, n, d, generator=g)
+        xs[0, :, 3, :] = 0.0                                  # a silent electrode: zero norm -> raw (zero) correlation
+        xs[-1] = xs[-1] * 0.5 + xs[-1, :, :1, :]              # strongly correlated channels
+        (s1, s2), adj = ops.correlation_supports(xs.to(device), top_k=top_k, return_adj=True)
+        for i in range(b):
+            a_ref = orc.correlation_adjacency(xs[i].numpy(), top_k=top_k)
+            sup = [orc.random_walk(a_ref).T, orc.random_walk(a_ref.T).T]
+            got = adj[i].cpu().numpy()
+            # a top-k tie broken the other way would move whole entries; values elsewhere agree to fp32 rounding
+            assert ((got != 0) == (a_ref != 0)).all(), (b, t_len, n, d, i)
+            assert np.abs(got - a_ref).max() <= 5e-6
+            assert np.abs(s1[i].cpu().numpy() - sup[0]).max() <= 5e-6
+            assert np.abs(s2[i].cpu().numpy() - sup[1]).max() <= 5e-6

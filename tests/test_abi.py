@@ -52,3 +52,16 @@ def test_product_has_no_cpu_path():
     cell = DCGRUCell(100, 64, 2, 19)
     with pytest.raises(RuntimeError, match="no CPU path"):
         cell([torch.eye(19)], torch.zeros(2, 1900), torch.zeros(2, 19 * 64))
+
+
+def test_cosine_schedule_matches_torch():
+    """utils.cosine_annealing_lr == CosineAnnealingLR(T_max=num_epochs) stepped per epoch (train.py:224,329)."""
+    import torch
+    from eeg_gnn_ssl_amd import utils
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=3e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=60)
+    for e in range(1, 61):
+        opt.step()
+        sch.step()
+        assert abs(sch.get_last_lr()[0] - utils.cosine_annealing_lr(3e-4, e, 60)) < 1e-12

@@ -51,3 +51,7 @@ def test_training_tail_kernels():
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle("cpu", filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
+
+
+def test_correlation_graph_supports(golden):
+    ps.check_correlation_supports("cpu", golden)

@@ -216,3 +216,7 @@ def test_hip_graph_replay_equals_eager_steps():
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
+
+
+def test_correlation_graph_supports(golden):
+    ps.check_correlation_supports(DEV, golden)
