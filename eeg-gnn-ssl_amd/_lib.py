@@ -119,6 +119,9 @@ def get_lib() -> EegDcrnnLib:
         lib = EegDcrnnLib(HIP_LIB_PATH)
         if not lib.is_device_build:
             raise ImportError(f"{HIP_LIB_PATH} is not a device build")
+        for kv in filter(None, os.environ.get("EEG_DCRNN_TUNE", "").split(",")):   # development: "key=value,..."
+            k, v = kv.split("=")
+            lib.call("eeg_dcrnn_set_tuning", int(k), int(v))
         _LIB = lib
     return _LIB
 

@@ -121,9 +121,6 @@ template <int NCTW>
 int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
               float* C, int ldc, int O, hipStream_t st) {
     if (g_tune[0] == 0 && ldc % 4 == 0) {            // v2 kernels (default)
-        if (g_tune[2] == 1 && F % 16 == 0) return run_nn2<NCTW, 16, 3, 1>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-        if (g_tune[2] == 2 && F % 16 == 0) return run_nn2<NCTW, 16, 2, 2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-        if (g_tune[2] == 2 && F % 20 == 0) return run_nn2<NCTW, 20, 2, 2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
         if (F % 16 == 0) return run_nn2<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
         if (F % 20 == 0) return run_nn2<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
     }
@@ -149,7 +146,11 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     const size_t lds = 2 * (size_t)(32 * 80 + 32 * YS) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_tn_kernel<NCTW>), lds);
     dim3 grid(nseg * ceil_div(F, 64), nsplit);
-    EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    // measured on MI355X (cfg2): co-locating the k-blocks of a split on one XCD is SLOWER (gemm_tn 1.19 vs 1.04 ms
+    // per step) -- the default round-robin spread already serves the shared dY rows from the Infinity Cache and
+    // keeps eight L2s busy; the remap stays available as knob 4 for re-measurement on other shapes.
+    const int remap = (g_tune[4] == 1 && nsplit % 8 == 0 && grid.x > 1) ? 1 : 0;
+    EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, remap);
     return check_launch("gemm_tn");
 }
 template <int KTW, int NCTW>
@@ -179,6 +180,7 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
     int rps = round_up(ceil_div(R, nsplit), 32);
     if (rps < 128) rps = 128;
     nsplit = ceil_div(R, rps);
+    if (nsplit >= 8) nsplit = round_up(nsplit, 8);   // multiple of 8: XCD-aware k-block placement (trailing splits may be empty)
     *rows_per_split = rps;
     return nsplit;
 }

@@ -10,6 +10,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 
 #if defined(EEG_SIMT_EMU)
 #include "simt_emu.h"
@@ -76,7 +77,11 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 #if defined(EEG_SIMT_EMU)
 __device__ __forceinline__ float unfused_mul_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
 #else
-__device__ __forceinline__ float unfused_mul_add(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }
+__device__ __forceinline__ float unfused_mul_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
 #endif
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }

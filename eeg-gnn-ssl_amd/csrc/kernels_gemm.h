@@ -233,25 +233,31 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn2_kernel(SegPtrs segs, int n
             }
         }
     }
-    // lane owns row (row0 + wr*64 + i*16 + lr), columns (ct*16 + 4*lg .. +3)
+    // lane owns row (row0 + wr*64 + i*16 + lr), columns (ct*16 + 4*lg .. +3).  Row groups are the
+    // outer loop: the NCTW consecutive stores of a group fill whole cache lines of those 16 rows
+    // (measured 5% faster than column-tile-outer on the layer-1 shape, tools/micro/nn_probe.hip).
+    float4 bv[NCTW];
 #pragma unroll
     for (int j = 0; j < NCTW; ++j) {
         const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias != nullptr && col + 3 < O) bv = *reinterpret_cast<const float4*>(bias + col);
+        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr && col + 3 < O) bv[j] = *reinterpret_cast<const float4*>(bias + col);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + wr * 64 + i * 16 + lr;
-            if (row < R) {
-                float* c = C + (size_t)row * ldc + col;
-                if (col + 3 < O) {
-                    *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y,
-                                                                acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
-                } else {
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + lr;
+        if (row >= R) continue;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (col + r < O) c[r] = acc[i][j][r] + (bias != nullptr ? bias[col + r] : 0.f);
-                }
+        for (int j = 0; j < NCTW; ++j) {
+            const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
+            float* c = C + (size_t)row * ldc + col;
+            if (col + 3 < O) {
+                *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y,
+                                                            acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < O) c[r] = acc[i][j][r] + (bias != nullptr ? bias[col + r] : 0.f);
             }
         }
     }
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn2_kernel(SegPtrs segs, int n
 template <int NCTW>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, int F, int R,
                                                       const float* __restrict__ dY, int ldy, int ycol0, int Ov,
-                                                      float* __restrict__ partial, int rows_per_split) {
+                                                      float* __restrict__ partial, int rows_per_split, int xcd_remap) {
     constexpr int RC = 32, O = 2 * NCTW * 16;
     constexpr int AS = 80;                                  // 64 + 16: stride % 32 == 16
     constexpr int YS = O + ((16 - (O % 32)) + 32) % 32;     // stride % 32 == 16
@@ -277,8 +283,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wk = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
     const int nfb = ceil_div(F, 64);
-    const int seg = blockIdx.x / nfb, f0 = (blockIdx.x % nfb) * 64;
-    const int rbeg = blockIdx.y * rows_per_split;
+    // Optional XCD-aware placement (off by default, see api.cpp: it measured slower): workgroups are
+    // dealt round-robin to the 8 XCDs by linear id and every XCD has its own L2; with the remap all
+    // k-blocks of one row split (they read the same dY rows) get linear ids congruent mod 8, i.e.
+    // the same XCD.  Correctness does not depend on the placement.
+    int kblock = blockIdx.x, split = blockIdx.y;
+    if (xcd_remap) {                                       // host guarantees gridDim.y % 8 == 0
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        split = xcd + 8 * (slot / (int)gridDim.x);
+        kblock = slot % (int)gridDim.x;
+    }
+    const int seg = kblock / nfb, f0 = (kblock % nfb) * 64;
+    const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
     const float* A = segs.p[seg];
 
@@ -349,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
         __syncthreads();
     }
     const size_t Ktot = (size_t)nseg * F;
-    float* out = partial + (size_t)blockIdx.y * Ktot * Ov;
+    float* out = partial + (size_t)split * Ktot * Ov;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -1,4 +1,11 @@
-for t in "" "--tune 3=1"; do python bench.py --steps 10 --warmup 3 --no-cpu-baseline $t 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); k=d['roofline']['kernels']; print('$t', d['value'], d['ms_per_step'], 'seq_fwd', k['seq_fwd']['ms_per_step'], 'seq_bwd', k['seq_bwd']['ms_per_step'])
-"; done
+#!/bin/bash
+# A/B timing of tuning-knob sets: ab.sh [--workload W] "k=v,k=v" "k=v" ...   ("-" = defaults)
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; mkdir -p gpurun_out
+WL=cfg2; if [ "$1" == "--workload" ]; then WL=$2; shift 2; fi
+for t in "$@"; do
+  args=""; if [ "$t" != "-" ]; then for kv in ${t//,/ }; do args="$args --tune $kv"; done; fi
+  python bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline $args 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['kernels']
+print('$t'.ljust(14), d['value'], d['ms_per_step'], 'loss', d['config']['final_loss'], ' '.join(f\"{n}={k[n]['ms_per_step']:.3f}\" for n in ('gemm_tn','gemm_nn','seq_fwd','seq_bwd','reduce_unpack','diffuse_fwd') if n in k))"
+done

@@ -1,0 +1,158 @@
+// Where does gemm_nn2 lose MFMA time?  Same tiling/loop as eeg::gemm_nn2_kernel<6,16> (K = 192, O = 192,
+// R = 291840) with parts of the loop removed:  MODE 0 full, 1 no global loads in the loop, 2 also no LDS
+// stores, 3 also no barrier (MFMA + LDS fragment reads only), 4 MFMA only.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include "../../eeg-gnn-ssl_amd/csrc/common.h"
+using namespace eeg;
+struct SegPtrs { const float* p[8]; };
+template <int NCTW, int KC, int MODE, int ST = 0>
+__global__ __launch_bounds__(256, 2) void nn(SegPtrs segs, int nseg, int F, int R, const float* __restrict__ Bp, int nct_total,
+                                             float* __restrict__ C, int ldc, int O) {
+    constexpr int KCS = lds_stride(KC), NB = 2 * NCTW, KSC = KC / 4;
+    constexpr int A_FLOATS = 128 * KCS, B_FLOATS = KSC * NB * 64;
+    constexpr int A_LD = (128 * KC / 4 + 255) / 256, B_LD = (B_FLOATS / 4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+    const int row0 = blockIdx.x * 128, ct0 = blockIdx.y * NB;
+    const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
+    f32x4 acc[4][NCTW];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int chunk) {
+        const int seg = chunk / nchunk_seg, kc0 = (chunk % nchunk_seg) * KC;
+        const float* A = segs.p[seg];
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < 128 * KC / 4 && row0 + row < R) v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + row) * F + kc0 + 4 * c4);
+            ra[i] = v;
+        }
+        const int gks0 = (seg * F + kc0) / 4;
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int q = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < B_FLOATS / 4) {
+                const int ks = q / (NB * 16), rem = q % (NB * 16), ct = rem / 16, l4 = rem % 16;
+                if (ct0 + ct < nct_total) v = *reinterpret_cast<const float4*>(Bp + ((size_t)(gks0 + ks) * nct_total + ct0 + ct) * 64 + 4 * l4);
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
+            if (q < 128 * KC / 4) { float* d = As + row * KCS + 4 * c4; d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) { const int q = tid + 256 * i; if (q < B_FLOATS / 4) *reinterpret_cast<float4*>(Bs + 4 * q) = rb[i]; }
+    };
+    auto compute = [&](int buf) {
+        const float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        const float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            float a[4], b[NCTW];
+            if (MODE < 4 || MODE == 6) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + lr) * KCS + 4 * ks + lg];
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) b[j] = Bs[(ks * NB + wc * NCTW + j) * 64 + lane];
+            } else {
+                for (int i = 0; i < 4; ++i) a[i] = (float)(lane + i);
+                for (int j = 0; j < NCTW; ++j) b[j] = (float)(lane - j);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);
+        }
+    };
+    if (MODE < 5 || MODE == 6) { gload(0); lstore(0); __syncthreads(); }
+    constexpr int LM = MODE == 6 ? 0 : (MODE == 7 ? 4 : MODE);      // 6: full loop, no C stores; 7: MFMA only + C stores, no prologue
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (LM < 1 && ch + 1 < nchunks) gload(ch + 1);
+        compute(buf);
+        if (LM < 2 && ch + 1 < nchunks) lstore(buf ^ 1);
+        if (LM < 3) __syncthreads();
+    }
+    if (MODE == 6) {
+        float t = 0.f;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < NCTW; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) C[tid] = t;
+        return;
+    }
+    if (MODE >= 5 && MODE != 7) {
+        float t = 0.f;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < NCTW; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) C[tid] = t;
+        return;
+    }
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (ST == 0) {
+        for (int j = 0; j < NCTW; ++j) {
+            const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + wr * 64 + i * 16 + lr;
+                if (row < R && col + 3 < O) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                     // rows outer: the six stores of a row group complete whole lines
+            const int row = row0 + wr * 64 + i * 16 + lr;
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) {
+                const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
+                if (row < R && col + 3 < O) {
+                    f4v v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (ST == 2) __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(C + (size_t)row * ldc + col));
+                    else *reinterpret_cast<f4v*>(C + (size_t)row * ldc + col) = v;
+                }
+            }
+        }
+    }
+}
+template <int MODE, int ST = 0>
+void run(const char* what, SegPtrs segs, int nseg, int F, int R, const float* Bp, float* C) {
+    constexpr int KC = 16, NCTW = 6;
+    const size_t lds = 2 * (size_t)(128 * lds_stride(KC) + (KC / 4) * 12 * 64) * sizeof(float);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((nn<NCTW, KC, MODE, ST>), dim3((R + 127) / 128, 1), dim3(256), lds, 0, segs, nseg, F, R, Bp, 12, C, 192, 192);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    const double fl = 2.0 * R * (double)(nseg * F) * 192;
+    printf("%-44s %.3f ms  %.1f TFLOP/s\n", what, best, fl / best / 1e9);
+}
+int main() {
+    const int R = 291840, F = 64, nseg = 3;   // allocation covers R up to 128*2560
+    float *A, *Bp, *C;
+    const size_t RM = 128 * 2560; hipMalloc(&A, (size_t)nseg * RM * F * 4); hipMalloc(&Bp, (size_t)nseg * F * 192 * 4); hipMalloc(&C, (size_t)RM * 192 * 4);
+    hipMemset(A, 0, (size_t)nseg * RM * F * 4); hipMemset(Bp, 0, (size_t)nseg * F * 192 * 4);
+    SegPtrs s{}; for (int m = 0; m < nseg; ++m) s.p[m] = A + (size_t)m * RM * F;
+    run<0>("full kernel", s, nseg, F, R, Bp, C);
+    run<1>("no global loads in the loop", s, nseg, F, R, Bp, C);
+    run<2>("... and no LDS stores", s, nseg, F, R, Bp, C);
+    run<3>("... and no barrier (MFMA + LDS reads)", s, nseg, F, R, Bp, C);
+    run<4>("MFMA only (+ prologue/epilogue)", s, nseg, F, R, Bp, C);
+    run<5>("MFMA only, no prologue, no C stores", s, nseg, F, R, Bp, C);
+    run<6>("full loop + prologue, NO C stores", s, nseg, F, R, Bp, C);
+    run<7>("MFMA only, no prologue, WITH C stores", s, nseg, F, R, Bp, C);
+    run<7, 1>("  same, stores ordered rows-outer", s, nseg, F, R, Bp, C);
+    run<7, 2>("  same, rows-outer + nontemporal", s, nseg, F, R, Bp, C);
+    run<0, 1>("full kernel, stores rows-outer", s, nseg, F, R, Bp, C);
+    run<0, 2>("full kernel, rows-outer + nontemporal", s, nseg, F, R, Bp, C);
+    return 0;
+}
