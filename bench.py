@@ -193,6 +193,8 @@ def main():
                     "on the host (the reference's DataLoader path) instead of building them on the GPU every step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the "
                     "captured HIP graph of forward+loss+backward")
+    ap.add_argument("--graph", action="store_true", help="replay the HIP graph also when launched on several GPUs "
+                    "(default there: eager launches; the replay measured no faster at 1 GPU, the host runs ahead anyway)")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning)")
     args = ap.parse_args()
 
@@ -251,7 +253,7 @@ def main():
     log(f"inputs on device, {args.warmup} warm-up steps")
     lib = _lib.get_lib()
     graphed = False
-    if not args.no_graph:
+    if not args.no_graph and (world == 1 or args.graph):
         # forward + loss + backward replayed as ONE HIP graph; all-reduce + fused clip/Adam stay eager
         try:
             stepper.capture(x, y, lengths, supports)
