@@ -208,9 +208,11 @@ int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
 int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M, float* planes,
                 hipStream_t st, size_t plane_stride = 0) {
     if (plane_stride == 0) plane_stride = (size_t)S * N * F;
-    if (N == 19 && F / 4 <= 128) {                // the EEG montage: streaming kernel (no LDS)
+    // the EEG montage: streaming kernel (no LDS); launches with < 4 samples per graph (decoder steps) leave most of its
+    // lanes idle and are faster through the LDS/MFMA kernel below
+    if (N == 19 && F / 4 <= 128 && S / (p_batched ? B : 1) >= 4) {
         const int F4 = F / 4, sB = p_batched ? B : 1, T = S / sB;
-        int threads = 256;                        // few samples per graph (decoder steps): narrower workgroups
+        int threads = 256;                        // few samples per graph: narrower workgroups
         while (threads > 64 && (threads / 2) / F4 >= T && (threads / 2) >= F4) threads /= 2;
         const int SPW = threads / F4;
         int ny = ceil_div(T, SPW);
@@ -239,6 +241,18 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
 }
 int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M, float* dX,
                 hipStream_t st, const float* add = nullptr) {
+    if (N == 19 && F / 4 <= 128 && g_tune[9] == 0 && (double)S * N * M * F < 1.7e10 && S / (p_batched ? B : 1) >= 4) {   // the EEG montage: streaming kernel (no LDS); 32-bit float4 offsets
+        const int F4 = F / 4, sB = p_batched ? B : 1, T = S / sB;
+        int threads = 256;
+        while (threads > 64 && (threads / 2) / F4 >= T && (threads / 2) >= F4) threads /= 2;
+        const int SPW = threads / F4;
+        int ny = ceil_div(T, SPW);
+        const int want = ceil_div(4096, sB);
+        if (ny > want) ny = want;
+        if (ny < 1) ny = 1;
+        EEG_LAUNCH_P("diffuse_adj", diffuse_adj_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, M, add, dX);
+        return check_launch("diffuse_adj");
+    }
     const int FP = round_up(F, 16), ZS = lds_stride(M * FP), NR = round_up(N, 4);
     const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * ZS) * sizeof(float);
     if (lds > 160 * 1024) return fail("diffuse_adj: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);

@@ -125,6 +125,82 @@ __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __
     }
 }
 
+// ---- streaming adjoint (same idea as diffuse_fwd_stream_kernel) -------------------------------
+// dX[s][n] = Z_0[s][n] + sum_{m>=1} sum_q P_m[q][n] Z_m[s][q]  [+ add[s][n]],  Z (S,N,M*F).
+// One thread = one 16-byte feature column of one sample; the hop planes are consumed one at a time
+// (N loads in flight, N accumulators), coefficients are wave-uniform scalars.  Algorithmic bytes per
+// sample: 4*N*F*(M+1).
+template <int N>
+__global__ __launch_bounds__(256, 3) void diffuse_adj_stream_kernel(const float* __restrict__ Z,
+                                                                    const float* __restrict__ P, int p_batched,
+                                                                    int S, int B, int F, int M,
+                                                                    const float* __restrict__ add,
+                                                                    float* __restrict__ dX) {
+    const int F4 = F / 4, SPW = blockDim.x / F4;
+    const int tl = threadIdx.x / F4, c4 = threadIdx.x % F4;
+    const int sB = p_batched ? B : 1, g = p_batched ? blockIdx.x : 0;
+    const int T = S / sB;
+    const float* __restrict__ Pg = P + (size_t)g * (M - 1) * N * N;
+    if (tl >= SPW) return;
+    const float4* Z4 = reinterpret_cast<const float4*>(Z);
+    const float4* A4 = reinterpret_cast<const float4*>(add);
+    float4* D4 = reinterpret_cast<float4*>(dX);
+    const unsigned zrow = (unsigned)(M * F4);               // float4 per node row of Z
+    constexpr int NCH = 4, NA = (N + NCH - 1) / NCH;        // operands are consumed in NCH chunks of NA nodes:
+    for (int t = blockIdx.y * SPW + tl; t < T; t += gridDim.y * SPW) {   // N accumulators + NA operands in flight
+        const unsigned s = (unsigned)t * sB + g;
+        // per-lane 32-bit element offsets; every load below is (wave-uniform pointer)[lane offset]
+        const unsigned zl = s * N * zrow + c4, xl = s * N * F4 + c4;        // < 2^32 float4 (host-checked)
+        float4 acc[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = (Z4 + n * zrow)[zl];
+        EEG_SCHED_FENCE();
+        if (add != nullptr) {
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) {
+                float4 a[NA];
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    if (h * NA + q < N) a[q] = (A4 + (h * NA + q) * F4)[xl];
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    if (h * NA + q < N) {
+                        float4& d = acc[h * NA + q];
+                        d.x += a[q].x; d.y += a[q].y; d.z += a[q].z; d.w += a[q].w;
+                    }
+                EEG_SCHED_FENCE();
+            }
+        }
+        for (int m1 = 0; m1 < M - 1; ++m1) {
+            const float* __restrict__ Pm = Pg + m1 * N * N;
+            const float4* zp = Z4 + (m1 + 1) * F4;
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) {
+                const int q0 = h * NA, nq = (N - q0) < NA ? (N - q0) : NA;
+                float4 z[NA];
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    if (q < nq) z[q] = (zp + (q0 + q) * zrow)[zl];
+#pragma unroll
+                for (int q = 0; q < NA; ++q) {
+                    if (q >= nq) continue;
+#pragma unroll
+                    for (int n = 0; n < N; ++n) {
+                        const float p = Pm[(q0 + q) * N + n];   // P_m^T[n][q]
+                        acc[n].x = fmaf(p, z[q].x, acc[n].x);
+                        acc[n].y = fmaf(p, z[q].y, acc[n].y);
+                        acc[n].z = fmaf(p, z[q].z, acc[n].z);
+                        acc[n].w = fmaf(p, z[q].w, acc[n].w);
+                    }
+                }
+                EEG_SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) (D4 + n * F4)[xl] = acc[n];
+    }
+}
+
 // ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m [+ add] -----------
 // LDS tile [NR][ZS], NR = round_up(N,4), ZS = lds_stride(M*FP): slot m holds Z_m (cols padded to FP).
 __global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restrict__ Z, const float* __restrict__ P,
