@@ -109,7 +109,7 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
         w["seq_bwd"] += s * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
         w["gemm_nn"] += 2.0 * r * (m * fin) * 3 * h
         w["gemm_tn"] += 2.0 * r * (m * fin) * 3 * h + 2.0 * r * (m * h) * 2 * h + 2.0 * r * (m * h) * h
-        w["diffuse_fwd"] += 4.0 * s * n * fin * m + 2 * 4.0 * s * n * h * m
+        w["diffuse_fwd"] += 4.0 * s * n * fin * m      # (the hop planes of h and r*h are by-products of seq_fwd)
         if l > 0:
             w["gemm_nn"] += 2.0 * r * 3 * h * (m * fin)
             w["diffuse_adj"] += 4.0 * s * n * fin * (m + 1)
@@ -123,7 +123,7 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
             w["dec_seq_bwd"] += sd * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
             w["dec_gemm_nn"] += 2.0 * rd * (m * fin) * 3 * h * 2
             w["dec_gemm_tn"] += 2.0 * rd * (m * fin) * 3 * h + 2.0 * rd * (m * h) * 3 * h
-            w["dec_diffuse_fwd"] += 4.0 * sd * n * fin * m + 2 * 4.0 * sd * n * h * m
+            w["dec_diffuse_fwd"] += 4.0 * sd * n * fin * m
             w["dec_diffuse_adj"] += 4.0 * sd * n * fin * (m + 1)
         w["dec_gemm_nn"] += 2 * 2.0 * rd * h * D_IN          # projection forward + d h_top
         w["dec_gemm_tn"] += 2.0 * rd * h * D_IN              # projection weight gradient

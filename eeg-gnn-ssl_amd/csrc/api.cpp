@@ -305,9 +305,11 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
 // Hoisted weight gradients of one cell over all R = T*B*N rows (split-K GEMMs with fixed-order
 // reduction): x-part [X | P_m X]^T [dR|dU|dC], h-part of the gate hops(h_{t-1})^T [dR|dU] and of the
 // candidate hops(r*h_{t-1})^T dC.  accumulate = add into dWg/dWc (a cell shared by several layers).
+// hpl_in / rpl_in: hop planes of h_{t-1} / r*h_{t-1} kept by the forward kernel (NULL: recomputed into hpl / rpl).
 int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* planes, const float* Hprev,
-                      const float* RHs, const float* dXW, const float* P, float* hpl, float* rpl, float* part,
-                      const BwdWs& w, bool accumulate, float* dWg, float* dWc, hipStream_t st) {
+                      const float* RHs, const float* dXW, const float* P, const float* hpl_in, const float* rpl_in,
+                      float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate, float* dWg, float* dWc,
+                      hipStream_t st) {
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const int acc = accumulate ? 8 : 0;
     SegPtrs sx;
@@ -316,14 +318,22 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0 | acc, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(x)")) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
-    if (diffuse_fwd(Hprev, P, d->p_batched, S, d->B, N, H, M, hpl, st)) return 1;
+    const float* hpl = hpl_in;
+    if (hpl == nullptr) {
+        if (diffuse_fwd(Hprev, P, d->p_batched, S, d->B, N, H, M, hpl_ws, st)) return 1;
+        hpl = hpl_ws;
+    }
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
     if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hg, M * H, 2 * H, 1 | acc, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hg)")) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
-    if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl, st)) return 1;
+    const float* rpl = rpl_in;
+    if (rpl == nullptr) {
+        if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl_ws, st)) return 1;
+        rpl = rpl_ws;
+    }
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
     if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
@@ -346,9 +356,9 @@ int colsum(const float* A, int R, int C, int split, float* ws, float* out0, floa
 struct DecLayout {
     // saved (forward -> backward)
     size_t xin, proj_pack, proj_bias, saved_total;
-    size_t planes[8], hext[8], rs[8], us[8], cs[8], rhs[8];
+    size_t planes[8], hext[8], rs[8], us[8], cs[8], rhs[8], hpl[8], rpl[8];
     // backward workspace
-    size_t dxw[8], dbias[8], dotot, da, dhn, z, hpl, rpl, partial, projt_pack, colsum, bwd_total;
+    size_t dxw[8], dbias[8], dotot, da, dhn, z, partial, projt_pack, colsum, bwd_total;
     int nsplit_p, rps_p;
     BwdWs lw[8];
     eeg_layer_dims ld[8];
@@ -371,6 +381,8 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
         y.us[l] = o;     o += align64((size_t)d->T * state);
         y.cs[l] = o;     o += align64((size_t)d->T * state);
         y.rhs[l] = o;    o += align64((size_t)d->T * state);
+        y.hpl[l] = o;    o += align64((size_t)(d->M - 1) * R * d->H);      // hop planes of h_{t-1} and r*h_{t-1}: by-products
+        y.rpl[l] = o;    o += align64((size_t)(d->M - 1) * R * d->H);      // of the forward kernel, A operands of the dW GEMMs
     }
     y.saved_total = o;
     o = 0;
@@ -387,8 +399,6 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
     y.da = o;     o += align64(state);
     y.dhn = o;    o += align64(2 * (size_t)d->L * state);
     y.z = o;      o += align64((size_t)d->B * d->N * d->M * (d->Dout > d->H ? d->Dout : d->H));
-    y.hpl = o;    o += align64((size_t)(d->M - 1) * R * d->H);
-    y.rpl = o;    o += align64((size_t)(d->M - 1) * R * d->H);
     y.nsplit_p = tn_split(1, d->Dout, (int)R, d->H, &y.rps_p);
     const size_t pp = (size_t)y.nsplit_p * d->Dout * d->H;
     part = pp > part ? pp : part;
@@ -511,8 +521,8 @@ int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, 
 size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return (size_t)d->T * d->B * d->N * 3 * d->H; }
 
 int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0, const float* P, const float* pack,
-                        float* planes, float* Hext, float* Rs, float* Us, float* Cs, float* RHs, float* ws,
-                        void* stream) {
+                        float* planes, float* Hext, float* Rs, float* Us, float* Cs, float* RHs, float* Hplanes,
+                        float* RHplanes, float* ws, void* stream) {
     if (check_dims(d->N, d->H, d->Fin, d->M)) return 1;
     if (d->T < 1 || d->B < 1) return fail("layer_fwd: empty sequence/batch (T=%d, B=%d)", d->T, d->B);
     const bool save = Rs != nullptr;
@@ -543,8 +553,9 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0
     float* XW = ws;
     if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
     // 3. the recurrence
-    SeqFwdArgs a{XW, Hext, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs,
-                 d->T, d->B, d->N, d->act, g_seq_probe, g_tune[3]};
+    if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
+    SeqFwdArgs a{XW, Hext, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
+                 (size_t)R * H, d->T, d->B, d->N, d->act, g_seq_probe, g_tune[3]};
     return seq_fwd(H, M, a, st);
 }
 
@@ -552,7 +563,8 @@ size_t eeg_dcrnn_layer_bwd_ws_floats(const eeg_layer_dims* d, int need_dx) { ret
 
 int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P, const float* pack,
                         const float* planes, const float* Hext, const float* Rs, const float* Us, const float* Cs,
-                        const float* RHs, const float* dHseq, const float* d_at_end, const float* d_at_len,
+                        const float* RHs, const float* Hplanes, const float* RHplanes, const float* dHseq,
+                        const float* d_at_end, const float* d_at_len,
                         const int64_t* lengths, float* dX, float* dh0, float* dWg, float* dbg, float* dWc,
                         float* dbc, float* ws, void* stream) {
     if (check_dims(d->N, d->H, d->Fin, d->M)) return 1;
@@ -571,8 +583,8 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction)
-    if (cell_weight_grads(d, X, planes, Hext, RHs, dXW, P, ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false,
-                          dWg, dWc, st)) return 1;
+    if (cell_weight_grads(d, X, planes, Hext, RHs, dXW, P, Hplanes, RHplanes, ws + w.hplanes, ws + w.rhplanes,
+                          ws + w.partial, w, false, dWg, dWc, st)) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {
         float* Z = ws + w.z;
@@ -655,7 +667,8 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
             SeqFwdArgs a{XW, Hext + (size_t)t * state, P, d->p_batched, pack + p.bhg, pack + p.bhc,
                          Hext + (size_t)(t + 1) * state, saved + y.rs[l] + (size_t)t * state,
                          saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state,
-                         saved + y.rhs[l] + (size_t)t * state, 1, B, N, d->act, nullptr, g_tune[3]};
+                         saved + y.rhs[l] + (size_t)t * state, saved + y.hpl[l] + (size_t)t * state,
+                         saved + y.rpl[l] + (size_t)t * state, Rall * H, 1, B, N, d->act, nullptr, g_tune[3]};
             if (seq_fwd(H, M, a, st)) return 1;
         }
         // projection (model.py:188-190): out_t = h_top W_p^T + b_p
@@ -729,7 +742,8 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
         const bool first_use = l <= 1;                    // layers >= 1 share one cell (model.py:126-143)
         const float* X = l == 0 ? saved + y.xin : saved + y.hext[l - 1] + state;
         if (cell_weight_grads(&y.ld[l], X, saved + y.planes[l], saved + y.hext[l], saved + y.rhs[l], ws + y.dxw[l], P,
-                              ws + y.hpl, ws + y.rpl, ws + y.partial, y.lw[l], !first_use, dWg[l], dWc[l], st)) return 1;
+                              saved + y.hpl[l], saved + y.rpl[l], nullptr, nullptr, ws + y.partial, y.lw[l], !first_use,
+                              dWg[l], dWc[l], st)) return 1;
     }
     if (colsum(ws + y.dbias[0], T * B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
     if (L > 1 && colsum(ws + y.dbias[1], (L - 1) * T * B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
     float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
-    float* __restrict__ RHs, int T, int B, int N, int act, long long* probe) {
+    float* __restrict__ RHs, float* __restrict__ Hpl, float* __restrict__ RHpl, size_t plane_stride,
+    int T, int B, int N, int act, long long* probe) {
     using G = SeqGeom<H, M>;
     constexpr int KAP = G::KAP, KS = G::KS, CT = G::CT, NGT = G::NGT, NCT = G::NCT;
     PhaseProbe<PROBE> pp;
@@ -171,13 +172,16 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
             oh[i][nt] = nodec[nt] * H + ct * 16 + 4 * lg;
         }
 
-    auto diffuse_own = [&](float* buf) {       // hop-diffuse this wave's own column tiles of buf
+    // hop-diffuse this wave's own column tiles of buf; planes != nullptr: the hop rows of step t also go to
+    // global memory (Hpl / RHpl, the A operands of the hoisted weight-gradient GEMMs)
+    auto diffuse_own = [&](float* buf, float* planes, int t) {
         EEG_WAVE_SYNC();
+        float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
 #pragma unroll
         for (int i = 0; i < CT; ++i)
-            if (wave + 4 * i < NCT) lds_diffuse_tile<M, NKS>(buf, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
+            if (wave + 4 * i < NCT) lds_diffuse_tile<M, NKS>(buf, KAP, (wave + 4 * i) * 16, H, pf, lr, lg, g, plane_stride, N);
     };
-    diffuse_own(A);                                                 // hops(h_0)
+    diffuse_own(A, Hpl, 0);                                         // hops(h_0)
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
         const float* xw = XW + s * N * (3 * H);
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
             }
         }
         pp.mark(2);
-        diffuse_own(A2);                                            // own column tiles: no barrier needed
+        diffuse_own(A2, RHpl, t);                                   // own column tiles: no barrier needed
         __syncthreads();                                            // (2) hops(r*h) complete
         pp.mark(3);
 
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         pp.mark(5);
         // hops(h_t) of the own column tiles for the next step (their slot-0 source was just written by
         // this wave; other waves only read A2 until barrier (1) of the next step)
-        if (t + 1 < T) diffuse_own(A);
+        if (t + 1 < T) diffuse_own(A, Hpl, t + 1);
     }
     pp.dump(probe, 0);
 }

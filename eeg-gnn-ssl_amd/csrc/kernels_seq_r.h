@@ -208,7 +208,8 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
     float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
-    float* __restrict__ RHs, int T, int B, int N, int act, long long* probe) {
+    float* __restrict__ RHs, float* __restrict__ Hpl, float* __restrict__ RHpl, size_t plane_stride,
+    int T, int B, int N, int act, long long* probe) {
     using G = SeqGeomR<H, M>;
     constexpr int KAP = G::KAP, KS = G::KS, CT = G::CT, NGT = G::NGT, NCT = G::NCT;
     EEG_DYN_SMEM(sm);
@@ -221,6 +222,18 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
     const int b = blockIdx.x;
     const bool save = Rs != nullptr;
     const bool remv = lg < NR;
+    // The hop rows of step t (slots 1..M-1 of a complete LDS tile) are kept in global memory as a
+    // by-product for the hoisted weight-gradient GEMMs.  The REM waves copy them out (they have slack;
+    // the TILE waves are the critical path): 256 lanes x 16 bytes per pass.
+    auto copy_planes = [&](const float* tile, float* planes, int t) {
+        if (planes == nullptr) return;
+        float* g = planes + ((size_t)t * B + b) * N * H;
+        constexpr int Q = H / 4;
+        for (int e = wave * 64 + lane; e < N * (M - 1) * Q; e += 256) {
+            const int node = e / ((M - 1) * Q), r = e % ((M - 1) * Q), m1 = r / Q, c4 = r % Q;
+            st4(g + (size_t)m1 * plane_stride + node * H + 4 * c4, ld4(tile + node * KAP + (m1 + 1) * H + 4 * c4));
+        }
+    };
 
     // both roles keep the gate/candidate fragments of their column tile(s) in registers
     float wg[2 * CT][KS], wc[CT][KS];       // [i] = r tile, [CT + i] = u tile
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
             }
             __syncthreads();                                        // (1)
             pp.mark(0);
+            copy_planes(A, Hpl, t);
             valu_nodes_rem<2 * CT, KS, NR>(A, KAP, lr, lg, wg, g2);
             pp.mark(1);
             float* r_t = Rs + s * N * H;
@@ -383,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
                 if (own[i]) diffuse_rem<M, NR, false>(A2, KAP, (wave + 4 * i) * 16, H, Pl, lr, lg);
             __syncthreads();                                        // (2)
             pp.mark(3);
+            copy_planes(A2, RHpl, t);
             valu_nodes_rem<CT, KS, NR>(A2, KAP, lr, lg, wc, c1);
             pp.mark(4);
             float* h_t = Hseq + s * N * H;

@@ -21,13 +21,13 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS, true>), lds);
             EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS, true>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P,
-                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
     EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS>), lds);
     EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched,
-                 a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+                 a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 // wave-specialised 16-node MFMA tile + VALU remainder (kernels_seq_r.h): the 19-electrode montage, M <= 3
@@ -38,13 +38,13 @@ int fwd_r(const SeqFwdArgs& a, hipStream_t st) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_fwd_r_kernel<H, M, NR, true>), lds);
             EEG_LAUNCH_P("seq_fwd", (seq_fwd_r_kernel<H, M, NR, true>), dim3(a.B), dim3(512), lds, st, a.XW, a.h0, a.P,
-                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
     EEG_SET_MAX_LDS((seq_fwd_r_kernel<H, M, NR>), lds);
     EEG_LAUNCH_P("seq_fwd", (seq_fwd_r_kernel<H, M, NR>), dim3(a.B), dim3(512), lds, st, a.XW, a.h0, a.P, a.p_batched,
-                 a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.T, a.B, a.N, a.act, a.probe);
+                 a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 template <int H, int M>

@@ -10,6 +10,8 @@ struct SeqFwdArgs {
     int p_batched;
     const float *bhg, *bhc;
     float *Hseq, *Rs, *Us, *Cs, *RHs;
+    float *Hpl, *RHpl;      // optional by-product: hop planes P_m h_{t-1} / P_m (r*h_{t-1}), plane m at + (m-1)*plane_stride
+    size_t plane_stride;
     int T, B, N, act;
     long long* probe;
     int force_generic;      // development knob: use the two-tile (padded) kernels even for N == 19

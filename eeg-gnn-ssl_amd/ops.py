@@ -213,11 +213,12 @@ class _DCGRULayerFn(torch.autograd.Function):
         hext = torch.empty((t_len + 1, b, n * h), dtype=torch.float32, device=dev)
         if need_grad:
             rs, us, cs, rhs = (torch.empty((t_len, b, n * h), dtype=torch.float32, device=dev) for _ in range(4))
+            hpl, rhpl = (torch.empty((m - 1, s, n, h), dtype=torch.float32, device=dev) for _ in range(2))
         else:
-            rs = us = cs = rhs = None
+            rs = us = cs = rhs = hpl = rhpl = None
         ws = torch.empty(lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
         lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(x), _p(h0), _p(p), _p(pack), _p(planes), _p(hext),
-                 _p(rs), _p(us), _p(cs), _p(rhs), _p(ws), _stream(x))
+                 _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
         hseq = hext[1:]
         if lengths is not None:
             lengths = lengths.to(device=dev, dtype=torch.int64).contiguous()
@@ -226,7 +227,7 @@ class _DCGRULayerFn(torch.autograd.Function):
         else:
             hsel = hseq[t_len - 1].clone()
         if need_grad:
-            ctx.save_for_backward(x, p, pack, planes, hext, rs, us, cs, rhs, lengths)
+            ctx.save_for_backward(x, p, pack, planes, hext, rs, us, cs, rhs, hpl, rhpl, lengths)
             ctx.meta = (t_len, b, n, h, fin, m, act, p_batched, h0 is not None)
             ctx.set_materialize_grads(False)
         return hseq, hsel
@@ -234,7 +235,7 @@ class _DCGRULayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_hseq, d_hsel):
         lib = _lib.get_lib()
-        x, p, pack, planes, hext, rs, us, cs, rhs, lengths = ctx.saved_tensors
+        x, p, pack, planes, hext, rs, us, cs, rhs, hpl, rhpl, lengths = ctx.saved_tensors
         t_len, b, n, h, fin, m, act, p_batched, has_h0 = ctx.meta
         dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
         dev = x.device
@@ -256,7 +257,7 @@ class _DCGRULayerFn(torch.autograd.Function):
         ws = torch.empty(lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),
                          dtype=torch.float32, device=dev)
         lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), _p(x), _p(p), _p(pack), _p(planes), _p(hext), _p(rs),
-                 _p(us), _p(cs), _p(rhs), _p(d_hseq), _p(d_at_end), _p(d_at_len), _p(lengths), _p(dx), _p(dh0),
+                 _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(d_hseq), _p(d_at_end), _p(d_at_len), _p(lengths), _p(dx), _p(dh0),
                  _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(x))
         return dx, dh0, None, dwg, dbg, dwc, dbc, None, None, None, None, None, None
 

@@ -102,22 +102,27 @@ int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, in
 
 /* One DCGRU layer over a whole sequence = the `for t` loop of model.py:93-96 around
  * DCGRUCell.forward (cell.py:182-210).  h0 may be NULL (zeros).  Rs/Us/Cs/RHs may all be NULL
- * (inference: nothing saved).  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch. */
+ * (inference: nothing saved).  Hplanes / RHplanes (each (M-1, S, N, H); both NULL or both set):
+ * the hop rows P_m h_{t-1} and P_m (r*h_{t-1}) that the recurrent kernel forms in LDS anyway,
+ * kept as a by-product so that the backward need not re-diffuse h and r*h for its weight-gradient
+ * GEMMs.  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch. */
 size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d);
 int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0, const float* P,
                         const float* pack, float* planes, float* Hext, float* Rs, float* Us,
-                        float* Cs, float* RHs, float* ws, void* stream);
+                        float* Cs, float* RHs, float* Hplanes, float* RHplanes, float* ws, void* stream);
 
 /* Backward of the same layer (replaces autograd's replay of model.py:93-96 / cell.py).
  * Incoming gradients (each may be NULL): dHseq (T,B,N,H) w.r.t. every h_t; d_at_end (B,N,H) w.r.t.
  * h_{T-1} (the encoder's per-layer final state, model.py:97); d_at_len (B,N,H) w.r.t.
  * h_{lengths[b]-1} (utils.last_relevant_pytorch; lengths int64 (B), NULL -> T).
+ * Hplanes / RHplanes: as written by eeg_dcrnn_layer_fwd, or NULL (recomputed here).
  * Outputs: dX (T,B,N,Fin) or NULL; dh0 (B,N,H) or NULL; dWg/dbg/dWc/dbc in reference layout
  * (overwritten).  Reductions are fixed-order: results are run-to-run deterministic. */
 size_t eeg_dcrnn_layer_bwd_ws_floats(const eeg_layer_dims* d, int need_dx);
 int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P, const float* pack,
                         const float* planes, const float* Hext, const float* Rs, const float* Us,
-                        const float* Cs, const float* RHs, const float* dHseq, const float* d_at_end,
+                        const float* Cs, const float* RHs, const float* Hplanes, const float* RHplanes,
+                        const float* dHseq, const float* d_at_end,
                         const float* d_at_len, const int64_t* lengths, float* dX, float* dh0,
                         float* dWg, float* dbg, float* dWc, float* dbc, float* ws, void* stream);
 
