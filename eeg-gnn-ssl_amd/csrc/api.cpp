@@ -117,10 +117,24 @@ int run_nn2(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nc
     EEG_LAUNCH_P("gemm_nn", (gemm_nn2_kernel<NCTW, KC, MINB, PD>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn2");
 }
+template <int NCTW, int KC, int MINB = 2>
+int run_nn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
+               float* C, int ldc, int O, hipStream_t st) {
+    constexpr int NB = 2 * NCTW;
+    const size_t lds = 2 * (size_t)(128 * KC + (KC / 4) * NB * 64) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_nn_dma_kernel<NCTW, KC, MINB>), lds);
+    dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
+    EEG_LAUNCH_P("gemm_nn", (gemm_nn_dma_kernel<NCTW, KC, MINB>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
+    return check_launch("gemm_nn_dma");
+}
 template <int NCTW>
 int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
               float* C, int ldc, int O, hipStream_t st) {
-    if (g_tune[0] == 0 && ldc % 4 == 0) {            // v2 kernels (default)
+    if (g_tune[0] == 0 && g_tune[2] != 7 && ldc % 4 == 0 && (double)R * F < 4.0e9) {   // v3: LDS-DMA staging (default)
+        if (F % 16 == 0) return run_nn_dma<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+        if (F % 20 == 0) return run_nn_dma<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    }
+    if (g_tune[0] == 0 && ldc % 4 == 0) {            // v2 kernels (register-staged)
         if (F % 16 == 0) return run_nn2<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
         if (F % 20 == 0) return run_nn2<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
     }
@@ -153,28 +167,17 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, remap);
     return check_launch("gemm_tn");
 }
-template <int KTW, int NCTW>
-int run_tn2(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
-            float* partial, int nsplit, int rows_per_split, hipStream_t st) {
-    constexpr int KP = KTW * 64, OT = 2 * NCTW * 16;
-    constexpr int AS = KP + ((16 - (KP % 32)) + 32) % 32, YS = OT + ((16 - (OT % 32)) + 32) % 32;
-    const size_t lds = 2 * (size_t)(32 * AS + 32 * YS) * sizeof(float);
-    EEG_SET_MAX_LDS((gemm_tn2_kernel<KTW, NCTW>), lds);
-    EEG_LAUNCH_P("gemm_tn", (gemm_tn2_kernel<KTW, NCTW>), dim3(nsplit), dim3(512), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
-    return check_launch("gemm_tn2");
-}
-// v2 applies when the whole K fits 4 wave-rows of KTW tiles and O % 4 == 0, H-sized columns
-bool tn2_ok(int nseg, int F, int O) {
-    const int kt = ceil_div(nseg * F, 16);
-    return g_tune[1] == 0 && F % 4 == 0 && (O == 64 || O == 128 || O == 192) && kt > 12 && (kt <= 20 || (kt <= 32 && O <= 128));   // small K: v1 is faster; (8,6) would spill
+template <int NCTW>
+int run_tn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+               float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+    constexpr int OT = 2 * NCTW * 16;
+    const size_t lds = 2 * (size_t)(32 * 64 + 32 * OT) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_tn_dma_kernel<NCTW>), lds);
+    dim3 grid(nseg * ceil_div(F, 64), nsplit);
+    EEG_LAUNCH_P("gemm_tn", (gemm_tn_dma_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    return check_launch("gemm_tn_dma");
 }
 int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
-    if (tn2_ok(nseg, F, O)) {                         // one workgroup per CU, equal row slices
-        int rps = round_up(ceil_div(R, 256), 32);
-        if (rps < 32) rps = 32;
-        *rows_per_split = rps;
-        return ceil_div(R, rps);
-    }
     const int blocks = nseg * ceil_div(F, 64);
     int nsplit = ceil_div(1024, blocks);
     int rps = round_up(ceil_div(R, nsplit), 32);
@@ -187,16 +190,10 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
 // partial[nsplit][nseg*F][O] = per-split A^T dY[:, ycol0:ycol0+O]
 int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
             float* partial, int nsplit, int rows_per_split, hipStream_t st) {
-    if (tn2_ok(nseg, F, O)) {
-        const int kt = ceil_div(nseg * F, 16);
-#define EEG_TN2(KTW)                                                                                              \
-    (O == 192 ? run_tn2<KTW, 6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st)        \
-     : O == 128 ? run_tn2<KTW, 4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st)     \
-                : run_tn2<KTW, 2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st))
-        if (kt <= 12) return EEG_TN2(3);
-        if (kt <= 20) return EEG_TN2(5);
-        return EEG_TN2(8);
-#undef EEG_TN2
+    if (g_tune[1] == 0 && O % 4 == 0 && F % 4 == 0 && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
+        if (O > 128 && O <= 192) return run_tn_dma<6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+        if (O > 64 && O <= 128) return run_tn_dma<4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+        if (O > 32 && O <= 64) return run_tn_dma<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     }
     if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);

@@ -40,6 +40,23 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 
+// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane of the wave copies 16 bytes from its own global
+// address to LDS at `lds_wave_base + lane * 16 B` (the LDS side is lane-linear; lds_wave_base must be
+// wave-uniform).  Asynchronous: completes with the vector-memory counter (the compiler waits before
+// the next barrier).  wave_uniform(): tell the compiler a value derived from threadIdx is wave-uniform.
+#if defined(EEG_SIMT_EMU)
+__device__ __forceinline__ void lds_dma16(float* lds_wave_base, const float* g) {
+    memcpy(lds_wave_base + 4 * (threadIdx.x & 63), g, 16);
+}
+__device__ __forceinline__ int wave_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ void lds_dma16(float* lds_wave_base, const float* g) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 namespace eeg {
 
 constexpr int kWave = 64;

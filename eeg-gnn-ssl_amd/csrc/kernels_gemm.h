@@ -7,8 +7,10 @@
 //  gemm_tn_kernel:  P[split][nseg*F x O] = sum over a row range of A^T dY      (weight grads;
 //                   split-K partials are reduced in fixed order by reduce_unpack_kernel).
 //
-// Both use v_mfma_f32_16x16x4_f32 on LDS-staged tiles, register-staged double buffering with one
-// barrier per K chunk.  Roofline: fp32 MFMA (157.3 TFLOP/s), see DESIGN.md.
+// Both use v_mfma_f32_16x16x4_f32 on LDS-staged, double-buffered tiles with one barrier per chunk.
+// The shipped variants (gemm_nn_dma_kernel, gemm_tn_dma_kernel) stage with LDS-DMA
+// (global_load_lds_dwordx4); the register-staged ones remain for shapes the DMA layouts do not cover.
+// Roofline: fp32 MFMA (157.3 TFLOP/s), see DESIGN.md.
 #pragma once
 #include "common.h"
 
@@ -264,6 +266,121 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn2_kernel(SegPtrs segs, int n
 }
 
 // ---------------------------------------------------------------------------------------------
+// NN v3: same tiling and MFMA schedule as v2, but the K chunks go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4): no staging registers, no ds_write pass, no vmcnt wait in front of it.
+// The LDS image of a DMA is lane-linear, so the A tile is stored unpadded, [128 rows][KC floats]:
+//   KC = 20: row stride 20 floats -> the 16 rows x 4 k-lanes of a fragment read fall on 64 distinct banks;
+//   KC = 16: row stride 16 would be 4-way conflicted, so the 16-byte pieces of a row are XOR-swizzled
+//            by ((row >> 2) & 3) on the SOURCE side (which piece a lane fetches) and on the READ side.
+// The B chunk is already fragment-ordered in the pack and is copied verbatim.
+// Rows >= R are clamped to R-1 (fetched, never stored); requires F % KC == 0, ldc % 4 == 0.
+template <int NCTW, int KC, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_nn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                                const float* __restrict__ Bp, int nct_total,
+                                                                const float* __restrict__ bias,
+                                                                float* __restrict__ C, int ldc, int O) {
+    constexpr int NB = 2 * NCTW, KSC = KC / 4, Q = KC / 4;              // Q = 16-byte pieces per A row
+    constexpr int A_FLOATS = 128 * KC, B_FLOATS = KSC * NB * 64;
+    constexpr int A_INS = A_FLOATS / 256, B_INS = B_FLOATS / 256, INS = A_INS + B_INS;   // wave-DMAs per chunk
+    constexpr int NI = (INS + 3) / 4;                                   // per wave
+    static_assert(A_FLOATS % 256 == 0 && B_FLOATS % 256 == 0, "chunk must be whole wave-DMAs");
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
+    const int row0 = blockIdx.x * 128, ct0 = blockIdx.y * NB;
+    const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
+
+    // per-lane source offsets of this wave's DMAs (chunk-independent part), in floats
+    unsigned src[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int j = wave + 4 * i;                                     // DMA index inside the chunk
+        if (j < A_INS) {
+            const int s4 = j * 64 + lane, row = s4 / Q, piece = s4 % Q;
+            const int grow = row0 + row < R ? row0 + row : R - 1;
+            const int c4 = Q == 4 ? (piece ^ ((row >> 2) & 3)) : piece;
+            src[i] = (unsigned)grow * F + 4 * c4;
+        } else {
+            const int s4 = (j - A_INS) * 64 + lane;                     // float4 index in [KSC][NB][16]
+            const int ks = s4 / (NB * 16), rem = s4 % (NB * 16), ct = rem / 16, l4 = rem % 16;
+            const int gct = ct0 + ct < nct_total ? ct0 + ct : nct_total - 1;
+            src[i] = ((unsigned)ks * nct_total + gct) * 64 + 4 * l4;
+        }
+    }
+    auto dma = [&](int chunk, int buf) {
+        const int seg = chunk / nchunk_seg, kc0 = (chunk % nchunk_seg) * KC;
+        const float* Ab = segs.p[seg] + kc0;
+        const float* Bb = Bp + (size_t)((seg * F + kc0) / 4) * nct_total * 64;
+        float* base = sm + buf * (A_FLOATS + B_FLOATS);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = wave + 4 * i;
+            if (j < INS) lds_dma16(base + j * 256, (j < A_INS ? Ab : Bb) + src[i]);
+        }
+    };
+
+    f32x4 acc[4][NCTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // fragment read offsets: A[row][4*ks + lg]
+    int arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) arow[i] = (wr * 64 + i * 16 + lr) * KC;
+    const int aswz = Q == 4 ? ((lr >> 2) & 3) : 0;                      // (row >> 2) & 3 with row = 16*x + lr
+    auto compute = [&](int buf) {
+        const float* As = sm + buf * (A_FLOATS + B_FLOATS);
+        const float* Bs = As + A_FLOATS;
+#pragma unroll
+        for (int ks = 0; ks < KSC; ++ks) {
+            float a[4], b[NCTW];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[arow[i] + 4 * (Q == 4 ? (ks ^ aswz) : ks) + lg];
+#pragma unroll
+            for (int j = 0; j < NCTW; ++j) b[j] = Bs[(ks * NB + wc * NCTW + j) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // transposed
+        }
+    };
+    dma(0, 0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) dma(ch + 1, buf ^ 1);                     // lands while this chunk is multiplied
+        compute(buf);
+        __syncthreads();                                                // (the compiler drains the DMA queue here)
+    }
+    float4 bv[NCTW];
+#pragma unroll
+    for (int j = 0; j < NCTW; ++j) {
+        const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
+        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias != nullptr && col + 3 < O) bv[j] = *reinterpret_cast<const float4*>(bias + col);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + wr * 64 + i * 16 + lr;
+        if (row >= R) continue;
+#pragma unroll
+        for (int j = 0; j < NCTW; ++j) {
+            const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
+            float* c = C + (size_t)row * ldc + col;
+            if (col + 3 < O) {
+                *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y,
+                                                            acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < O) c[r] = acc[i][j][r] + (bias != nullptr ? bias[col + r] : 0.f);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN: workgroup output tile = 64 k-rows (one 64-wide feature block of one hop plane) x
 // (2*NCTW*16) columns of dY; 4 waves as 2 (k) x 2 (cols), each 2 k-tiles x NCTW col tiles.
 // The reduction runs over rows [split*rows_per_split, ...) in chunks of 32 rows.
@@ -382,112 +499,116 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// TN v2: ONE 8-wave workgroup accumulates the whole (nseg*F) x Ov gradient block for its row slice,
-// so every A plane row and every dY row is read from HBM exactly once per launch.
-// Waves: 4 (k) x 2 (cols); each wave KTW k-tiles x NCTW col tiles (KTW*4*16 >= nseg*F,
-// 2*NCTW*16 >= Ov).  MFMAs are issued transposed (dY fragment as A operand) so a lane owns 4
-// consecutive output columns of one k row -> 16-byte partial stores.
-// grid = nsplit; partial: [nsplit][nseg*F][Ov].
-template <int KTW, int NCTW>
-__global__ __launch_bounds__(512, 2) void gemm_tn2_kernel(SegPtrs segs, int nseg, int F, int R,
+// TN with LDS-DMA staging: same tiling / split-K as gemm_tn_kernel (64 k-columns x O columns per
+// workgroup, 32-row chunks), the chunk goes global -> LDS with global_load_lds_dwordx4 (no staging
+// registers, no ds_write pass).  LDS rows are unpadded (64 and O floats); the transposed fragment
+// reads (lane group g reads row 4*ks + g) would then all hit the same banks, so the 16-byte pieces
+// of row r are XOR-swizzled by 4*(r & 3), on the source side of the DMA and on the read side.
+// Pieces past the valid columns and rows past R are clamped (fetched, finite, never used: their
+// outputs are not stored / the rows are zeroed in LDS before the last chunk is multiplied).
+// Requires O % 64 == 0 (NCTW in {2,4,6}), F % 4 == 0, Ov % 4 == 0, rows_per_split % 32 == 0.
+template <int NCTW>
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
                                                           const float* __restrict__ dY, int ldy, int ycol0, int Ov,
                                                           float* __restrict__ partial, int rows_per_split) {
-    constexpr int RC = 32, KP = KTW * 64, OT = 2 * NCTW * 16;
-    constexpr int AS = KP + ((16 - (KP % 32)) + 32) % 32;      // stride % 32 == 16
-    constexpr int YS = OT + ((16 - (OT % 32)) + 32) % 32;
-    constexpr int A_FLOATS = RC * AS, Y_FLOATS = RC * YS;
-    constexpr int A_LD = (RC * KP / 4 + 511) / 512;
-    constexpr int Y_LD = (RC * OT / 4 + 511) / 512;
+    constexpr int RC = 32, O = 2 * NCTW * 16, OQ = O / 4;
+    constexpr int A_FLOATS = RC * 64, Y_FLOATS = RC * O;
+    constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, INS = A_INS + Y_INS, NI = (INS + 3) / 4;
     EEG_DYN_SMEM(sm);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int wk = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
-    const int Ktot = nseg * F, F4 = F / 4;
-    const int rbeg = blockIdx.x * rows_per_split;
+    const int nfb = ceil_div(F, 64);
+    const int kblock = blockIdx.x, split = blockIdx.y;
+    const int seg = kblock / nfb, f0 = (kblock % nfb) * 64;
+    const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
+    const float* A = segs.p[seg];
 
-    f32x4 acc[KTW][NCTW];
+    // this wave's DMAs: tile row and (clamped) source column of the 16-byte piece every lane fetches
+    int drow[NI], dcol[NI];
 #pragma unroll
-    for (int i = 0; i < KTW; ++i)
+    for (int i = 0; i < NI; ++i) {
+        const int j = wave + 4 * i;
+        if (j < A_INS) {
+            const int s4 = j * 64 + lane, row = s4 / 16, piece = (s4 % 16) ^ (4 * (row & 3));
+            const int col = f0 + 4 * piece;
+            drow[i] = row;
+            dcol[i] = col < F ? col : F - 4;
+        } else {
+            const int s4 = (j - A_INS) * 64 + lane, row = s4 / OQ, piece = (s4 % OQ) ^ (4 * (row & 3));
+            drow[i] = row;
+            dcol[i] = ycol0 + (4 * piece < Ov ? 4 * piece : Ov - 4);
+        }
+    }
+    auto dma = [&](int r0, int buf) {
+        float* base = sm + buf * (A_FLOATS + Y_FLOATS);
+        const bool tail = r0 + RC > R;                      // only the last chunk of the last split
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int j = wave + 4 * i;
+            if (j >= INS) continue;
+            int row = r0 + drow[i];
+            if (tail && row >= R) row = R - 1;
+            const float* src = j < A_INS ? A + (size_t)row * F + dcol[i] : dY + (size_t)row * ldy + dcol[i];
+            lds_dma16(base + j * 256, src);
+        }
+    };
+
+    f32x4 acc[2][NCTW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    float4 ra[A_LD], ry[Y_LD];
-    auto gload = [&](int r0) {
+    // swizzled fragment columns: element (row 4*ks + lg, col 16*ct + lr) lives at piece (4*ct + lr/4) ^ (4*lg)
+    int acol[2], ycol[NCTW];
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int q = tid + 512 * i, row = q / (KP / 4), k4 = q % (KP / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < RC * KP / 4 && r0 + row < rend && 4 * k4 < Ktot) {
-                const int seg = k4 / F4, c4 = k4 % F4;
-                v = *reinterpret_cast<const float4*>(segs.p[seg] + (size_t)(r0 + row) * F + 4 * c4);
-            }
-            ra[i] = v;
-        }
+    for (int i = 0; i < 2; ++i) acol[i] = (((4 * (wk * 2 + i) + (lr >> 2)) ^ (4 * lg)) << 2) + (lr & 3);
 #pragma unroll
-        for (int i = 0; i < Y_LD; ++i) {
-            const int q = tid + 512 * i, row = q / (OT / 4), c4 = q % (OT / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < RC * OT / 4 && r0 + row < rend && 4 * c4 < Ov)
-                v = *reinterpret_cast<const float4*>(dY + (size_t)(r0 + row) * ldy + ycol0 + 4 * c4);
-            ry[i] = v;
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* At = sm + buf * (A_FLOATS + Y_FLOATS);
-        float* Ys = At + A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int q = tid + 512 * i, row = q / (KP / 4), k4 = q % (KP / 4);
-            if (q < RC * KP / 4) *reinterpret_cast<float4*>(At + row * AS + 4 * k4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < Y_LD; ++i) {
-            const int q = tid + 512 * i, row = q / (OT / 4), c4 = q % (OT / 4);
-            if (q < RC * OT / 4) *reinterpret_cast<float4*>(Ys + row * YS + 4 * c4) = ry[i];
-        }
-    };
+    for (int j = 0; j < NCTW; ++j) ycol[j] = (((4 * (wc * NCTW + j) + (lr >> 2)) ^ (4 * lg)) << 2) + (lr & 3);
 
     const int nchunks = rend > rbeg ? ceil_div(rend - rbeg, RC) : 0;
-    if (nchunks > 0) {
-        gload(rbeg);
-        lstore(0);
-    }
+    if (nchunks > 0) dma(rbeg, 0);
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        if (ch + 1 < nchunks) gload(rbeg + (ch + 1) * RC);
-        const float* At = sm + buf * (A_FLOATS + Y_FLOATS);
-        const float* Ys = At + A_FLOATS;
+        const int buf = ch & 1, r0 = rbeg + ch * RC;
+        if (ch + 1 < nchunks) dma(r0 + RC, buf ^ 1);
+        float* At = sm + buf * (A_FLOATS + Y_FLOATS);
+        float* Ys = At + A_FLOATS;
+        if (r0 + RC > rend) {                               // partial last chunk: rows past the end contribute zero
+            const int valid = rend - r0;
+            for (int e = tid; e < (RC - valid) * OQ; e += 256)
+                *reinterpret_cast<float4*>(Ys + valid * O + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+        }
 #pragma unroll
         for (int ks = 0; ks < RC / 4; ++ks) {
-            float a[KTW], b[NCTW];
+            float a[2], b[NCTW];
 #pragma unroll
-            for (int i = 0; i < KTW; ++i) a[i] = At[(4 * ks + lg) * AS + (wk * KTW + i) * 16 + lr];
+            for (int i = 0; i < 2; ++i) a[i] = At[(4 * ks + lg) * 64 + acol[i]];
 #pragma unroll
-            for (int j = 0; j < NCTW; ++j) b[j] = Ys[(4 * ks + lg) * YS + (wc * NCTW + j) * 16 + lr];
+            for (int j = 0; j < NCTW; ++j) b[j] = Ys[(4 * ks + lg) * O + ycol[j]];
 #pragma unroll
-            for (int i = 0; i < KTW; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // D[o][k]
+                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
-        if (ch + 1 < nchunks) lstore(buf ^ 1);
         __syncthreads();
     }
-    // lane owns k = (wk*KTW + i)*16 + lr, columns (wc*NCTW + j)*16 + 4*lg .. +3
-    float* out = partial + (size_t)blockIdx.x * Ktot * Ov;
+    const size_t Ktot = (size_t)nseg * F;
+    float* out = partial + (size_t)split * Ktot * Ov;
 #pragma unroll
-    for (int i = 0; i < KTW; ++i) {
-        const int k = (wk * KTW + i) * 16 + lr;
-        if (k < Ktot) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NCTW; ++j) {
-                const int col = (wc * NCTW + j) * 16 + 4 * lg;
-                if (col < Ov)
-                    *reinterpret_cast<float4*>(out + (size_t)k * Ov + col) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        for (int r = 0; r < 4; ++r) {
+            const int f = f0 + (wk * 2 + i) * 16 + 4 * lg + r;
+            if (f < F) {
+#pragma unroll
+                for (int j = 0; j < NCTW; ++j) {
+                    const int col = (wc * NCTW + j) * 16 + lr;
+                    if (col < Ov) out[((size_t)seg * F + f) * Ov + col] = acc[i][j][r];
+                }
             }
         }
-    }
 }
 
 }  // namespace eeg
