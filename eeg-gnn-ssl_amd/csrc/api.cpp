@@ -179,7 +179,7 @@ int run_tn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int
 }
 int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
     const int blocks = nseg * ceil_div(F, 64);
-    int nsplit = ceil_div(1024, blocks);
+    int nsplit = ceil_div(768, blocks);             // ~3 workgroups per CU; more splits only add partial-sum traffic (measured)
     int rps = round_up(ceil_div(R, nsplit), 32);
     if (rps < 128) rps = 128;
     nsplit = ceil_div(R, rps);
