@@ -182,19 +182,30 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
             if (wave + 4 * i < NCT) lds_diffuse_tile<M, NKS>(buf, KAP, (wave + 4 * i) * 16, H, pf, lr, lg, g, plane_stride, N);
     };
     diffuse_own(A, Hpl, 0);                                         // hops(h_0)
+    // The hoisted pre-activations of step t+1 are fetched in the middle of step t, AHEAD of that step's
+    // h / c stores in the memory queue, so that waiting for them does not have to drain those stores.
+    f32x4 nxr[CT][2], nxu[CT][2], nxc[CT][2];
+    auto fetch_xw = [&](int t) {
+        const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                nxr[i][nt] = ld4(xw + oxw[i][nt]);
+                nxu[i][nt] = ld4(xw + oxw[i][nt] + H);
+                nxc[i][nt] = ld4(xw + oxw[i][nt] + 2 * H);
+            }
+    };
+    fetch_xw(0);
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
-        const float* xw = XW + s * N * (3 * H);
-        // this step's hoisted pre-activations (added in the epilogues: a whole GEMM to land)
         f32x4 xr[CT][2], xu[CT][2], xc[CT][2], ar[CT][2], au[CT][2], ac[CT][2], ug[CT][2];
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 ar[i][nt] = zero4; au[i][nt] = zero4; ac[i][nt] = zero4;
-                xr[i][nt] = ld4(xw + oxw[i][nt]);
-                xu[i][nt] = ld4(xw + oxw[i][nt] + H);
-                xc[i][nt] = ld4(xw + oxw[i][nt] + 2 * H);
+                xr[i][nt] = nxr[i][nt]; xu[i][nt] = nxu[i][nt]; xc[i][nt] = nxc[i][nt];
             }
         __syncthreads();                                            // (1) hops(h) complete
         pp.mark(0);
@@ -235,6 +246,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         diffuse_own(A2, RHpl, t);                                   // own column tiles: no barrier needed
         __syncthreads();                                            // (2) hops(r*h) complete
         pp.mark(3);
+        if (t + 1 < T) fetch_xw(t + 1);
 
         // candidate GEMM: (H cols) x (32 nodes), K = M*H
         mfma_nodes32<CT, KS>(A2, KAP, lr, lg, wc, ac);

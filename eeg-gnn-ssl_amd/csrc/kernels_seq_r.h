@@ -275,14 +275,21 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
 #pragma unroll
         for (int i = 0; i < CT; ++i)
             if (own[i]) diffuse_tile16<M>(A, KAP, (wave + 4 * i) * 16, H, pf0, lr, lg);
+        // XW of step t+1 is fetched in the middle of step t, AHEAD of that step's h / c stores in the
+        // memory queue: waiting for it later does not have to drain those stores
+        f32x4 nr[CT], nu[CT], nc[CT];
+#pragma unroll
+        for (int i = 0; i < CT; ++i) {
+            const float* xw0 = XW + (size_t)b * N * (3 * H);
+            nr[i] = ld4(xw0 + oxw[i]); nu[i] = ld4(xw0 + oxw[i] + H); nc[i] = ld4(xw0 + oxw[i] + 2 * H);
+        }
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
-            const float* xw = XW + s * N * (3 * H);
             f32x4 xr[CT], xu[CT], xc[CT], ag[2 * CT], ac[CT], ug[CT];
 #pragma unroll
             for (int i = 0; i < CT; ++i) {
                 ag[i] = zero4; ag[CT + i] = zero4; ac[i] = zero4;
-                xr[i] = ld4(xw + oxw[i]); xu[i] = ld4(xw + oxw[i] + H); xc[i] = ld4(xw + oxw[i] + 2 * H);
+                xr[i] = nr[i]; xu[i] = nu[i]; xc[i] = nc[i];
             }
             __syncthreads();                                        // (1) hops(h) complete
             pp.mark(0);
@@ -316,6 +323,13 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
                 if (own[i]) diffuse_tile16<M>(A2, KAP, (wave + 4 * i) * 16, H, pf0, lr, lg);
             __syncthreads();                                        // (2) hops(r*h) complete
             pp.mark(3);
+            if (t + 1 < T) {
+                const float* xwn = XW + (s + B) * N * (3 * H);
+#pragma unroll
+                for (int i = 0; i < CT; ++i) {
+                    nr[i] = ld4(xwn + oxw[i]); nu[i] = ld4(xwn + oxw[i] + H); nc[i] = ld4(xwn + oxw[i] + 2 * H);
+                }
+            }
             mfma_nodes16<CT, KS>(A2, KAP, lr, lg, wc, ac);
             pp.mark(4);
             float* h_t = Hseq + s * N * H;
