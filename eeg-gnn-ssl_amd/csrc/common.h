@@ -18,6 +18,7 @@
 #define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
     emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::mfma4(a, b, c); }
 #define EEG_SCHED_FENCE() ((void)0)
 #define EEG_WAVE_SYNC() emu::wave_sync()
 #define EEG_SETPRIO(p) ((void)0)
@@ -30,6 +31,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products; D[lane l][reg r] += A(lane 4*(l/4) + r) * B(lane l)
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
 // pins the instruction order at this point (keeps hand-placed LDS prefetches ahead of the MFMAs)
 #define EEG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

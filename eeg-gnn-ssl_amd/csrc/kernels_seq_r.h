@@ -22,6 +22,9 @@
 #include "common.h"
 #include "kernels_seq.h"
 
+#ifndef EEG_REM_PRIO
+#define EEG_REM_PRIO 2
+#endif
 namespace eeg {
 
 constexpr int kRNKS = 5;      // node-mix k-steps: nodes 0..19
@@ -159,47 +162,55 @@ __device__ __forceinline__ void diffuse_rem(float* buf, int stride, int src_col,
         for (int m1 = 0; m1 < M - 1; ++m1) buf[(16 + lg) * stride + (m1 + 1) * slot_w + src_col + lr] = pick<NR>(v[m1], lg);
     }
 }
-// out[i] = (sum over all k) W[k][col lr of tile i] * X[node 16+lg][k]  for the lane's own node
-template <int NT, int NKS, int NR>
-__device__ __forceinline__ void valu_nodes_rem(const float* __restrict__ X, int stride, int lr, int lg,
-                                               const float (&w)[NT][NKS], float (&out)[NT]) {
-    const float* pr = X + 16 * stride + 4 * lg;
-    float rem[NT][NR];
+// out[i] = (sum over all k) W[k][col lr of tile i] * X[node 16+lg][k]  for the lane's own node.
+// The remainder GEMM runs on the matrix pipe too, as v_mfma_f32_4x4x1 (16 independent 4x4 outer
+// products per instruction, a quarter of the cost of a 16x16x4): block = (lane group lg, column
+// quad), so the B operand is the SAME weight register as in the 16-node path (lane (lr, lg) holds
+// W[k(ks, lg)][col lr]) and the A operand is X[node 16 + (lane & 3)][k(ks, lg)] (row 19 is the zero
+// pad row).  Result register r of a lane = this lane group's partial of out[node 16 + r][col lr];
+// the four lane groups are summed with the permlane butterfly.  (VALU FMAs were tried first: fp32
+// MFMA and VALU share the FP32 ALUs, so that stream only ran in the gaps of the tile wave's MFMAs.)
+template <int NT, int NKS>
+__device__ __forceinline__ void mfma_nodes_rem(const float* __restrict__ X, int stride, int lane, int lg,
+                                               const float (&w)[NT][NKS], f32x4 (&acc)[NT]) {
+    static_assert(NKS % 4 == 0, "K must be a multiple of 16");
+    const float* p = X + (16 + (lane & 3)) * stride + 4 * lg;
+    f32x4 acc2[NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // a quad of k-steps is only 4*NT short MFMAs (8 cycles each): keep PD quads of operands in flight
+    constexpr int NQ = NKS / 4, PD = NQ < 4 ? NQ : 4;
+    f32x4 ring[PD];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) rem[i][j] = 0.f;
-    // LDS latency (not FMA throughput) bounds this loop: keep PD quads of node rows in flight
-    constexpr int NQ = NKS / 4, PD = NQ < 3 ? NQ : 3;
-    f32x4 ring[PD][NR];
-#pragma unroll
-    for (int d = 0; d < PD; ++d)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) ring[d][j] = ld4(pr + j * stride + 16 * d);
+    for (int d = 0; d < PD; ++d) ring[d] = ld4(p + 16 * d);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        f32x4 xr[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) xr[j] = ring[q % PD][j];
-        if (q + PD < NQ) {
-#pragma unroll
-            for (int j = 0; j < NR; ++j) ring[q % PD][j] = ld4(pr + j * stride + 16 * (q + PD));
-        }
+        const f32x4 a0 = ring[q % PD];
+        if (q + PD < NQ) ring[q % PD] = ld4(p + 16 * (q + PD));
         EEG_SCHED_FENCE();
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int j = 0; j < NR; ++j) rem[i][j] = fmaf(w[i][4 * q + j4], xr[j][j4], rem[i][j]);
+            for (int i = 0; i < NT; ++i) {
+                if (j4 & 1) acc2[i] = mfma4(a0[j4], w[i][4 * q + j4], acc2[i]);
+                else acc[i] = mfma4(a0[j4], w[i][4 * q + j4], acc[i]);
+            }
         EEG_SCHED_FENCE();
     }
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) acc[i] += acc2[i];
+}
+// sum the lane-group partials of mfma_nodes_rem; out[i] = the value of the lane's own node 16 + lg
+template <int NT, int NR>
+__device__ __forceinline__ void reduce_rem(const f32x4 (&acc)[NT], int lg, float (&out)[NT]) {
+    static_assert(NR <= 4, "at most 4 remainder nodes");
 #pragma unroll
-        for (int j = 0; j < NR; ++j) rem[i][j] = lg_allreduce(rem[i][j]);
+    for (int i = 0; i < NT; ++i) {
+        float tot[NR];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) out[i] = pick<NR>(rem[i], lg);
+        for (int j = 0; j < NR; ++j) tot[j] = lg_allreduce(acc[i][j]);
+        out[i] = pick<NR>(tot, lg);
+    }
 }
 
 // ================================================================================================
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
         pp.dump(probe, 0);
     } else {
         // ====================================== REM waves ======================================
-        EEG_SETPRIO(2);      // the younger half of the workgroup: give its VALU stream priority
+        EEG_SETPRIO(EEG_REM_PRIO);      // the younger half of the workgroup
         PhaseProbe<PROBE> pp;
         pp.start();
         int oxw[CT], oh[CT], lt[CT];
@@ -385,8 +396,10 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
             __syncthreads();                                        // (1)
             pp.mark(0);
             copy_planes(A, Hpl, t);
-            valu_nodes_rem<2 * CT, KS, NR>(A, KAP, lr, lg, wg, g2);
+            f32x4 g4[2 * CT];
+            mfma_nodes_rem<2 * CT, KS>(A, KAP, lane, lg, wg, g4);
             pp.mark(1);
+            reduce_rem<2 * CT, NR>(g4, lg, g2);
             float* r_t = Rs + s * N * H;
             float* rh_t = RHs + s * N * H;
             float* u_t = Us + s * N * H;
@@ -412,8 +425,10 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
             __syncthreads();                                        // (2)
             pp.mark(3);
             copy_planes(A2, RHpl, t);
-            valu_nodes_rem<CT, KS, NR>(A2, KAP, lr, lg, wc, c1);
+            f32x4 c4[CT];
+            mfma_nodes_rem<CT, KS>(A2, KAP, lane, lg, wc, c4);
             pp.mark(4);
+            reduce_rem<CT, NR>(c4, lg, c1);
             float* h_t = Hseq + s * N * H;
             float* c_t = Cs + s * N * H;
 #pragma unroll
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void seq_bwd_r_kernel(
         pp.dump(probe, 8);
     } else {
         // ====================================== REM waves ======================================
-        EEG_SETPRIO(2);
+        EEG_SETPRIO(EEG_REM_PRIO);
         int oh[CT], oxw[CT], lc[CT], lgt[CT];
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -656,7 +671,9 @@ __global__ __launch_bounds__(512, 2) void seq_bwd_r_kernel(
                 if (own[i]) diffuse_rem<M, NR, true>(EC, KAP, (wave + 4 * i) * 16, H, Pl, lr, lg);
             __syncthreads();                                        // (1)
             float drh[CT];
-            valu_nodes_rem<CT, KS, NR>(EC, KAP, lr, lg, w1, drh);
+            f32x4 drh4[CT];
+            mfma_nodes_rem<CT, KS>(EC, KAP, lane, lg, w1, drh4);
+            reduce_rem<CT, NR>(drh4, lg, drh);
 #pragma unroll
             for (int i = 0; i < CT; ++i) {
                 const bool ok = own[i] && remv;
@@ -679,7 +696,9 @@ __global__ __launch_bounds__(512, 2) void seq_bwd_r_kernel(
                 }
             __syncthreads();                                        // (2)
             float d2[CT];
-            valu_nodes_rem<CT, KSG, NR>(EG, KGP, lr, lg, w2, d2);
+            f32x4 d24[CT];
+            mfma_nodes_rem<CT, KSG>(EG, KGP, lane, lg, w2, d24);
+            reduce_rem<CT, NR>(d24, lg, d2);
 #pragma unroll
             for (int i = 0; i < CT; ++i) dh[i] = (own[i] && remv) ? dhn[i] + d2[i] : 0.f;
         }

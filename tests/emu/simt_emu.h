@@ -39,6 +39,7 @@ struct Fiber {
     float ma = 0, mb = 0;
     f32x4 mc, md;
     bool sync_only = false;
+    bool mfma4 = false;          // this rendezvous is a v_mfma_f32_4x4x1_16B_f32
     int shfl_mask = -1;          // >= 0: this rendezvous is a __shfl_xor with that lane mask
     float shfl_val = 0.f;
 };
@@ -60,6 +61,18 @@ inline f32x4 mfma16(float a, float b, f32x4 c) {
     cur->mc = c;
     cur->st = WAIT_WAVE;
     yield_to_sched();
+    return cur->md;
+}
+// v_mfma_f32_4x4x1_16B_f32: 16 blocks of 4 lanes; D[lane l][reg r] = c + A(lane 4*(l/4) + r) * B(lane l)
+// (layout measured on gfx950 with tools/micro/mfma4_layout.hip)
+inline f32x4 mfma4(float a, float b, f32x4 c) {
+    cur->ma = a;
+    cur->mb = b;
+    cur->mc = c;
+    cur->mfma4 = true;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    cur->mfma4 = false;
     return cur->md;
 }
 // rendezvous of the 64 lanes of a wave: stands for the lockstep execution of real hardware where
@@ -150,6 +163,20 @@ static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
     }
     if (nshfl != 0) {
         fprintf(stderr, "emu: wave mixes shfl and mfma at one rendezvous\n");
+        abort();
+    }
+    unsigned n4 = 0;
+    for (unsigned l = 0; l < 64; ++l) n4 += f[w0 + l].mfma4;
+    if (n4 == 64) {
+        for (unsigned l = 0; l < 64; ++l) {
+            Fiber& x = f[w0 + l];
+            for (int r = 0; r < 4; ++r) x.md[r] = fmaf(f[w0 + 4 * (l / 4) + r].ma, x.mb, x.mc[r]);
+            x.st = RUNNABLE;
+        }
+        return;
+    }
+    if (n4 != 0) {
+        fprintf(stderr, "emu: wave mixes 4x4x1 and 16x16x4 mfma at one rendezvous\n");
         abort();
     }
     float A[16][4], B[4][16];
