@@ -167,18 +167,24 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, remap);
     return check_launch("gemm_tn");
 }
-template <int NCTW>
+// k-block width of the DMA TN kernel.  128-wide blocks halve the re-reads of dY (PMC: 862 -> ~600 MB per
+// launch) but measured SLOWER (gemm_tn 1.08-1.15 vs 0.92 ms/step, cfg2): the re-reads are served by the
+// Infinity Cache, and the wider tile costs occupancy.
+constexpr int kTnKbw = 64;
+template <int KTW, int NCTW, int RC>
 int run_tn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
                float* partial, int nsplit, int rows_per_split, hipStream_t st) {
-    constexpr int OT = 2 * NCTW * 16;
-    const size_t lds = 2 * (size_t)(32 * 64 + 32 * OT) * sizeof(float);
-    EEG_SET_MAX_LDS((gemm_tn_dma_kernel<NCTW>), lds);
-    dim3 grid(nseg * ceil_div(F, 64), nsplit);
-    EEG_LAUNCH_P("gemm_tn", (gemm_tn_dma_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    constexpr int OT = 2 * NCTW * 16, KBW = 32 * KTW;
+    static_assert(KBW == kTnKbw, "tn_split assumes this k-block width");
+    const size_t lds = 2 * (size_t)(RC * KBW + RC * OT) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_tn_dma_kernel<KTW, NCTW, RC>), lds);
+    dim3 grid(ceil_div(nseg * F, KBW), nsplit);
+    EEG_LAUNCH_P("gemm_tn", (gemm_tn_dma_kernel<KTW, NCTW, RC>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
     return check_launch("gemm_tn_dma");
 }
 int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
-    const int blocks = nseg * ceil_div(F, 64);
+    const bool dma = g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0;
+    const int blocks = dma ? ceil_div(nseg * F, kTnKbw) : nseg * ceil_div(F, 64);
     int nsplit = ceil_div(768, blocks);             // ~3 workgroups per CU; more splits only add partial-sum traffic (measured)
     int rps = round_up(ceil_div(R, nsplit), 32);
     if (rps < 128) rps = 128;
@@ -190,10 +196,10 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
 // partial[nsplit][nseg*F][O] = per-split A^T dY[:, ycol0:ycol0+O]
 int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
             float* partial, int nsplit, int rows_per_split, hipStream_t st) {
-    if (g_tune[1] == 0 && O % 4 == 0 && F % 4 == 0 && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
-        if (O > 128 && O <= 192) return run_tn_dma<6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-        if (O > 64 && O <= 128) return run_tn_dma<4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-        if (O > 32 && O <= 64) return run_tn_dma<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+    if (g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0 && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
+        if (O > 128 && O <= 192) return run_tn_dma<2, 6, 32>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+        if (O > 64 && O <= 128) return run_tn_dma<2, 4, 32>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+        return run_tn_dma<2, 2, 32>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     }
     if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);

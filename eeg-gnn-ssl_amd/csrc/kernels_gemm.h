@@ -499,45 +499,51 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// TN with LDS-DMA staging: same tiling / split-K as gemm_tn_kernel (64 k-columns x O columns per
-// workgroup, 32-row chunks), the chunk goes global -> LDS with global_load_lds_dwordx4 (no staging
-// registers, no ds_write pass).  LDS rows are unpadded (64 and O floats); the transposed fragment
-// reads (lane group g reads row 4*ks + g) would then all hit the same banks, so the 16-byte pieces
-// of row r are XOR-swizzled by 4*(r & 3), on the source side of the DMA and on the read side.
-// Pieces past the valid columns and rows past R are clamped (fetched, finite, never used: their
-// outputs are not stored / the rows are zeroed in LDS before the last chunk is multiplied).
-// Requires O % 64 == 0 (NCTW in {2,4,6}), F % 4 == 0, Ov % 4 == 0, rows_per_split % 32 == 0.
-template <int NCTW>
+// TN with LDS-DMA staging: split-K over rows like gemm_tn_kernel; a workgroup owns KBW = 32*KTW
+// consecutive columns of the CONCATENATED K axis (k = seg*F + f, so a block may span hop planes:
+// every lane fetches from its own plane pointer) x O columns of dY, in RC-row chunks that go
+// global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass).
+// LDS rows are unpadded (KBW and O floats); the transposed fragment reads (lane group g reads row
+// 4*ks + g) would then all hit the same banks, so the 16-byte pieces of row r are XOR-swizzled by
+// 4*(r & 3), on the source side of the DMA and on the read side.  Pieces past the valid columns
+// and rows past R are clamped (fetched, finite, never used: their outputs are not stored / the
+// rows are zeroed in LDS before the last chunk is multiplied).
+// 4 waves = 2 (k) x 2 (cols), each KTW k-tiles x NCTW col tiles.  grid = (ceil(K / KBW), nsplit).
+// Requires O % 64 == 0 (NCTW in {2,4,6}), F % 4 == 0, Ov % 4 == 0, rows_per_split % RC == 0.
+template <int KTW, int NCTW, int RC>
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
                                                           const float* __restrict__ dY, int ldy, int ycol0, int Ov,
                                                           float* __restrict__ partial, int rows_per_split) {
-    constexpr int RC = 32, O = 2 * NCTW * 16, OQ = O / 4;
-    constexpr int A_FLOATS = RC * 64, Y_FLOATS = RC * O;
+    constexpr int KBW = 32 * KTW, KQ = KBW / 4, O = 2 * NCTW * 16, OQ = O / 4;
+    constexpr int A_FLOATS = RC * KBW, Y_FLOATS = RC * O;
     constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, INS = A_INS + Y_INS, NI = (INS + 3) / 4;
+    static_assert(A_FLOATS % 256 == 0 && Y_FLOATS % 256 == 0 && RC % 4 == 0, "chunk must be whole wave-DMAs");
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int wk = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
-    const int nfb = ceil_div(F, 64);
-    const int kblock = blockIdx.x, split = blockIdx.y;
-    const int seg = kblock / nfb, f0 = (kblock % nfb) * 64;
+    const int K = nseg * F, k0 = blockIdx.x * KBW, split = blockIdx.y;
     const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
-    const float* A = segs.p[seg];
 
-    // this wave's DMAs: tile row and (clamped) source column of the 16-byte piece every lane fetches
-    int drow[NI], dcol[NI];
+    // this wave's DMAs: tile row, source base (plane of the lane's k column / dY) and (clamped) column
+    int drow[NI];
+    const float* dsrc[NI];
+    int dld[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = wave + 4 * i;
         if (j < A_INS) {
-            const int s4 = j * 64 + lane, row = s4 / 16, piece = (s4 % 16) ^ (4 * (row & 3));
-            const int col = f0 + 4 * piece;
+            const int s4 = j * 64 + lane, row = s4 / KQ, piece = (s4 % KQ) ^ (4 * (row & 3));
+            int k = k0 + 4 * piece;
+            if (k >= K) k = K - 4;
             drow[i] = row;
-            dcol[i] = col < F ? col : F - 4;
+            dsrc[i] = segs.p[k / F] + k % F;
+            dld[i] = F;
         } else {
             const int s4 = (j - A_INS) * 64 + lane, row = s4 / OQ, piece = (s4 % OQ) ^ (4 * (row & 3));
             drow[i] = row;
-            dcol[i] = ycol0 + (4 * piece < Ov ? 4 * piece : Ov - 4);
+            dsrc[i] = dY + ycol0 + (4 * piece < Ov ? 4 * piece : Ov - 4);
+            dld[i] = ldy;
         }
     }
     auto dma = [&](int r0, int buf) {
@@ -549,20 +555,19 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
             if (j >= INS) continue;
             int row = r0 + drow[i];
             if (tail && row >= R) row = R - 1;
-            const float* src = j < A_INS ? A + (size_t)row * F + dcol[i] : dY + (size_t)row * ldy + dcol[i];
-            lds_dma16(base + j * 256, src);
+            lds_dma16(base + j * 256, dsrc[i] + (size_t)row * dld[i]);
         }
     };
 
-    f32x4 acc[2][NCTW];
+    f32x4 acc[KTW][NCTW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < KTW; ++i)
 #pragma unroll
         for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // swizzled fragment columns: element (row 4*ks + lg, col 16*ct + lr) lives at piece (4*ct + lr/4) ^ (4*lg)
-    int acol[2], ycol[NCTW];
+    int acol[KTW], ycol[NCTW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) acol[i] = (((4 * (wk * 2 + i) + (lr >> 2)) ^ (4 * lg)) << 2) + (lr & 3);
+    for (int i = 0; i < KTW; ++i) acol[i] = (((4 * (wk * KTW + i) + (lr >> 2)) ^ (4 * lg)) << 2) + (lr & 3);
 #pragma unroll
     for (int j = 0; j < NCTW; ++j) ycol[j] = (((4 * (wc * NCTW + j) + (lr >> 2)) ^ (4 * lg)) << 2) + (lr & 3);
 
@@ -582,30 +587,29 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
         }
 #pragma unroll
         for (int ks = 0; ks < RC / 4; ++ks) {
-            float a[2], b[NCTW];
+            float a[KTW], b[NCTW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = At[(4 * ks + lg) * 64 + acol[i]];
+            for (int i = 0; i < KTW; ++i) a[i] = At[(4 * ks + lg) * KBW + acol[i]];
 #pragma unroll
             for (int j = 0; j < NCTW; ++j) b[j] = Ys[(4 * ks + lg) * O + ycol[j]];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < KTW; ++i)
 #pragma unroll
                 for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
-    const size_t Ktot = (size_t)nseg * F;
-    float* out = partial + (size_t)split * Ktot * Ov;
+    float* out = partial + (size_t)split * K * Ov;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < KTW; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int f = f0 + (wk * 2 + i) * 16 + 4 * lg + r;
-            if (f < F) {
+            const int k = k0 + (wk * KTW + i) * 16 + 4 * lg + r;
+            if (k < K) {
 #pragma unroll
                 for (int j = 0; j < NCTW; ++j) {
                     const int col = (wc * NCTW + j) * 16 + lr;
-                    if (col < Ov) out[((size_t)seg * F + f) * Ov + col] = acc[i][j][r];
+                    if (col < Ov) out[(size_t)k * Ov + col] = acc[i][j][r];
                 }
             }
         }
