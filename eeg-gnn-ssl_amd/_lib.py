@@ -49,7 +49,8 @@ _SIGNATURES = {
     "eeg_dcrnn_dconv_fwd_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "eeg_dcrnn_dconv_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, _FP, _FP, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_layer_fwd_ws_floats": (c_size_t, [POINTER(LayerDims)]),
-    "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 13 + [c_void_p]),
+    "eeg_dcrnn_batch_major_ok": (c_int, [POINTER(LayerDims)]),
+    "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 14 + [c_void_p]),
     "eeg_dcrnn_layer_bwd_ws_floats": (c_size_t, [POINTER(LayerDims), c_int]),
     "eeg_dcrnn_layer_bwd": (c_int, [POINTER(LayerDims)] + [_FP] * 22 + [c_void_p]),
     "eeg_dcrnn_decoder_saved_floats": (c_size_t, [POINTER(DecoderDims)]),

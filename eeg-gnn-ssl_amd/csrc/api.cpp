@@ -208,12 +208,17 @@ int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
     return fail("gemm_tn: O=%d unsupported", O);
 }
 
+// the streaming kernel applies (and with it the batch-major input option of eeg_dcrnn_layer_fwd)
+bool diffuse_streams(int p_batched, int S, int B, int N, int F) { return N == 19 && F / 4 <= 128 && S / (p_batched ? B : 1) >= 4; }
+
+// x_bt: X is batch-major (B, S/B, N, F) and xcopy gets its time-major copy (streaming kernel only)
 int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M, float* planes,
-                hipStream_t st, size_t plane_stride = 0) {
+                hipStream_t st, size_t plane_stride = 0, int x_bt = 0, float* xcopy = nullptr) {
     if (plane_stride == 0) plane_stride = (size_t)S * N * F;
+    if (x_bt && !diffuse_streams(p_batched, S, B, N, F)) return fail("diffuse_fwd: batch-major input needs the streaming kernel");
     // the EEG montage: streaming kernel (no LDS); launches with < 4 samples per graph (decoder steps) leave most of its
     // lanes idle and are faster through the LDS/MFMA kernel below
-    if (N == 19 && F / 4 <= 128 && S / (p_batched ? B : 1) >= 4) {
+    if (diffuse_streams(p_batched, S, B, N, F)) {
         const int F4 = F / 4, sB = p_batched ? B : 1, T = S / sB;
         int threads = 256;                        // few samples per graph: narrower workgroups
         while (threads > 64 && (threads / 2) / F4 >= T && (threads / 2) >= F4) threads /= 2;
@@ -222,7 +227,7 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
         const int want = ceil_div(4096, sB);     // ~16 workgroups per CU in total
         if (ny > want) ny = want;
         if (ny < 1) ny = 1;
-        EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, X, P, p_batched, S, B, F, M, planes, plane_stride);
+        EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, X, P, p_batched, S, B, F, M, planes, plane_stride, x_bt, xcopy);
         return check_launch("diffuse_fwd");
     }
     const int FP = round_up(F, 16), FS = lds_stride(M * FP), NR = round_up(N, 4);
@@ -523,9 +528,13 @@ int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, 
 
 size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return (size_t)d->T * d->B * d->N * 3 * d->H; }
 
-int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0, const float* P, const float* pack,
-                        float* planes, float* Hext, float* Rs, float* Us, float* Cs, float* RHs, float* Hplanes,
-                        float* RHplanes, float* ws, void* stream) {
+int eeg_dcrnn_batch_major_ok(const eeg_layer_dims* d) {
+    return diffuse_streams(d->p_batched, d->T * d->B, d->B, d->N, d->Fin) ? 1 : 0;
+}
+
+int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, const float* h0, const float* P,
+                        const float* pack, float* planes, float* Hext, float* Rs, float* Us, float* Cs, float* RHs,
+                        float* Hplanes, float* RHplanes, float* ws, void* stream) {
     if (check_dims(d->N, d->H, d->Fin, d->M)) return 1;
     if (d->T < 1 || d->B < 1) return fail("layer_fwd: empty sequence/batch (T=%d, B=%d)", d->T, d->B);
     const bool save = Rs != nullptr;
@@ -535,21 +544,12 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin;
     const size_t state = (size_t)d->B * d->N * H;
     CellPack p = make_cell_pack(Fin, H, M);
-    // slot 0 of Hext = initial state
-    if (h0 != nullptr) {
-        if (h0 != Hext) {
-#if defined(EEG_SIMT_EMU)
-            memcpy(Hext, h0, state * sizeof(float));
-#else
-            if (hipMemcpyAsync(Hext, h0, state * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-                return fail("layer_fwd: h0 copy failed");
-#endif
-        }
-    } else if (hipMemsetAsync(Hext, 0, state * sizeof(float), st) != hipSuccess) {
-        return fail("layer_fwd: h0 memset failed");
-    }
-    // 1. hoisted diffusion of the layer input: planes[m-1] = P_m X
-    if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st)) return 1;
+    // slot 0 of Hext = initial state (h0 == NULL: the recurrent kernel clears it)
+    if (h0 != nullptr && h0 != Hext && copy_floats(Hext, h0, state, st)) return 1;
+    // 1. hoisted diffusion of the layer input: planes[m-1] = P_m X  (Xtm != NULL: X is batch-major and Xtm
+    //    receives the time-major copy that everything after this point reads)
+    if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, 0, Xtm != nullptr ? 1 : 0, Xtm)) return 1;
+    if (Xtm != nullptr) X = Xtm;
     // 2. hoisted x-part GEMM: XW = [X | planes] @ Bx + [bg|bc]
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
@@ -557,7 +557,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0
     if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
-    SeqFwdArgs a{XW, Hext, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
+    SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
                  (size_t)R * H, d->T, d->B, d->N, d->act, g_seq_probe, g_tune[3]};
     return seq_fwd(H, M, a, st);
 }

@@ -87,24 +87,34 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
 // work on samples of ONE graph (g = blockIdx.x), so the polynomial coefficients are wave-uniform:
 // the compiler keeps them in SGPRs (scalar loads), there is no LDS and no barrier.
 // Algorithmic bytes per sample: 4*N*F*M; VALU work 2*(M-1)*N*N*F flop is ~4x below the HBM time.
+// x_bt != 0: X is batch-major (B, S/B, N, F) (the model input as the trainer holds it) and xcopy
+// receives its time-major copy as a by-product (the GEMMs read time-major rows): the separate
+// transpose pass (117 MB in + out at cfg2) disappears.
 template <int N>
 __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __restrict__ X,
                                                                  const float* __restrict__ P, int p_batched,
                                                                  int S, int B, int F, int M,
-                                                                 float* __restrict__ planes, size_t plane_stride) {
+                                                                 float* __restrict__ planes, size_t plane_stride,
+                                                                 int x_bt, float* __restrict__ xcopy) {
     const int F4 = F / 4, SPW = blockDim.x / F4;     // float4 columns per sample, samples per pass
     const int tl = threadIdx.x / F4, c4 = threadIdx.x % F4;
     const int sB = p_batched ? B : 1, g = p_batched ? blockIdx.x : 0;
-    const int T = S / sB;
+    const int T = S / sB, Tc = S / B;                // samples of this graph; time steps per clip
     const float* __restrict__ Pg = P + (size_t)g * (M - 1) * N * N;
     if (tl >= SPW) return;
     const float4* X4 = reinterpret_cast<const float4*>(X);
     float4* O4 = reinterpret_cast<float4*>(planes);
+    float4* C4 = reinterpret_cast<float4*>(xcopy);
     for (int t = blockIdx.y * SPW + tl; t < T; t += gridDim.y * SPW) {
-        const size_t s = (size_t)t * sB + g;
+        const size_t s = (size_t)t * sB + g;         // time-major sample index (t_clip * B + b)
+        const size_t ssrc = x_bt ? (s % B) * Tc + s / B : s;
         float4 x[N];
 #pragma unroll
-        for (int n = 0; n < N; ++n) x[n] = X4[(s * N + n) * F4 + c4];
+        for (int n = 0; n < N; ++n) x[n] = X4[(ssrc * N + n) * F4 + c4];
+        if (xcopy != nullptr) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) C4[(s * N + n) * F4 + c4] = x[n];
+        }
         for (int m1 = 0; m1 < M - 1; ++m1) {
             const float* __restrict__ Pm = Pg + m1 * N * N;
             float4* out = O4 + (size_t)m1 * (plane_stride / 4) + (s * N) * F4 + c4;

@@ -153,8 +153,11 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     __syncthreads();
     float pf[(M - 1) * 2][NKS];
     load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
-    if (h0 != nullptr)
+    if (h0 != nullptr) {
         for (int e = tid; e < N * H; e += 256) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
+    } else {      // zero initial state: clear this clip's row of the slot in front of Hseq (= Hext slot 0, read by the backward)
+        for (int e = tid; e < N * H; e += 256) (Hseq - (size_t)B * N * H)[(size_t)b * N * H + e] = 0.f;
+    }
     __syncthreads();
 
     // nodes owned by this lane (per node tile), clamped copies for branch-free loads

@@ -261,8 +261,11 @@ __global__ __launch_bounds__(512, 2) void seq_fwd_r_kernel(
     for (int e = tid; e < 2 * kRRows * KAP; e += 512) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
-    if (h0 != nullptr)
+    if (h0 != nullptr) {
         for (int e = tid; e < N * H; e += 512) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
+    } else {      // zero initial state: clear this clip's row of the slot in front of Hseq (= Hext slot 0, read by the backward)
+        for (int e = tid; e < N * H; e += 512) (Hseq - (size_t)B * N * H)[(size_t)b * N * H + e] = 0.f;
+    }
     bool own[CT];
 #pragma unroll
     for (int i = 0; i < CT; ++i) own[i] = wave + 4 * i < NCT;

@@ -6,6 +6,7 @@
 namespace eeg {
 
 struct SeqFwdArgs {
+    // h0 == nullptr: zero initial state; the kernel then clears the (B,N,H) slot in FRONT of Hseq (Hext slot 0)
     const float *XW, *h0, *P;
     int p_batched;
     const float *bhg, *bhc;

@@ -36,8 +36,8 @@ class DCRNNEncoder(nn.Module):
                                    nonlinearity=dcgru_activation, filter_type=filter_type))
         self.encoding_cells = nn.ModuleList(cells)
 
-    def run(self, inputs, initial_hidden_state, supports, lengths=None):
-        """Layer-major pass (model.py:90-99).  Returns (finals (L,B,N*H), top sequence (T,B,N*H),
+    def run(self, inputs, initial_hidden_state, supports, lengths=None, want_finals=True):
+        """Layer-major pass (model.py:90-99).  Returns (finals (L,B,N*H) or None, top sequence (T,B,N*H),
         top state at t = lengths-1 (B,N*H) or None)."""
         t_len, b = inputs.shape[0], inputs.shape[1]
         self.encoding_cells[0]._check_supports(supports)
@@ -55,7 +55,7 @@ class DCRNNEncoder(nn.Module):
                 hseq, hfin = cell.run_sequence(cur, h0, p, p_batched)
                 finals.append(hfin)
             cur = hseq.view(t_len, b, self.num_nodes, self.hid_dim)
-        return torch.stack(finals, dim=0), cur.reshape(t_len, b, -1), top_sel
+        return (torch.stack(finals, dim=0) if want_finals else None), cur.reshape(t_len, b, -1), top_sel
 
     def forward(self, inputs, initial_hidden_state, supports):
         """inputs (T,B,N,Din), initial_hidden_state (L,B,N*H) ->
@@ -160,7 +160,7 @@ class DCRNNModel_classification(nn.Module):
     def forward(self, input_seq, seq_lengths, supports):
         b = input_seq.shape[0]
         x = input_seq.transpose(0, 1)                         # (T,B,N,Din); made contiguous by the op
-        _, _, last = self.encoder.run(x, None, supports, lengths=seq_lengths)
+        _, _, last = self.encoder.run(x, None, supports, lengths=seq_lengths, want_finals=False)
         last = self.dropout(last.view(b, self.num_nodes, self.rnn_units))
         return ops.cls_head(last, self.fc.weight, self.fc.bias)    # relu -> fc -> max over nodes
 

@@ -69,6 +69,41 @@ _poly_memo = _Memo()
 _pack_memo = _Memo(16)
 
 
+class GradSink:
+    """Lets the backward operators write parameter gradients straight into caller-owned buffers
+    (TrainStep's flat gradient bucket) instead of returning fresh tensors that autograd then adds into
+    `p.grad` with one small kernel per parameter.  Active only inside `with GradSink(params): ...`;
+    a parameter that receives a second gradient in the same pass falls back to the returned-tensor path
+    (autograd accumulates), so results never depend on the sink."""
+    _active: Optional["GradSink"] = None
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.targets = {p.data_ptr(): p.grad for p in params if p.grad is not None}
+        self.seen = set()
+
+    def __enter__(self):
+        GradSink._active = self
+        self.seen.clear()
+        return self
+
+    def __exit__(self, *exc):
+        GradSink._active = None
+        return False
+
+    @staticmethod
+    def take(param: torch.Tensor) -> Optional[torch.Tensor]:
+        """the buffer to write `param`'s gradient into, or None (-> allocate and return it to autograd)"""
+        sink = GradSink._active
+        if sink is None:
+            return None
+        key = param.data_ptr()
+        tgt = sink.targets.get(key)
+        if tgt is None or key in sink.seen or not tgt.is_contiguous() or tgt.shape != param.shape:
+            return None
+        sink.seen.add(key)
+        return tgt
+
+
 def new_forward_scope():
     """Drop the memoised hop polynomials / weight packs.  Called at the start of every encoder /
     decoder forward, so the memo only ever serves repeated cell calls INSIDE one forward (the
@@ -199,16 +234,26 @@ class _DCGRULayerFn(torch.autograd.Function):
         lib = _lib.get_lib()
         t_len, b = x.shape[0], x.shape[1]
         fin = x.shape[3]
-        x = x.contiguous()
-        _check(lib, x, "inputs")
+        dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
+        # a transposed view of a contiguous batch-major (B,T,N,Fin) tensor (what model.py:253 produces) is
+        # consumed as it is: the diffusion kernel emits the time-major copy as a by-product
+        xsrc, xtm = None, None
+        if not x.is_contiguous() and x.transpose(0, 1).is_contiguous() and lib.query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)):
+            xsrc = x.transpose(0, 1)
+            _check(lib, xsrc, "inputs")
+            xtm = torch.empty((t_len, b, n, fin), dtype=torch.float32, device=x.device)
+            x = xtm
+        else:
+            x = x.contiguous()
+            _check(lib, x, "inputs")
         if h0 is not None:
             h0 = h0.contiguous()
             _check(lib, h0, "initial_hidden_state")
         need_grad = any(ctx.needs_input_grad)
         pack = pack_cell(wg, bg, wc, bc, fin, h, m)
+        ctx.params = (wg, bg, wc, bc)
         dev = x.device
         s = t_len * b
-        dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
         planes = torch.empty((m - 1, s, n, fin), dtype=torch.float32, device=dev)
         hext = torch.empty((t_len + 1, b, n * h), dtype=torch.float32, device=dev)
         if need_grad:
@@ -217,8 +262,8 @@ class _DCGRULayerFn(torch.autograd.Function):
         else:
             rs = us = cs = rhs = hpl = rhpl = None
         ws = torch.empty(lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
-        lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(x), _p(h0), _p(p), _p(pack), _p(planes), _p(hext),
-                 _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
+        lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(xsrc if xsrc is not None else x), _p(xtm), _p(h0), _p(p),
+                 _p(pack), _p(planes), _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
         hseq = hext[1:]
         if lengths is not None:
             lengths = lengths.to(device=dev, dtype=torch.int64).contiguous()
@@ -250,16 +295,17 @@ class _DCGRULayerFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_dx else None
         dh0 = torch.empty((b, n * h), dtype=torch.float32, device=dev) if need_dh0 else None
         rows = (fin + h) * m
-        dwg = torch.empty((rows, 2 * h), dtype=torch.float32, device=dev)
-        dbg = torch.empty((2 * h,), dtype=torch.float32, device=dev)
-        dwc = torch.empty((rows, h), dtype=torch.float32, device=dev)
-        dbc = torch.empty((h,), dtype=torch.float32, device=dev)
+        shapes = ((rows, 2 * h), (2 * h,), (rows, h), (h,))
+        sunk = [GradSink.take(q) for q in ctx.params]           # written in place -> nothing for autograd to add
+        dwg, dbg, dwc, dbc = (t if t is not None else torch.empty(sh, dtype=torch.float32, device=dev)
+                              for t, sh in zip(sunk, shapes))
         ws = torch.empty(lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),
                          dtype=torch.float32, device=dev)
         lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), _p(x), _p(p), _p(pack), _p(planes), _p(hext), _p(rs),
                  _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(d_hseq), _p(d_at_end), _p(d_at_len), _p(lengths), _p(dx), _p(dh0),
                  _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(x))
-        return dx, dh0, None, dwg, dbg, dwc, dbc, None, None, None, None, None, None
+        ret = [None if t is not None else g for t, g in zip(sunk, (dwg, dbg, dwc, dbc))]
+        return (dx, dh0, None, *ret, None, None, None, None, None, None)
 
 
 def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None):
@@ -306,6 +352,7 @@ class _DecoderFn(torch.autograd.Function):
         lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_arr, _p(h0), _p(p), pk_arr,
                  _p(wp), _p(bp), _p(out), _p(saved), _p(ws), _stream(h0))
         ctx.save_for_backward(p, saved, wp, *packs[:2])
+        ctx.params = (wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp)
         ctx.meta, ctx.teacher = meta, (tuple(bool(v) for v in teacher) if use_tf else None)
         ctx.shapes = (wg0.shape, bg0.shape, wc0.shape, bc0.shape,
                       None if wg1 is None else (wg1.shape, bg1.shape, wc1.shape, bc1.shape))
@@ -322,10 +369,11 @@ class _DecoderFn(torch.autograd.Function):
         packs = [packs[0]] + ([packs[1]] * (n_layers - 1) if n_layers > 1 else [])
         new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)   # noqa: E731
         s0 = ctx.shapes
-        g0 = [new(s0[0]), new(s0[1]), new(s0[2]), new(s0[3])]
-        g1 = [new(sh) for sh in s0[4]] if n_layers > 1 else [None] * 4
+        shapes = list(s0[:4]) + (list(s0[4]) if n_layers > 1 else [None] * 4) + [(dout, h), (dout,)]
+        sunk = [GradSink.take(q) if (q is not None and sh is not None) else None for q, sh in zip(ctx.params, shapes)]
+        bufs = [t if t is not None else (new(sh) if sh is not None else None) for t, sh in zip(sunk, shapes)]
+        g0, g1, dwp, dbp = bufs[0:4], bufs[4:8], bufs[8], bufs[9]
         dh0 = new((n_layers, b, n * h))
-        dwp, dbp = new((dout, h)), new((dout,))
         ws = new((lib.query("eeg_dcrnn_decoder_bwd_ws_floats", ctypes.byref(dims)),))
         teacher = ctx.teacher
         tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if teacher else None
@@ -333,7 +381,8 @@ class _DecoderFn(torch.autograd.Function):
         pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
         lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_arr, _p(p), pk_arr, _p(wp), _p(saved), _p(d_out), _p(dh0),
                  arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
-        return (None, dh0, None, g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3], dwp, dbp, None, None)
+        ret = [None if t is not None else g for t, g in zip(sunk, bufs)]        # sunk: already in the caller's buffer
+        return (None, dh0, None, *ret, None, None)
 
 
 def dcgru_decoder(targets, h0, p, p_batched, first_cell, shared_cell, wp, bp, n, h, dout, m, n_layers,
@@ -367,6 +416,7 @@ class _ClsHeadFn(torch.autograd.Function):
         arg = torch.empty((b, c), dtype=torch.int32, device=z.device)
         lib.call("eeg_dcrnn_cls_head_fwd", _p(z), _p(w), _p(bias), b, n, h, c, _p(logits), _p(arg), _stream(z))
         ctx.save_for_backward(z, w, arg)
+        ctx.params = (w, bias)
         return logits
 
     @staticmethod
@@ -377,10 +427,11 @@ class _ClsHeadFn(torch.autograd.Function):
         c = w.shape[0]
         dlogits = dlogits.contiguous()
         dz = torch.empty_like(z)
-        dw = torch.empty_like(w)
-        db = torch.empty((c,), dtype=torch.float32, device=z.device)
+        sunk = [GradSink.take(q) for q in ctx.params]
+        dw = sunk[0] if sunk[0] is not None else torch.empty_like(w)
+        db = sunk[1] if sunk[1] is not None else torch.empty((c,), dtype=torch.float32, device=z.device)
         lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, c, _p(dz), _p(dw), _p(db), _stream(z))
-        return dz, dw, db
+        return dz, (None if sunk[0] is not None else dw), (None if sunk[1] is not None else db)
 
 
 def cls_head(z, w, bias):

@@ -95,7 +95,8 @@ class TrainStep:
         else:
             out = self.model(x, seq_lengths, supports)
         loss = self.loss(out, y)
-        loss.backward()
+        with ops.GradSink(self.fp.params):       # backward operators write into the flat gradient bucket
+            loss.backward()
         return loss.detach()
 
     # -- HIP-graph replay of forward + loss + backward -------------------------------------------

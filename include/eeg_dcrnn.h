@@ -105,9 +105,14 @@ int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, in
  * (inference: nothing saved).  Hplanes / RHplanes (each (M-1, S, N, H); both NULL or both set):
  * the hop rows P_m h_{t-1} and P_m (r*h_{t-1}) that the recurrent kernel forms in LDS anyway,
  * kept as a by-product so that the backward need not re-diffuse h and r*h for its weight-gradient
- * GEMMs.  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch. */
+ * GEMMs.  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch.
+ * Xtm (nullable): when given, X is BATCH-major (B,T,N,Fin) -- the trainer's `input_seq` before
+ * model.py:253's transpose -- and Xtm (T,B,N,Fin) receives its time-major copy as a by-product of
+ * the diffusion kernel (pass Xtm as X to eeg_dcrnn_layer_bwd); only where
+ * eeg_dcrnn_batch_major_ok() returns 1. */
 size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d);
-int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, const float* h0, const float* P,
+int eeg_dcrnn_batch_major_ok(const eeg_layer_dims* d);
+int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, const float* h0, const float* P,
                         const float* pack, float* planes, float* Hext, float* Rs, float* Us,
                         float* Cs, float* RHs, float* Hplanes, float* RHplanes, float* ws, void* stream);
 

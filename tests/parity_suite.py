@@ -326,3 +326,33 @@ def check_correlation_supports(device, golden):
             assert np.abs(got - a_ref).max() <= 5e-6
             assert np.abs(s1[i].cpu().numpy() - sup[0]).max() <= 5e-6
             assert np.abs(s2[i].cpu().numpy() - sup[1]).max() <= 5e-6
+
+
+def check_grad_sink(device, adj3d):
+    """TrainStep writes parameter gradients straight into its flat bucket (ops.GradSink): the bucket must
+    equal the gradients of the ordinary autograd path, for the classification and the SSL model
+    (shared decoder cell: two uses of one parameter set)."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    g = torch.Generator().manual_seed(21)
+    for task, layers in (("classification", 2), ("ssl", 3)):
+        cfg = orc.DCRNNConfig(filter_type="dual_random_walk", input_dim=8, output_dim=8, rnn_units=16,
+                              num_rnn_layers=layers, num_classes=4)
+        torch.manual_seed(3)
+        if task == "ssl":
+            model = DCRNNModel_nextTimePred(make_args(cfg), device=device).to(device).train()
+            y = torch.randn(3, 4, 19, 8, generator=g).to(device)
+        else:
+            model = DCRNNModel_classification(make_args(cfg), 4, device=device).to(device).train()
+            y = torch.randint(0, 4, (3,), generator=g).to(device)
+        x = torch.randn(3, 6, 19, 8, generator=g).to(device)
+        lengths = torch.tensor([6, 4, 5]).to(device)
+        sup = [s.to(device) for s in cases.supports_for("dual_random_walk", adj3d, 3)]
+        ts = TrainStep(model, task=task)
+        ts.forward_backward(x, y, lengths, sup)
+        sunk = ts.fp.flat_grad.clone()
+        ts.fp.zero_grad()
+        out = model(x, y, sup) if task == "ssl" else model(x, lengths, sup)
+        ts.loss(out, y).backward()                      # no sink: autograd accumulates into the views
+        plain = ts.fp.flat_grad.clone()
+        assert torch.equal(sunk, plain), (task, (sunk - plain).abs().max().item())

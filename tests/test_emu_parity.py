@@ -55,3 +55,7 @@ def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
 
 def test_correlation_graph_supports(golden):
     ps.check_correlation_supports("cpu", golden)
+
+
+def test_grad_sink_equals_autograd_accumulation(adj3d):
+    ps.check_grad_sink("cpu", adj3d)
