@@ -66,8 +66,8 @@ void prof_end(hipStream_t st) {
 namespace {
 
 thread_local char g_err[512] = "";
-long long* g_seq_probe = nullptr;
-int g_tune[16] = {0};               // development knobs, see eeg_dcrnn_set_tuning     // development aid: see eeg_dcrnn_set_seq_probe
+long long* g_seq_probe = nullptr;  // development aid: see eeg_dcrnn_set_seq_probe
+int g_tune[16] = {0};               // development knobs, see eeg_dcrnn_set_tuning
 
 int fail(const char* fmt, ...) {
     va_list ap;
@@ -107,16 +107,6 @@ int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct
     EEG_LAUNCH_P("gemm_nn", (gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn");
 }
-template <int NCTW, int KC, int MINB = 2, int PD = 1>
-int run_nn2(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
-            float* C, int ldc, int O, hipStream_t st) {
-    constexpr int KCS = lds_stride(KC), NB = 2 * NCTW;
-    const size_t lds = 2 * (size_t)(128 * KCS + (KC / 4) * NB * 64) * sizeof(float);
-    EEG_SET_MAX_LDS((gemm_nn2_kernel<NCTW, KC, MINB, PD>), lds);
-    dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
-    EEG_LAUNCH_P("gemm_nn", (gemm_nn2_kernel<NCTW, KC, MINB, PD>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
-    return check_launch("gemm_nn2");
-}
 template <int NCTW, int KC, int MINB = 2>
 int run_nn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
                float* C, int ldc, int O, hipStream_t st) {
@@ -130,13 +120,9 @@ int run_nn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int
 template <int NCTW>
 int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
               float* C, int ldc, int O, hipStream_t st) {
-    if (g_tune[0] == 0 && g_tune[2] != 7 && ldc % 4 == 0 && (double)R * F < 4.0e9) {   // v3: LDS-DMA staging (default)
+    if (g_tune[0] == 0 && ldc % 4 == 0 && (double)R * F < 4.0e9) {   // LDS-DMA staging (default)
         if (F % 16 == 0) return run_nn_dma<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
         if (F % 20 == 0) return run_nn_dma<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-    }
-    if (g_tune[0] == 0 && ldc % 4 == 0) {            // v2 kernels (register-staged)
-        if (F % 16 == 0) return run_nn2<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-        if (F % 20 == 0) return run_nn2<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
     }
     if (F % 32 == 0) return run_nn<NCTW, 32>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
     if (F % 20 == 0) return run_nn<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);

@@ -9,7 +9,8 @@
 //
 // Both use v_mfma_f32_16x16x4_f32 on LDS-staged, double-buffered tiles with one barrier per chunk.
 // The shipped variants (gemm_nn_dma_kernel, gemm_tn_dma_kernel) stage with LDS-DMA
-// (global_load_lds_dwordx4); the register-staged ones remain for shapes the DMA layouts do not cover.
+// (global_load_lds_dwordx4); the register-staged gemm_nn_kernel / gemm_tn_kernel remain for shapes the
+// DMA layouts do not cover (odd leading dimensions, O <= 32, K chunks that are not multiples of 16/20).
 // Roofline: fp32 MFMA (157.3 TFLOP/s), see DESIGN.md.
 #pragma once
 #include "common.h"
@@ -124,150 +125,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(SegPtrs segs, int nseg, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// NN v2: same tiling, but (i) MFMAs issued transposed (weights as A operand) so a lane owns 4
-// consecutive output columns of one row -> 16-byte bias loads / C stores; (ii) register budget
-// capped so two workgroups share a CU (one hides the other's barrier / staging stalls).
-template <int NCTW, int KC, int MINB = 2, int PD = 1>
-__global__ __launch_bounds__(256, MINB) void gemm_nn2_kernel(SegPtrs segs, int nseg, int F, int R,
-                                                          const float* __restrict__ Bp, int nct_total,
-                                                          const float* __restrict__ bias,
-                                                          float* __restrict__ C, int ldc, int O) {
-    constexpr int KCS = lds_stride(KC), NB = 2 * NCTW, KSC = KC / 4;
-    constexpr int A_FLOATS = 128 * KCS, B_FLOATS = KSC * NB * 64;
-    constexpr int A_LD = (128 * KC / 4 + 255) / 256;
-    constexpr int B_LD = (B_FLOATS / 4 + 255) / 256;
-    EEG_DYN_SMEM(sm);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
-    const int row0 = blockIdx.x * 128, ct0 = blockIdx.y * NB;
-    const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
-
-    f32x4 acc[4][NCTW];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NCTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    float4 ra[PD][A_LD], rb[PD][B_LD];       // PD register sets: chunk c+1 (and c+2) in flight
-    auto gload = [&](int chunk, int set) {
-        const int seg = chunk / nchunk_seg, kc0 = (chunk % nchunk_seg) * KC;
-        const float* A = segs.p[seg];
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < 128 * KC / 4 && row0 + row < R)
-                v = *reinterpret_cast<const float4*>(A + (size_t)(row0 + row) * F + kc0 + 4 * c4);
-            ra[set][i] = v;
-        }
-        const int gks0 = (seg * F + kc0) / 4;
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int q = tid + 256 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < B_FLOATS / 4) {
-                const int ks = q / (NB * 16), rem = q % (NB * 16), ct = rem / 16, l4 = rem % 16;
-                if (ct0 + ct < nct_total)
-                    v = *reinterpret_cast<const float4*>(Bp + ((size_t)(gks0 + ks) * nct_total + ct0 + ct) * 64 + 4 * l4);
-            }
-            rb[set][i] = v;
-        }
-    };
-    auto lstore = [&](int buf, int set) {
-        float* As = sm + buf * (A_FLOATS + B_FLOATS);
-        float* Bs = As + A_FLOATS;
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int q = tid + 256 * i, row = q / (KC / 4), c4 = q % (KC / 4);
-            if (q < 128 * KC / 4) {
-                float* d = As + row * KCS + 4 * c4;
-                d[0] = ra[set][i].x; d[1] = ra[set][i].y; d[2] = ra[set][i].z; d[3] = ra[set][i].w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int q = tid + 256 * i;
-            if (q < B_FLOATS / 4) *reinterpret_cast<float4*>(Bs + 4 * q) = rb[set][i];
-        }
-    };
-
-    auto compute = [&](int buf) {
-        const float* As = sm + buf * (A_FLOATS + B_FLOATS);
-        const float* Bs = As + A_FLOATS;
-#pragma unroll
-        for (int ks = 0; ks < KSC; ++ks) {
-            float a[4], b[NCTW];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[(wr * 64 + i * 16 + lr) * KCS + 4 * ks + lg];
-#pragma unroll
-            for (int j = 0; j < NCTW; ++j) b[j] = Bs[(ks * NB + wc * NCTW + j) * 64 + lane];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NCTW; ++j) acc[i][j] = mfma16(b[j], a[i], acc[i][j]);   // transposed
-        }
-    };
-    gload(0, 0);
-    lstore(0, 0);
-    __syncthreads();
-    if (PD == 1) {
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int buf = ch & 1;
-            if (ch + 1 < nchunks) gload(ch + 1, 0);
-            compute(buf);
-            if (ch + 1 < nchunks) lstore(buf ^ 1, 0);
-            __syncthreads();
-        }
-    } else {
-        // distance-2 prefetch: chunk c+1 sits in register set (c+1)&1 (issued one iteration ago),
-        // chunk c+2 is issued now; a load has two MFMA phases to land before it is stored to LDS.
-        if (nchunks > 1) gload(1, PD - 1);
-        for (int ch = 0; ch < nchunks; ch += 2) {
-            if (ch + 2 < nchunks) gload(ch + 2, 0);
-            compute(0);
-            if (ch + 1 < nchunks) lstore(1, PD - 1);
-            __syncthreads();
-            if (ch + 1 < nchunks) {
-                if (ch + 3 < nchunks) gload(ch + 3, PD - 1);
-                compute(1);
-                if (ch + 2 < nchunks) lstore(0, 0);
-                __syncthreads();
-            }
-        }
-    }
-    // lane owns row (row0 + wr*64 + i*16 + lr), columns (ct*16 + 4*lg .. +3).  Row groups are the
-    // outer loop: the NCTW consecutive stores of a group fill whole cache lines of those 16 rows
-    // (measured 5% faster than column-tile-outer on the layer-1 shape, tools/micro/nn_probe.hip).
-    float4 bv[NCTW];
-#pragma unroll
-    for (int j = 0; j < NCTW; ++j) {
-        const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
-        bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias != nullptr && col + 3 < O) bv[j] = *reinterpret_cast<const float4*>(bias + col);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = row0 + wr * 64 + i * 16 + lr;
-        if (row >= R) continue;
-#pragma unroll
-        for (int j = 0; j < NCTW; ++j) {
-            const int col = (ct0 + wc * NCTW + j) * 16 + 4 * lg;
-            float* c = C + (size_t)row * ldc + col;
-            if (col + 3 < O) {
-                *reinterpret_cast<float4*>(c) = make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y,
-                                                            acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (col + r < O) c[r] = acc[i][j][r] + (bias != nullptr ? bias[col + r] : 0.f);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// NN v3: same tiling and MFMA schedule as v2, but the K chunks go global -> LDS by LDS-DMA
-// (global_load_lds_dwordx4): no staging registers, no ds_write pass, no vmcnt wait in front of it.
+// NN with LDS-DMA staging (the shipped variant): same 128 x (2*NCTW*16) workgroup tile as above, but
+//  (i) MFMAs are issued transposed (weights as A operand), so a lane owns 4 consecutive output columns of
+//      one row -> 16-byte bias loads / C stores;
+//  (ii) the K chunks go global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+//      ds_write pass, no vmcnt wait in front of it; 2-3 workgroups share a CU.
 // The LDS image of a DMA is lane-linear, so the A tile is stored unpadded, [128 rows][KC floats]:
 //   KC = 20: row stride 20 floats -> the 16 rows x 4 k-lanes of a fragment read fall on 64 distinct banks;
 //   KC = 16: row stride 16 would be 4-way conflicted, so the 16-byte pieces of a row are XOR-swizzled

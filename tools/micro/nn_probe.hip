@@ -1,4 +1,4 @@
-// Where does gemm_nn2 lose MFMA time?  Same tiling/loop as eeg::gemm_nn2_kernel<6,16> (K = 192, O = 192,
+// Where does a register-staged NN GEMM lose MFMA time?  128x192 tile, transposed issue, 16-float K chunks (K = 192, O = 192,
 // R = 291840) with parts of the loop removed:  MODE 0 full, 1 no global loads in the loop, 2 also no LDS
 // stores, 3 also no barrier (MFMA + LDS fragment reads only), 4 MFMA only.
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // Times the product NN GEMM kernel (eeg-gnn-ssl_amd/csrc/kernels_gemm.h) in isolation at the cfg2 shapes.
-// (Round-1 experiments with persistent / 64- and 96-row-tile variants measured within +-3% of it: DESIGN.md.)
+// (Round-1 experiments with persistent / 64- and 96-row-tile register-staged variants: DESIGN.md section 4.2.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../eeg-gnn-ssl_amd/csrc/kernels_gemm.h"
@@ -25,7 +25,9 @@ void shape(const char* name, int R, int F, int nseg) {
     SegPtrs s{}; for (int m = 0; m < nseg; ++m) s.p[m] = A + (size_t)m * R * F;
     const double fl = 2.0 * R * (double)(nseg * F) * 192;
     printf("-- %s: R=%d K=%d O=192\n", name, R, nseg * F);
-    timeit("nn2<6,KC,2,1>  (shipped)", fl, gemm_nn2_kernel<6, KC, 2, 1>, dim3((R + 127) / 128, 1), lds3<KC, 4>(), s, nseg, F, R, Bp, 12, bias, C, 192, 192);
+    timeit("gemm_nn_dma<6,KC,2>  (shipped)", fl, gemm_nn_dma_kernel<6, KC, 2>, dim3((R + 127) / 128, 1),
+           2 * (size_t)(128 * KC + (KC / 4) * 12 * 64) * sizeof(float), s, nseg, F, R, Bp, 12, bias, C, 192, 192);
+    timeit("gemm_nn<6,KC>  (register-staged fallback)", fl, gemm_nn_kernel<6, KC>, dim3((R + 127) / 128, 1), lds3<KC, 4>(), s, nseg, F, R, Bp, 12, bias, C, 192, 192);
 }
 int main() {
     const size_t R = 291840;
