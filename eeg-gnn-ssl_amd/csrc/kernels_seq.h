@@ -38,8 +38,9 @@ struct SeqGeom {
     static constexpr int KG = M * 2 * H, KGP = lds_stride_q(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
     static constexpr int NGT = 2 * H / 16, NCT = H / 16;                         // gate / cand col tiles
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
-    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP; }
-    static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP; }
+    static constexpr int kRemScratch = 4 * CT * 256;                             // 4 waves x CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
+    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + kRemScratch; }
+    static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP + kRemScratch; }
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) {
@@ -50,12 +51,23 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float
 
 // acc[i][nt] += W-frag[i][.] x X(32 nodes x 4*NKS, LDS, stride)^T for NT column tiles; the node
 // fragments are read as float4 (k = 16q + 4*(lane>>4) + j) one quad ahead of their use.
-template <int NT, int NKS>
-__device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lr, int lg,
-                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2]) {
+//
+// REM4 (montages with at most 20 nodes): the second node tile holds at most 4 real nodes, so instead
+// of a second 16x16x4 stream (100 % extra matrix work for 3 nodes) it is computed with
+// v_mfma_f32_4x4x1 (16 independent 4x4 outer products per instruction = 25 % extra): block = (lane
+// group lg, column quad), B operand = the SAME weight register, A operand = X[node 16 + (lane&3)][k];
+// register r of a lane is then the lane group's partial of out[node 16 + r][col lr].  The partials
+// are handed through `scratch` (per-wave LDS, NT*256 floats) to the lanes that own these nodes in the
+// tile layout (lane (lr < 4, lg): node 16 + lr, columns 4*lg..4*lg+3), which also sums the 4 groups.
+template <int NT, int NKS, bool REM4>
+__device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
+                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
     const float* p0 = X + lr * stride + 4 * lg;
-    const float* p1 = p0 + 16 * stride;
+    const float* p1 = REM4 ? X + (16 + (lane & 3)) * stride + 4 * lg : p0 + 16 * stride;
+    f32x4 rem[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) rem[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 a0 = *reinterpret_cast<const float4*>(p0);
     float4 a1 = *reinterpret_cast<const float4*>(p1);
 #pragma unroll
@@ -72,11 +84,28 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 acc[i][0] = mfma16(w[i][4 * q + j], x0[j], acc[i][0]);
-                acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
+                if (REM4) rem[i] = mfma4(x1[j], w[i][4 * q + j], rem[i]);
+                else acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
             }
         EEG_SCHED_FENCE();
         a0 = n0;
         a1 = n1;
+    }
+    if (REM4) {
+        // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr);  reader (lr < 4, lg): sum over the 4 groups
+        // of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[((i * 4 + lg) * 4 + r) * 16 + lr] = rem[i][r];
+        EEG_WAVE_SYNC();
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const float* q = scratch + (i * 16 + (lr & 3)) * 16 + 4 * lg;
+            const f32x4 s = (ld4(q) + ld4(q + 64)) + (ld4(q + 128) + ld4(q + 192));
+            if (lr < 4) acc[i][1] += s;
+        }
+        EEG_WAVE_SYNC();        // the next call may overwrite the scratch
     }
 }
 
@@ -129,7 +158,9 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* Pl = sm;
     float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
+    constexpr bool REM4 = NKS == 5;         // at most 20 nodes: the second node tile runs as 4x4x1 MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    float* RS = A2 + 32 * KAP + wave * (CT * 256);       // this wave's REM4 hand-over scratch
     const int b = blockIdx.x;
     const bool save = Rs != nullptr;
 
@@ -214,8 +245,8 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         pp.mark(0);
 
         // gate GEMM: (2H cols) x (32 nodes), K = M*H
-        mfma_nodes32<CT, KS>(A, KAP, lr, lg, wr, ar);
-        mfma_nodes32<CT, KS>(A, KAP, lr, lg, wu, au);
+        mfma_nodes32<CT, KS, REM4>(A, KAP, lane, lr, lg, wr, ar, RS);
+        mfma_nodes32<CT, KS, REM4>(A, KAP, lane, lr, lg, wu, au, RS);
         pp.mark(1);
         float* r_t = Rs + s * N * H;
         float* rh_t = RHs + s * N * H;
@@ -252,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         if (t + 1 < T) fetch_xw(t + 1);
 
         // candidate GEMM: (H cols) x (32 nodes), K = M*H
-        mfma_nodes32<CT, KS>(A2, KAP, lr, lg, wc, ac);
+        mfma_nodes32<CT, KS, REM4>(A2, KAP, lane, lr, lg, wc, ac, RS);
         pp.mark(4);
         float* h_t = Hseq + s * N * H;
         float* c_t = Cs + s * N * H;
@@ -305,7 +336,9 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float* Pl = sm;
     float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC
     float* EG = EC + 32 * KAP;              // [32][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
+    constexpr bool REM4 = NKS == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    float* RS = EG + 32 * KGP + wave * (CT * 256);
     const int b = blockIdx.x;
 
     // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             acc[i][0] = zero4;
             acc[i][1] = zero4;
         }
-        mfma_nodes32<CT, KS>(EC, KAP, lr, lg, w1, acc);
+        mfma_nodes32<CT, KS, REM4>(EC, KAP, lane, lr, lg, w1, acc, RS);
         pp.mark(2);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -457,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
-        mfma_nodes32<CT, KSG>(EG, KGP, lr, lg, w2, dhn);
+        mfma_nodes32<CT, KSG, REM4>(EG, KGP, lane, lr, lg, w2, dhn, RS);
         pp.mark(5);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
