@@ -544,7 +544,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
-                 (size_t)R * H, d->T, d->B, d->N, d->act, g_seq_probe, g_tune[3]};
+                 (size_t)R * H, d->T, d->B, d->N, d->act, g_seq_probe};
     return seq_fwd(H, M, a, st);
 }
 
@@ -567,7 +567,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     // 1. BPTT through the recurrence: dXW = [dR|dU|dC] per step, dh0, per-clip bias partials
     SeqBwdArgs a{Hext + state, Hext, Rs, Us, Cs, dHseq, d_at_end, d_at_len,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
-                 dXW, dh0, dbias, d->T, d->B, N, d->act, g_seq_probe, g_tune[3]};
+                 dXW, dh0, dbias, d->T, d->B, N, d->act, g_seq_probe};
     if (seq_bwd(H, M, a, st)) return 1;
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
@@ -657,7 +657,7 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
                          Hext + (size_t)(t + 1) * state, saved + y.rs[l] + (size_t)t * state,
                          saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state,
                          saved + y.rhs[l] + (size_t)t * state, saved + y.hpl[l] + (size_t)t * state,
-                         saved + y.rpl[l] + (size_t)t * state, Rall * H, 1, B, N, d->act, nullptr, g_tune[3]};
+                         saved + y.rpl[l] + (size_t)t * state, Rall * H, 1, B, N, d->act, nullptr};
             if (seq_fwd(H, M, a, st)) return 1;
         }
         // projection (model.py:188-190): out_t = h_top W_p^T + b_p
@@ -710,7 +710,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
                          saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state, dA,
                          t == T - 1 ? nullptr : dhn_in, nullptr, nullptr, P, d->p_batched, pack + p.b1, pack + p.b2,
                          dXW, t == 0 ? dh0 + (size_t)l * state : dhn_out, ws + y.dbias[l] + (size_t)t * B * 3 * H,
-                         1, B, N, d->act, nullptr, g_tune[3]};
+                         1, B, N, d->act, nullptr};
             if (seq_bwd(H, M, a, st)) return 1;
             const bool need_dx = l > 0 || (t > 0 && feeds_back(t - 1));
             if (need_dx) {

@@ -1,6 +1,5 @@
 // Instantiations of the recurrent kernels for one hidden size (compile with -DEEG_SEQ_H=16|32|64).
 #include "kernels_seq.h"
-#include "kernels_seq_r.h"
 #include "prof.h"
 #include "seq_launch.h"
 
@@ -30,27 +29,8 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
                  a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
-// wave-specialised 16-node MFMA tile + VALU remainder (kernels_seq_r.h): the 19-electrode montage, M <= 3
-template <int H, int M, int NR>
-int fwd_r(const SeqFwdArgs& a, hipStream_t st) {
-    const size_t lds = SeqGeomR<H, M>::fwd_lds_floats() * sizeof(float);
-    if constexpr (H == 64 && M == 3) {
-        if (a.probe != nullptr) {
-            EEG_SET_MAX_LDS((seq_fwd_r_kernel<H, M, NR, true>), lds);
-            EEG_LAUNCH_P("seq_fwd", (seq_fwd_r_kernel<H, M, NR, true>), dim3(a.B), dim3(512), lds, st, a.XW, a.h0, a.P,
-                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
-            return hipGetLastError() == hipSuccess ? 0 : 2;
-        }
-    }
-    EEG_SET_MAX_LDS((seq_fwd_r_kernel<H, M, NR>), lds);
-    EEG_LAUNCH_P("seq_fwd", (seq_fwd_r_kernel<H, M, NR>), dim3(a.B), dim3(512), lds, st, a.XW, a.h0, a.P, a.p_batched,
-                 a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
-}
 template <int H, int M>
 int fwd_one(const SeqFwdArgs& a, hipStream_t st) {
-    if constexpr (M <= 3)
-        if (a.N == 19 && !a.force_generic) return fwd_r<H, M, 3>(a, st);
     return a.N <= 20 ? fwd_nks<H, M, 5>(a, st) : fwd_nks<H, M, 8>(a, st);
 }
 template <int H, int M, int NKS>
@@ -71,28 +51,8 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
                  a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
-template <int H, int M, int NR>
-int bwd_r(const SeqBwdArgs& a, hipStream_t st) {
-    const size_t lds = SeqGeomR<H, M>::bwd_lds_floats() * sizeof(float);
-    if constexpr (H == 64 && M == 3) {
-        if (a.probe != nullptr) {
-            EEG_SET_MAX_LDS((seq_bwd_r_kernel<H, M, NR, true>), lds);
-            EEG_LAUNCH_P("seq_bwd", (seq_bwd_r_kernel<H, M, NR, true>), dim3(a.B), dim3(512), lds, st, a.Hseq, a.h0, a.Rs, a.Us,
-                         a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
-            return hipGetLastError() == hipSuccess ? 0 : 2;
-        }
-    }
-    EEG_SET_MAX_LDS((seq_bwd_r_kernel<H, M, NR>), lds);
-    EEG_LAUNCH_P("seq_bwd", (seq_bwd_r_kernel<H, M, NR>), dim3(a.B), dim3(512), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
-                 a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
-}
 template <int H, int M>
 int bwd_one(const SeqBwdArgs& a, hipStream_t st) {
-    if constexpr (M <= 3)
-        if (a.N == 19 && !a.force_generic) return bwd_r<H, M, 3>(a, st);
     return a.N <= 20 ? bwd_nks<H, M, 5>(a, st) : bwd_nks<H, M, 8>(a, st);
 }
 

@@ -15,7 +15,6 @@ struct SeqFwdArgs {
     size_t plane_stride;
     int T, B, N, act;
     long long* probe;
-    int force_generic;      // development knob: use the two-tile (padded) kernels even for N == 19
 };
 struct SeqBwdArgs {
     const float *Hseq, *h0, *Rs, *Us, *Cs, *dHseq, *d_at_end, *d_at_len;
@@ -26,7 +25,6 @@ struct SeqBwdArgs {
     float *dXW, *dh0, *dbias_part;
     int T, B, N, act;
     long long* probe;
-    int force_generic;
 };
 
 // return 0 ok, 1 unsupported M for this H, 2 launch error

@@ -56,11 +56,10 @@ int eeg_dcrnn_is_device_build(void);
 int eeg_dcrnn_prof_enable(int on);
 int eeg_dcrnn_prof_report(char* buf, size_t cap);
 /* Development aid: when set to a device buffer of B*4*32 int64, the recurrent kernels store the
- * shader-clock cycles each wave spent per phase (slots 0-5 forward, 8-13 backward, 16-21 forward
- * remainder waves); NULL disables.  Only the H=64, M=3 instantiations carry the probe. */
+ * shader-clock cycles each wave spent per phase (slots 0-5 forward, 8-13 backward); NULL disables.  Only the H=64, M=3 instantiations carry the probe. */
 int eeg_dcrnn_set_seq_probe(int64_t* probe);
 /* Development aid: integer knobs selecting kernel variants for A/B timing.  key 0 = 1: register-staged NN
- * GEMM; key 1 = 1: register-staged TN GEMM; key 3 = 1: generic two-tile recurrent kernels also for N = 19;
+ * GEMM; key 1 = 1: register-staged TN GEMM;
  * key 4 = 1: XCD-aware placement of the TN k-blocks; key 9 = 1: LDS/MFMA adjoint diffusion.
  * Defaults (all 0) are the shipped configuration. */
 int eeg_dcrnn_set_tuning(int key, int value);

@@ -38,8 +38,7 @@ lib.query("eeg_dcrnn_set_seq_probe", None)
 p = probe.view(batch, 4, 32).double().cpu()
 names_f = ["diffuse(h)+bar", "gate GEMM", "gate epilogue+bar", "diffuse(rh)+bar", "cand GEMM", "cand epilogue+bar"]
 names_b = ["E1+bar", "adj diffuse dC+bar", "GEMM1", "epi1+bar", "adj diffuse dG+bar", "GEMM2"]
-names_rf = ["diffuse+loads+bar(1)", "gate VALU", "gate epi+bar(1b)", "diffuse+bar(2)", "cand VALU", "cand epi+bar(2b)"]
-for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b), ("seq_fwd REM waves", 16, names_rf)):
+for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
     tot = p[:, :, off:off + 6].sum(-1).mean().item() / t_len
     print(f"{title}: {tot:9.0f} cycles/step/wave (mean over {batch} WGs x 4 waves)")
     for k, nm in enumerate(names):
