@@ -38,7 +38,7 @@ struct SeqGeom {
     static constexpr int KG = M * 2 * H, KGP = lds_stride_q(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
     static constexpr int NGT = 2 * H / 16, NCT = H / 16;                         // gate / cand col tiles
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
-    static constexpr int kRemScratch = 4 * CT * 256;                             // 4 waves x CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
+    static constexpr int kRemScratch = 4 * 2 * CT * 256;                         // 4 waves x up to 2*CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
     static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + kRemScratch; }
     static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP + kRemScratch; }
 };
@@ -65,9 +65,11 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
     const float* p0 = X + lr * stride + 4 * lg;
     const float* p1 = REM4 ? X + (16 + (lane & 3)) * stride + 4 * lg : p0 + 16 * stride;
-    f32x4 rem[NT];
+    f32x4 rem[NT][4];           // one chain per k-step of the quad: consecutive 4x4x1 MFMAs are independent
 #pragma unroll
-    for (int i = 0; i < NT; ++i) rem[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 a0 = *reinterpret_cast<const float4*>(p0);
     float4 a1 = *reinterpret_cast<const float4*>(p1);
 #pragma unroll
@@ -84,9 +86,14 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 acc[i][0] = mfma16(w[i][4 * q + j], x0[j], acc[i][0]);
-                if (REM4) rem[i] = mfma4(x1[j], w[i][4 * q + j], rem[i]);
-                else acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
+                if (!REM4) acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
             }
+        if (REM4) {                 // the quad's 4x4x1 MFMAs as one group (fewer switches between MFMA shapes)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) rem[i][j] = mfma4(x1[j], w[i][4 * q + j], rem[i][j]);
+        }
         EEG_SCHED_FENCE();
         a0 = n0;
         a1 = n1;
@@ -97,7 +104,8 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) scratch[((i * 4 + lg) * 4 + r) * 16 + lr] = rem[i][r];
+            for (int r = 0; r < 4; ++r)
+                scratch[((i * 4 + lg) * 4 + r) * 16 + lr] = (rem[i][0][r] + rem[i][1][r]) + (rem[i][2][r] + rem[i][3][r]);
         EEG_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -160,21 +168,21 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
     constexpr bool REM4 = NKS == 5;         // at most 20 nodes: the second node tile runs as 4x4x1 MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = A2 + 32 * KAP + wave * (CT * 256);       // this wave's REM4 hand-over scratch
+    float* RS = A2 + 32 * KAP + wave * (2 * CT * 256);   // this wave's REM4 hand-over scratch
     const int b = blockIdx.x;
     const bool save = Rs != nullptr;
 
     // Wave w owns column tiles ct = w + 4*i of r, u, c and h (so gate tiles ct and NCT+ct): the
     // epilogue -> diffusion hand-offs are wave-local and u never leaves registers.
     // recurrent weights -> registers (MFMA fragments), once for all T steps
-    float wr[CT][KS], wu[CT][KS], wc[CT][KS];
+    float wg[2 * CT][KS], wc[CT][KS];       // gate fragments: [i] = r tile, [CT + i] = u tile
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
         const int ct = wave + 4 * i < NCT ? wave + 4 * i : 0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            wr[i][ks] = bhg[((size_t)ks * NGT + ct) * 64 + lane];
-            wu[i][ks] = bhg[((size_t)ks * NGT + NCT + ct) * 64 + lane];
+            wg[i][ks] = bhg[((size_t)ks * NGT + ct) * 64 + lane];
+            wg[CT + i][ks] = bhg[((size_t)ks * NGT + NCT + ct) * 64 + lane];
             wc[i][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
         }
     }
@@ -233,20 +241,19 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     fetch_xw(0);
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
-        f32x4 xr[CT][2], xu[CT][2], xc[CT][2], ar[CT][2], au[CT][2], ac[CT][2], ug[CT][2];
+        f32x4 xr[CT][2], xu[CT][2], xc[CT][2], ag[2 * CT][2], ac[CT][2], ug[CT][2];
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                ar[i][nt] = zero4; au[i][nt] = zero4; ac[i][nt] = zero4;
+                ag[i][nt] = zero4; ag[CT + i][nt] = zero4; ac[i][nt] = zero4;
                 xr[i][nt] = nxr[i][nt]; xu[i][nt] = nxu[i][nt]; xc[i][nt] = nxc[i][nt];
             }
         __syncthreads();                                            // (1) hops(h) complete
         pp.mark(0);
 
         // gate GEMM: (2H cols) x (32 nodes), K = M*H
-        mfma_nodes32<CT, KS, REM4>(A, KAP, lane, lr, lg, wr, ar, RS);
-        mfma_nodes32<CT, KS, REM4>(A, KAP, lane, lr, lg, wu, au, RS);
+        mfma_nodes32<2 * CT, KS, REM4>(A, KAP, lane, lr, lg, wg, ag, RS);
         pp.mark(1);
         float* r_t = Rs + s * N * H;
         float* rh_t = RHs + s * N * H;
@@ -261,8 +268,8 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                     f32x4 rg, u;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        rg[r] = sigmoidf_(ar[i][nt][r] + xr[i][nt][r]);
-                        u[r] = sigmoidf_(au[i][nt][r] + xu[i][nt][r]);
+                        rg[r] = sigmoidf_(ag[i][nt][r] + xr[i][nt][r]);
+                        u[r] = sigmoidf_(ag[CT + i][nt][r] + xu[i][nt][r]);
                     }
                     ug[i][nt] = u;
                     f32x4 rh = rg * ld4(A + node[nt] * KAP + col);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float* EG = EC + 32 * KAP;              // [32][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
     constexpr bool REM4 = NKS == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = EG + 32 * KGP + wave * (CT * 256);
+    float* RS = EG + 32 * KGP + wave * (2 * CT * 256);
     const int b = blockIdx.x;
 
     // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
