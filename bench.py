@@ -109,7 +109,9 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
         w["seq_bwd"] += s * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
         w["gemm_nn"] += 2.0 * r * (m * fin) * 3 * h
         w["gemm_tn"] += 2.0 * r * (m * fin) * 3 * h + 2.0 * r * (m * h) * 2 * h + 2.0 * r * (m * h) * h
-        w["diffuse_fwd"] += 4.0 * s * n * fin * m      # (the hop planes of h and r*h are by-products of seq_fwd)
+        # read X once, write M-1 planes; layer 0 also writes the time-major copy of the batch-major input
+        # (the hop planes of h and r*h are by-products of seq_fwd, not of this kernel)
+        w["diffuse_fwd"] += 4.0 * s * n * fin * (m + 1 if l == 0 else m)
         if l > 0:
             w["gemm_nn"] += 2.0 * r * 3 * h * (m * fin)
             w["diffuse_adj"] += 4.0 * s * n * fin * (m + 1)
