@@ -9,6 +9,7 @@
 
 #include "../../include/eeg_dcrnn.h"
 #include "kernels_diffuse.h"
+#include "kernels_feat.h"
 #include "kernels_gemm.h"
 #include "kernels_graph.h"
 #include "kernels_head.h"
@@ -585,6 +586,20 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     return 0;
 }
 
+
+/* ---- input featurisation -------------------------------------------------------------------------- */
+int eeg_dcrnn_fft_features(const float* raw, int B, int N, int T, int W, const int32_t* perm, const float* log_scale,
+                           float mean, float std_, float* feat_raw, float* feat_std, void* stream) {
+    if (B < 1 || N < 1 || T < 1) return fail("fft_features: empty input (B=%d, N=%d, T=%d)", B, N, T);
+    if (W < 4 || W % 4 != 0 || W / 4 + 1 > 64) return fail("fft_features: window=%d unsupported (multiple of 4, <= 252)", W);
+    if (feat_raw == nullptr && feat_std == nullptr) return fail("fft_features: no output requested");
+    if (feat_std != nullptr && !(std_ != 0.f)) return fail("fft_features: std must be non-zero");
+    int tchunk = T;                                   // ~8 waves per SIMD in total
+    while (tchunk > 1 && (long long)B * N * ceil_div(T, tchunk) < 8192) tchunk = ceil_div(tchunk, 2);
+    EEG_LAUNCH_P("fft_features", fft_features_kernel, dim3(B * N, ceil_div(T, tchunk)), dim3(64), (size_t)W * sizeof(double), S_(stream),
+                 raw, N, T, W, tchunk, reinterpret_cast<const int*>(perm), log_scale, mean, 1.0f / std_, feat_raw, feat_std);
+    return check_launch("fft_features");
+}
 
 /* ---- per-clip correlation graph -> supports --------------------------------------------------- */
 static int corr_nsplit(int B, int T) {

@@ -149,6 +149,34 @@ def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: 
     return out, flag
 
 
+def fft_features(raw: torch.Tensor, window: int = 200, mean: Optional[float] = None, std: Optional[float] = None,
+                 perm: Optional[torch.Tensor] = None, log_scale: Optional[torch.Tensor] = None):
+    """Input featurisation on the device: raw (B,N,T*window) resampled signals ->
+    (feat_raw (B,T,N,window/2) log|FFT| per 1-s step, feat_std = the standardised (and optionally
+    augmented) model input or None when mean/std are not given).
+
+    Replaces `computeFFT` per step (data_utils.py:13-35, dataloader_detection.py:57-71), the reflection /
+    amplitude-jitter augmentation (perm (B,N) int32 source channel per node, log_scale (B);
+    dataloader_detection.py:233-256) and `StandardScaler.transform` (utils.py:393-428)."""
+    lib = _lib.get_lib()
+    raw = raw.contiguous()
+    _check(lib, raw, "raw signals")
+    if raw.dim() != 3 or raw.shape[2] % window != 0:
+        raise RuntimeError(f"raw signals must be (B, N, T*{window}), got {tuple(raw.shape)}")
+    b, n, total = raw.shape
+    t_len = total // window
+    feat_raw = torch.empty((b, t_len, n, window // 2), dtype=torch.float32, device=raw.device)
+    feat_std = torch.empty_like(feat_raw) if mean is not None else None
+    if perm is not None:
+        perm = perm.to(device=raw.device, dtype=torch.int32).contiguous()
+    if log_scale is not None:
+        log_scale = log_scale.to(device=raw.device, dtype=torch.float32).contiguous()
+    lib.call("eeg_dcrnn_fft_features", _p(raw), b, n, t_len, window, _p(perm), _p(log_scale),
+             float(mean) if mean is not None else 0.0, float(std) if std is not None else 1.0,
+             _p(feat_raw), _p(feat_std), _stream(raw))
+    return feat_raw, feat_std
+
+
 def correlation_supports(x: torch.Tensor, top_k: int = 3, return_adj: bool = False):
     """Per-clip correlation graph -> [S1, S2] dual random-walk supports, on the device.
 

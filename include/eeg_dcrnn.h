@@ -71,6 +71,18 @@ int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K,
                         float* P_out, void* stream);
 
+/* Input featurisation (replaces the DataLoader-side CPU code: data_utils.py:13-35 `computeFFT` applied to
+ * every 1-second step as dataloader_detection.py:57-71 does; :233-256 augmentation; utils.py:393-428
+ * StandardScaler.transform).  raw (B,N,T*W) resampled signals; W = samples per step (200).
+ *   feat_raw (B,T,N,W/2), nullable : log|FFT| of the W/2 positive frequencies (amp == 0 -> 1e-8), the
+ *                                    un-augmented clip the correlation graph is built from;
+ *   feat_std (B,T,N,W/2), nullable : ((log|FFT| of channel perm[b][n]) + log_scale[b] - mean) / std,
+ *                                    the model input.  perm (B,N) int32 / log_scale (B) may be NULL
+ *                                    (no reflection / no amplitude jitter).  The transform runs in fp64. */
+int eeg_dcrnn_fft_features(const float* raw, int B, int N, int T, int W, const int32_t* perm,
+                           const float* log_scale, float mean, float std_, float* feat_raw,
+                           float* feat_std, void* stream);
+
 /* Per-clip correlation graph and its dual random-walk supports, from the clips themselves
  * (replaces the DataLoader-side CPU code: dataloader_detection.py:258-307 `_get_indiv_graphs`
  * = |normalised lag-0 cross-correlation| of every electrode pair of the (N, T*D) clip, diag 1;

@@ -137,6 +137,22 @@ def correlation_adjacency(clip: np.ndarray, top_k: int = 3) -> np.ndarray:
     return keep_topk(adj, top_k=top_k, directed=True)
 
 
+def fft_features(raw: np.ndarray, window: int = 200) -> np.ndarray:
+    """data_utils.py:13-35 (computeFFT) applied per window as dataloader_detection.py:57-71 does.
+
+    raw (N, T*window) -> (T, N, window//2) float64 log amplitudes of the positive-frequency half of the
+    FFT of every `window`-sample step; exact-zero amplitudes are replaced by 1e-8 before the log."""
+    n_ch, total = raw.shape
+    steps = total // window
+    out = np.empty((steps, n_ch, window // 2), dtype=np.float64)
+    for t in range(steps):
+        spec = np.fft.fft(np.asarray(raw[:, t * window:(t + 1) * window], dtype=np.float64), n=window, axis=-1)
+        amp = np.abs(spec[:, :window // 2])
+        amp[amp == 0.0] = 1e-8
+        out[t] = np.log(amp)
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # diffusion graph convolution and DCGRU cell
 # --------------------------------------------------------------------------------------

@@ -22,3 +22,8 @@ def golden():
 @pytest.fixture(scope="session")
 def adj3d():
     return np.load(os.path.join(ROOT, "tests", "golden", "adj_mx_3d.npy"))
+
+
+@pytest.fixture(scope="session")
+def golden_fft():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_fft_v1.npz"))

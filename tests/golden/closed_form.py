@@ -40,3 +40,17 @@ def sample_view(a, step=97):
     """Strided sample + summary stats: a compact fingerprint of a large gradient tensor."""
     flat = np.asarray(a, dtype=np.float64).reshape(-1)
     return np.concatenate([[flat.sum(), np.abs(flat).sum(), np.square(flat).sum()], flat[::step]])
+
+
+def fft_raw_signal(n_ch=19, n_samples=800):
+    """Closed-form 'raw EEG' (float64, microvolt-like scale) for the featurisation goldens: a few
+    sinusoids, a chirp and hash noise so that every FFT bin carries energy; channel 5 is silent in the
+    second window (exact zeros -> the amp == 0 -> 1e-8 rule of computeFFT)."""
+    i = np.arange(n_ch * n_samples, dtype=np.float64).reshape(n_ch, n_samples)
+    t = np.arange(n_samples, dtype=np.float64)[None, :]
+    ch = np.arange(n_ch, dtype=np.float64)[:, None]
+    x = 30.0 * np.sin(0.211 * t + 0.3 * ch) + 12.0 * np.sin(1.37 * t + 0.11 * ch * ch) + 5.0 * np.sin(0.0007 * t * t + ch)
+    noise = np.sin(12.9898 * i + 78.233) * 43758.5453
+    x = x + 8.0 * (noise - np.floor(noise) - 0.5)
+    x[5, 200:400] = 0.0
+    return x

@@ -356,3 +356,35 @@ def check_grad_sink(device, adj3d):
         ts.loss(out, y).backward()                      # no sink: autograd accumulates into the views
         plain = ts.fp.flat_grad.clone()
         assert torch.equal(sunk, plain), (task, (sunk - plain).abs().max().item())
+
+
+def check_fft_features(device, golden_fft):
+    """On-device featurisation (1-s windows -> log|FFT| -> reflection / amplitude jitter -> z-score) vs the
+    goldens of the genuine reference pipeline and, for the augmented variant and a ragged shape, the oracle."""
+    from closed_form import fft_raw_signal
+    from eeg_gnn_ssl_amd import ops
+    mean, std = (float(v) for v in golden_fft["fft/mean_std"])
+    raw64 = fft_raw_signal()
+    raw = torch.from_numpy(raw64.astype(np.float32)).unsqueeze(0).to(device)          # (1, 19, 800)
+    feat_raw, feat_std = ops.fft_features(raw, window=200, mean=mean, std=std)
+    assert feat_raw.shape == (1, 4, 19, 100)
+    # the operator takes float32 signals (the reference float64): rounding the samples to float32 moves the
+    # weakest bins (|X| ~ 1 next to 30-uV components) by ~1e-5 in the log; the transform itself is fp64
+    assert np.abs(feat_raw[0].cpu().numpy() - golden_fft["fft/logamp"]).max() <= 3e-5
+    assert np.abs(feat_std[0].cpu().numpy() - golden_fft["fft/standardized"]).max() <= 3e-5
+    same_input = orc.fft_features(raw64.astype(np.float32).astype(np.float64), window=200)
+    assert np.abs(feat_raw[0].cpu().numpy() - same_input).max() <= 2e-6           # same (rounded) samples: fp32 output rounding only
+    assert abs(feat_raw[0, 1, 5, 0].item() - np.log(1e-8)) < 1e-5                      # silent window: amp == 0 -> 1e-8
+    # augmentation: left/right reflection (node permutation) + amplitude jitter, two clips, other window length
+    g = torch.Generator().manual_seed(2)
+    rawb = torch.randn(2, 19, 3 * 40, generator=g) * 20.0
+    perm = torch.stack([torch.arange(19), torch.arange(19)]).to(torch.int32)
+    perm[1, [0, 1]] = torch.tensor([1, 0], dtype=torch.int32)                         # swap one channel pair in clip 1
+    perm[1, [4, 7]] = torch.tensor([7, 4], dtype=torch.int32)
+    ls = torch.tensor([0.0, float(np.log(1.137))])
+    fr, fs = ops.fft_features(rawb.to(device), window=40, mean=0.5, std=2.0, perm=perm.to(device), log_scale=ls.to(device))
+    for b in range(2):
+        ref = orc.fft_features(rawb[b].numpy().astype(np.float64), window=40)          # (3, 19, 20)
+        assert np.abs(fr[b].cpu().numpy() - ref).max() <= 5e-6
+        exp = ((ref[:, perm[b].numpy(), :] + float(ls[b])) - 0.5) / 2.0
+        assert np.abs(fs[b].cpu().numpy() - exp).max() <= 5e-6

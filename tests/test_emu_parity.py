@@ -59,3 +59,7 @@ def test_correlation_graph_supports(golden):
 
 def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink("cpu", adj3d)
+
+
+def test_fft_features(golden_fft):
+    ps.check_fft_features("cpu", golden_fft)

@@ -224,3 +224,7 @@ def test_correlation_graph_supports(golden):
 
 def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink(DEV, adj3d)
+
+
+def test_fft_features(golden_fft):
+    ps.check_fft_features(DEV, golden_fft)

@@ -170,3 +170,13 @@ def test_param_counts_match_survey():
     assert count(orc.DCRNNConfig(num_classes=4), "classification") == 168836
     assert count(orc.DCRNNConfig(filter_type="dual_random_walk"), "ssl") == 567908
     assert count(orc.DCRNNConfig(filter_type="dual_random_walk", num_rnn_layers=3), "ssl") == 690980
+
+
+def test_fft_features_match_reference(golden_fft):
+    """oracle.fft_features (numpy FFT restatement of computeFFT per 1-s step) vs the reference's own output."""
+    from closed_form import fft_raw_signal
+    got = orc.fft_features(fft_raw_signal(), window=200)
+    assert got.shape == golden_fft["fft/logamp"].shape
+    assert np.abs(got - golden_fft["fft/logamp"]).max() <= 1e-9
+    mean, std = golden_fft["fft/mean_std"]
+    assert np.abs(((got - mean) / std).astype(np.float32) - golden_fft["fft/standardized"]).max() <= 1e-6
