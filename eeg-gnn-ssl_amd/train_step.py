@@ -141,3 +141,37 @@ class TrainStep:
         loss = self.forward_backward(x, y, seq_lengths, supports)
         self.reduce_and_update()
         return loss
+
+    # -- checkpointing (utils.CheckpointSaver / load_model_checkpoint use these like an optimizer's) -------
+    def state_dict(self):
+        return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
+
+    def load_state_dict(self, state):
+        self.step_count, self.lr = int(state["step"]), float(state["lr"])
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+
+
+@torch.no_grad()
+def predict(model, batches, task: str = "detection"):
+    """Evaluation forward passes (train.py:343-404 without the host round trip per batch): returns
+    (y_prob, y_true) as numpy arrays gathered from ALL ranks on every rank (RCCL all_gather when launched
+    data-parallel).  batches: iterable of (x, y, seq_lengths, supports) device tensors."""
+    was_training = model.training
+    model.eval()
+    probs, labels = [], []
+    for x, y, seq_lengths, supports in batches:
+        if supports is None:
+            supports = ops.correlation_supports(x, top_k=3)
+        logits = model(x, seq_lengths, supports)
+        probs.append(torch.sigmoid(logits.view(-1)) if task == "detection" else torch.softmax(logits, dim=1))
+        labels.append(y.view(-1))
+    prob, lab = torch.cat(probs), torch.cat(labels)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        gp = [torch.empty_like(prob) for _ in range(dist.get_world_size())]
+        gl = [torch.empty_like(lab) for _ in range(dist.get_world_size())]
+        dist.all_gather(gp, prob)
+        dist.all_gather(gl, lab)
+        prob, lab = torch.cat(gp), torch.cat(gl)
+    model.train(was_training)
+    return prob.cpu().numpy(), lab.cpu().numpy()

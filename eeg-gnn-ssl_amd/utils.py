@@ -191,3 +191,64 @@ def build_finetune_model(model_new, model_pretrained, num_rnn_layers, num_layers
         dst.dconv_gate = src.dconv_gate
         dst.dconv_candidate = src.dconv_candidate
     return model_new
+
+
+class CheckpointSaver:
+    """`last.pth.tar` after every call, `best.pth.tar` whenever the tracked metric does not get worse
+    (ties count as better): the file protocol of the reference (utils.py:84-150), so its scripts and
+    `load_model_checkpoint` read these files unchanged.  `optimizer` is anything with a `state_dict()`
+    (e.g. `TrainStep`)."""
+
+    def __init__(self, save_dir, metric_name, maximize_metric=False, log=None):
+        self.save_dir, self.metric_name, self.maximize_metric, self.log = save_dir, metric_name, maximize_metric, log
+        self.best_val = None
+
+    def is_best(self, metric_val):
+        if metric_val is None:
+            return False
+        if self.best_val is None:
+            return True
+        return self.best_val <= metric_val if self.maximize_metric else self.best_val >= metric_val
+
+    def save(self, epoch, model, optimizer, metric_val):
+        import os
+        import shutil
+        last = os.path.join(self.save_dir, "last.pth.tar")
+        torch.save({"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict()}, last)
+        if self.is_best(metric_val):
+            self.best_val = metric_val
+            shutil.copy(last, os.path.join(self.save_dir, "best.pth.tar"))
+            if self.log is not None:
+                self.log.info(f"new best checkpoint at epoch {epoch} ({self.metric_name} = {metric_val})")
+
+
+def eval_dict(y_pred, y, y_prob=None, file_names=None, average="macro"):
+    """Score dictionary of the reference's evaluation (utils.py:285-317): accuracy, F1 / precision / recall
+    with the given averaging, AUROC for binary problems when probabilities are given; plus the per-file
+    prediction / label dictionaries."""
+    from sklearn import metrics
+    pred = dict(zip(file_names, y_pred)) if file_names is not None else {}
+    true = dict(zip(file_names, y)) if file_names is not None else {}
+    scores = {}
+    if y is not None:
+        scores["acc"] = metrics.accuracy_score(y, y_pred)
+        scores["F1"] = metrics.f1_score(y, y_pred, average=average)
+        scores["precision"] = metrics.precision_score(y, y_pred, average=average)
+        scores["recall"] = metrics.recall_score(y, y_pred, average=average)
+        if y_prob is not None and len(set(np.asarray(y).tolist())) <= 2:
+            scores["auroc"] = metrics.roc_auc_score(y, y_prob)
+    return scores, pred, true
+
+
+def thresh_max_f1(y_true, y_prob):
+    """Decision threshold that maximises F1 along the precision-recall curve (binary only;
+    utils.py:320-343: the dev-set threshold search of the detection task)."""
+    from sklearn.metrics import precision_recall_curve
+    if len(set(np.asarray(y_true).tolist())) > 2:
+        raise NotImplementedError("thresh_max_f1 is defined for binary labels")
+    precision, recall, thresholds = precision_recall_curve(y_true, y_prob)
+    p, r = precision[:len(thresholds)], recall[:len(thresholds)]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f1 = 2 * p * r / (p + r)
+    keep = ~np.isnan(f1)
+    return thresholds[keep][int(np.argmax(f1[keep]))]

@@ -65,3 +65,36 @@ def test_cosine_schedule_matches_torch():
         opt.step()
         sch.step()
         assert abs(sch.get_last_lr()[0] - utils.cosine_annealing_lr(3e-4, e, 60)) < 1e-12
+
+
+def test_eval_and_checkpoint_helpers(tmp_path):
+    """utils.thresh_max_f1 / eval_dict / CheckpointSaver (reference utils.py:84-150,285-343): the threshold
+    maximises F1 over all candidate thresholds; best/last checkpoint protocol."""
+    import numpy as np
+    import torch
+    from sklearn.metrics import f1_score
+    from eeg_gnn_ssl_amd import utils
+    rng = np.random.RandomState(0)
+    y = (rng.rand(300) > 0.7).astype(int)
+    prob = np.clip(0.35 * y + 0.65 * rng.rand(300), 0, 1)
+    th = utils.thresh_max_f1(y, prob)
+    best = max(f1_score(y, (prob >= t).astype(int)) for t in np.unique(prob))
+    assert abs(f1_score(y, (prob >= th).astype(int)) - best) < 1e-12
+    scores, pred, true = utils.eval_dict((prob > th).astype(int), y, y_prob=prob, file_names=[f"f{i}" for i in range(300)])
+    assert set(scores) == {"acc", "F1", "precision", "recall", "auroc"} and len(pred) == 300 and true["f3"] == y[3]
+
+    class Opt:
+        def state_dict(self):
+            return {"k": 1}
+    model = torch.nn.Linear(3, 2)
+    saver = utils.CheckpointSaver(str(tmp_path), "auroc", maximize_metric=True)
+    saver.save(1, model, Opt(), 0.6)
+    with torch.no_grad():
+        model.weight.add_(1.0)
+    saver.save(2, model, Opt(), 0.5)                       # worse: only last.pth.tar moves
+    best_ck = torch.load(tmp_path / "best.pth.tar", weights_only=False)
+    last_ck = torch.load(tmp_path / "last.pth.tar", weights_only=False)
+    assert best_ck["epoch"] == 1 and last_ck["epoch"] == 2 and saver.best_val == 0.6
+    fresh = torch.nn.Linear(3, 2)
+    utils.load_model_checkpoint(str(tmp_path / "last.pth.tar"), fresh)
+    assert torch.equal(fresh.weight, model.weight)
