@@ -19,7 +19,8 @@ ABI_VERSION = 1
 class LayerDims(ctypes.Structure):
     """mirror of `eeg_layer_dims` (include/eeg_dcrnn.h)."""
     _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Fin", c_int32),
-                ("M", c_int32), ("act", c_int32), ("p_batched", c_int32)]
+                ("M", c_int32), ("act", c_int32), ("p_batched", c_int32), ("x_planes_ready", c_int32),
+                ("reserved", c_int32), ("x_plane_stride", c_int64)]
 
 
 class DecoderDims(ctypes.Structure):

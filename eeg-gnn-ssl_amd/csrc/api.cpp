@@ -301,36 +301,41 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
 // reduction): x-part [X | P_m X]^T [dR|dU|dC], h-part of the gate hops(h_{t-1})^T [dR|dU] and of the
 // candidate hops(r*h_{t-1})^T dC.  accumulate = add into dWg/dWc (a cell shared by several layers).
 // hpl_in / rpl_in: hop planes of h_{t-1} / r*h_{t-1} kept by the forward kernel (NULL: recomputed into hpl / rpl).
-int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* planes, const float* Hprev,
+// x_stride / h_stride: floats between two hop planes of `planes` / of hpl_in, rpl_in.
+int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* planes, size_t x_stride, const float* Hprev,
                       const float* RHs, const float* dXW, const float* P, const float* hpl_in, const float* rpl_in,
-                      float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate, float* dWg, float* dWc,
-                      hipStream_t st) {
+                      size_t h_stride, float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate,
+                      float* dWg, float* dWc, hipStream_t st) {
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const int acc = accumulate ? 8 : 0;
     SegPtrs sx;
-    for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
+    for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
     if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0 | acc, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(x)")) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
+    size_t hs = h_stride;
     if (hpl == nullptr) {
         if (diffuse_fwd(Hprev, P, d->p_batched, S, d->B, N, H, M, hpl_ws, st)) return 1;
         hpl = hpl_ws;
+        hs = (size_t)R * H;
     }
     SegPtrs sh;
-    for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * R * H : nullptr);
+    for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * hs : nullptr);
     if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hg, M * H, 2 * H, 1 | acc, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hg)")) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     const float* rpl = rpl_in;
+    size_t rs = h_stride;
     if (rpl == nullptr) {
         if (diffuse_fwd(RHs, P, d->p_batched, S, d->B, N, H, M, rpl_ws, st)) return 1;
         rpl = rpl_ws;
+        rs = (size_t)R * H;
     }
     SegPtrs sr;
-    for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * R * H : nullptr);
+    for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * rs : nullptr);
     if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hc, M * H, H, 2 | acc, Fin, H, M, dWg, dWc);
     return check_launch("reduce_unpack(hc)");
@@ -369,15 +374,17 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
     y.proj_bias = o; o += align64((size_t)nct_o * 16);
     for (int l = 0; l < d->L; ++l) {
         const int fin = l == 0 ? d->Dout : d->H;
-        y.ld[l] = eeg_layer_dims{d->T, d->B, d->N, d->H, fin, d->M, d->act, d->p_batched};
-        y.planes[l] = o; o += align64((size_t)(d->M - 1) * R * fin);
+        y.ld[l] = eeg_layer_dims{d->T, d->B, d->N, d->H, fin, d->M, d->act, d->p_batched, 0, 0, 0};
+        y.planes[l] = o; if (l == 0) o += align64((size_t)(d->M - 1) * R * fin);   // layers >= 1: the hpl of the layer below
         y.hext[l] = o;   o += align64((size_t)(d->T + 1) * state);
         y.rs[l] = o;     o += align64((size_t)d->T * state);
         y.us[l] = o;     o += align64((size_t)d->T * state);
         y.cs[l] = o;     o += align64((size_t)d->T * state);
         y.rhs[l] = o;    o += align64((size_t)d->T * state);
-        y.hpl[l] = o;    o += align64((size_t)(d->M - 1) * R * d->H);      // hop planes of h_{t-1} and r*h_{t-1}: by-products
-        y.rpl[l] = o;    o += align64((size_t)(d->M - 1) * R * d->H);      // of the forward kernel, A operands of the dW GEMMs
+        // hop planes of h_{t-1} (slots 0..T; slot t+1 = hops of this layer's output at step t = the next layer's
+        // input planes) and of r*h_{t-1}: by-products of the forward kernel, A operands of the dW GEMMs
+        y.hpl[l] = o;    o += align64((size_t)(d->M - 1) * (d->T + 1) * state);
+        y.rpl[l] = o;    o += align64((size_t)(d->M - 1) * (d->T + 1) * state);
     }
     y.saved_total = o;
     o = 0;
@@ -534,18 +541,24 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     // slot 0 of Hext = initial state (h0 == NULL: the recurrent kernel clears it)
     if (h0 != nullptr && h0 != Hext && copy_floats(Hext, h0, state, st)) return 1;
     // 1. hoisted diffusion of the layer input: planes[m-1] = P_m X  (Xtm != NULL: X is batch-major and Xtm
-    //    receives the time-major copy that everything after this point reads)
-    if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, 0, Xtm != nullptr ? 1 : 0, Xtm)) return 1;
-    if (Xtm != nullptr) X = Xtm;
+    //    receives the time-major copy that everything after this point reads) -- unless the previous layer's
+    //    recurrent kernel already left these planes behind (x_planes_ready)
+    const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
+    if (d->x_planes_ready) {
+        if (Xtm != nullptr) return fail("layer_fwd: x_planes_ready excludes a batch-major input");
+    } else {
+        if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, xs, Xtm != nullptr ? 1 : 0, Xtm)) return 1;
+        if (Xtm != nullptr) X = Xtm;
+    }
     // 2. hoisted x-part GEMM: XW = [X | planes] @ Bx + [bg|bc]
     SegPtrs segs;
-    for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * Fin : nullptr);
+    for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * xs : nullptr);
     float* XW = ws;
     if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
-                 (size_t)R * H, d->T, d->B, d->N, d->act, g_seq_probe};
+                 (size_t)(d->T + 1) * state, d->T, d->B, d->N, d->act, g_seq_probe};
     return seq_fwd(H, M, a, st);
 }
 
@@ -573,8 +586,9 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction)
-    if (cell_weight_grads(d, X, planes, Hext, RHs, dXW, P, Hplanes, RHplanes, ws + w.hplanes, ws + w.rhplanes,
-                          ws + w.partial, w, false, dWg, dWc, st)) return 1;
+    const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
+    if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
+                          ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st)) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {
         float* Z = ws + w.z;
@@ -658,21 +672,23 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
     for (int t = 0; t < d->T; ++t) {
         for (int l = 0; l < L; ++l) {
             const int Fin = l == 0 ? Dout : H;
-            const size_t Rall = (size_t)d->T * RB;
+            const size_t Rall = (size_t)d->T * RB, hstride = (size_t)(d->T + 1) * state;
             const float* X = l == 0 ? xin + (size_t)t * xstep : saved + y.hext[l - 1] + (size_t)(t + 1) * state;
-            float* planes = saved + y.planes[l] + (size_t)t * RB * Fin;     // plane m at + (m-1)*Rall*Fin
+            // input hop planes: layer 0 diffuses its input; above, the layer below has just left them behind
+            float* planes = l == 0 ? saved + y.planes[0] + (size_t)t * RB * Fin : saved + y.hpl[l - 1] + (size_t)(t + 1) * state;
+            const size_t xs = l == 0 ? Rall * Fin : hstride;
             const CellPack p = make_cell_pack(Fin, H, M);
             const float* pack = packs[l];
-            if (diffuse_fwd(X, P, d->p_batched, B, B, N, Fin, M, planes, st, Rall * Fin)) return 1;
+            if (l == 0 && diffuse_fwd(X, P, d->p_batched, B, B, N, Fin, M, planes, st, xs)) return 1;
             SegPtrs segs;
-            for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * Rall * Fin : nullptr);
+            for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * xs : nullptr);
             if (gemm_nn(segs, M, Fin, RB, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
             float* Hext = saved + y.hext[l];
             SeqFwdArgs a{XW, Hext + (size_t)t * state, P, d->p_batched, pack + p.bhg, pack + p.bhc,
                          Hext + (size_t)(t + 1) * state, saved + y.rs[l] + (size_t)t * state,
                          saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state,
                          saved + y.rhs[l] + (size_t)t * state, saved + y.hpl[l] + (size_t)t * state,
-                         saved + y.rpl[l] + (size_t)t * state, Rall * H, 1, B, N, d->act, nullptr};
+                         saved + y.rpl[l] + (size_t)t * state, hstride, 1, B, N, d->act, nullptr};
             if (seq_fwd(H, M, a, st)) return 1;
         }
         // projection (model.py:188-190): out_t = h_top W_p^T + b_p
@@ -745,9 +761,11 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
     for (int l = 0; l < L; ++l) {
         const bool first_use = l <= 1;                    // layers >= 1 share one cell (model.py:126-143)
         const float* X = l == 0 ? saved + y.xin : saved + y.hext[l - 1] + state;
-        if (cell_weight_grads(&y.ld[l], X, saved + y.planes[l], saved + y.hext[l], saved + y.rhs[l], ws + y.dxw[l], P,
-                              saved + y.hpl[l], saved + y.rpl[l], nullptr, nullptr, ws + y.partial, y.lw[l], !first_use,
-                              dWg[l], dWc[l], st)) return 1;
+        const size_t hstride = (size_t)(T + 1) * state;
+        const float* xpl = l == 0 ? saved + y.planes[0] : saved + y.hpl[l - 1] + state;
+        if (cell_weight_grads(&y.ld[l], X, xpl, l == 0 ? Rall * Dout : hstride, saved + y.hext[l], saved + y.rhs[l],
+                              ws + y.dxw[l], P, saved + y.hpl[l], saved + y.rpl[l], hstride, nullptr, nullptr,
+                              ws + y.partial, y.lw[l], !first_use, dWg[l], dWc[l], st)) return 1;
     }
     if (colsum(ws + y.dbias[0], T * B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
     if (L > 1 && colsum(ws + y.dbias[1], (L - 1) * T * B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;

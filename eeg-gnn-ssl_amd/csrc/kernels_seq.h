@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         pp.mark(5);
         // hops(h_t) of the own column tiles for the next step (their slot-0 source was just written by
         // this wave; other waves only read A2 until barrier (1) of the next step)
-        if (t + 1 < T) diffuse_own(A, Hpl, t + 1);
+        if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);   // slot T = hops(h_{T-1}): the next layer's input planes
     }
     pp.dump(probe, 0);
 }

@@ -111,6 +111,16 @@ def new_forward_scope():
     that updates parameters through an aliased flat buffer, which does not bump `_version`)."""
     _poly_memo.items.clear()
     _pack_memo.items.clear()
+    _hop_planes.clear()
+
+
+# hop planes P_m h_t that a layer's recurrent kernel left behind (slots 1..T of its Hplanes), keyed by the
+# data pointer of the hidden sequence they belong to: the next layer, fed that very tensor and the same
+# hop polynomials, takes them as its input planes instead of diffusing again.  The entry keeps the hidden
+# sequence's storage alive (no pointer reuse inside a scope); cleared by new_forward_scope().
+_hop_planes: dict = {}
+hop_plane_handovers = 0            # diagnostics: how often a layer took its input planes from the layer below
+hop_plane_handover_enabled = True  # tests switch it off to compare against the separately diffused planes
 
 
 def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: int) -> Tuple[torch.Tensor, int]:
@@ -258,11 +268,21 @@ class _DCGRULayerFn(torch.autograd.Function):
     outputs: hseq (T,B,N*H), hsel (B,N*H) = h at t = lengths-1 (or T-1 when lengths is None)."""
 
     @staticmethod
-    def forward(ctx, x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act):
+    def forward(ctx, x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act, track):
         lib = _lib.get_lib()
         t_len, b = x.shape[0], x.shape[1]
         fin = x.shape[3]
         dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
+        # input = the hidden sequence of the layer below, whose kernel already formed P_m x: take its planes
+        ready = _hop_planes.get(x.data_ptr()) if (x.is_contiguous() and hop_plane_handover_enabled) else None
+        if ready is not None and (ready["key"] != (t_len, b, n, fin, m, p.data_ptr(), p_batched)
+                                  or ready["hext"]._version != ready["version"]):
+            ready = None
+        if ready is not None:
+            global hop_plane_handovers
+            hop_plane_handovers += 1
+            dims.x_planes_ready = 1
+            dims.x_plane_stride = (t_len + 1) * b * n * fin
         # a transposed view of a contiguous batch-major (B,T,N,Fin) tensor (what model.py:253 produces) is
         # consumed as it is: the diffusion kernel emits the time-major copy as a by-product
         xsrc, xtm = None, None
@@ -277,22 +297,30 @@ class _DCGRULayerFn(torch.autograd.Function):
         if h0 is not None:
             h0 = h0.contiguous()
             _check(lib, h0, "initial_hidden_state")
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = track and any(ctx.needs_input_grad)      # track: grad mode of the caller (off inside forward)
         pack = pack_cell(wg, bg, wc, bc, fin, h, m)
         ctx.params = (wg, bg, wc, bc)
         dev = x.device
         s = t_len * b
-        planes = torch.empty((m - 1, s, n, fin), dtype=torch.float32, device=dev)
+        if ready is not None:
+            planes = ready["hpl"]                               # (M-1, T+1, B, N, Fin): slots 1..T are P_m x
+            planes_ptr = planes.data_ptr() + 4 * b * n * fin
+        else:
+            planes = torch.empty((m - 1, s, n, fin), dtype=torch.float32, device=dev)
+            planes_ptr = planes.data_ptr()
         hext = torch.empty((t_len + 1, b, n * h), dtype=torch.float32, device=dev)
         if need_grad:
             rs, us, cs, rhs = (torch.empty((t_len, b, n * h), dtype=torch.float32, device=dev) for _ in range(4))
-            hpl, rhpl = (torch.empty((m - 1, s, n, h), dtype=torch.float32, device=dev) for _ in range(2))
+            hpl, rhpl = (torch.empty((m - 1, t_len + 1, b, n, h), dtype=torch.float32, device=dev) for _ in range(2))
         else:
             rs = us = cs = rhs = hpl = rhpl = None
         ws = torch.empty(lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
         lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(xsrc if xsrc is not None else x), _p(xtm), _p(h0), _p(p),
-                 _p(pack), _p(planes), _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
+                 _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
         hseq = hext[1:]
+        if hpl is not None:
+            _hop_planes[hseq.data_ptr()] = {"key": (t_len, b, n, h, m, p.data_ptr(), p_batched), "hpl": hpl,
+                                            "hext": hext, "version": hext._version}
         if lengths is not None:
             lengths = lengths.to(device=dev, dtype=torch.int64).contiguous()
             hsel = torch.empty((b, n * h), dtype=torch.float32, device=dev)
@@ -301,7 +329,7 @@ class _DCGRULayerFn(torch.autograd.Function):
             hsel = hseq[t_len - 1].clone()
         if need_grad:
             ctx.save_for_backward(x, p, pack, planes, hext, rs, us, cs, rhs, hpl, rhpl, lengths)
-            ctx.meta = (t_len, b, n, h, fin, m, act, p_batched, h0 is not None)
+            ctx.meta = (t_len, b, n, h, fin, m, act, p_batched, h0 is not None, ready is not None)
             ctx.set_materialize_grads(False)
         return hseq, hsel
 
@@ -309,8 +337,13 @@ class _DCGRULayerFn(torch.autograd.Function):
     def backward(ctx, d_hseq, d_hsel):
         lib = _lib.get_lib()
         x, p, pack, planes, hext, rs, us, cs, rhs, hpl, rhpl, lengths = ctx.saved_tensors
-        t_len, b, n, h, fin, m, act, p_batched, has_h0 = ctx.meta
+        t_len, b, n, h, fin, m, act, p_batched, has_h0, planes_ready = ctx.meta
         dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
+        planes_ptr = planes.data_ptr()
+        if planes_ready:                                        # the layer below's Hplanes, slots 1..T
+            dims.x_planes_ready = 1
+            dims.x_plane_stride = (t_len + 1) * b * n * fin
+            planes_ptr += 4 * b * n * fin
         dev = x.device
         need_dx = ctx.needs_input_grad[0]
         need_dh0 = has_h0 and ctx.needs_input_grad[1]
@@ -329,11 +362,11 @@ class _DCGRULayerFn(torch.autograd.Function):
                               for t, sh in zip(sunk, shapes))
         ws = torch.empty(lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),
                          dtype=torch.float32, device=dev)
-        lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), _p(x), _p(p), _p(pack), _p(planes), _p(hext), _p(rs),
+        lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), _p(x), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs),
                  _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(d_hseq), _p(d_at_end), _p(d_at_len), _p(lengths), _p(dx), _p(dh0),
                  _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(x))
         ret = [None if t is not None else g for t, g in zip(sunk, (dwg, dbg, dwc, dbc))]
-        return (dx, dh0, None, *ret, None, None, None, None, None, None)
+        return (dx, dh0, None, *ret, None, None, None, None, None, None, None)
 
 
 def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None):
@@ -342,7 +375,7 @@ def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh",
     lib = _lib.get_lib()
     if not lib.query("eeg_dcrnn_supported", n, h, x.shape[3], m):
         raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
-    return _DCGRULayerFn.apply(x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act)
+    return _DCGRULayerFn.apply(x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act, torch.is_grad_enabled())
 
 
 class _DecoderFn(torch.autograd.Function):

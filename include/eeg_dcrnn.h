@@ -35,6 +35,9 @@ typedef struct eeg_layer_dims {
     int32_t T, B, N, H, Fin, M;
     int32_t act;        /* 0 = tanh, 1 = relu  (cell.py:146 `nonlinearity`) */
     int32_t p_batched;  /* 1: P holds one graph per clip (B graphs); 0: one shared graph */
+    int32_t x_planes_ready;  /* 1: `planes` already holds P_m X (the previous layer's Hplanes, slots 1..T) */
+    int32_t reserved;
+    int64_t x_plane_stride;  /* floats between two hop planes of `planes`; 0 = T*B*N*Fin (contiguous) */
 } eeg_layer_dims;
 
 typedef struct eeg_decoder_dims {
@@ -115,10 +118,11 @@ int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, in
 
 /* One DCGRU layer over a whole sequence = the `for t` loop of model.py:93-96 around
  * DCGRUCell.forward (cell.py:182-210).  h0 may be NULL (zeros).  Rs/Us/Cs/RHs may all be NULL
- * (inference: nothing saved).  Hplanes / RHplanes (each (M-1, S, N, H); both NULL or both set):
- * the hop rows P_m h_{t-1} and P_m (r*h_{t-1}) that the recurrent kernel forms in LDS anyway,
- * kept as a by-product so that the backward need not re-diffuse h and r*h for its weight-gradient
- * GEMMs.  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch.
+ * (inference: nothing saved).  Hplanes / RHplanes (each (M-1, T+1, B, N, H); both NULL or both set):
+ * the hop rows P_m h_{t-1} (slot t; slot T = P_m h_{T-1}) and P_m (r*h_{t-1}) (slots 0..T-1) that the
+ * recurrent kernel forms in LDS anyway, kept as a by-product: the backward need not re-diffuse h and
+ * r*h for its weight-gradient GEMMs, and Hplanes + B*N*H (slots 1..T) ARE the input hop planes of the
+ * next layer (pass them as its `planes` with d->x_planes_ready = 1, d->x_plane_stride = (T+1)*B*N*H).  ws: eeg_dcrnn_layer_fwd_ws_floats() floats of scratch.
  * Xtm (nullable): when given, X is BATCH-major (B,T,N,Fin) -- the trainer's `input_seq` before
  * model.py:253's transpose -- and Xtm (T,B,N,Fin) receives its time-major copy as a by-product of
  * the diffusion kernel (pass Xtm as X to eeg_dcrnn_layer_bwd); only where

@@ -358,6 +358,40 @@ def check_grad_sink(device, adj3d):
         assert torch.equal(sunk, plain), (task, (sunk - plain).abs().max().item())
 
 
+def check_plane_handover(device, adj3d):
+    """Layers >= 1 take their input hop planes from the recurrent kernel of the layer below (slots 1..T of
+    its Hplanes) instead of diffusing the hidden sequence again: same logits and gradients as with the
+    hand-over switched off, and the hand-over must actually happen (training only: inference keeps no planes)."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, ops
+    g = torch.Generator().manual_seed(5)
+    for filt in ("dual_random_walk", "laplacian"):              # shared graph / one graph per clip
+        cfg = orc.DCRNNConfig(filter_type=filt, input_dim=8, rnn_units=16, num_rnn_layers=3, num_classes=4)
+        torch.manual_seed(2)
+        model = DCRNNModel_classification(make_args(cfg), 4, device=device).to(device).train()
+        x = torch.randn(3, 5, 19, 8, generator=g).to(device)
+        lengths = torch.tensor([5, 2, 4]).to(device)
+        sup = [s.to(device) for s in cases.supports_for(filt, adj3d, 3)]
+        res = []
+        for on in (True, False):
+            ops.hop_plane_handover_enabled = on
+            try:
+                before = ops.hop_plane_handovers
+                model.zero_grad()
+                out = model(x, lengths, sup)
+                out.square().sum().backward()
+                assert ops.hop_plane_handovers - before == (2 if on else 0)
+                res.append((out.detach().clone(), [q.grad.clone() for q in model.parameters()]))
+            finally:
+                ops.hop_plane_handover_enabled = True
+        assert_close(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), f"{filt} logits", tol=1e-6)
+        for a, b_, (nm, _) in zip(res[0][1], res[1][1], model.named_parameters()):
+            assert_close_scaled(a.cpu().numpy(), b_.cpu().numpy(), f"{filt} grad {nm}", tol=1e-6)
+        with torch.no_grad():                               # inference: nothing saved, nothing handed over
+            before = ops.hop_plane_handovers
+            model(x, lengths, sup)
+            assert ops.hop_plane_handovers == before
+
+
 def check_fft_features(device, golden_fft):
     """On-device featurisation (1-s windows -> log|FFT| -> reflection / amplitude jitter -> z-score) vs the
     goldens of the genuine reference pipeline and, for the augmented variant and a ragged shape, the oracle."""

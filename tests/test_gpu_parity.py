@@ -226,5 +226,9 @@ def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink(DEV, adj3d)
 
 
+def test_hop_plane_handover_between_layers(adj3d):
+    ps.check_plane_handover(DEV, adj3d)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features(DEV, golden_fft)
