@@ -148,3 +148,12 @@ def ssl_inputs(tag, adj3d):
     y = T(cf((b, t_out, N, din), scale=1.0, freq=0.3319, phase=1.9))
     y[0, 0, 0, :3] = 0.0
     return dict(cfg=cfg, params=p, sup=sup, x=x, y=y, full=full)
+
+
+def train_inputs(adj3d):
+    """the closed-form training task of tests/golden/make_golden_train.py"""
+    from closed_form import train_task
+    cfg = orc.DCRNNConfig(filter_type="laplacian", input_dim=100, rnn_units=64, num_rnn_layers=2, num_classes=1)
+    x, y = (T(a) for a in train_task(32, 12))
+    return dict(cfg=cfg, x=x, y=y, seq=torch.full((32,), 12, dtype=torch.long), sup=lap_supports(adj3d, 32),
+                base_phase=4.1)

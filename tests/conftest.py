@@ -25,5 +25,10 @@ def adj3d():
 
 
 @pytest.fixture(scope="session")
+def golden_train():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_train_v1.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_fft():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_fft_v1.npz"))

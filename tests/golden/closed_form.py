@@ -54,3 +54,16 @@ def fft_raw_signal(n_ch=19, n_samples=800):
     x = x + 8.0 * (noise - np.floor(noise) - 0.5)
     x[5, 200:400] = 0.0
     return x
+
+
+def train_task(b=32, t=12, n=19, d=100):
+    """Closed-form synthetic detection task for the training-trajectory golden: noise-like clips (hash
+    noise, unit variance) whose first ten features carry a per-clip offset; label = 1[offset > 0]
+    (the synthetic-label rule of SURVEY.md §8d, made learnable).  Returns x (b,t,n,d) f32, y (b,) f32."""
+    i = np.arange(b * t * n * d, dtype=np.float64)
+    h = np.sin(12.9898 * i + 78.233) * 43758.5453
+    x = ((h - np.floor(h)) - 0.5) * math.sqrt(12.0)
+    x = x.reshape(b, t, n, d)
+    off = 0.1 * np.sin(2.1 * np.arange(b, dtype=np.float64) + 0.4)
+    x[:, :, :, :10] += off[:, None, None, None]
+    return x.astype(np.float32), (off > 0).astype(np.float32)

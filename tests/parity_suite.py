@@ -392,6 +392,40 @@ def check_plane_handover(device, adj3d):
             assert ops.hop_plane_handovers == before
 
 
+def check_training_trajectory(device, golden_train, adj3d, steps=None):
+    """TrainStep (HIP forward/backward + fused clip/Adam) follows the loss and gradient-norm trajectory of the
+    GENUINE reference trained with its own recipe (tests/golden/make_golden_train.py), and ends at the same
+    probabilities."""
+    from closed_form import cf_params
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    c = cases.train_inputs(adj3d)
+    n_steps, lr, wd, clip = (float(v) for v in golden_train["train/hparams"][:4])
+    n_steps = int(n_steps) if steps is None else steps
+    model = DCRNNModel_classification(make_args(c["cfg"]), 1, device=device)
+    shapes = orc.param_shapes(c["cfg"], "classification")
+    load(model, {k: torch.from_numpy(v) for k, v in cf_params(shapes, base_phase=c["base_phase"]).items()}, device)
+    model.train()
+    ts = TrainStep(model, task="detection", lr=lr, weight_decay=wd, max_grad_norm=clip)
+    x, y, seq = c["x"].to(device), c["y"].to(device), c["seq"].to(device)
+    sup = [s.to(device) for s in c["sup"]]
+    for i in range(n_steps):
+        loss = ts.step(x, y, seq, sup).item()
+        tol = 2e-5 * (1 + i)                                # rounding differences compound through Adam
+        assert abs(loss - golden_train["train/losses"][i]) <= tol, (i, loss, golden_train["train/losses"][i])
+        assert abs(ts.grad_norm.item() - golden_train["train/grad_norms"][i]) <= 10 * tol, (i, ts.grad_norm.item())
+    if n_steps == int(golden_train["train/hparams"][0]):
+        with torch.no_grad():
+            prob = torch.sigmoid(model(x, seq, sup)).view(-1).cpu().numpy()
+        assert np.abs(prob - golden_train["train/final_prob"]).max() <= 2e-3
+        from closed_form import sample_view
+        for k, v in model.state_dict().items():
+            key = f"train/final/{k}"
+            if key in golden_train:
+                got, ref = sample_view(v.cpu().numpy(), 53), golden_train[key]
+                assert np.abs(got[3:] - ref[3:]).max() <= 2e-3 * np.abs(ref[3:]).max(), k
+
+
 def check_fft_features(device, golden_fft):
     """On-device featurisation (1-s windows -> log|FFT| -> reflection / amplitude jitter -> z-score) vs the
     goldens of the genuine reference pipeline and, for the augmented variant and a ragged shape, the oracle."""

@@ -230,5 +230,9 @@ def test_hop_plane_handover_between_layers(adj3d):
     ps.check_plane_handover(DEV, adj3d)
 
 
+def test_training_trajectory_matches_reference(golden_train, adj3d):
+    ps.check_training_trajectory(DEV, golden_train, adj3d)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features(DEV, golden_fft)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import cases
-from closed_form import cf, sample_view
+from closed_form import cf, cf_params, sample_view
 from oracle import dcrnn_oracle as orc
 
 ATOL = 2e-6
@@ -132,6 +132,29 @@ def test_ssl_model(tag, golden, adj3d):
         close(pred.detach().numpy(), ref_pred)
     else:
         close_view(pred.detach().numpy(), ref_pred, step=7)
+
+
+def test_training_trajectory_matches_reference(golden_train, adj3d):
+    """20 optimiser steps of the reference recipe (Adam + L2, clip_grad_norm_, BCE) on the closed-form
+    task: the oracle follows the genuine reference's loss / gradient-norm trajectory."""
+    c = cases.train_inputs(adj3d)
+    steps, lr, wd, clip = (float(v) for v in golden_train["train/hparams"][:4])
+    shapes = orc.param_shapes(c["cfg"], "classification")
+    p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in cf_params(shapes, base_phase=c["base_phase"]).items()}
+    opt = torch.optim.Adam(list(p.values()), lr=lr, weight_decay=wd)
+    for i in range(int(steps)):
+        opt.zero_grad()
+        logits = orc.classification_forward(p, c["cfg"], c["x"], c["seq"], c["sup"])
+        loss = orc.bce_with_logits(logits, c["y"])
+        loss.backward()
+        norm = float(torch.nn.utils.clip_grad_norm_(list(p.values()), clip))
+        opt.step()
+        tol = 2e-5 * (1 + i)                              # rounding differences compound through Adam
+        assert abs(loss.item() - golden_train["train/losses"][i]) <= tol, (i, loss.item())
+        assert abs(norm - golden_train["train/grad_norms"][i]) <= 10 * tol, (i, norm)
+    with torch.no_grad():
+        prob = torch.sigmoid(orc.classification_forward(p, c["cfg"], c["x"], c["seq"], c["sup"])).view(-1).numpy()
+    assert np.abs(prob - golden_train["train/final_prob"]).max() <= 2e-3
 
 
 def test_q1_carried_x0_is_not_textbook(adj3d):
