@@ -157,3 +157,23 @@ def train_inputs(adj3d):
     x, y = (T(a) for a in train_task(32, 12))
     return dict(cfg=cfg, x=x, y=y, seq=torch.full((32,), 12, dtype=torch.long), sup=lap_supports(adj3d, 32),
                 base_phase=4.1)
+
+
+def ssl_train_inputs(golden_train):
+    """the closed-form SSL training task of tests/golden/make_golden_train.py (shared decoder cell, 3 layers)"""
+    steps, lr, wd, clip, b, t_in, t_out, mean, std = (float(v) for v in golden_train["ssl_train/hparams"])
+    b, t_in, t_out = int(b), int(t_in), int(t_out)
+    cfg = orc.DCRNNConfig(filter_type="dual_random_walk", input_dim=20, output_dim=20, rnn_units=32, num_rnn_layers=3)
+    raw = cf_params(orc.param_shapes(cfg, "ssl"), base_phase=5.3)
+    p = {}
+    for k, v in raw.items():                              # Q6: decoding_cells.2 IS decoding_cells.1
+        src = k.replace("decoding_cells.2.", "decoding_cells.1.")
+        p[k] = p[src] if (src != k and src in p) else T(raw[src])
+    for k in list(p):
+        if "decoding_cells.2." in k:
+            p[k] = p[k.replace("decoding_cells.2.", "decoding_cells.1.")]
+    x = T(cf((b, t_in, N, 20), scale=1.0, freq=0.4177, phase=0.9))
+    y = T(cf((b, t_out, N, 20), scale=1.0, freq=0.3319, phase=1.9))
+    y[0, 0, 0, :3] = -mean / std
+    return dict(cfg=cfg, params=p, x=x, y=y, sup=dual_supports(b), steps=int(steps), lr=lr, wd=wd, clip=clip,
+                mean=mean, std=std)

@@ -426,6 +426,32 @@ def check_training_trajectory(device, golden_train, adj3d, steps=None):
                 assert np.abs(got[3:] - ref[3:]).max() <= 2e-3 * np.abs(ref[3:]).max(), k
 
 
+def check_ssl_training_trajectory(device, golden_train, steps=None):
+    """TrainStep(task="ssl") (native decoder operator, masked-RMSE kernel, fused clip/Adam) follows the
+    genuine reference's SSL training trajectory (train_ssl.py recipe, shared decoder cell)."""
+    from closed_form import sample_view
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    c = cases.ssl_train_inputs(golden_train)
+    model = DCRNNModel_nextTimePred(make_args(c["cfg"]), device=device)
+    load(model, c["params"], device)
+    model.train()
+    ts = TrainStep(model, task="ssl", lr=c["lr"], weight_decay=c["wd"], max_grad_norm=c["clip"],
+                   scaler_mean=c["mean"], scaler_std=c["std"])
+    x, y = c["x"].to(device), c["y"].to(device)
+    sup = [s.to(device) for s in c["sup"]]
+    n_steps = c["steps"] if steps is None else steps
+    for i in range(n_steps):
+        loss = ts.step(x, y, None, sup).item()
+        tol = 2e-5 * (1 + i)
+        assert abs(loss - golden_train["ssl_train/losses"][i]) <= tol, (i, loss, golden_train["ssl_train/losses"][i])
+        assert abs(ts.grad_norm.item() - golden_train["ssl_train/grad_norms"][i]) <= 10 * tol, (i, ts.grad_norm.item())
+    if n_steps == c["steps"]:
+        with torch.no_grad():
+            pred = model(x, y, sup).cpu().numpy()
+        assert np.abs(sample_view(pred, 31)[3:] - golden_train["ssl_train/final_pred"][3:]).max() <= 2e-3
+
+
 def check_fft_features(device, golden_fft):
     """On-device featurisation (1-s windows -> log|FFT| -> reflection / amplitude jitter -> z-score) vs the
     goldens of the genuine reference pipeline and, for the augmented variant and a ragged shape, the oracle."""

@@ -234,5 +234,9 @@ def test_training_trajectory_matches_reference(golden_train, adj3d):
     ps.check_training_trajectory(DEV, golden_train, adj3d)
 
 
+def test_ssl_training_trajectory_matches_reference(golden_train):
+    ps.check_ssl_training_trajectory(DEV, golden_train)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features(DEV, golden_fft)

@@ -157,6 +157,33 @@ def test_training_trajectory_matches_reference(golden_train, adj3d):
     assert np.abs(prob - golden_train["train/final_prob"]).max() <= 2e-3
 
 
+def test_ssl_training_trajectory_matches_reference(golden_train):
+    """12 steps of train_ssl.py's recipe on the 3-layer SSL model (shared decoder cell): loss and gradient
+    norm per step, final predictions."""
+    c = cases.ssl_train_inputs(golden_train)
+    uniq, p = {}, {}
+    for k, v in c["params"].items():
+        if id(v) not in uniq:
+            uniq[id(v)] = v.clone().requires_grad_(True)
+        p[k] = uniq[id(v)]
+    leaves = list(uniq.values())
+    opt = torch.optim.Adam(leaves, lr=c["lr"], weight_decay=c["wd"])
+    for i in range(c["steps"]):
+        opt.zero_grad()
+        pred = orc.next_time_pred_forward(p, c["cfg"], c["x"], c["y"], c["sup"])
+        loss = orc.regression_loss(c["y"], pred, c["mean"], c["std"], loss_fn="MAE")
+        loss.backward()
+        norm = float(torch.nn.utils.clip_grad_norm_(leaves, c["clip"]))
+        opt.step()
+        tol = 2e-5 * (1 + i)
+        assert abs(loss.item() - golden_train["ssl_train/losses"][i]) <= tol, (i, loss.item())
+        assert abs(norm - golden_train["ssl_train/grad_norms"][i]) <= 10 * tol, (i, norm)
+    with torch.no_grad():
+        pred = orc.next_time_pred_forward(p, c["cfg"], c["x"], c["y"], c["sup"]).numpy()
+    ref = golden_train["ssl_train/final_pred"]
+    assert np.abs(sample_view(pred, 31)[3:] - ref[3:]).max() <= 2e-3
+
+
 def test_q1_carried_x0_is_not_textbook(adj3d):
     """the hop list with two supports is [X, S1X, (2S1^2-I)X, S2S1X, (2S2^2-I)S1X]."""
     sup = cases.dual_supports(2)
