@@ -94,6 +94,12 @@ int check_dims(int N, int H, int Fin, int M) {
     if (!h_supported(H)) return fail("rnn_units=%d unsupported (16, 32 or 64)", H);
     if (Fin < 4 || Fin % 4 != 0) return fail("per-node input dim=%d unsupported (must be a positive multiple of 4)", Fin);
     if (!m_supported(M)) return fail("num hop matrices M=%d unsupported (2,3,4,5,7)", M);
+    // LDS of the BPTT kernel (SeqGeom::bwd_lds_floats): the widest case (H=64, M=7) only fits montages of <= 20 nodes
+    const int ka = M * H, rows = N <= 20 ? 20 : 32, ct = ceil_div(H / 16, 4);
+    const size_t bwd = ((size_t)(M - 1) * kPFloats + (size_t)rows * (lds_stride_q(ka) + lds_stride_q(2 * ka)) + 4 * 2 * ct * 256) * sizeof(float);
+    if (bwd > kMaxLdsBytes)
+        return fail("rnn_units=%d with %d hop matrices and %d nodes needs %zu KB of LDS for the backward pass (160 available)",
+                    H, M, N, bwd / 1024);
     return 0;
 }
 
@@ -261,12 +267,14 @@ int seq_fwd(int H, int M, const SeqFwdArgs& a, hipStream_t st) {
     int rc = H == 16 ? launch_seq_fwd_h16(M, a, st) : H == 32 ? launch_seq_fwd_h32(M, a, st) : launch_seq_fwd_h64(M, a, st);
     if (rc == 1) return fail("seq_fwd: no kernel for H=%d M=%d", H, M);
     if (rc == 2) return fail("seq_fwd: kernel launch failed (H=%d M=%d)", H, M);
+    if (rc == 3) return fail("seq_fwd: H=%d M=%d N=%d exceeds the LDS of a CU", H, M, a.N);
     return 0;
 }
 int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
     int rc = H == 16 ? launch_seq_bwd_h16(M, a, st) : H == 32 ? launch_seq_bwd_h32(M, a, st) : launch_seq_bwd_h64(M, a, st);
     if (rc == 1) return fail("seq_bwd: no kernel for H=%d M=%d", H, M);
     if (rc == 2) return fail("seq_bwd: kernel launch failed (H=%d M=%d)", H, M);
+    if (rc == 3) return fail("seq_bwd: H=%d M=%d N=%d exceeds the LDS of a CU", H, M, a.N);
     return 0;
 }
 

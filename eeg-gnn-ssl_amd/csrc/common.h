@@ -64,6 +64,7 @@ namespace eeg {
 
 constexpr int kWave = 64;
 constexpr int kMaxNodes = 32;   // node rows are padded to two 16-row MFMA tiles
+constexpr size_t kMaxLdsBytes = 160 * 1024;   // LDS of one gfx950 CU
 constexpr int kMaxM = 8;        // hop matrices incl. identity (K<=3 with two supports -> 7)
 
 __host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }

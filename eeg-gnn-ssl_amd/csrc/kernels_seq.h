@@ -40,7 +40,11 @@ struct SeqGeom {
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
     static constexpr int kRemScratch = 4 * 2 * CT * 256;                         // 4 waves x up to 2*CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
     static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + kRemScratch; }
-    static constexpr size_t bwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 32 * KAP + 32 * KGP + kRemScratch; }
+    // Node rows of the backward kernel's LDS tiles: 32 (two MFMA node tiles), or -- where 32 rows exceed the
+    // 160 KB of a CU (H=64, M=7) and the montage has at most 20 nodes, so that the second tile runs on the
+    // 4x4x1 MFMA and only rows 16..19 are ever read -- 20.
+    static constexpr size_t bwd_lds_floats(int rows) { return (size_t)(M - 1) * kPFloats + (size_t)rows * (KAP + KGP) + kRemScratch; }
+    static constexpr int bwd_rows(int nks) { return (nks == 5 && bwd_lds_floats(32) * sizeof(float) > kMaxLdsBytes) ? 20 : 32; }
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) {
@@ -341,11 +345,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     pp.start();
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
-    float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC
-    float* EG = EC + 32 * KAP;              // [32][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
+    constexpr int ROWS = G::bwd_rows(NKS);
+    float* EC = Pl + (M - 1) * kPFloats;    // [ROWS][KAP]  slot 0 = dC, slots m = P_m^T dC
+    float* EG = EC + ROWS * KAP;            // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
     constexpr bool REM4 = NKS == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = EG + 32 * KGP + wave * (2 * CT * 256);
+    float* RS = EG + ROWS * KGP + wave * (2 * CT * 256);
     const int b = blockIdx.x;
 
     // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
         for (int ks = 0; ks < KSG; ++ks) w2[i][ks] = b2p[((size_t)ks * NCT + ct) * 64 + lane];
     }
-    for (int e = tid; e < 32 * KAP + 32 * KGP; e += 256) EC[e] = 0.f;
+    for (int e = tid; e < ROWS * (KAP + KGP); e += 256) EC[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
     __syncthreads();
@@ -441,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
                     du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
                 }
-                if (own[i]) st4(EC + node[nt] * KAP + col, dC);              // zeros on padding nodes
+                if (own[i] && (ROWS == 32 || node[nt] < ROWS)) st4(EC + node[nt] * KAP + col, dC);   // zeros on padding nodes
                 if (ok) {
                     st4(dxw + oxw[i][nt] + 2 * H, dC);
                     st4(dxw + oxw[i][nt] + H, du_);
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         EEG_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < CT; ++i)
-            if (own[i]) lds_diffuse_tile<M, NKS>(EC, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
+            if (own[i]) lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
         __syncthreads();                                            // (1) P_m^T dC complete
         pp.mark(1);
 
@@ -478,8 +483,10 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     const f32x4 drh = acc[i][nt], rg = rr[i][nt];    // exact 0 on padding nodes
                     const f32x4 dR = drh * hp[i][nt] * rg * (1.f - rg);
                     dhn[i][nt] += drh * rg;
-                    st4(EG + node[nt] * KGP + col, dR);
-                    st4(EG + node[nt] * KGP + H + col, dU[i][nt]);
+                    if (ROWS == 32 || node[nt] < ROWS) {
+                        st4(EG + node[nt] * KGP + col, dR);
+                        st4(EG + node[nt] * KGP + H + col, dU[i][nt]);
+                    }
                     if (valid[nt]) st4(dxw + oxw[i][nt], dR);
                     sb_r[i] += dR;
                 }
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < CT; ++i)
             if (own[i]) {
-                lds_diffuse_tile<M, NKS>(EG, KGP, (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
-                lds_diffuse_tile<M, NKS>(EG, KGP, H + (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
+                lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
+                lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
             }
         __syncthreads();                                            // (2) P_m^T [dR|dU] complete
         pp.mark(4);

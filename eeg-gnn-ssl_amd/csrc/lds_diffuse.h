@@ -95,7 +95,8 @@ __device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[(M 
 // workgroup barrier) is needed before the call.
 // gout != nullptr: the hop rows are also stored to global planes (forward by-product kept for the
 // weight-gradient GEMMs): plane m at gout + (m-1)*gplane, element (node, col) at node*slot_w + col.
-template <int M, int NKS>
+// ROWS < 32: the LDS tile holds only ROWS node rows (ROWS >= 4*NKS); result rows beyond are dropped.
+template <int M, int NKS, int ROWS = 32>
 __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src_col, int slot_w,
                                                  const float (&pf)[(M - 1) * 2][NKS], int lr, int lg,
                                                  float* __restrict__ gout = nullptr, size_t gplane = 0, int n_nodes = 0) {
@@ -112,9 +113,9 @@ __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src
         for (int c = 0; c < NC; ++c) acc[c] = mfma16(b[ks], pf[c][ks], acc[c]);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        float* d = buf + ((c & 1) * 16 + lr) * stride + ((c >> 1) + 1) * slot_w + src_col + 4 * lg;
-        *reinterpret_cast<float4*>(d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
         const int node = (c & 1) * 16 + lr;
+        float* d = buf + node * stride + ((c >> 1) + 1) * slot_w + src_col + 4 * lg;
+        if (ROWS == 32 || node < ROWS) *reinterpret_cast<float4*>(d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
         if (gout != nullptr && node < n_nodes)
             *reinterpret_cast<float4*>(gout + (size_t)(c >> 1) * gplane + node * slot_w + src_col + 4 * lg) =
                 make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);

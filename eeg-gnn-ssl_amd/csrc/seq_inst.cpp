@@ -16,6 +16,7 @@ namespace {
 template <int H, int M, int NKS>
 int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
+    if (lds > kMaxLdsBytes) return 3;
     if constexpr (H == 64 && M == 3 && NKS == 5) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS, true>), lds);
@@ -35,7 +36,8 @@ int fwd_one(const SeqFwdArgs& a, hipStream_t st) {
 }
 template <int H, int M, int NKS>
 int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
-    const size_t lds = SeqGeom<H, M>::bwd_lds_floats() * sizeof(float);
+    const size_t lds = SeqGeom<H, M>::bwd_lds_floats(SeqGeom<H, M>::bwd_rows(NKS)) * sizeof(float);
+    if (lds > kMaxLdsBytes) return 3;
     if constexpr (H == 64 && M == 3 && NKS == 5) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS, true>), lds);

@@ -31,6 +31,8 @@ def dual_supports(b, phase0=0.3):
 
 
 def supports_for(filt, adj3d, b, batched=True):
+    if filt == "random_walk":
+        return [dual_supports(b)[0]]
     return dual_supports(b) if filt == "dual_random_walk" else lap_supports(adj3d, b, batched)
 
 
@@ -64,21 +66,34 @@ CELL_CASES = {
 }
 
 
-def cell_shapes(filt, din, h):
-    m = 5 if filt == "dual_random_walk" else 3
+# other diffusion orders / filter types (tests/golden/make_golden_k.py): (filter, din, h, b, act, K)
+CELL_K_CASES = {
+    "lap_k1": ("laplacian", 8, 16, 3, "tanh", 1),
+    "lap_k3": ("laplacian", 8, 16, 3, "tanh", 3),
+    "dual_k1": ("dual_random_walk", 8, 16, 3, "tanh", 1),
+    "dual_k3": ("dual_random_walk", 8, 16, 3, "relu", 3),
+    "rw_k2": ("random_walk", 12, 32, 2, "tanh", 2),
+}
+
+
+def cell_shapes(filt, din, h, k=2):
+    m = (2 if filt == "dual_random_walk" else 1) * k + 1
     rows = (din + h) * m
     return {"dconv_gate.weight": (rows, 2 * h), "dconv_gate.biases": (2 * h,),
             "dconv_candidate.weight": (rows, h), "dconv_candidate.biases": (h,)}
 
 
 def cell_inputs(tag, adj3d):
-    filt, din, h, b, act, full = CELL_CASES[tag]
-    p = {k: T(v) for k, v in cf_params(cell_shapes(filt, din, h), base_phase=1.1).items()}
+    if tag in CELL_K_CASES:
+        (filt, din, h, b, act, kk), full = CELL_K_CASES[tag], True
+    else:
+        (filt, din, h, b, act, full), kk = CELL_CASES[tag], 2
+    p = {k: T(v) for k, v in cf_params(cell_shapes(filt, din, h, kk), base_phase=1.1).items()}
     sup = supports_for(filt, adj3d, b)
     x = T(cf((b, N * din), scale=1.0, freq=0.371, phase=0.1))
     s = T(cf((b, N * h), scale=0.8, freq=0.533, phase=0.7))
     wout = T(cf((b, N * h), scale=1.0, freq=0.291, phase=0.4))
-    return dict(filt=filt, din=din, h=h, b=b, act=act, full=full, params=p, sup=sup, x=x, s=s, wout=wout)
+    return dict(filt=filt, din=din, h=h, b=b, act=act, full=full, params=p, sup=sup, x=x, s=s, wout=wout, k=kk)
 
 
 CLS_CASES = {

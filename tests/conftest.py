@@ -16,7 +16,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def golden():
-    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    out = {}
+    for name in ("golden_v1.npz", "golden_k_v1.npz"):     # model / cell goldens + other diffusion orders
+        with np.load(os.path.join(ROOT, "tests", "golden", name)) as z:
+            out.update({k: z[k] for k in z.files})
+    return out
 
 
 @pytest.fixture(scope="session")

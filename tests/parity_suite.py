@@ -68,7 +68,7 @@ def load(module, params, device):
 def check_cell_case(tag, golden, adj3d, device):
     from eeg_gnn_ssl_amd import DCGRUCell
     c = cases.cell_inputs(tag, adj3d)
-    cell = DCGRUCell(c["din"], c["h"], 2, 19, filter_type=c["filt"], nonlinearity=c["act"])
+    cell = DCGRUCell(c["din"], c["h"], c["k"], 19, filter_type=c["filt"], nonlinearity=c["act"])
     load(cell, c["params"], device)
     x = c["x"].to(device).requires_grad_(True)
     s = c["s"].to(device).requires_grad_(True)
@@ -163,12 +163,12 @@ def check_dconv_case(tag, golden, adj3d, device):
     assert_close(out.cpu().numpy(), golden[f"dconv/{tag}/out"], f"dconv/{tag}/out")
 
 
-def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3d, seed=0, lengths=None, act="tanh"):
+def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3d, seed=0, lengths=None, act="tanh", k=2):
     """Random-input model-level parity vs the oracle (logits + all parameter gradients)."""
     from eeg_gnn_ssl_amd import DCRNNModel_classification
     g = torch.Generator().manual_seed(seed)
     cfg = orc.DCRNNConfig(filter_type=filt, input_dim=din, rnn_units=h, num_rnn_layers=layers, num_classes=classes,
-                          dcgru_activation=act)
+                          dcgru_activation=act, max_diffusion_step=k)
     params = orc.init_params(cfg, "classification", seed=seed)
     for k in params:
         if k.endswith("biases"):

@@ -16,7 +16,7 @@ def emulator():
     emu_support.uninstall()
 
 
-@pytest.mark.parametrize("tag", list(cases.CELL_CASES))
+@pytest.mark.parametrize("tag", list(cases.CELL_CASES) + list(cases.CELL_K_CASES))
 def test_cell(tag, golden, adj3d):
     ps.check_cell_case(tag, golden, adj3d, "cpu")
 
@@ -38,6 +38,12 @@ def test_ssl_model(tag, golden, adj3d):
 
 def test_random_vs_oracle_h32_relu_varlen(adj3d):
     ps.check_vs_oracle_random("cpu", "dual_random_walk", 12, 32, 2, 4, 3, 4, adj3d, seed=3, lengths=[4, 2, 1], act="relu")
+
+
+def test_widest_cell_uses_the_20_row_backward_layout(adj3d):
+    """rnn_units=64 with 7 hop matrices (dual random walk, K=3): the BPTT kernel's LDS tiles only fit with 20
+    node rows (SeqGeom::bwd_rows); logits and all gradients vs the oracle."""
+    ps.check_vs_oracle_random("cpu", "dual_random_walk", 8, 64, 2, 3, 2, 1, adj3d, seed=5, k=3)
 
 
 def test_training_tail_kernels():

@@ -24,7 +24,7 @@ def hip_library():
     yield lib
 
 
-@pytest.mark.parametrize("tag", list(cases.CELL_CASES))
+@pytest.mark.parametrize("tag", list(cases.CELL_CASES) + list(cases.CELL_K_CASES))
 def test_cell(tag, golden, adj3d):
     ps.check_cell_case(tag, golden, adj3d, DEV)
 
@@ -49,9 +49,23 @@ def test_ssl_model(tag, golden, adj3d):
     ("dual_random_walk", 100, 64, 2, 7, 5, 4, [7, 3, 1, 6, 2], "tanh"),
     ("dual_random_walk", 12, 32, 3, 5, 3, 4, [5, 2, 4], "relu"),
     ("laplacian", 20, 16, 1, 9, 6, 1, None, "tanh"),
+    ("laplacian", 8, 16, 1, 1, 1, 1, None, "tanh"),                     # a single step of a single clip
 ])
 def test_random_vs_oracle(filt, din, h, layers, t_len, b, classes, lengths, act, adj3d):
     ps.check_vs_oracle_random(DEV, filt, din, h, layers, t_len, b, classes, adj3d, seed=11, lengths=lengths, act=act)
+
+
+@pytest.mark.parametrize("filt,k,din,h,layers,t_len,b,classes,lengths", [
+    ("laplacian", 1, 100, 64, 2, 6, 3, 1, None),                        # M = 2
+    ("laplacian", 3, 100, 64, 2, 5, 3, 4, [5, 1, 3]),                   # M = 4
+    ("dual_random_walk", 1, 100, 64, 2, 6, 2, 1, None),                 # M = 3 with two supports
+    ("dual_random_walk", 3, 100, 64, 2, 5, 3, 1, None),                 # M = 7: the widest register-resident weights
+    ("random_walk", 2, 20, 32, 3, 4, 3, 4, [4, 2, 3]),
+])
+def test_other_diffusion_orders_vs_oracle(filt, k, din, h, layers, t_len, b, classes, lengths, adj3d):
+    """max_diffusion_step 1 and 3 and filter_type random_walk at the default width (the oracle is pinned for
+    these against the genuine reference at cell level: tests/golden/golden_k_v1.npz)."""
+    ps.check_vs_oracle_random(DEV, filt, din, h, layers, t_len, b, classes, adj3d, seed=4, lengths=lengths, k=k)
 
 
 def _full_size_model(filt, classes):

@@ -55,14 +55,14 @@ def test_diffusion_conv(tag, golden, adj3d):
     close(out.numpy(), golden[f"dconv/{tag}/out"])
 
 
-@pytest.mark.parametrize("tag", list(cases.CELL_CASES))
+@pytest.mark.parametrize("tag", list(cases.CELL_CASES) + list(cases.CELL_K_CASES))
 def test_cell_forward_backward(tag, golden, adj3d):
     c = cases.cell_inputs(tag, adj3d)
     p = {k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
     x = c["x"].clone().requires_grad_(True)
     s = c["s"].clone().requires_grad_(True)
     out = orc.dcgru_cell(c["sup"], x, s, p["dconv_gate.weight"], p["dconv_gate.biases"],
-                         p["dconv_candidate.weight"], p["dconv_candidate.biases"], 19, c["h"], 2, c["act"])
+                         p["dconv_candidate.weight"], p["dconv_candidate.biases"], 19, c["h"], c["k"], c["act"])
     (out * c["wout"]).sum().backward()
     close(out.detach().numpy(), golden[f"cell/{tag}/out"])
     grads = {"dx": x.grad, "dh": s.grad}
