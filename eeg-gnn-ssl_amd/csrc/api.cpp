@@ -223,10 +223,13 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
         EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, X, P, p_batched, S, B, F, M, planes, plane_stride, x_bt, xcopy);
         return check_launch("diffuse_fwd");
     }
-    const int FP = round_up(F, 16), FS = lds_stride(M * FP), NR = round_up(N, 4);
-    const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * FS) * sizeof(float);
-    if (lds > 160 * 1024) return fail("diffuse_fwd: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
-    if (N * (F / 4) > 256 * kDiffPrefetch) return fail("diffuse_fwd: N*F=%d exceeds %d floats per sample", N * F, 1024 * kDiffPrefetch);
+    // LDS kernel: rows wider than one tile (LDS budget / prefetch registers) go in column chunks, one launch each
+    const int NR = round_up(N, 4);
+    int Fc = F;
+    auto lds_of = [&](int fc) { return ((size_t)(M - 1) * kPFloats + (size_t)NR * lds_stride(M * round_up(fc, 16))) * sizeof(float); };
+    while (Fc > 16 && (lds_of(Fc) > 96 * 1024 || N * (Fc / 4) > 256 * kDiffPrefetch)) Fc = round_up(ceil_div(Fc, 2), 16);
+    const size_t lds = lds_of(Fc);
+    if (lds > kMaxLdsBytes || N * (Fc / 4) > 256 * kDiffPrefetch) return fail("diffuse_fwd: N=%d M=%d does not fit the LDS tile", N, M);
     EEG_SET_MAX_LDS(diffuse_fwd_kernel, lds);
     dim3 grid;
     if (p_batched) {
@@ -237,8 +240,12 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
     } else {
         grid = dim3(S < 2048 ? S : 2048, 1);
     }
-    EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, grid, dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes, plane_stride);
-    return check_launch("diffuse_fwd");
+    for (int c0 = 0; c0 < F; c0 += Fc) {
+        EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_kernel, grid, dim3(256), lds, st, X, P, p_batched, S, B, N, F, M, planes, plane_stride,
+                     c0, F - c0 < Fc ? F - c0 : Fc);
+        if (check_launch("diffuse_fwd")) return 1;
+    }
+    return 0;
 }
 int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M, float* dX,
                 hipStream_t st, const float* add = nullptr) {
@@ -254,13 +261,20 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
         EEG_LAUNCH_P("diffuse_adj", diffuse_adj_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, M, add, dX);
         return check_launch("diffuse_adj");
     }
-    const int FP = round_up(F, 16), ZS = lds_stride(M * FP), NR = round_up(N, 4);
-    const size_t lds = ((size_t)(M - 1) * kPFloats + (size_t)NR * ZS) * sizeof(float);
-    if (lds > 160 * 1024) return fail("diffuse_adj: F=%d M=%d needs %zu B of LDS (> 160 KiB)", F, M, lds);
+    const int NR = round_up(N, 4);
+    int Fc = F;
+    auto lds_of = [&](int fc) { return ((size_t)(M - 1) * kPFloats + (size_t)NR * lds_stride(M * round_up(fc, 16))) * sizeof(float); };
+    while (Fc > 16 && lds_of(Fc) > 96 * 1024) Fc = round_up(ceil_div(Fc, 2), 16);
+    const size_t lds = lds_of(Fc);
+    if (lds > kMaxLdsBytes) return fail("diffuse_adj: N=%d M=%d does not fit the LDS tile", N, M);
     EEG_SET_MAX_LDS(diffuse_adj_kernel, lds);
     const int grid = S < 2048 ? S : 2048;
-    EEG_LAUNCH_P("diffuse_adj", diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, add, dX);
-    return check_launch("diffuse_adj");
+    for (int c0 = 0; c0 < F; c0 += Fc) {
+        EEG_LAUNCH_P("diffuse_adj", diffuse_adj_kernel, dim3(grid), dim3(256), lds, st, Z, P, p_batched, S, B, N, F, M, add, dX,
+                     c0, F - c0 < Fc ? F - c0 : Fc);
+        if (check_launch("diffuse_adj")) return 1;
+    }
+    return 0;
 }
 
 int seq_fwd(int H, int M, const SeqFwdArgs& a, hipStream_t st) {

@@ -23,15 +23,16 @@ namespace eeg {
 // slot 0 = X, slots 1..M-1 = results (staged so the global stores are full coalesced rows).
 constexpr int kDiffPrefetch = 4;        // float4 per thread per sample: covers N*F <= 4096 floats
 
+// Wide rows are processed in column chunks: this launch covers columns [c0, c0+Fc) of the F-wide rows.
 __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restrict__ X, const float* __restrict__ P,
                                                           int p_batched, int S, int B, int N, int F, int M,
-                                                          float* __restrict__ planes, size_t plane_stride) {
+                                                          float* __restrict__ planes, size_t plane_stride, int c0, int Fc) {
     EEG_DYN_SMEM(sm);
-    const int FP = round_up(F, 16), FS = lds_stride(M * FP);
+    const int FP = round_up(Fc, 16), FS = lds_stride(M * FP);
     float* Pl = sm;
     float* tile = sm + (M - 1) * kPFloats;
     const int tid = threadIdx.x, NR = round_up(N, 4);
-    const int nf4 = F / 4, nq = N * nf4;            // F % 4 == 0, nq <= 1024 (checked by the host)
+    const int nf4 = Fc / 4, nq = N * nf4;           // Fc % 4 == 0, nq <= 1024 (the host sizes the chunk)
     // sample walk: per-clip graphs -> s = t*B + g for t = tg, tg+TG, ...; shared graph -> s = wg, wg+nwg, ...
     int s_first, s_step, g;
     if (p_batched) {
@@ -48,11 +49,12 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
 
     float4 pre[kDiffPrefetch];
     auto fetch = [&](int s) {
-        const float4* src = reinterpret_cast<const float4*>(X + (size_t)s * N * F);
+        const float* src = X + (size_t)s * N * F + c0;
 #pragma unroll
         for (int i = 0; i < kDiffPrefetch; ++i) {
             const int q = tid + 256 * i;
-            pre[i] = (s < S && q < nq) ? src[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre[i] = (s < S && q < nq) ? *reinterpret_cast<const float4*>(src + (size_t)(q / nf4) * F + 4 * (q % nf4))
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     fetch(s_first);
@@ -71,10 +73,10 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
         lds_diffuse_tiles<false>(tile, FS, 0, FP, FP, FP, Pl, M, N, NR);
         __syncthreads();
         for (int m1 = 0; m1 < M - 1; ++m1) {
-            float4* dst = reinterpret_cast<float4*>(planes + (size_t)m1 * plane_stride + (size_t)s * N * F);
+            float* dst = planes + (size_t)m1 * plane_stride + (size_t)s * N * F + c0;
             for (int q = tid; q < nq; q += 256) {
                 const float* t = tile + (q / nf4) * FS + FP * (m1 + 1) + 4 * (q % nf4);
-                dst[q] = make_float4(t[0], t[1], t[2], t[3]);
+                *reinterpret_cast<float4*>(dst + (size_t)(q / nf4) * F + 4 * (q % nf4)) = make_float4(t[0], t[1], t[2], t[3]);
             }
         }
     }
@@ -213,25 +215,26 @@ __global__ __launch_bounds__(256, 3) void diffuse_adj_stream_kernel(const float*
 
 // ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m [+ add] -----------
 // LDS tile [NR][ZS], NR = round_up(N,4), ZS = lds_stride(M*FP): slot m holds Z_m (cols padded to FP).
+// Column chunk [c0, c0+Fc) of every F-wide slot per launch (wide rows).
 __global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restrict__ Z, const float* __restrict__ P,
                                                           int p_batched, int S, int B, int N, int F, int M,
-                                                          const float* __restrict__ add, float* __restrict__ dX) {
+                                                          const float* __restrict__ add, float* __restrict__ dX, int c0, int Fc) {
     EEG_DYN_SMEM(sm);
-    const int FP = round_up(F, 16), ZS = lds_stride(M * FP);
+    const int FP = round_up(Fc, 16), ZS = lds_stride(M * FP);
     float* Pl = sm;
     float* tile = sm + (M - 1) * kPFloats;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int lr = lane & 15, lg = lane >> 4, NR = round_up(N, 4);
     for (int e = tid; e < NR * ZS; e += blockDim.x) tile[e] = 0.f;
     if (!p_batched) lds_load_polys(Pl, P, 0, M, N);
-    const int nf4 = F / 4, nct = FP / 16, nks = ceil_div(N, 4);
+    const int nf4 = Fc / 4, nct = FP / 16, nks = ceil_div(N, 4);
     for (int s = blockIdx.x; s < S; s += gridDim.x) {
         __syncthreads();
         if (p_batched) lds_load_polys(Pl, P, s % B, M, N);
-        const float4* src = reinterpret_cast<const float4*>(Z + (size_t)s * N * M * F);
+        const float* src = Z + (size_t)s * N * M * F + c0;
         for (int q = tid; q < N * M * nf4; q += blockDim.x) {
             const int n = q / (M * nf4), rem = q % (M * nf4), m = rem / nf4, c4 = rem % nf4;
-            const float4 v = src[q];
+            const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)n * M + m) * F + 4 * c4);
             float* d = tile + n * ZS + m * FP + 4 * c4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -256,8 +259,8 @@ __global__ __launch_bounds__(256) void diffuse_adj_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = rt * 16 + 4 * lg + r;
-                if (n < N && col < F) {
-                    const size_t o = ((size_t)s * N + n) * F + col;
+                if (n < N && col < Fc) {
+                    const size_t o = ((size_t)s * N + n) * F + c0 + col;
                     dX[o] = add != nullptr ? acc[r] + add[o] : acc[r];
                 }
             }

@@ -191,6 +191,41 @@ def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3
         assert_close_scaled(p.grad.cpu().numpy(), po[k].grad.numpy(), f"d_{k} vs oracle", tol=5e-5)
 
 
+def check_shape_sweep(device, n, h, filt, k, din=8, layers=2, t_len=3, b=2, classes=4, seed=0):
+    """Model-level parity vs the oracle away from the 19-electrode defaults: other node counts (second MFMA
+    node tile empty / partial / full), hidden sizes and hop counts.  Random graph of n nodes."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    g = torch.Generator().manual_seed(seed + 17 * n + h + k)
+    cfg = orc.DCRNNConfig(num_nodes=n, filter_type=filt, input_dim=din, rnn_units=h, num_rnn_layers=layers,
+                          num_classes=classes, max_diffusion_step=k)
+    params = orc.init_params(cfg, "classification", seed=seed)
+    for name in params:
+        if name.endswith("biases"):
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+    sups = []
+    for i in range(b):                                       # one random directed graph per clip
+        a = torch.rand(n, n, generator=g).numpy().astype(np.float32)
+        np.fill_diagonal(a, 1.0)
+        sups.append(orc.compute_supports(a, filt))
+    sup = [torch.stack([s[j] for s in sups]) for j in range(len(sups[0]))]
+    x = torch.randn(b, t_len, n, din, generator=g)
+    seq = torch.tensor([t_len] + [max(1, t_len - 1)] * (b - 1), dtype=torch.int64)
+    y = torch.randint(0, max(classes, 2), (b,), generator=g)
+    if classes == 1:
+        y = y.float()
+    po = {name: v.clone().requires_grad_(True) for name, v in params.items()}
+    lo = orc.classification_forward(po, cfg, x, seq, sup)
+    (orc.bce_with_logits(lo, y) if classes == 1 else orc.cross_entropy(lo, y)).backward()
+    model = DCRNNModel_classification(make_args(cfg), classes, device=device)
+    load(model, params, device)
+    lg = model(x.to(device), seq.to(device), [s.to(device) for s in sup])
+    (torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), y.to(device)) if classes == 1
+     else torch.nn.functional.cross_entropy(lg, y.to(device))).backward()
+    assert_close(lg.detach().cpu().numpy(), lo.detach().numpy(), f"logits n={n} h={h} {filt} k={k}")
+    for name, p in model.named_parameters():
+        assert_close_scaled(p.grad.cpu().numpy(), po[name].grad.numpy(), f"d_{name} n={n} h={h} {filt} k={k}", tol=5e-5)
+
+
 def check_training_tail(device):
     """HIP loss kernels and the fused clip+Adam step vs their torch definitions
     (train.py:203-206,273-275: BCEWithLogits / CrossEntropy, clip_grad_norm_(5), Adam + coupled L2)."""

@@ -46,6 +46,17 @@ def test_widest_cell_uses_the_20_row_backward_layout(adj3d):
     ps.check_vs_oracle_random("cpu", "dual_random_walk", 8, 64, 2, 3, 2, 1, adj3d, seed=5, k=3)
 
 
+@pytest.mark.parametrize("n,h,filt,k", [(3, 16, "laplacian", 1), (21, 16, "dual_random_walk", 2), (32, 32, "random_walk", 3)])
+def test_shape_sweep_vs_oracle(n, h, filt, k):
+    ps.check_shape_sweep("cpu", n, h, filt, k)
+
+
+def test_wide_rows_diffuse_in_column_chunks():
+    """24 nodes x 200 input features x 5 hop matrices exceed one LDS tile: the diffusion kernels walk the rows
+    in column chunks"""
+    ps.check_shape_sweep("cpu", 24, 16, "dual_random_walk", 2, din=200, t_len=2, b=2, layers=2)
+
+
 def test_training_tail_kernels():
     ps.check_training_tail("cpu")
 

@@ -68,6 +68,27 @@ def test_other_diffusion_orders_vs_oracle(filt, k, din, h, layers, t_len, b, cla
     ps.check_vs_oracle_random(DEV, filt, din, h, layers, t_len, b, classes, adj3d, seed=4, lengths=lengths, k=k)
 
 
+@pytest.mark.parametrize("n", [3, 16, 19, 20, 21, 32])
+@pytest.mark.parametrize("h", [16, 32, 64])
+@pytest.mark.parametrize("filt,k", [("laplacian", 1), ("laplacian", 2), ("random_walk", 3), ("dual_random_walk", 2),
+                                    ("dual_random_walk", 3)])
+def test_shape_sweep_vs_oracle(n, h, filt, k):
+    """every (node count, hidden size, hop count) class the library claims to support"""
+    from eeg_gnn_ssl_amd import _lib
+    m = (2 if filt == "dual_random_walk" else 1) * k + 1
+    if not _lib.get_lib().query("eeg_dcrnn_supported", n, h, 8, m):
+        assert (h, m) == (64, 7) and n > 20, _lib.get_lib().last_error()     # the one refused combination
+        pytest.skip("refused loudly: " + _lib.get_lib().last_error())
+    ps.check_shape_sweep(DEV, n, h, filt, k)
+
+
+@pytest.mark.parametrize("din", [4, 36, 100, 200, 516])
+@pytest.mark.parametrize("filt,n,b,t_len", [("laplacian", 19, 5, 4), ("dual_random_walk", 19, 3, 7), ("dual_random_walk", 24, 2, 3)])
+def test_input_width_sweep_vs_oracle(din, filt, n, b, t_len):
+    """per-node input widths around the kernels' tile sizes (streaming / LDS diffusion, DMA / register GEMMs)"""
+    ps.check_shape_sweep(DEV, n, 64, filt, 2, din=din, b=b, t_len=t_len, classes=1 if din == 100 else 4)
+
+
 def _full_size_model(filt, classes):
     import bench
     from eeg_gnn_ssl_amd import DCRNNModel_classification
