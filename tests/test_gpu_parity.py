@@ -144,6 +144,41 @@ def test_full_size_slice_vs_oracle_and_determinism(workload, adj3d):
     assert err < 1e-4, f"{workload}: logits of the first clips differ from the oracle by {err:.2e}"
 
 
+@pytest.mark.parametrize("filt,batch,t_len", [("laplacian", 1531, 60), ("dual_random_walk", 517, 150)])
+def test_beyond_benchmark_sizes(filt, batch, t_len, adj3d):
+    """Batches / clip lengths several times the benchmark's, with odd counts (grid tails, 32-bit offset
+    headroom: up to 1.7e8 rows x 3H columns): clips far into the batch equal the oracle on just those clips;
+    the full-batch gradient equals the sum over two uneven parts; everything finite."""
+    import bench
+    from oracle import dcrnn_oracle as orc
+    x, y, lengths, sup = bench.synthetic_batch("detection", filt, t_len, batch, 1, seed=9)
+    lengths = torch.randint(1, t_len + 1, (batch,), generator=torch.Generator().manual_seed(1))
+    model = _full_size_model(filt, 1)
+    xd, yd, ld = x.to(DEV), y.to(DEV), lengths.to(DEV)
+    supd = [s.to(DEV) for s in sup]
+
+    def run(sl):
+        model.zero_grad()
+        lg = model(xd[sl], ld[sl], [s[sl] for s in supd])
+        torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), yd[sl], reduction="sum").backward()
+        return lg.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    lg, g = run(slice(0, batch))
+    assert torch.isfinite(lg).all() and all(torch.isfinite(v).all() for v in g.values())
+    cut = batch // 3 + 1
+    _, ga = run(slice(0, cut))
+    _, gb = run(slice(cut, batch))
+    for k in g:
+        err = ((ga[k] + gb[k]) - g[k]).abs().max() / g[k].abs().max().clamp_min(1e-6)
+        assert err < 1e-4, f"{k}: full-batch gradient != sum of its parts ({err:.2e})"
+    pick = [0, batch // 2 + 1, batch - 1]
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=1)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    lo = orc.classification_forward(params, cfg, x[pick], lengths[pick], [s[pick] for s in sup])
+    err = (lg[pick].cpu() - lo).abs().max().item()
+    assert err < 1e-4, f"logits of clips {pick} differ from the oracle by {err:.2e}"
+
+
 def test_full_size_hidden_sequence_vs_oracle(adj3d):
     """cfg2 shape: the top-layer hidden sequence (all 60 steps) of the first clips vs the oracle."""
     import bench
