@@ -287,7 +287,17 @@ def check_training_tail(device):
         assert (pd.cpu() - pr.detach()).abs().max().item() < 2e-6, step
 
 
-def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed=0, ratio=None, act="tanh"):
+def random_supports(n, b, filt, g):
+    """one random directed graph of n nodes per clip -> the filter type's batched supports"""
+    per_clip = []
+    for _ in range(b):
+        a = torch.rand(n, n, generator=g).numpy().astype(np.float32)
+        np.fill_diagonal(a, 1.0)
+        per_clip.append(orc.compute_supports(a, filt))
+    return [torch.stack([s[j] for s in per_clip]) for j in range(len(per_clip[0]))]
+
+
+def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed=0, ratio=None, act="tanh", n=19, order=2):
     """DCGRUDecoder (the native decoder operator) vs the oracle on random inputs: outputs, gradient
     w.r.t. the initial hidden states and all parameter gradients (shared cell for layers >= 1),
     with the teacher-forcing coin flips (model.py:194-200) replayed from the same `random` seed."""
@@ -295,15 +305,15 @@ def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed
     from eeg_gnn_ssl_amd import DCGRUDecoder
     g = torch.Generator().manual_seed(seed)
     cfg = orc.DCRNNConfig(filter_type=filt, input_dim=dout, output_dim=dout, rnn_units=h, num_rnn_layers=layers,
-                          dcgru_activation=act)
+                          dcgru_activation=act, num_nodes=n, max_diffusion_step=order)
     params = {k: v for k, v in orc.init_params(cfg, "ssl", seed=seed).items() if k.startswith("decoder.")}
     for k in params:
         if k.endswith("biases") and not any(params[k] is params[q] for q in params if q < k):
             params[k].copy_(0.1 * torch.randn(params[k].shape, generator=g))
-    sup = cases.supports_for(filt, adj3d, b)
-    targets = torch.randn(t_out, b, 19, dout, generator=g)
-    h0 = 0.5 * torch.randn(layers, b, 19 * h, generator=g)
-    wout = torch.randn(t_out, b, 19 * dout, generator=g)
+    sup = cases.supports_for(filt, adj3d, b) if n == 19 else random_supports(n, b, filt, g)
+    targets = torch.randn(t_out, b, n, dout, generator=g)
+    h0 = 0.5 * torch.randn(layers, b, n * h, generator=g)
+    wout = torch.randn(t_out, b, n * dout, generator=g)
     mask = None
     if ratio is not None:
         random.seed(seed)
@@ -319,7 +329,7 @@ def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed
     h0o = h0.clone().requires_grad_(True)
     oo = orc.decoder_forward(po, cfg, targets, h0o, sup, mask)
     (oo * wout).sum().backward()
-    dec = DCGRUDecoder(input_dim=dout, max_diffusion_step=2, num_nodes=19, hid_dim=h, output_dim=dout,
+    dec = DCGRUDecoder(input_dim=dout, max_diffusion_step=order, num_nodes=n, hid_dim=h, output_dim=dout,
                        num_rnn_layers=layers, dcgru_activation=act, filter_type=filt)
     load(dec, {k[len("decoder."):]: v for k, v in params.items()}, device)
     dec.train()

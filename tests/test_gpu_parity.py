@@ -288,6 +288,16 @@ def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
 
 
+@pytest.mark.parametrize("n", [3, 20, 21, 32])
+@pytest.mark.parametrize("filt,k,dout,h,layers", [("laplacian", 1, 4, 16, 1), ("dual_random_walk", 2, 36, 64, 3),
+                                                   ("random_walk", 3, 100, 32, 2), ("dual_random_walk", 3, 20, 64, 2)])
+def test_decoder_shape_sweep_vs_oracle(n, filt, k, dout, h, layers, adj3d):
+    """the decoder operator away from the defaults: node counts, hop counts, widths, 1-3 layers"""
+    if (h, filt, k) == (64, "dual_random_walk", 3) and n > 20:
+        pytest.skip("64 units x 7 hop matrices beyond 20 nodes is refused (LDS)")
+    ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, 3, 2, adj3d, seed=2, ratio=0.5, n=n, order=k)
+
+
 def test_correlation_graph_supports(golden):
     ps.check_correlation_supports(DEV, golden)
 
