@@ -357,7 +357,8 @@ def check_correlation_supports(device, golden):
     assert np.abs(s1[0].cpu().numpy() - golden["corr/s1"]).max() <= 2e-6
     assert np.abs(s2[0].cpu().numpy() - golden["corr/s2"]).max() <= 2e-6
     g = torch.Generator().manual_seed(9)
-    for (b, t_len, n, d, top_k) in ((5, 7, 19, 100, 3), (3, 60, 19, 100, 3), (2, 1, 19, 8, 2), (4, 9, 12, 20, 4)):
+    for (b, t_len, n, d, top_k) in ((5, 7, 19, 100, 3), (3, 60, 19, 100, 3), (2, 1, 19, 8, 2), (4, 9, 12, 20, 4),
+                                    (2, 60, 32, 128, 31), (3, 2, 4, 4, 0), (300, 3, 19, 100, 3)):
         xs = torch.randn(b, t_len, n, d, generator=g)
         xs[0, :, 3, :] = 0.0                                  # a silent electrode: zero norm -> raw (zero) correlation
         xs[-1] = xs[-1] * 0.5 + xs[-1, :, :1, :]              # strongly correlated channels
@@ -527,3 +528,10 @@ def check_fft_features(device, golden_fft):
         assert np.abs(fr[b].cpu().numpy() - ref).max() <= 5e-6
         exp = ((ref[:, perm[b].numpy(), :] + float(ls[b])) - 0.5) / 2.0
         assert np.abs(fs[b].cpu().numpy() - exp).max() <= 5e-6
+    for (b, n, w, nwin) in ((1, 1, 4, 1), (2, 32, 252, 2), (3, 19, 200, 60), (70, 19, 8, 5)):   # smallest / widest window, long clip
+        rawb = torch.randn(b, n, w * nwin, generator=g) * 10.0
+        fr, _ = ops.fft_features(rawb.to(device), window=w, mean=0.0, std=1.0)
+        assert fr.shape == (b, nwin, n, w // 2)
+        for i in (0, b - 1):
+            ref = orc.fft_features(rawb[i].numpy().astype(np.float64), window=w)
+            assert np.abs(fr[i].cpu().numpy() - ref).max() <= 5e-6, (b, n, w, nwin)
