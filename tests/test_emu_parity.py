@@ -82,9 +82,5 @@ def test_hop_plane_handover_between_layers(adj3d):
     ps.check_plane_handover("cpu", adj3d)
 
 
-def test_ssl_training_trajectory_matches_reference(golden_train):
-    ps.check_ssl_training_trajectory("cpu", golden_train, steps=2)
-
-
 def test_fft_features(golden_fft):
     ps.check_fft_features("cpu", golden_fft)
