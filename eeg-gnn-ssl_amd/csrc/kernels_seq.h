@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     constexpr bool REM4 = NKS == 5;         // at most 20 nodes: the second node tile runs as 4x4x1 MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     float* RS = A2 + 32 * KAP + wave * (2 * CT * 256);   // this wave's REM4 hand-over scratch
-    const int b = blockIdx.x;
     const bool save = Rs != nullptr;
 
     // Wave w owns column tiles ct = w + 4*i of r, u, c and h (so gate tiles ct and NCT+ct): the
@@ -191,6 +190,11 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         }
     }
 
+    // A workgroup walks clips b = blockIdx.x, + gridDim.x, ... (the host launches min(B, #CUs) workgroups): the
+    // register-resident weights are fetched once per workgroup, not once per clip -- what matters for the
+    // decoder's single-step launches at batches beyond one clip per CU.
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();                                                // previous clip: all waves done with A / A2 / Pl
     for (int e = tid; e < 2 * 32 * KAP; e += 256) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         // this wave; other waves only read A2 until barrier (1) of the next step)
         if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);   // slot T = hops(h_{T-1}): the next layer's input planes
     }
+    }   // clips of this workgroup
     pp.dump(probe, 0);
 }
 
@@ -351,7 +356,6 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     constexpr bool REM4 = NKS == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
     float* RS = EG + ROWS * KGP + wave * (2 * CT * 256);
-    const int b = blockIdx.x;
 
     // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
     // the 2H-wide gate gradient): all elementwise -> diffusion hand-offs are wave-local.
@@ -364,6 +368,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
         for (int ks = 0; ks < KSG; ++ks) w2[i][ks] = b2p[((size_t)ks * NCT + ct) * 64 + lane];
     }
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {               // clips of this workgroup (see seq_fwd_kernel)
+    __syncthreads();                                                // previous clip: the bias reduction has read EG
     for (int e = tid; e < ROWS * (KAP + KGP); e += 256) EC[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
         dbias_part[(size_t)b * 3 * H + j] = sacc;
     }
+    }   // clips of this workgroup
     pp.dump(probe, 8);
 }
 

@@ -12,6 +12,8 @@
 namespace eeg {
 namespace {
 
+constexpr int kSeqMaxGrid = 256;   // one workgroup per CU; larger batches are walked by the resident workgroups
+
 // NKS = k-steps of the node mix: 5 covers N <= 20 (the 19-electrode graph), 8 covers N <= 32.
 template <int H, int M, int NKS>
 int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
@@ -20,13 +22,13 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
     if constexpr (H == 64 && M == 3 && NKS == 5) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS, true>), lds);
-            EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS, true>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P,
+            EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.XW, a.h0, a.P,
                          a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
     EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS>), lds);
-    EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched,
+    EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched,
                  a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -41,14 +43,14 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
     if constexpr (H == 64 && M == 3 && NKS == 5) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS, true>), lds);
-            EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS, true>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us,
+            EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us,
                          a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
                          a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
     EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS>), lds);
-    EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS>), dim3(a.B), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
+    EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                  a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
                  a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
     return hipGetLastError() == hipSuccess ? 0 : 2;
