@@ -128,12 +128,12 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
 // wait states (observed on gfx950 / ROCm 7.2: components 2,3 of the accumulator read stale).
 template <bool ON>
 struct PhaseProbe {
-    long long acc[6];
+    long long acc[8];
     long long last;
     __device__ __forceinline__ void start() {
         if (ON) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) acc[i] = 0;
+            for (int i = 0; i < 8; ++i) acc[i] = 0;
             last = cycle_now();
         }
     }
@@ -149,7 +149,7 @@ struct PhaseProbe {
             if (p != nullptr && (threadIdx.x & 63) == 0) {
                 long long* d = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 32 + slot0;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) d[i] = acc[i];
+                for (int i = 0; i < 8; ++i) d[i] = acc[i];
             }
         }
     }
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         }
         pp.mark(2);
         diffuse_own(A2, RHpl, t);                                   // own column tiles: no barrier needed
+        pp.mark(7);
         __syncthreads();                                            // (2) hops(r*h) complete
         pp.mark(3);
         if (t + 1 < T) fetch_xw(t + 1);
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         // hops(h_t) of the own column tiles for the next step (their slot-0 source was just written by
         // this wave; other waves only read A2 until barrier (1) of the next step)
         if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);   // slot T = hops(h_{T-1}): the next layer's input planes
+        pp.mark(6);
     }
     }   // clips of this workgroup
     pp.dump(probe, 0);

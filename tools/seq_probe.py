@@ -36,10 +36,10 @@ lib.query("eeg_dcrnn_set_seq_probe", ctypes.c_void_p(probe.data_ptr()))
 run()          # last launches of each direction (layer 0 bwd, layer 1 fwd) leave their counters
 lib.query("eeg_dcrnn_set_seq_probe", None)
 p = probe.view(batch, 4, 32).double().cpu()
-names_f = ["diffuse(h)+bar", "gate GEMM", "gate epilogue+bar", "diffuse(rh)+bar", "cand GEMM", "cand epilogue+bar"]
-names_b = ["E1+bar", "adj diffuse dC+bar", "GEMM1", "epi1+bar", "adj diffuse dG+bar", "GEMM2"]
+names_f = ["loop top + barrier(1)", "gate GEMM", "gate epilogue", "barrier(2)", "cand GEMM", "cand epilogue", "diffuse(h) issue", "diffuse(rh) issue"]
+names_b = ["E1+bar", "adj diffuse dC+bar", "GEMM1", "epi1+bar", "adj diffuse dG+bar", "GEMM2", "-", "-"]
 for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
-    tot = p[:, :, off:off + 6].sum(-1).mean().item() / t_len
+    tot = p[:, :, off:off + 8].sum(-1).mean().item() / t_len
     print(f"{title}: {tot:9.0f} cycles/step/wave (mean over {batch} WGs x 4 waves)")
     for k, nm in enumerate(names):
         v = p[:, :, off + k] / t_len
