@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                 hp[i][nt] = nh[i][nt]; rr[i][nt] = nr[i][nt]; uu[i][nt] = nu[i][nt]; cc[i][nt] = nc[i][nt]; gg[i][nt] = ng[i][nt];
             }
         if (t > 0) fetch(t - 1);
+        pp.mark(6);
         // ---- E1: gate blend backward on the owned elements (padding nodes zeroed)
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -470,6 +471,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < CT; ++i)
             if (own[i]) lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
+        pp.mark(7);
         __syncthreads();                                            // (1) P_m^T dC complete
         pp.mark(1);
 

@@ -37,7 +37,7 @@ run()          # last launches of each direction (layer 0 bwd, layer 1 fwd) leav
 lib.query("eeg_dcrnn_set_seq_probe", None)
 p = probe.view(batch, 4, 32).double().cpu()
 names_f = ["loop top + barrier(1)", "gate GEMM", "gate epilogue", "barrier(2)", "cand GEMM", "cand epilogue", "diffuse(h) issue", "diffuse(rh) issue"]
-names_b = ["E1+bar", "adj diffuse dC+bar", "GEMM1", "epi1+bar", "adj diffuse dG+bar", "GEMM2", "-", "-"]
+names_b = ["E1", "barrier(1)", "GEMM1", "epi1", "adj diffuse dG+bar", "GEMM2", "operand copy + prefetch issue", "adj diffuse dC issue"]
 for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
     tot = p[:, :, off:off + 8].sum(-1).mean().item() / t_len
     print(f"{title}: {tot:9.0f} cycles/step/wave (mean over {batch} WGs x 4 waves)")
