@@ -109,9 +109,10 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
         w["seq_bwd"] += s * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
         w["gemm_nn"] += 2.0 * r * (m * fin) * 3 * h
         w["gemm_tn"] += 2.0 * r * (m * fin) * 3 * h + 2.0 * r * (m * h) * 2 * h + 2.0 * r * (m * h) * h
-        # read X once, write M-1 planes; layer 0 also writes the time-major copy of the batch-major input
-        # (the hop planes of h and r*h are by-products of seq_fwd, not of this kernel)
-        w["diffuse_fwd"] += 4.0 * s * n * fin * (m + 1 if l == 0 else m)
+        # layer 0 only: read X once, write M-1 planes + the time-major copy of the batch-major input (the hop
+        # planes of h and r*h -- and with them the input planes of the layers above -- are by-products of seq_fwd)
+        if l == 0:
+            w["diffuse_fwd"] += 4.0 * s * n * fin * (m + 1)
         if l > 0:
             w["gemm_nn"] += 2.0 * r * 3 * h * (m * fin)
             w["diffuse_adj"] += 4.0 * s * n * fin * (m + 1)
@@ -120,12 +121,13 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
         rd = sd * n
         for k in list(w):
             w["dec_" + k] = 0.0
-        for fin in fins:
+        for l, fin in enumerate(fins):
             w["dec_seq_fwd"] += sd * (2 * (m - 1) * 2 * n * n * h + 2 * n * (h * m) * 3 * h)
             w["dec_seq_bwd"] += sd * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
             w["dec_gemm_nn"] += 2.0 * rd * (m * fin) * 3 * h * 2
             w["dec_gemm_tn"] += 2.0 * rd * (m * fin) * 3 * h + 2.0 * rd * (m * h) * 3 * h
-            w["dec_diffuse_fwd"] += 4.0 * sd * n * fin * m
+            if l == 0:
+                w["dec_diffuse_fwd"] += 4.0 * sd * n * fin * m     # first decoder layer only (as above)
             w["dec_diffuse_adj"] += 4.0 * sd * n * fin * (m + 1)
         w["dec_gemm_nn"] += 2 * 2.0 * rd * h * D_IN          # projection forward + d h_top
         w["dec_gemm_tn"] += 2.0 * rd * h * D_IN              # projection weight gradient
