@@ -190,9 +190,14 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
 int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
             float* partial, int nsplit, int rows_per_split, hipStream_t st) {
     if (g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0 && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
-        if (O > 128 && O <= 192) return run_tn_dma<2, 6, 32>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-        if (O > 64 && O <= 128) return run_tn_dma<2, 4, 32>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-        return run_tn_dma<2, 2, 32>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+#define EEG_TN(NCTW, RC) run_tn_dma<2, NCTW, RC>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st)
+        // row-chunk depth: the 192-column tile stages 16 rows at a time (32 KB of LDS per workgroup -> 4 workgroups
+        // per CU instead of 2 with 32-row stages: -3.5 % on that shape); the narrower tiles are better off with 32
+        // rows (measured both ways); 8-row stages are 15 % slower
+        if (O > 128 && O <= 192) return EEG_TN(6, 16);
+        if (O > 64 && O <= 128) return EEG_TN(4, 32);
+        return EEG_TN(2, 32);
+#undef EEG_TN
     }
     if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
     if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
