@@ -338,7 +338,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     SegPtrs sx;
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
     if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_x, M * Fin, 3 * H, 0 | acc, Fin, H, M, dWg, dWc);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * Fin * 3 * H, 64)), dim3(256), 256 * sizeof(float4), st, part, w.nsplit_x, M * Fin, 3 * H, 0 | acc, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(x)")) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
@@ -351,7 +351,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * hs : nullptr);
     if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hg, M * H, 2 * H, 1 | acc, Fin, H, M, dWg, dWc);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * H * 2 * H, 64)), dim3(256), 256 * sizeof(float4), st, part, w.nsplit_hg, M * H, 2 * H, 1 | acc, Fin, H, M, dWg, dWc);
     if (check_launch("reduce_unpack(hg)")) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     const float* rpl = rpl_in;
@@ -364,7 +364,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * rs : nullptr);
     if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(256), dim3(256), 0, st, part, w.nsplit_hc, M * H, H, 2 | acc, Fin, H, M, dWg, dWc);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * H * H, 64)), dim3(256), 256 * sizeof(float4), st, part, w.nsplit_hc, M * H, H, 2 | acc, Fin, H, M, dWg, dWc);
     return check_launch("reduce_unpack(hc)");
 }
 
@@ -800,7 +800,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
     SegPtrs so;
     for (int m = 0; m < kMaxM; ++m) so.p[m] = m == 0 ? dOtot : nullptr;
     if (gemm_tn(so, 1, Dout, (int)Rall, saved + y.hext[L - 1] + state, H, 0, H, ws + y.partial, y.nsplit_p, y.rps_p, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(64), dim3(256), 0, st, ws + y.partial, y.nsplit_p, Dout, H, 3, Dout, H, 1, dWp, dWp);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(Dout * H, 64)), dim3(256), 256 * sizeof(float4), st, ws + y.partial, y.nsplit_p, Dout, H, 3, Dout, H, 1, dWp, dWp);
     if (check_launch("reduce_unpack(proj)")) return 1;
     return colsum(dOtot, (int)Rall, Dout, Dout, ws + y.colsum, dbp, nullptr, st);
 }

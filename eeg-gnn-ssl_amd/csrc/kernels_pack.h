@@ -136,51 +136,53 @@ __global__ void pack_linear_kernel(const float* __restrict__ W, int Out, int In,
 // Sum split-K partials [nsplit][K][O] in fixed order (deterministic) and scatter into the
 // reference-layout gradient tensors.  kind 0: x-part (K = M*Fin, O = 3H); 1: h-gate (K = M*H,
 // O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f); 3: dWg = plain (K x O).
-__global__ void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O, int kind_flags,
-                                     int Fin, int H, int M, float* __restrict__ dWg, float* __restrict__ dWc) {
+// Block = 16 split groups x 16 float4 columns (64 consecutive elements of the K x O matrix): group g sums
+// splits g, g+16, g+32, ... in that order (all its loads independent and in flight together -- the partials
+// are read once from HBM, so the launch lives on memory-level parallelism), the 16 group sums are then added
+// in group order.  Requires (K * O) % 4 == 0.
+__global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O,
+                                                            int kind_flags, int Fin, int H, int M,
+                                                            float* __restrict__ dWg, float* __restrict__ dWc) {
+    EEG_DYN_SMEM(sm);                                 // [16 groups][16 float4]
+    float4 (*red)[16] = reinterpret_cast<float4 (*)[16]>(sm);
     const size_t total = (size_t)K * O;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        // 8 independent partial sums keep 8 loads in flight; combined in a fixed order
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int sp = 0;
-        for (; sp + 8 <= nsplit; sp += 8) {
+    const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const size_t idx4 = ((size_t)blockIdx.x * 16 + q) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx4 < total) {
+        for (int sp = g; sp < nsplit; sp += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)sp * total + idx4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    red[g][q] = a;
+    __syncthreads();
+    if (g != 0 || idx4 >= total) return;
+    float4 sum = red[0][q];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += part[(size_t)(sp + u) * total + idx];
-        }
-        for (int u = 0; sp + u < nsplit; ++u) acc[u] += part[(size_t)(sp + u) * total + idx];
-        float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    for (int u = 1; u < 16; ++u) {
+        const float4 v = red[u][q];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+    const bool accumulate = (kind_flags & 8) != 0;   // += into the gradient (shared decoder cell, model.py:126-143)
+    const int kind = kind_flags & 7;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t idx = idx4 + e;
         const int k = idx / O, o = idx % O;
-        const bool accumulate = (kind_flags & 8) != 0;   // += into the gradient (shared decoder cell, model.py:126-143)
-        const int kind = kind_flags & 7;
-        if (accumulate) {
-            float* dst;
-            if (kind == 0) {
-                const int m = k / Fin, f = k % Fin;
-                dst = o < 2 * H ? &dWg[((size_t)f * M + m) * (2 * H) + o] : &dWc[((size_t)f * M + m) * H + (o - 2 * H)];
-            } else if (kind == 1) {
-                dst = &dWg[((size_t)(Fin + k % H) * M + k / H) * (2 * H) + o];
-            } else if (kind == 3) {
-                dst = &dWg[idx];
-            } else {
-                dst = &dWc[((size_t)(Fin + k % H) * M + k / H) * H + o];
-            }
-            *dst += s;
-            continue;
-        }
+        float* dst;
         if (kind == 0) {
             const int m = k / Fin, f = k % Fin;
-            if (o < 2 * H) dWg[((size_t)f * M + m) * (2 * H) + o] = s;
-            else dWc[((size_t)f * M + m) * H + (o - 2 * H)] = s;
+            dst = o < 2 * H ? &dWg[((size_t)f * M + m) * (2 * H) + o] : &dWc[((size_t)f * M + m) * H + (o - 2 * H)];
         } else if (kind == 1) {
-            const int m = k / H, f = k % H;
-            dWg[((size_t)(Fin + f) * M + m) * (2 * H) + o] = s;
+            dst = &dWg[((size_t)(Fin + k % H) * M + k / H) * (2 * H) + o];
         } else if (kind == 3) {                       // plain (K x O) matrix
-            dWg[idx] = s;
+            dst = &dWg[idx];
         } else {
-            const int m = k / H, f = k % H;
-            dWc[((size_t)(Fin + f) * M + m) * H + o] = s;
+            dst = &dWc[((size_t)(Fin + k % H) * M + k / H) * H + o];
         }
+        *dst = accumulate ? *dst + sv[e] : sv[e];
     }
 }
 
