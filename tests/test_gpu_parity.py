@@ -179,6 +179,63 @@ def test_beyond_benchmark_sizes(filt, batch, t_len, adj3d):
     assert err < 1e-4, f"logits of clips {pick} differ from the oracle by {err:.2e}"
 
 
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_full_size_gradients_vs_oracle(workload, adj3d):
+    """BASELINE cfg2 / cfg3 at FULL size (B=256, T=60, ragged lengths; cfg3: one correlation graph per clip):
+    logits of every clip and every parameter gradient of the whole batch against the oracle run on the host on
+    the same batch (fp32 tolerance 1e-4 of each tensor's largest entry, the bar north_star states)."""
+    import bench
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS[workload]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=77)
+    lengths = torch.randint(t_len // 2, t_len + 1, (batch,), generator=torch.Generator().manual_seed(3))
+    model = _full_size_model(filt, classes)
+    lg = model(x.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup])
+    torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), y.to(DEV)).backward()
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
+    po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    torch.set_num_threads(16)
+    lo = orc.classification_forward(po, cfg, x, lengths, sup)
+    orc.bce_with_logits(lo, y).backward()
+    assert (lg.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    for k, p in model.named_parameters():
+        ref = po[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 1e-4, f"{k}: {err:.2e}"
+
+
+def test_ssl_full_size_gradients_vs_oracle():
+    """BASELINE cfg5 at FULL per-GPU size (B=512; 60-s encoder, 12-s decoder, dual random walk, 100 features,
+    64 units): predictions, masked-RMSE loss and every parameter gradient against the oracle on the same batch."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred, utils
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS["cfg5"]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=5)
+    torch.manual_seed(9)
+    model = DCRNNModel_nextTimePred(bench.make_args(filt), device=DEV).to(DEV).train()
+    pred = model(x.to(DEV), y.to(DEV), [s.to(DEV) for s in sup])
+    loss = utils.compute_regression_loss(y_true=y.to(DEV), y_predicted=pred, standard_scaler=None, loss_fn="MAE")
+    loss.backward()
+    cfg = orc.DCRNNConfig(filter_type=filt)
+    uniq, po = {}, {}
+    for k, v in model.state_dict().items():                 # decoding_cells.1 (no shared layers at L=2, but keep aliases)
+        key = v.data_ptr()
+        if key not in uniq:
+            uniq[key] = v.detach().cpu().clone().requires_grad_(True)
+        po[k] = uniq[key]
+    torch.set_num_threads(16)
+    pr = orc.next_time_pred_forward(po, cfg, x, y, sup)
+    lo = orc.regression_loss(y, pr, loss_fn="MAE")
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    assert (pred.detach().cpu() - pr.detach()).abs().max().item() < 1e-4
+    for k, p in model.named_parameters():
+        ref = po[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 1e-4, f"{k}: {err:.2e}"
+
+
 def test_full_size_hidden_sequence_vs_oracle(adj3d):
     """cfg2 shape: the top-layer hidden sequence (all 60 steps) of the first clips vs the oracle."""
     import bench
