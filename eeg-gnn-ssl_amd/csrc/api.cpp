@@ -298,7 +298,7 @@ int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
 }
 
 struct BwdWs {
-    size_t dxw, dbias, hplanes, rhplanes, partial, z, total;
+    size_t dxw, dbias, hplanes, rhplanes, partial, part_g, part_c, z, total;   // partial = x-part region; part_g / part_c follow it
     int nsplit_x, rps_x, nsplit_hg, rps_hg, nsplit_hc, rps_hc;
 };
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
@@ -315,9 +315,9 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     size_t px = (size_t)w.nsplit_x * d->M * d->Fin * 3 * d->H;
     size_t pg = (size_t)w.nsplit_hg * d->M * d->H * 2 * d->H;
     size_t pc = (size_t)w.nsplit_hc * d->M * d->H * d->H;
-    size_t pm = px > pg ? px : pg;
-    pm = pm > pc ? pm : pc;
-    w.partial = o;  o += (pm + 63) / 64 * 64;
+    w.partial = o;  o += (px + 63) / 64 * 64;      // one region per GEMM: the three are reduced by one launch
+    w.part_g = o;   o += (pg + 63) / 64 * 64;
+    w.part_c = o;   o += (pc + 63) / 64 * 64;
     w.z = o;        o += need_dx ? R * d->M * d->Fin : 0;
     w.total = o;
     return w;
@@ -337,9 +337,9 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     const int acc = accumulate ? 8 : 0;
     SegPtrs sx;
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
+    float* part_g = part + (w.part_g - w.partial);
+    float* part_c = part + (w.part_c - w.partial);
     if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * Fin * 3 * H, 64)), dim3(256), 256 * sizeof(float4), st, part, w.nsplit_x, M * Fin, 3 * H, 0 | acc, Fin, H, M, dWg, dWc);
-    if (check_launch("reduce_unpack(x)")) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
     size_t hs = h_stride;
@@ -350,9 +350,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * hs : nullptr);
-    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part, w.nsplit_hg, w.rps_hg, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * H * 2 * H, 64)), dim3(256), 256 * sizeof(float4), st, part, w.nsplit_hg, M * H, 2 * H, 1 | acc, Fin, H, M, dWg, dWc);
-    if (check_launch("reduce_unpack(hg)")) return 1;
+    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st)) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     const float* rpl = rpl_in;
     size_t rs = h_stride;
@@ -363,9 +361,19 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * rs : nullptr);
-    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part, w.nsplit_hc, w.rps_hc, st)) return 1;
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * H * H, 64)), dim3(256), 256 * sizeof(float4), st, part, w.nsplit_hc, M * H, H, 2 | acc, Fin, H, M, dWg, dWc);
-    return check_launch("reduce_unpack(hc)");
+    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st)) return 1;
+    //   one fixed-order reduction of the three sets of split-K partials into the reference's gradient layout
+    ReduceJobs jobs;
+    const int Ks[3] = {M * Fin, M * H, M * H}, Os[3] = {3 * H, 2 * H, H}, ns[3] = {w.nsplit_x, w.nsplit_hg, w.nsplit_hc};
+    const float* parts[3] = {part, part_g, part_c};
+    int nblocks = 0;
+    for (int j = 0; j < 3; ++j) {
+        jobs.part[j] = parts[j]; jobs.nsplit[j] = ns[j]; jobs.K[j] = Ks[j]; jobs.O[j] = Os[j];
+        jobs.nblocks[j] = ceil_div(Ks[j] * Os[j], 64);
+        nblocks += jobs.nblocks[j];
+    }
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack3_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, acc, Fin, H, M, dWg, dWc);
+    return check_launch("reduce_unpack");
 }
 
 // out0[c] (c < split) / out1[c - split] = sum_r A[r][c]: two fixed-order stages.

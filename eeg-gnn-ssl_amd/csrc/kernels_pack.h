@@ -140,14 +140,14 @@ __global__ void pack_linear_kernel(const float* __restrict__ W, int Out, int In,
 // splits g, g+16, g+32, ... in that order (all its loads independent and in flight together -- the partials
 // are read once from HBM, so the launch lives on memory-level parallelism), the 16 group sums are then added
 // in group order.  Requires (K * O) % 4 == 0.
-__global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O,
-                                                            int kind_flags, int Fin, int H, int M,
-                                                            float* __restrict__ dWg, float* __restrict__ dWc) {
+__device__ __forceinline__ void reduce_unpack_block(int block, const float* __restrict__ part, int nsplit, int K, int O,
+                                                    int kind_flags, int Fin, int H, int M,
+                                                    float* __restrict__ dWg, float* __restrict__ dWc) {
     EEG_DYN_SMEM(sm);                                 // [16 groups][16 float4]
     float4 (*red)[16] = reinterpret_cast<float4 (*)[16]>(sm);
     const size_t total = (size_t)K * O;
     const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
-    const size_t idx4 = ((size_t)blockIdx.x * 16 + q) * 4;
+    const size_t idx4 = ((size_t)block * 16 + q) * 4;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx4 < total) {
         for (int sp = g; sp < nsplit; sp += 16) {
@@ -184,6 +184,21 @@ __global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* __restr
         }
         *dst = accumulate ? *dst + sv[e] : sv[e];
     }
+}
+__global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* __restrict__ part, int nsplit, int K, int O,
+                                                            int kind_flags, int Fin, int H, int M,
+                                                            float* __restrict__ dWg, float* __restrict__ dWc) {
+    reduce_unpack_block(blockIdx.x, part, nsplit, K, O, kind_flags, Fin, H, M, dWg, dWc);
+}
+// The three weight-gradient GEMMs of one cell (x-part, h-gate, h-candidate: kinds 0, 1, 2) reduced by ONE launch:
+// blocks [0, nb0) serve job 0, [nb0, nb0 + nb1) job 1, the rest job 2.
+struct ReduceJobs { const float* part[3]; int nsplit[3]; int K[3]; int O[3]; int nblocks[3]; };
+__global__ __launch_bounds__(256) void reduce_unpack3_kernel(ReduceJobs jobs, int flags, int Fin, int H, int M,
+                                                             float* __restrict__ dWg, float* __restrict__ dWc) {
+    int b = blockIdx.x, j = 0;
+    if (b >= jobs.nblocks[0]) { b -= jobs.nblocks[0]; j = 1; }
+    if (j == 1 && b >= jobs.nblocks[1]) { b -= jobs.nblocks[1]; j = 2; }
+    reduce_unpack_block(b, jobs.part[j], jobs.nsplit[j], jobs.K[j], jobs.O[j], j | flags, Fin, H, M, dWg, dWc);
 }
 
 // Column sums of a dense (R x C) matrix in two fixed-order stages (projection bias gradient):
