@@ -175,3 +175,62 @@ def predict(model, batches, task: str = "detection"):
         prob, lab = torch.cat(gp), torch.cat(gl)
     model.train(was_training)
     return prob.cpu().numpy(), lab.cpu().numpy()
+
+
+@torch.no_grad()
+def evaluate(model, batches, task: str = "detection", is_test: bool = False, eval_set: str = "dev",
+             best_thresh: float = 0.5):
+    """The reference's evaluation pass (train.py:332-431) on device tensors: forward in eval mode, sample-weighted
+    mean loss (BCE-with-logits / cross-entropy, computed by the HIP loss kernels), predictions at `best_thresh`
+    (detection; on the dev set of a test run the threshold is re-chosen by `utils.thresh_max_f1`,
+    train.py:406-412) or arg-max (classification), and the score dictionary in the reference's order:
+    loss, acc, F1, recall, precision, best_thresh[, auroc].  Launched data-parallel, every rank evaluates its
+    shard and all ranks return the scores of the union (all_gather of probabilities, labels and loss sums).
+    batches: iterable of (x, y, seq_lengths, supports) device tensors (supports None: built on the device)."""
+    from collections import OrderedDict
+    import numpy as np
+    from . import utils
+    was_training = model.training
+    model.eval()
+    probs, labels = [], []
+    loss_sum = None
+    n_seen = 0
+    for x, y, seq_lengths, supports in batches:
+        if supports is None:
+            supports = ops.correlation_supports(x, top_k=3)
+        logits = model(x, seq_lengths, supports)
+        if task == "detection":
+            lg = logits.view(-1)
+            loss = ops.bce_with_logits(lg, y.view(-1).float())
+            probs.append(torch.sigmoid(lg))
+        else:
+            loss = ops.cross_entropy(logits, y.view(-1))
+            probs.append(torch.softmax(logits, dim=1))
+        labels.append(y.view(-1))
+        loss_sum = loss * x.shape[0] if loss_sum is None else loss_sum + loss * x.shape[0]
+        n_seen += x.shape[0]
+    prob, lab = torch.cat(probs), torch.cat(labels)
+    tot = torch.stack([loss_sum.reshape(()).double(), torch.tensor(float(n_seen), device=prob.device, dtype=torch.float64)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        gp = [torch.empty_like(prob) for _ in range(dist.get_world_size())]
+        gl = [torch.empty_like(lab) for _ in range(dist.get_world_size())]
+        dist.all_gather(gp, prob)
+        dist.all_gather(gl, lab)
+        dist.all_reduce(tot)
+        prob, lab = torch.cat(gp), torch.cat(gl)
+    model.train(was_training)
+    y_prob, y_true = prob.cpu().numpy(), lab.cpu().numpy().astype(int)
+    eval_loss = float((tot[0] / tot[1]).item())
+    if task == "detection":
+        if eval_set == "dev" and is_test:
+            best_thresh = float(utils.thresh_max_f1(y_true=y_true, y_prob=y_prob))
+        y_pred = (y_prob > best_thresh).astype(int)
+    else:
+        y_pred = np.argmax(y_prob, axis=1).reshape(-1)
+    scores, _, _ = utils.eval_dict(y_pred=y_pred, y=y_true, y_prob=y_prob if task == "detection" else None,
+                                   average="binary" if task == "detection" else "weighted")
+    res = [("loss", eval_loss), ("acc", scores["acc"]), ("F1", scores["F1"]), ("recall", scores["recall"]),
+           ("precision", scores["precision"]), ("best_thresh", best_thresh)]
+    if "auroc" in scores:
+        res.append(("auroc", scores["auroc"]))
+    return OrderedDict(res)

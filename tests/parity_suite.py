@@ -498,6 +498,53 @@ def check_ssl_training_trajectory(device, golden_train, steps=None):
         assert np.abs(sample_view(pred, 31)[3:] - golden_train["ssl_train/final_pred"][3:]).max() <= 2e-3
 
 
+def check_eval_driver(device, adj3d):
+    """train_step.evaluate / predict (the reference's evaluation pass, train.py:332-431) against the same
+    quantities computed by hand from the oracle's logits: sample-weighted loss, thresholded / arg-max
+    predictions, the dev-set threshold search, score dictionary in the reference's order."""
+    from sklearn import metrics
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, utils
+    from eeg_gnn_ssl_amd.train_step import evaluate, predict
+    g = torch.Generator().manual_seed(12)
+    for task, classes in (("detection", 1), ("classification", 4)):
+        cfg = orc.DCRNNConfig(filter_type="laplacian", input_dim=8, rnn_units=16, num_rnn_layers=2, num_classes=classes)
+        params = orc.init_params(cfg, "classification", seed=3)
+        model = DCRNNModel_classification(make_args(cfg), classes, device=device)
+        load(model, params, device)
+        model.train()                                       # evaluate() must switch to eval mode and back
+        batches, ref_logits, ref_y = [], [], []
+        for b in (5, 3):                                    # two batches of different size: the loss is sample-weighted
+            x = torch.randn(b, 4, 19, 8, generator=g)
+            seq = torch.randint(1, 5, (b,), generator=g)
+            y = (torch.rand(b, generator=g) > 0.5).float() if classes == 1 else torch.randint(0, classes, (b,), generator=g)
+            sup = cases.supports_for("laplacian", adj3d, b)
+            batches.append((x.to(device), y.to(device), seq.to(device), [s.to(device) for s in sup]))
+            ref_logits.append(orc.classification_forward(params, cfg, x, seq, sup))
+            ref_y.append(y)
+        lo, yy = torch.cat(ref_logits), torch.cat(ref_y)
+        res = evaluate(model, batches, task=task, is_test=True, eval_set="dev")
+        assert model.training
+        assert list(res.keys())[:6] == ["loss", "acc", "F1", "recall", "precision", "best_thresh"]
+        if classes == 1:
+            ref_loss = torch.nn.functional.binary_cross_entropy_with_logits(lo.view(-1), yy).item()
+            prob = torch.sigmoid(lo.view(-1)).numpy()
+            thr = utils.thresh_max_f1(y_true=yy.numpy().astype(int), y_prob=prob)
+            pred = (prob > thr).astype(int)
+            assert abs(res["best_thresh"] - thr) < 1e-5
+            assert abs(res["auroc"] - metrics.roc_auc_score(yy.numpy().astype(int), prob)) < 1e-6
+            assert abs(res["F1"] - metrics.f1_score(yy.numpy().astype(int), pred, average="binary")) < 1e-6
+        else:
+            ref_loss = torch.nn.functional.cross_entropy(lo, yy).item()
+            pred = lo.argmax(dim=1).numpy()
+            assert "auroc" not in res and res["best_thresh"] == 0.5
+            assert abs(res["F1"] - metrics.f1_score(yy.numpy(), pred, average="weighted")) < 1e-6
+        assert abs(res["loss"] - ref_loss) < 1e-5, (task, res["loss"], ref_loss)
+        assert abs(res["acc"] - metrics.accuracy_score(yy.numpy().astype(int), pred)) < 1e-6
+        y_prob, y_true = predict(model, batches, task=task)
+        ref_prob = torch.sigmoid(lo.view(-1)).numpy() if classes == 1 else torch.softmax(lo, dim=1).numpy()
+        assert np.abs(y_prob - ref_prob).max() < 1e-5 and (y_true == yy.numpy()).all()
+
+
 def check_fft_features(device, golden_fft):
     """On-device featurisation (1-s windows -> log|FFT| -> reflection / amplitude jitter -> z-score) vs the
     goldens of the genuine reference pipeline and, for the augmented variant and a ragged shape, the oracle."""

@@ -82,5 +82,9 @@ def test_hop_plane_handover_between_layers(adj3d):
     ps.check_plane_handover("cpu", adj3d)
 
 
+def test_evaluation_driver(adj3d):
+    ps.check_eval_driver("cpu", adj3d)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features("cpu", golden_fft)

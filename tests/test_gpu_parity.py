@@ -375,5 +375,9 @@ def test_ssl_training_trajectory_matches_reference(golden_train):
     ps.check_ssl_training_trajectory(DEV, golden_train)
 
 
+def test_evaluation_driver(adj3d):
+    ps.check_eval_driver(DEV, adj3d)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features(DEV, golden_fft)
