@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     for (int e = tid; e < 2 * 32 * KAP; e += 256) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
-    float pf[(M - 1) * 2][NKS];
+    float pf[poly_chains<M, NKS>()][NKS];
     load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
     if (h0 != nullptr) {
         for (int e = tid; e < N * H; e += 256) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
     __syncthreads();
-    float pf[(M - 1) * 2][NKS];
+    float pf[poly_chains<M, NKS>()][NKS];
     load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
 
     const int node[2] = {lr, 16 + lr};

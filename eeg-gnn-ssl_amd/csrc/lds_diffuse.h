@@ -71,36 +71,62 @@ __device__ __forceinline__ void lds_diffuse_tiles(float* buf, int stride, int sr
 }
 
 // ---- register-resident variant used by the persistent recurrent kernels -----------------------
-// The hop polynomials never change during a sequence, so each lane keeps its MFMA A-fragments of
-// all (m, row-tile) pairs in registers: pf[(m-1)*2 + rt][ks].  NKS = ceil(N/4) k-steps (5 for the
-// 19-electrode graph).
+// The hop polynomials never change during a sequence, so each lane keeps its MFMA B-fragments in registers.
+// NKS = ceil(N/4) k-steps of the node mix (5 for the 19-electrode graph, 8 for up to 32 nodes).
+//   NKS == 8: one chain per (hop m, node tile rt): pf[(m-1)*2 + rt][ks]                     -> (M-1)*2 chains
+//   NKS == 5 (at most 20 nodes): the second node tile holds only output nodes 16..19, so the second tiles of up
+//     to FOUR hops share one chain: its 16 output slots are (hop, r) pairs, slot lr = 4*(hop % 4) + r <-> row
+//     16 + r of hop plane `hop`.  Chains: M-1 first tiles + ceil((M-1)/4) packed ones -- 3 instead of 4 at M = 3,
+//     5 instead of 8 at M = 5 -- and a lane of a packed chain still ends up with 4 consecutive columns of ONE
+//     (hop, node) row, so its result goes out as one 16-byte write like every other.
+template <int M, int NKS>
+constexpr int poly_chains() { return NKS == 5 ? (M - 1) + (M - 1 + 3) / 4 : (M - 1) * 2; }
+
 template <int M, int NKS, bool ADJ>
-__device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[(M - 1) * 2][NKS], int lr, int lg) {
+__device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[poly_chains<M, NKS>()][NKS], int lr, int lg) {
+    if constexpr (NKS == 5) {
 #pragma unroll
-    for (int c = 0; c < (M - 1) * 2; ++c) {
-        const int m1 = c >> 1, rt = c & 1;
+        for (int c = 0; c < M - 1; ++c)
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-            pf[c][ks] = ADJ ? Pl[m1 * kPFloats + (4 * ks + lg) * kPStride + rt * 16 + lr]
-                            : Pl[m1 * kPFloats + (rt * 16 + lr) * kPStride + 4 * ks + lg];
+            for (int ks = 0; ks < NKS; ++ks)
+                pf[c][ks] = ADJ ? Pl[c * kPFloats + (4 * ks + lg) * kPStride + lr] : Pl[c * kPFloats + lr * kPStride + 4 * ks + lg];
+#pragma unroll
+        for (int pc = 0; pc < (M - 1 + 3) / 4; ++pc) {
+            const int hop = 4 * pc + (lr >> 2), r = 16 + (lr & 3);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                float v = 0.f;
+                if (hop < M - 1) v = ADJ ? Pl[hop * kPFloats + (4 * ks + lg) * kPStride + r] : Pl[hop * kPFloats + r * kPStride + 4 * ks + lg];
+                pf[M - 1 + pc][ks] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < (M - 1) * 2; ++c) {
+            const int m1 = c >> 1, rt = c & 1;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                pf[c][ks] = ADJ ? Pl[m1 * kPFloats + (4 * ks + lg) * kPStride + rt * 16 + lr]
+                                : Pl[m1 * kPFloats + (rt * 16 + lr) * kPStride + 4 * ks + lg];
+        }
     }
 }
 
 // Diffuse ONE 16-column tile: source buf[:, src_col : src_col+16) (rows = nodes) -> slots
 // m = 1..M-1 at columns src_col + m*slot_w.  The wave reads the NKS feature fragments once and runs
-// the (M-1)*2 independent MFMA chains (all hops x both node tiles) on them.  Issued transposed
-// (features as A operand, polynomial as B operand) so that a lane ends up with 4 consecutive
-// columns of one node row: one ds_write_b128 per chain.
+// all chains (see above) on them.  Issued transposed (features as A operand, polynomial as B operand) so
+// that a lane ends up with 4 consecutive columns of one node row: one ds_write_b128 per chain.
 // Wave-local use: when the source tile was written by this same wave, only EEG_WAVE_SYNC() (no
 // workgroup barrier) is needed before the call.
 // gout != nullptr: the hop rows are also stored to global planes (forward by-product kept for the
 // weight-gradient GEMMs): plane m at gout + (m-1)*gplane, element (node, col) at node*slot_w + col.
 // ROWS < 32: the LDS tile holds only ROWS node rows (ROWS >= 4*NKS); result rows beyond are dropped.
+// (NKS == 5: rows 20..31 of the hop slots are never written -- nothing reads them in that regime.)
 template <int M, int NKS, int ROWS = 32>
 __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src_col, int slot_w,
-                                                 const float (&pf)[(M - 1) * 2][NKS], int lr, int lg,
+                                                 const float (&pf)[poly_chains<M, NKS>()][NKS], int lr, int lg,
                                                  float* __restrict__ gout = nullptr, size_t gplane = 0, int n_nodes = 0) {
-    constexpr int NC = (M - 1) * 2;
+    constexpr int NC = poly_chains<M, NKS>();
     float b[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + src_col + lr];
@@ -113,12 +139,19 @@ __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src
         for (int c = 0; c < NC; ++c) acc[c] = mfma16(b[ks], pf[c][ks], acc[c]);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int node = (c & 1) * 16 + lr;
-        float* d = buf + node * stride + ((c >> 1) + 1) * slot_w + src_col + 4 * lg;
-        if (ROWS == 32 || node < ROWS) *reinterpret_cast<float4*>(d) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
-        if (gout != nullptr && node < n_nodes)
-            *reinterpret_cast<float4*>(gout + (size_t)(c >> 1) * gplane + node * slot_w + src_col + 4 * lg) =
-                make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        int node, hop;                                   // the (hop plane, node row) this lane's 4 columns belong to
+        bool live = true;
+        if constexpr (NKS == 5) {
+            if (c < M - 1) { node = lr; hop = c; }
+            else { node = 16 + (lr & 3); hop = 4 * (c - (M - 1)) + (lr >> 2); live = hop < M - 1; }
+        } else {
+            node = (c & 1) * 16 + lr; hop = c >> 1;
+        }
+        const float4 v = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        if (live && (ROWS == 32 || node < ROWS))
+            *reinterpret_cast<float4*>(buf + node * stride + (hop + 1) * slot_w + src_col + 4 * lg) = v;
+        if (gout != nullptr && live && node < n_nodes)
+            *reinterpret_cast<float4*>(gout + (size_t)hop * gplane + node * slot_w + src_col + 4 * lg) = v;
     }
 }
 
