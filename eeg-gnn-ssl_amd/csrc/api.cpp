@@ -594,6 +594,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
                  (size_t)(d->T + 1) * state, d->T, d->B, d->N, d->act, g_seq_probe};
+    a.variant = g_tune[12] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 12 = 1: off)
     return seq_fwd(H, M, a, st);
 }
 
@@ -724,6 +725,7 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
                          saved + y.us[l] + (size_t)t * state, saved + y.cs[l] + (size_t)t * state,
                          saved + y.rhs[l] + (size_t)t * state, saved + y.hpl[l] + (size_t)t * state,
                          saved + y.rpl[l] + (size_t)t * state, hstride, 1, B, N, d->act, nullptr};
+            a.variant = g_tune[12] == 0 ? 1 : 0;
             if (seq_fwd(H, M, a, st)) return 1;
         }
         // projection (model.py:188-190): out_t = h_top W_p^T + b_p

@@ -337,6 +337,154 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     pp.dump(probe, 0);
 }
 
+// ---- two waves per SIMD (rnn_units = 64, at most 20 nodes) -----------------------------------------------------
+// Same step as seq_fwd_kernel, but 8 waves: wave w (0..3, role A) owns column tile w of r, c and h exactly as above;
+// wave 4+w (role B, same SIMD) owns column tile w of the UPDATE gate u, which depends on nothing but hops(h) and is
+// only needed by the final blend.  The matrix pipe of a SIMD is shared, so this adds no MFMA capacity: it lets one
+// wave's LDS reads, hand-overs and epilogue latencies be filled by the other wave's MFMAs.  u travels through a
+// [20][H+4] LDS tile (written before barrier (2), read after it).  Both roles pass the same two barriers per step.
+template <int H, int M, int NKS>
+__global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
+    const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
+    const float* __restrict__ bhg, const float* __restrict__ bhc,
+    float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
+    float* __restrict__ RHs, float* __restrict__ Hpl, float* __restrict__ RHpl, size_t plane_stride,
+    int T, int B, int N, int act) {
+    using G = SeqGeom<H, M>;
+    static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
+    constexpr int KAP = G::KAP, KS = G::KS, NGT = G::NGT, NCT = G::NCT, UST = H + 4;
+    EEG_DYN_SMEM(sm);
+    float* Pl = sm;
+    float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
+    float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, wave = wave8 & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+    float* RS = A2 + 32 * KAP + wave8 * 256;          // this wave's hand-over scratch (one column tile)
+    float* U = A2 + 32 * KAP + 8 * 256;               // [20][UST] update gate of the current step
+    const bool save = Rs != nullptr;
+    const int ct = wave;                               // NCT == 4 == waves per role
+
+    float w0[1][KS], w1[1][KS];                        // role A: r and c fragments; role B: u fragments (w1 unused)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        w0[0][ks] = bhg[((size_t)ks * NGT + (role == 0 ? ct : NCT + ct)) * 64 + lane];
+        w1[0][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
+    }
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int e = tid; e < 2 * 32 * KAP; e += 512) A[e] = 0.f;
+    lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
+    __syncthreads();
+    float pf[poly_chains<M, NKS>()][NKS];
+    load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
+    if (h0 != nullptr) {
+        for (int e = tid; e < N * H; e += 512) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
+    } else {
+        for (int e = tid; e < N * H; e += 512) (Hseq - (size_t)B * N * H)[(size_t)b * N * H + e] = 0.f;
+    }
+    __syncthreads();
+
+    const int node[2] = {lr, 16 + lr};
+    const bool valid[2] = {lr < N, 16 + lr < N};
+    const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int col = ct * 16 + 4 * lg;
+    int oxw[2], oh[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        oxw[nt] = nodec[nt] * (3 * H) + col;
+        oh[nt] = nodec[nt] * H + col;
+    }
+    if (role == 0) {
+        auto diffuse_own = [&](float* buf, float* planes, int t) {
+            EEG_WAVE_SYNC();
+            float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
+            lds_diffuse_tile<M, NKS>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N);
+        };
+        diffuse_own(A, Hpl, 0);
+        f32x4 nxr[2], nxc[2];
+        auto fetch_xw = [&](int t) {
+            const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                nxr[nt] = ld4(xw + oxw[nt]);
+                nxc[nt] = ld4(xw + oxw[nt] + 2 * H);
+            }
+        };
+        fetch_xw(0);
+        for (int t = 0; t < T; ++t) {
+            const size_t s = (size_t)t * B + b;
+            f32x4 ar[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
+            const f32x4 xr[2] = {nxr[0], nxr[1]}, xc[2] = {nxc[0], nxc[1]};
+            __syncthreads();                                        // (1) hops(h) complete
+            mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, ar, RS);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 rg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rg[r] = sigmoidf_(ar[0][nt][r] + xr[nt][r]);
+                f32x4 rh = rg * ld4(A + node[nt] * KAP + col);
+                rh = valid[nt] ? rh : zero4;
+                st4(A2 + node[nt] * KAP + col, rh);
+                if (save && valid[nt]) {
+                    st4(Rs + s * N * H + oh[nt], rg);
+                    st4(RHs + s * N * H + oh[nt], rh);
+                }
+            }
+            diffuse_own(A2, RHpl, t);
+            __syncthreads();                                        // (2) hops(r*h) and u complete
+            if (t + 1 < T) fetch_xw(t + 1);
+            mfma_nodes32<1, KS, true>(A2, KAP, lane, lr, lg, w1, ac, RS);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 u = ld4(U + nodec[nt] * UST + col), h = ld4(A + node[nt] * KAP + col);
+                f32x4 c, hn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = ac[0][nt][r] + xc[nt][r];
+                    c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
+                    hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
+                }
+                hn = valid[nt] ? hn : zero4;
+                st4(A + node[nt] * KAP + col, hn);
+                if (valid[nt]) {
+                    st4(Hseq + s * N * H + oh[nt], hn);
+                    if (save) st4(Cs + s * N * H + oh[nt], c);
+                }
+            }
+            if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);
+        }
+    } else {
+        f32x4 nxu[2];
+        auto fetch_xu = [&](int t) {
+            const float* xw = XW + ((size_t)t * B + b) * N * (3 * H) + H;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) nxu[nt] = ld4(xw + oxw[nt]);
+        };
+        fetch_xu(0);
+        for (int t = 0; t < T; ++t) {
+            const size_t s = (size_t)t * B + b;
+            f32x4 au[1][2] = {{zero4, zero4}};
+            const f32x4 xu[2] = {nxu[0], nxu[1]};
+            __syncthreads();                                        // (1)
+            if (t + 1 < T) fetch_xu(t + 1);
+            mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, au, RS);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = sigmoidf_(au[0][nt][r] + xu[nt][r]);
+                if (valid[nt]) {
+                    st4(U + node[nt] * UST + col, u);
+                    if (save) st4(Us + s * N * H + oh[nt], u);
+                }
+            }
+            __syncthreads();                                        // (2)
+        }
+    }
+    }   // clips of this workgroup
+}
+
 // lengths: optional int64 (B); d_at_len is added at t = lengths[b]-1, d_at_end at t = T-1.
 template <int H, int M, int NKS, bool PROBE = false>
 __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(

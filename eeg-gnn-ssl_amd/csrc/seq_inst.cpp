@@ -27,6 +27,15 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
+    if constexpr (H == 64 && NKS == 5 && M <= 3) {   // M >= 4: the r + c weights of a wave no longer fit in 256 registers
+        if (a.variant == 1 && a.probe == nullptr) {
+            const size_t lds2 = lds + 20 * (H + 4) * sizeof(float);
+            EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS>), lds2);
+            EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act);
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS>), lds);
     EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.XW, a.h0, a.P, a.p_batched,
                  a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);

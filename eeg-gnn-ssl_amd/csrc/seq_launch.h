@@ -15,6 +15,7 @@ struct SeqFwdArgs {
     size_t plane_stride;
     int T, B, N, act;
     long long* probe;
+    int variant = 0;        // 1: two waves per SIMD (seq_fwd2_kernel) where it exists
 };
 struct SeqBwdArgs {
     const float *Hseq, *h0, *Rs, *Us, *Cs, *dHseq, *d_at_end, *d_at_len;

@@ -63,7 +63,8 @@ int eeg_dcrnn_prof_report(char* buf, size_t cap);
 int eeg_dcrnn_set_seq_probe(int64_t* probe);
 /* Development aid: integer knobs selecting kernel variants for A/B timing.  key 0 = 1: register-staged NN
  * GEMM; key 1 = 1: register-staged TN GEMM;
- * key 4 = 1: XCD-aware placement of the TN k-blocks; key 9 = 1: LDS/MFMA adjoint diffusion.
+ * key 4 = 1: XCD-aware placement of the TN k-blocks; key 9 = 1: LDS/MFMA adjoint diffusion;
+ * key 12 = 1: single-wave-per-SIMD forward recurrent kernel also where the two-wave one exists (64 units, M <= 3).
  * Defaults (all 0) are the shipped configuration. */
 int eeg_dcrnn_set_tuning(int key, int value);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */

@@ -57,6 +57,17 @@ def test_wide_rows_diffuse_in_column_chunks():
     ps.check_shape_sweep("cpu", 24, 16, "dual_random_walk", 2, din=200, t_len=2, b=2, layers=2)
 
 
+def test_single_wave_forward_kernel_at_default_width(emulator, adj3d, golden):
+    """64 units with M <= 3 run the two-wave-per-SIMD forward kernel by default; the single-wave kernel (still used
+    by the cycle probe and for every other width / hop count) must give the same results at that shape."""
+    emulator.call("eeg_dcrnn_set_tuning", 12, 1)
+    try:
+        ps.check_cell_case("lap_default", golden, adj3d, "cpu")
+        ps.check_cls_case("lap_default_ce_varlen", golden, adj3d, "cpu")
+    finally:
+        emulator.call("eeg_dcrnn_set_tuning", 12, 0)
+
+
 def test_training_tail_kernels():
     ps.check_training_tail("cpu")
 
