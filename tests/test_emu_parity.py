@@ -76,6 +76,7 @@ def test_training_tail_kernels():
     ("laplacian", 8, 16, 2, 5, 3, 0.5, "tanh"),            # teacher forcing on some steps
     ("dual_random_walk", 12, 32, 3, 4, 2, 0.6, "relu"),    # shared cell used by two layers + teacher forcing
     ("laplacian", 20, 16, 1, 3, 2, None, "tanh"),          # single layer, fully autoregressive
+    ("laplacian", 8, 64, 2, 2, 2, None, "tanh"),           # 64 units, M = 3: single-step launches of the two-wave kernel
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle("cpu", filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)

@@ -346,7 +346,7 @@ def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
 
 
 @pytest.mark.parametrize("n", [3, 20, 21, 32])
-@pytest.mark.parametrize("filt,k,dout,h,layers", [("laplacian", 1, 4, 16, 1), ("dual_random_walk", 2, 36, 64, 3),
+@pytest.mark.parametrize("filt,k,dout,h,layers", [("laplacian", 1, 4, 16, 1), ("laplacian", 2, 20, 64, 2), ("dual_random_walk", 2, 36, 64, 3),
                                                    ("random_walk", 3, 100, 32, 2), ("dual_random_walk", 3, 20, 64, 2)])
 def test_decoder_shape_sweep_vs_oracle(n, filt, k, dout, h, layers, adj3d):
     """the decoder operator away from the defaults: node counts, hop counts, widths, 1-3 layers"""
