@@ -21,6 +21,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu:
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::mfma4(a, b, c); }
 #define EEG_SCHED_FENCE() ((void)0)
 #define EEG_WAVE_SYNC() emu::wave_sync()
+#define EEG_SETPRIO(p) ((void)0)
 __device__ __forceinline__ long long cycle_now() { return 0; }
 #else
 #include <hip/hip_runtime.h>
@@ -40,6 +41,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // A wave executes in lockstep and its LDS operations complete in order, so data a wave wrote to LDS
 // is visible to its own later LDS reads; this only stops the compiler from reordering across it.
 #define EEG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#define EEG_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
 __device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         oh[nt] = nodec[nt] * H + col;
     }
     if (role == 0) {
+        EEG_SETPRIO(3);         // the r -> r*h -> c chain is the critical path: its instructions issue first, u fills the gaps
         auto diffuse_own = [&](float* buf, float* planes, int t) {
             EEG_WAVE_SYNC();
             float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
