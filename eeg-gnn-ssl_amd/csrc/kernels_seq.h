@@ -63,10 +63,14 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float
 // register r of a lane is then the lane group's partial of out[node 16 + r][col lr].  The partials
 // are handed through `scratch` (per-wave LDS, NT*256 floats) to the lanes that own these nodes in the
 // tile layout (lane (lr < 4, lg): node 16 + lr, columns 4*lg..4*lg+3), which also sums the 4 groups.
-template <int NT, int NKS, bool REM4>
+// MODE (REM4 only): 0 = both node tiles; 1 = only the 16-node tile (acc[.][0]); 2 = only the 4x4x1 remainder
+// (acc[.][1]) -- the two-wave forward kernel splits a GEMM between its waves that way.
+template <int NT, int NKS, bool REM4, int MODE = 0>
 __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
                                              const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
+    static_assert(MODE == 0 || REM4, "split modes exist for the 4x4x1 remainder only");
+    constexpr bool DO16 = MODE != 2, DO4 = REM4 && MODE != 1;
     const float* p0 = X + lr * stride + 4 * lg;
     const float* p1 = REM4 ? X + (16 + (lane & 3)) * stride + 4 * lg : p0 + 16 * stride;
     f32x4 rem[NT][4];           // one chain per k-step of the quad: consecutive 4x4x1 MFMAs are independent
@@ -74,25 +78,28 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 a0 = *reinterpret_cast<const float4*>(p0);
-    float4 a1 = *reinterpret_cast<const float4*>(p1);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (DO16) a0 = *reinterpret_cast<const float4*>(p0);
+    if (!REM4 || DO4) a1 = *reinterpret_cast<const float4*>(p1);
 #pragma unroll
     for (int q = 0; q < NKS / 4; ++q) {
         float4 n0 = a0, n1 = a1;
         if (q + 1 < NKS / 4) {
-            n0 = *reinterpret_cast<const float4*>(p0 + 16 * (q + 1));
-            n1 = *reinterpret_cast<const float4*>(p1 + 16 * (q + 1));
+            if (DO16) n0 = *reinterpret_cast<const float4*>(p0 + 16 * (q + 1));
+            if (!REM4 || DO4) n1 = *reinterpret_cast<const float4*>(p1 + 16 * (q + 1));
         }
         EEG_SCHED_FENCE();      // next quad's fragments are in flight while this quad's MFMAs issue
         const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
+        if (DO16) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                acc[i][0] = mfma16(w[i][4 * q + j], x0[j], acc[i][0]);
-                if (!REM4) acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
-            }
-        if (REM4) {                 // the quad's 4x4x1 MFMAs as one group (fewer switches between MFMA shapes)
+                for (int i = 0; i < NT; ++i) {
+                    acc[i][0] = mfma16(w[i][4 * q + j], x0[j], acc[i][0]);
+                    if (!REM4) acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
+                }
+        }
+        if (DO4) {                  // the quad's 4x4x1 MFMAs as one group (fewer switches between MFMA shapes)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -102,7 +109,7 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
         a0 = n0;
         a1 = n1;
     }
-    if (REM4) {
+    if (DO4) {
         // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr);  reader (lr < 4, lg): sum over the 4 groups
         // of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
 #pragma unroll
@@ -338,19 +345,24 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 }
 
 // ---- two waves per SIMD (rnn_units = 64, at most 20 nodes) -----------------------------------------------------
-// Same step as seq_fwd_kernel, but 8 waves: wave w (0..3, role A) owns column tile w of r, c and h exactly as above;
-// wave 4+w (role B, same SIMD) owns column tile w of the UPDATE gate u, which depends on nothing but hops(h) and is
-// only needed by the final blend.  The matrix pipe of a SIMD is shared, so this adds no MFMA capacity: it lets one
-// wave's LDS reads, hand-overs and epilogue latencies be filled by the other wave's MFMAs.  u travels through a
-// [20][H+4] LDS tile (written before barrier (2), read after it).  Both roles pass the same two barriers per step.
-template <int H, int M, int NKS>
+// Same step as seq_fwd_kernel, but 8 waves: wave w (0..3, role A) owns column tile w of r, r*h and the 16-node
+// part of c and h; wave 4+w (role B, same SIMD) owns column tile w of the UPDATE gate u -- which depends on nothing
+// but hops(h) and is only needed by the final blend -- and the remainder nodes 16..19 of c and h.  The matrix pipe
+// of a SIMD is shared, so this adds no MFMA capacity: it takes work off the critical chain (r -> r*h -> c -> h) and
+// lets one wave's LDS reads, hand-overs and epilogue latencies be filled by the other wave's MFMAs.
+//   phase 1 (after barrier 1: hops(h) complete)   A: r (both node tiles), r*h, hops(r*h)      B: u (nodes 0..15 -> LDS U)
+//   phase 2 (after barrier 2: hops(r*h) complete) A: c, h' of nodes 0..15 (u from LDS U)      B: c, h' of nodes 16..19
+//   phase 3 (after barrier 3: h' complete)        A: hops(h') for the next step              B: -
+template <int H, int M, int NKS, bool PROBE = false>
 __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
     float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
     float* __restrict__ RHs, float* __restrict__ Hpl, float* __restrict__ RHpl, size_t plane_stride,
-    int T, int B, int N, int act) {
+    int T, int B, int N, int act, long long* probe) {
     using G = SeqGeom<H, M>;
+    PhaseProbe<PROBE> pp;
+    pp.start();
     static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
     constexpr int KAP = G::KAP, KS = G::KS, NGT = G::NGT, NCT = G::NCT, UST = H + 4;
     EEG_DYN_SMEM(sm);
@@ -360,11 +372,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, wave = wave8 & 3;
     const int lr = lane & 15, lg = lane >> 4;
     float* RS = A2 + 32 * KAP + wave8 * 256;          // this wave's hand-over scratch (one column tile)
-    float* U = A2 + 32 * KAP + 8 * 256;               // [20][UST] update gate of the current step
+    float* U = A2 + 32 * KAP + 8 * 256;               // [16][UST] update gate of nodes 0..15 of the current step
     const bool save = Rs != nullptr;
     const int ct = wave;                               // NCT == 4 == waves per role
 
-    float w0[1][KS], w1[1][KS];                        // role A: r and c fragments; role B: u fragments (w1 unused)
+    float w0[1][KS], w1[1][KS];                        // role A: r and c fragments; role B: u and c fragments
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         w0[0][ks] = bhg[((size_t)ks * NGT + (role == 0 ? ct : NCT + ct)) * 64 + lane];
@@ -375,8 +387,6 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     for (int e = tid; e < 2 * 32 * KAP; e += 512) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
-    float pf[poly_chains<M, NKS>()][NKS];
-    load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
     if (h0 != nullptr) {
         for (int e = tid; e < N * H; e += 512) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
     } else {
@@ -396,29 +406,31 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         oh[nt] = nodec[nt] * H + col;
     }
     if (role == 0) {
-        EEG_SETPRIO(3);         // the r -> r*h -> c chain is the critical path: its instructions issue first, u fills the gaps
+        EEG_SETPRIO(3);         // the r -> r*h -> c chain is the critical path: its instructions issue first
+        float pf[poly_chains<M, NKS>()][NKS];
+        load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
         auto diffuse_own = [&](float* buf, float* planes, int t) {
             EEG_WAVE_SYNC();
             float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
             lds_diffuse_tile<M, NKS>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N);
         };
         diffuse_own(A, Hpl, 0);
-        f32x4 nxr[2], nxc[2];
+        f32x4 nxr[2], nxc;
         auto fetch_xw = [&](int t) {
             const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                nxr[nt] = ld4(xw + oxw[nt]);
-                nxc[nt] = ld4(xw + oxw[nt] + 2 * H);
-            }
+            nxr[0] = ld4(xw + oxw[0]);
+            nxr[1] = ld4(xw + oxw[1]);
+            nxc = ld4(xw + oxw[0] + 2 * H);
         };
         fetch_xw(0);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
             f32x4 ar[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
-            const f32x4 xr[2] = {nxr[0], nxr[1]}, xc[2] = {nxc[0], nxc[1]};
+            const f32x4 xr[2] = {nxr[0], nxr[1]}, xc = nxc;
             __syncthreads();                                        // (1) hops(h) complete
+            pp.mark(0);
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, ar, RS);
+            pp.mark(1);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 rg;
@@ -432,58 +444,89 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     st4(RHs + s * N * H + oh[nt], rh);
                 }
             }
+            pp.mark(2);
             diffuse_own(A2, RHpl, t);
-            __syncthreads();                                        // (2) hops(r*h) and u complete
+            pp.mark(7);
+            __syncthreads();                                        // (2) hops(r*h) and u of nodes 0..15 complete
+            pp.mark(3);
             if (t + 1 < T) fetch_xw(t + 1);
-            mfma_nodes32<1, KS, true>(A2, KAP, lane, lr, lg, w1, ac, RS);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 u = ld4(U + nodec[nt] * UST + col), h = ld4(A + node[nt] * KAP + col);
+            mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac, RS);
+            pp.mark(4);
+            {
+                const f32x4 u = ld4(U + lr * UST + col), h = ld4(A + lr * KAP + col);
                 f32x4 c, hn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pre = ac[0][nt][r] + xc[nt][r];
+                    const float pre = ac[0][0][r] + xc[r];
                     c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
                     hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                 }
-                hn = valid[nt] ? hn : zero4;
-                st4(A + node[nt] * KAP + col, hn);
-                if (valid[nt]) {
-                    st4(Hseq + s * N * H + oh[nt], hn);
-                    if (save) st4(Cs + s * N * H + oh[nt], c);
+                hn = valid[0] ? hn : zero4;
+                st4(A + lr * KAP + col, hn);
+                if (valid[0]) {
+                    st4(Hseq + s * N * H + oh[0], hn);
+                    if (save) st4(Cs + s * N * H + oh[0], c);
                 }
             }
+            pp.mark(5);
+            __syncthreads();                                        // (3) h' complete (rows 16..19 come from role B)
             if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);
+            pp.mark(6);
         }
     } else {
-        f32x4 nxu[2];
-        auto fetch_xu = [&](int t) {
-            const float* xw = XW + ((size_t)t * B + b) * N * (3 * H) + H;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) nxu[nt] = ld4(xw + oxw[nt]);
+        f32x4 nxu[2], nxc;
+        auto fetch_x = [&](int t) {
+            const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
+            nxu[0] = ld4(xw + oxw[0] + H);
+            nxu[1] = ld4(xw + oxw[1] + H);
+            nxc = ld4(xw + oxw[1] + 2 * H);
         };
-        fetch_xu(0);
+        fetch_x(0);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
-            f32x4 au[1][2] = {{zero4, zero4}};
-            const f32x4 xu[2] = {nxu[0], nxu[1]};
+            f32x4 au[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
+            const f32x4 xu[2] = {nxu[0], nxu[1]}, xc = nxc;
             __syncthreads();                                        // (1)
-            if (t + 1 < T) fetch_xu(t + 1);
+            if (t + 1 < T) fetch_x(t + 1);
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, au, RS);
+            f32x4 u;                                                // nodes 16..19: stays in registers for the blend
+            {
+                f32x4 u0;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                f32x4 u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = sigmoidf_(au[0][nt][r] + xu[nt][r]);
-                if (valid[nt]) {
-                    st4(U + node[nt] * UST + col, u);
-                    if (save) st4(Us + s * N * H + oh[nt], u);
+                for (int r = 0; r < 4; ++r) {
+                    u0[r] = sigmoidf_(au[0][0][r] + xu[0][r]);
+                    u[r] = sigmoidf_(au[0][1][r] + xu[1][r]);
                 }
+                st4(U + lr * UST + col, u0);                        // nodes >= N: finite, never used
+                if (save && valid[0]) st4(Us + s * N * H + oh[0], u0);
             }
             __syncthreads();                                        // (2)
+            // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend
+            mfma_nodes32<1, KS, true, 2>(A2, KAP, lane, lr, lg, w1, ac, RS);
+            {
+                const f32x4 h = ld4(A + node[1] * KAP + col);
+                f32x4 c, hn;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = ac[0][1][r] + xc[r];
+                    c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
+                    hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
+                }
+                hn = valid[1] ? hn : zero4;
+                if (lr < 4) st4(A + node[1] * KAP + col, hn);       // rows 16..19 (the others belong to nobody here)
+                if (valid[1]) {
+                    st4(Hseq + s * N * H + oh[1], hn);
+                    if (save) {
+                        st4(Cs + s * N * H + oh[1], c);
+                        st4(Us + s * N * H + oh[1], u);
+                    }
+                }
+            }
+            __syncthreads();                                        // (3)
         }
     }
     }   // clips of this workgroup
+    if (role == 0) pp.dump(probe, 0);
 }
 
 // lengths: optional int64 (B); d_at_len is added at t = lengths[b]-1, d_at_end at t = T-1.

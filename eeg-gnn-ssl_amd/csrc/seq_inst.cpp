@@ -20,7 +20,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
     if (lds > kMaxLdsBytes) return 3;
     if constexpr (H == 64 && M == 3 && NKS == 5) {
-        if (a.probe != nullptr) {
+        if (a.probe != nullptr && a.variant != 1) {
             EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS, true>), lds);
             EEG_LAUNCH_P("seq_fwd", (seq_fwd_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.XW, a.h0, a.P,
                          a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
@@ -28,11 +28,19 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
         }
     }
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // M >= 4: the r + c weights of a wave no longer fit in 256 registers
-        if (a.variant == 1 && a.probe == nullptr) {
+        if (a.variant == 1) {
             const size_t lds2 = lds + 20 * (H + 4) * sizeof(float);
+            if constexpr (M == 3) {
+                if (a.probe != nullptr) {
+                    EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, true>), lds2);
+                    EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
+                                 a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
+                    return hipGetLastError() == hipSuccess ? 0 : 2;
+                }
+            }
             EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS>), lds2);
             EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
-                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act);
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
