@@ -63,7 +63,7 @@ def test_single_wave_forward_kernel_at_default_width(emulator, adj3d, golden):
     emulator.call("eeg_dcrnn_set_tuning", 12, 1)
     try:
         ps.check_cell_case("lap_default", golden, adj3d, "cpu")
-        ps.check_cls_case("lap_default_ce_varlen", golden, adj3d, "cpu")
+        ps.check_cell_case("lap_l1_default", golden, adj3d, "cpu")
     finally:
         emulator.call("eeg_dcrnn_set_tuning", 12, 0)
 
