@@ -36,7 +36,7 @@ lib.query("eeg_dcrnn_set_seq_probe", ctypes.c_void_p(probe.data_ptr()))
 run()          # last launches of each direction (layer 0 bwd, layer 1 fwd) leave their counters
 lib.query("eeg_dcrnn_set_seq_probe", None)
 p = probe.view(batch, 4, 32).double().cpu()
-names_f = ["loop top + barrier(1)", "gate GEMM", "gate epilogue", "barrier(2)", "cand GEMM", "cand epilogue", "diffuse(h) issue", "diffuse(rh) issue"]
+names_f = ["loop top + barrier(1)", "gate GEMM", "gate epilogue", "barrier(2)", "cand GEMM (16-node part)", "cand epilogue", "barrier(3) + diffuse(h)", "diffuse(rh) issue"]   # chain waves of seq_fwd2_kernel
 names_b = ["E1", "barrier(1)", "GEMM1", "epi1", "adj diffuse dG+bar", "GEMM2", "operand copy + prefetch issue", "adj diffuse dC issue"]
 for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
     tot = p[:, :, off:off + 8].sum(-1).mean().item() / t_len
