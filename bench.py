@@ -79,7 +79,7 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed):
         q = torch.quantile(stat, torch.tensor([0.25, 0.5, 0.75]))
         y = torch.bucketize(stat, q).to(torch.int64)
     if filter_type == "laplacian":
-        adj = np.load(os.path.join(ROOT, "eeg-gnn-ssl_amd", "data", "electrode_adj_3d.npy"))
+        adj = np.load(os.path.join(ROOT, "eeg_gnn_ssl_amd", "data", "electrode_adj_3d.npy"))
         s = utils.compute_supports(adj, "laplacian")[0]
         supports = [s.unsqueeze(0).repeat(batch, 1, 1)]     # the trainers always pass batched supports (Q5)
     else:

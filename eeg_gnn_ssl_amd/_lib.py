@@ -85,7 +85,7 @@ class EegDcrnnLib:
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} not found: the MI355X HIP library is not built. Run `python -c 'import "
-                f"__graft_entry__ as g; g.build()'` (or `make -C eeg-gnn-ssl_amd/csrc`). There is no CPU fallback.")
+                f"__graft_entry__ as g; g.build()'` (or `make -C eeg_gnn_ssl_amd/csrc`). There is no CPU fallback.")
         self.path = path
         self._dll = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():

@@ -8,7 +8,7 @@
  *
  * The reference has no FFI of its own (pure Python); each entry point below states
  * the reference code it replaces.  The ctypes binding that a maintainer of the reference would
- * add is shown in INTEGRATION.md and lives in eeg-gnn-ssl_amd/_lib.py.
+ * add is shown in INTEGRATION.md and lives in eeg_gnn_ssl_amd/_lib.py.
  *
  * Layouts.  N = nodes (<= 32), H = rnn_units (16 | 32 | 64), F/Fin = per-node input features of a
  * layer (multiple of 4), M = number of hop matrices incl. identity = n_supports*K + 1 (<= 8),

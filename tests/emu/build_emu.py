@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE: compile the kernel SOURCES of eeg-gnn-ssl_amd/csrc against the fiber-based
+"""TEST INFRASTRUCTURE: compile the kernel SOURCES of eeg_gnn_ssl_amd/csrc against the fiber-based
 SIMT emulator (simt_emu.h) into tests/_emu_build/libeeg_dcrnn_emu.so so that the kernel logic,
 the C ABI orchestration and the Python host layer can be exercised on a machine without a GPU.
 The product never loads this library; only tests do (see tests/emu_support.py)."""
@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-CSRC = os.path.join(ROOT, "eeg-gnn-ssl_amd", "csrc")
+CSRC = os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc")
 OUT_DIR = os.path.join(ROOT, "tests", "_emu_build")
 OUT = os.path.join(OUT_DIR, "libeeg_dcrnn_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY — a tiny single-OS-thread SIMT emulator used by tests/ to execute the
-// HIP kernel SOURCES of eeg-gnn-ssl_amd/csrc on the CPU (no GPU in the build container; GPU
+// HIP kernel SOURCES of eeg_gnn_ssl_amd/csrc on the CPU (no GPU in the build container; GPU
 // minutes are scarce).  It is NOT a CPU fallback: the product library never includes this file
 // (it is only reachable with -DEEG_SIMT_EMU, which only tests/emu/build_emu.py passes).
 //

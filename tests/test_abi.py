@@ -7,7 +7,7 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "eeg_dcrnn.h")
-LIB = os.path.join(ROOT, "eeg-gnn-ssl_amd", "libeeg_dcrnn_hip.so")
+LIB = os.path.join(ROOT, "eeg_gnn_ssl_amd", "libeeg_dcrnn_hip.so")
 
 
 def declared_symbols():
@@ -24,7 +24,7 @@ def test_header_declares_the_expected_surface():
 
 
 def test_library_builds_loads_and_exports_every_declared_symbol():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "eeg-gnn-ssl_amd", "csrc"), "-j", "8"],
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc"), "-j", "8"],
                           stdout=subprocess.DEVNULL)
     dll = ctypes.CDLL(LIB)
     for s in declared_symbols():
