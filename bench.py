@@ -95,37 +95,44 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed):
 
 
 def algorithmic_work(filter_type, t_len, batch, task="detection"):
-    """Per-step algorithmic FLOPs / bytes of every kernel class."""
+    """Per-step algorithmic FLOPs / bytes of every profiled kernel role.  Roles = the names the
+    library's event recorder uses; at the benchmark shapes each role is ONE kernel symbol per layer
+    (`ROLE_SYMBOLS`), so `roofline.kernels` is a by-symbol table."""
     m = (2 if filter_type == "dual_random_walk" else 1) * K_DIFF + 1
     n, h = N_NODES, H_UNITS
     s = t_len * batch
     r = s * n
     fins = [D_IN] + [h] * (LAYERS - 1)
-    w = {"seq_fwd": 0.0, "seq_bwd": 0.0, "gemm_nn": 0.0, "gemm_tn": 0.0, "diffuse_fwd": 0.0, "diffuse_adj": 0.0}
+    w = {k: 0.0 for k in ("seq_fwd", "seq_bwd", "gemm_nn_xw", "gemm_nn_dx", "gemm_tn_x", "gemm_tn_hg", "gemm_tn_hc",
+                          "diffuse_fwd", "diffuse_adj")}
     if filter_type == "dual_random_walk":
         w["corr_gram"] = 4.0 * s * n * D_IN          # per-clip correlation graph: every clip read once
     for l, fin in enumerate(fins):
         w["seq_fwd"] += s * (2 * (m - 1) * 2 * n * n * h + 2 * n * (h * m) * 3 * h)
         w["seq_bwd"] += s * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
-        w["gemm_nn"] += 2.0 * r * (m * fin) * 3 * h
-        w["gemm_tn"] += 2.0 * r * (m * fin) * 3 * h + 2.0 * r * (m * h) * 2 * h + 2.0 * r * (m * h) * h
-        # layer 0 only: read X once, write M-1 planes + the time-major copy of the batch-major input (the hop
-        # planes of h and r*h -- and with them the input planes of the layers above -- are by-products of seq_fwd)
+        w["gemm_nn_xw"] += 2.0 * r * (m * fin) * 3 * h
+        w["gemm_tn_x"] += 2.0 * r * (m * fin) * 3 * h
+        w["gemm_tn_hg"] += 2.0 * r * (m * h) * 2 * h
+        w["gemm_tn_hc"] += 2.0 * r * (m * h) * h
+        # layer 0 only (the layers above take their input planes from the recurrent kernel below): SURVEY.md §8(d)'s
+        # bytes = read X once, write M-1 planes
         if l == 0:
-            w["diffuse_fwd"] += 4.0 * s * n * fin * (m + 1)
+            w["diffuse_fwd"] += 4.0 * s * n * fin * m
         if l > 0:
-            w["gemm_nn"] += 2.0 * r * 3 * h * (m * fin)
+            w["gemm_nn_dx"] += 2.0 * r * 3 * h * (m * fin)
             w["diffuse_adj"] += 4.0 * s * n * fin * (m + 1)
     if task == "ssl":       # decoder: T_OUT autoregressive steps; every layer's dx is needed (feedback / layer below)
         sd = T_OUT * batch
         rd = sd * n
-        for k in list(w):
+        for k in ("seq_fwd", "seq_bwd", "gemm_nn", "gemm_tn_x", "gemm_tn_hg", "gemm_tn_hc", "gemm_tn", "diffuse_fwd", "diffuse_adj"):
             w["dec_" + k] = 0.0
         for l, fin in enumerate(fins):
             w["dec_seq_fwd"] += sd * (2 * (m - 1) * 2 * n * n * h + 2 * n * (h * m) * 3 * h)
             w["dec_seq_bwd"] += sd * ((m - 1) * 2 * n * n * 3 * h + 2 * n * (h * m) * 3 * h)
             w["dec_gemm_nn"] += 2.0 * rd * (m * fin) * 3 * h * 2
-            w["dec_gemm_tn"] += 2.0 * rd * (m * fin) * 3 * h + 2.0 * rd * (m * h) * 3 * h
+            w["dec_gemm_tn_x"] += 2.0 * rd * (m * fin) * 3 * h
+            w["dec_gemm_tn_hg"] += 2.0 * rd * (m * h) * 2 * h
+            w["dec_gemm_tn_hc"] += 2.0 * rd * (m * h) * h
             if l == 0:
                 w["dec_diffuse_fwd"] += 4.0 * sd * n * fin * m     # first decoder layer only (as above)
             w["dec_diffuse_adj"] += 4.0 * sd * n * fin * (m + 1)
@@ -134,17 +141,32 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
     return w
 
 
-def cpu_baseline(workload, sample_clips=32, budget_s=60.0):
-    """The oracle (torch-eager restatement of the reference's op sequence, autograd backward)
-    timed on this host's cores on a bounded sample of the same workload.  The op stream is ~10^4
-    tiny ATen calls per step, so more threads is not faster: a few thread counts are probed on a
-    small sample and the best one is used (and reported as `cores`)."""
+# kernel symbol behind every role at the cfg2 shapes (64 units, M = 3, 19 nodes)
+ROLE_SYMBOLS = {
+    "seq_fwd": "seq_fwd2_kernel<64,3,5>", "seq_bwd": "seq_bwd_kernel<64,3,5>",
+    "gemm_nn_xw": "gemm_nn_dma_kernel<6,20,2> (layer 0, K=300) + gemm_nn_dma_kernel<6,16,2> (layer 1, K=192)",
+    "gemm_nn_dx": "gemm_nn_dma_kernel<6,16,2>", "gemm_tn_x": "gemm_tn_dma_kernel<2,6,16>",
+    "gemm_tn_hg": "gemm_tn_dma_kernel<2,4,32>", "gemm_tn_hc": "gemm_tn_dma_kernel<2,2,32>",
+    "diffuse_fwd": "diffuse_fwd_stream_kernel<19>", "diffuse_adj": "diffuse_adj_stream_kernel<19>",
+}
+# per-clip algorithmic FLOPs (fwd+bwd) and compulsory HBM bytes -> the roofs the whole step is priced against
+CLIP_GFLOP = {"cfg1": 1.302 * 12 / 60, "cfg2": 1.302, "cfg3": 2.221, "cfg4": 1.302, "cfg5": 2.674}
+CLIP_BYTES = {"cfg1": 8.208e6 * 12 / 60, "cfg2": 8.208e6, "cfg3": 8.213776e6, "cfg4": 8.208e6, "cfg5": 10.1e6}
+# the GENUINE reference on the survey container's 8 Xeon vCPUs at the same per-GPU batch (clips/s)
+REFERENCE_CPU_CLIPS_PER_S = {"cfg1": 136.0, "cfg2": 173.0, "cfg3": 108.0, "cfg4": 237.0, "cfg5": 110.0}
+
+
+def cpu_baseline(workload, budget_s=45.0):
+    """The oracle (torch-eager restatement of the reference's op sequence, autograd backward) timed on this host's
+    cores at the workload's PER-GPU batch (SURVEY.md §8(d) / BASELINE.md §4: B=256 for cfg2; ~2 s per step), fwd + loss +
+    bwd, one warm-up + best of up to 3 inside the time budget.  The op stream is ~10^4 small ATen calls per step, so
+    more threads is not faster: a few thread counts are probed on a 4-clip sample and the best one is used (`cores`)."""
     from oracle import dcrnn_oracle as orc
-    task, filt, t_len, _, classes = WORKLOADS[workload]
+    task, filt, t_len, batch, classes = WORKLOADS[workload]
     cfg = orc.DCRNNConfig(filter_type=filt, num_classes=max(classes, 1))
     kind = "nextTimePred" if task == "ssl" else "classification"
     params = {k: v.requires_grad_(True) for k, v in orc.init_params(cfg, kind, seed=0).items()}
-    x, y, lengths, sup = synthetic_batch(task, filt, t_len, sample_clips, classes, seed=123)
+    x, y, lengths, sup = synthetic_batch(task, filt, t_len, batch, classes, seed=123)
 
     def one(nclips):
         for p in params.values():
@@ -162,26 +184,27 @@ def cpu_baseline(workload, sample_clips=32, budget_s=60.0):
     ncpu = os.cpu_count() or 1
     t_start = time.perf_counter()
     probe = {}
-    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32)}):
         torch.set_num_threads(nt)
         one(4)                                   # warm-up
         probe[nt] = one(4)
         print(f"[bench] cpu baseline probe: {nt} threads -> {4 / probe[nt]:.1f} clips/s", file=sys.stderr, flush=True)
-        if time.perf_counter() - t_start > budget_s / 2:
-            break
     best_nt = min(probe, key=probe.get)
     torch.set_num_threads(best_nt)
-    one(sample_clips)
+    one(min(batch, 32))                          # warm-up of the allocator at a larger size
     best = float("inf")
     reps = 0
-    while reps < 3 and time.perf_counter() - t_start < budget_s:
-        best = min(best, one(sample_clips))
+    while reps < 3 and (reps == 0 or time.perf_counter() - t_start < budget_s):
+        best = min(best, one(batch))
         reps += 1
-    return {"value": round(sample_clips / best, 2), "unit": "clips/s", "cores": best_nt, "host_logical_cpus": ncpu,
-            "kind": "port",
-            "sample": f"{sample_clips} clips x T={t_len} of {workload} (fwd+loss+bwd, best of {reps} after 1 warm-up; "
-                      f"torch-eager oracle = op-for-op restatement of the reference; thread count chosen by probe "
-                      f"{ {k: round(4 / v, 1) for k, v in probe.items()} } clips/s)"}
+    value = batch / best
+    ref = REFERENCE_CPU_CLIPS_PER_S.get(workload)
+    return {"value": round(value, 2), "unit": "clips/s", "cores": best_nt, "host_logical_cpus": ncpu, "kind": "port",
+            "sample": f"{batch} clips x T={t_len} of {workload} = the per-GPU batch (fwd+loss+bwd, {best:.2f} s/step, best of {reps} "
+                      f"after a warm-up; torch-eager oracle = op-for-op restatement of the reference; thread count chosen by probe "
+                      f"{ {k: round(4 / v, 1) for k, v in probe.items()} } clips/s on 4 clips)",
+            "reference_8vcpu_clips_per_s": ref,
+            "ratio_to_reference_8vcpu": None if not ref else round(value / ref, 3)}
 
 
 def main():
@@ -196,10 +219,11 @@ def main():
     ap.add_argument("--host-supports", action="store_true", help="correlation-graph workloads: use supports prepared "
                     "on the host (the reference's DataLoader path) instead of building them on the GPU every step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the "
-                    "captured HIP graph of forward+loss+backward")
-    ap.add_argument("--graph", action="store_true", help="replay the HIP graph also when launched on several GPUs "
-                    "(default there: eager launches; the replay measured no faster at 1 GPU, the host runs ahead anyway)")
-    ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning)")
+                    "captured HIP graph of forward+loss+backward (default: replay, at any number of GPUs)")
+    ap.add_argument("--no-stream-inputs", action="store_true", help="skip the second timed pass that feeds a fresh pinned "
+                    "host batch into the step's input tensors on a side stream every step")
+    ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning); loads "
+                    "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
     args = ap.parse_args()
 
     t_boot = time.perf_counter()
@@ -218,9 +242,11 @@ def main():
     from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib, ops
     from eeg_gnn_ssl_amd.train_step import TrainStep
 
-    for kv in args.tune:
-        k, v = kv.split("=")
-        _lib.get_lib().call("eeg_dcrnn_set_tuning", int(k), int(v))
+    if args.tune:                                                    # development A/B runs only
+        _lib._LIB = _lib.EegDcrnnLib(_lib.DEV_LIB_PATH)
+        for kv in args.tune:
+            k, v = kv.split("=")
+            _lib._LIB.call("eeg_dcrnn_set_tuning", int(k), int(v))
     task, filt, t_len, batch, classes = WORKLOADS[args.workload]
     if args.batch:
         batch = args.batch
@@ -232,9 +258,9 @@ def main():
         model = DCRNNModel_classification(make_args(filt), classes, device=dev).to(dev)
     model.train()
     stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0)
-    x, y, lengths, supports = synthetic_batch(task, filt, t_len, batch, classes, seed=123 + rank)
-    x, y, lengths = x.to(dev), y.to(dev), lengths.to(dev)
-    supports = [s.to(dev) for s in supports]
+    hx, hy, hlen, hsup = synthetic_batch(task, filt, t_len, batch, classes, seed=123 + rank)
+    x, y, lengths = hx.to(dev), hy.to(dev), hlen.to(dev)
+    supports = [s.to(dev) for s in hsup]
     device_graph = filt == "dual_random_walk" and not args.host_supports
     if device_graph:
         # per-clip correlation graph + supports are rebuilt from the clips on the GPU inside every step
@@ -257,8 +283,9 @@ def main():
     log(f"inputs on device, {args.warmup} warm-up steps")
     lib = _lib.get_lib()
     graphed = False
-    if not args.no_graph and (world == 1 or args.graph):
-        # forward + loss + backward replayed as ONE HIP graph; all-reduce + fused clip/Adam stay eager
+    if not args.no_graph:
+        # forward + loss + backward replayed as ONE HIP graph at any number of GPUs (one launch per step and rank
+        # instead of ~60: what the multi-GPU scaling hinges on); the all-reduce + fused clip/Adam stay eager
         try:
             stepper.capture(x, y, lengths, supports)
             graphed = True
@@ -266,15 +293,62 @@ def main():
             log(f"HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly")
             torch.cuda.synchronize()
     one_step = stepper.replay_step if graphed else (lambda: stepper.step(x, y, lengths, supports))
-    for _ in range(args.warmup):
-        one_step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+
+    def timed(step_fn):
+        for _ in range(args.warmup):
+            step_fn()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step_fn()
+        sync_all()
+        return time.perf_counter() - t0, loss
+
+    elapsed, loss = timed(one_step)
     log(f"timed {args.steps} steps ({'graph replay' if graphed else 'eager'}): {elapsed / args.steps * 1e3:.3f} ms/step")
+
+    # second timed pass: every step first receives a FRESH batch from pinned host memory (the trainer's situation: at
+    # 80 k clips/s the input stream is ~37 GB/s per GPU).  The copy of step k+1 runs on a side stream into a second
+    # device buffer while step k computes; the step's static input tensors are refreshed by a device-to-device copy.
+    streamed = None
+    if not args.no_stream_inputs:
+        pin = [t.pin_memory() for t in (hx, hy)]
+        stage = [torch.empty_like(x), torch.empty_like(y)]
+        side = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        consumed = torch.cuda.Event()
+        consumed.record()
+
+        def fetch():
+            with torch.cuda.stream(side):
+                side.wait_event(consumed)                        # previous contents of the staging buffers were used
+                stage[0].copy_(pin[0], non_blocking=True)
+                stage[1].copy_(pin[1], non_blocking=True)
+                ready.record(side)
+
+        fetch()
+
+        def streamed_step():
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ready)
+            x.copy_(stage[0])
+            y.copy_(stage[1])
+            consumed.record(cur)
+            fetch()                                              # next batch travels while this step computes
+            return one_step()
+
+        el2, _ = timed(streamed_step)
+        t2 = torch.tensor([el2], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        el2 = float(t2.item())
+        streamed = {"value": round(batch * world / (el2 / args.steps), 1), "unit": "clips/s",
+                    "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                    "host_bytes_per_step_per_gpu": int(hx.numel() * 4 + hy.numel() * hy.element_size()),
+                    "note": "a fresh batch per step from pinned host memory: H2D copy on a side stream into a staging buffer, "
+                            "overlapped with the previous step; D2D refresh of the step's input tensors inside the step"}
+        log(f"streamed inputs: {streamed['ms_per_step']} ms/step")
+
     prof = {}
     if not args.no_prof:
         # per-kernel durations: the SAME K steps once more, launched eagerly with a HIP-event pair
@@ -290,10 +364,16 @@ def main():
         for line in buf.value.decode().strip().splitlines():
             name, cnt, ms = line.split()
             prof[name] = (int(cnt), float(ms))
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    per_rank = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        allr = [torch.empty_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+        per_rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in allr]
+        elapsed = max(float(t.item()) for t in allr)             # MAX over ranks
+        backend = dist.get_backend()
+        world_seen = dist.get_world_size()
+    else:
+        per_rank_ms, backend, world_seen = [round(elapsed / args.steps * 1e3, 3)], None, 1
     loss_val = float(loss.item())
     if rank != 0:
         if world > 1:
@@ -306,7 +386,10 @@ def main():
     kernels = {}
     for name, (cnt, ms) in prof.items():
         per_step_ms = ms / args.steps
-        ent = {"launches_per_step": cnt / args.steps, "ms_per_step": round(per_step_ms, 4)}
+        ent = {"launches_per_step": cnt / args.steps, "ms_per_step": round(per_step_ms, 4),
+               "avg_launch_ms": round(per_step_ms / (cnt / args.steps), 4)}
+        if name in ROLE_SYMBOLS and args.workload in ("cfg2", "cfg4"):
+            ent["symbol"] = ROLE_SYMBOLS[name]
         if name in work and work[name] > 0 and per_step_ms > 0:
             if "diffuse" in name or name == "corr_gram":
                 gbs = work[name] / (per_step_ms * 1e-3) / 1e9
@@ -317,24 +400,38 @@ def main():
                            frac=round(tf / PEAK_MFMA_F32_TFLOPS, 4))
         kernels[name] = ent
     roofline = None
-    timed = {k: v for k, v in kernels.items() if "bound" in v}
-    if timed:
-        dom = max(timed, key=lambda k: timed[k]["ms_per_step"])
-        d = timed[dom]
-        traffic = None            # HBM bytes per launch from the committed PMC passes (same command, cfg2)
+    timed_k = {k: v for k, v in kernels.items() if "bound" in v}
+    if timed_k:
+        dom = max(timed_k, key=lambda k: timed_k[k]["ms_per_step"])     # the kernel SYMBOL with the most time per step
+        d = timed_k[dom]
+        traffic = None            # HBM bytes per launch from the committed PMC passes (same command)
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         for name, tb in (traffic or {}).items():
-            if name in kernels:
-                kernels[name]["traffic_bytes_per_launch_pmc"] = tb
-        roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"], "unit": d["unit"],
-                    "frac": d["frac"], "traffic": (traffic or {}).get(dom), "avg_launch_ms": round(d["ms_per_step"] / d["launches_per_step"], 4),
+            for k in kernels:
+                if k == name or (k.startswith(name + "_") and name in ("gemm_nn", "gemm_tn")):
+                    kernels[k]["traffic_bytes_per_launch_pmc" + ("" if k == name else "_class_avg")] = tb
+        classes_ms = {}
+        for k, v in timed_k.items():
+            cls = "gemm_tn" if k.startswith("gemm_tn") else "gemm_nn" if k.startswith("gemm_nn") else k
+            c = classes_ms.setdefault(cls, {"ms_per_step": 0.0, "work": 0.0, "bound": v["bound"]})
+            c["ms_per_step"] += v["ms_per_step"]
+            c["work"] += work[k]
+        by_class = {k: {"ms_per_step": round(v["ms_per_step"], 4),
+                        "frac": round(v["work"] / (v["ms_per_step"] * 1e-3) / (PEAK_HBM_GBS * 1e9 if v["bound"] == "hbm" else PEAK_MFMA_F32_TFLOPS * 1e12), 4)}
+                    for k, v in classes_ms.items()}
+        flops = sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram")
+        roofline = {"kernel": dom, "symbol": d.get("symbol"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                    "unit": d["unit"], "frac": d["frac"],
+                    "traffic": (traffic or {}).get(dom), "avg_launch_ms": d["avg_launch_ms"],
+                    "top_class": max(by_class, key=lambda k: by_class[k]["ms_per_step"]), "by_class": by_class,
                     "kernels": kernels,
                     "kernel_ms_per_step_total": round(sum(v["ms_per_step"] for v in kernels.values()), 3),
-                    "whole_step_flops": round(sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram") / 1e9, 1),
-                    "whole_step_mfma_frac": round(sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram")
-                                                  / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)}
+                    "whole_step_flops": round(flops / 1e9, 1),
+                    "whole_step_mfma_frac": round(flops / (ms_per_step * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)}
+    per_gpu = clips_per_s / world
+    mfma_roof = PEAK_MFMA_F32_TFLOPS * 1e12 / (CLIP_GFLOP[args.workload] * 1e9)          # clips/s/GPU, SURVEY.md §8(d)
     out = {
         "metric": "EEG clips/sec (60s, 19ch, K=2, 2-layer x64) fwd+bwd",
         "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
@@ -346,16 +443,26 @@ def main():
                                 if device_graph else "prepared on the host (distance graph is fixed)"
                                 if filt == "laplacian" else "prepared on the host"),
                    "launch": "hip-graph replay (fwd+loss+bwd) + eager all-reduce/clip+Adam" if graphed else "eager",
+                   "timed_region": f"{args.steps} steps on one batch resident in HBM = {elapsed * 1e3:.1f} ms wall",
+                   "library": "DEV build with tuning knobs " + ",".join(args.tune) if args.tune else "product",
                    "final_loss": round(loss_val, 5)},
-        # SURVEY.md §8d asks for both figures: `value` is the training-loop rate (optimiser step included); the
-        # kernel figure takes the optimiser tail (norm + fused clip/Adam, live HIP-event times) out of the step
+        "distributed": {"world_size": world_seen, "backend": backend, "per_rank_ms_per_step": per_rank_ms,
+                        "exchange": "one all-reduce of the flat fp32 gradient bucket per step "
+                                    f"({stepper.fp.flat_grad.numel() * 4} bytes), outside the HIP graph"},
+        # the whole step against BOTH roofs: the binding fp32-MFMA roof and the HBM roof north_star names
+        "whole_step": {"mfma_roof_clips_per_s_per_gpu": round(mfma_roof, 0), "mfma_roof_frac": round(per_gpu / mfma_roof, 4),
+                       "hbm_frac": round(per_gpu * CLIP_BYTES[args.workload] / (PEAK_HBM_GBS * 1e9), 4),
+                       "hbm_roof_clips_per_s_per_gpu": round(PEAK_HBM_GBS * 1e9 / CLIP_BYTES[args.workload], 0)},
+        # `value` is the training-loop rate (optimiser step included); the kernel figure takes the optimiser tail
+        # (norm + fused clip/Adam, live HIP-event times) out of the step
         "fwd_bwd_only": (None if not prof or world > 1 else {
             "clips_per_s": round(batch / ((ms_per_step - sum(prof.get(k, (0, 0.0))[1] for k in ("grad_sqnorm", "clip_adam")) / args.steps) * 1e-3), 1),
             "excluded_ms_per_step": round(sum(prof.get(k, (0, 0.0))[1] for k in ("grad_sqnorm", "clip_adam")) / args.steps, 4)}),
+        "streamed_inputs": streamed,
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
-        log("cpu baseline (oracle on host cores)")
+        log("cpu baseline (oracle on host cores, per-GPU batch)")
         out["cpu_baseline"] = cpu_baseline(args.workload)
         out["speedup_vs_cpu_baseline"] = round(clips_per_s / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)

@@ -2,8 +2,9 @@
 
 This is the stub a maintainer of the reference would add to call the MI355X kernels from
 Python.  The product loads ONLY the in-tree HIP library and fails loudly if it
-is missing: there is no CPU fallback.  (tests/ can construct `EegDcrnnLib(path)` on the
-emulator build of the same sources to check kernel logic without a GPU — the product never does.)
+is missing: there is no CPU fallback.  (`EegDcrnnLib(path)` can be constructed on any build of the
+same ABI; the module-level `_LIB` slot is what `get_lib()` hands out — tests/ point it at the emulator
+build of the same sources to check kernel logic without a GPU, the product never does.)
 """
 from __future__ import annotations
 
@@ -13,14 +14,15 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip.so")
-ABI_VERSION = 1
+DEV_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip_dev.so")     # `make dev`: tools/ and `bench.py --tune` only
+ABI_VERSION = 2
 
 
 class LayerDims(ctypes.Structure):
     """mirror of `eeg_layer_dims` (include/eeg_dcrnn.h)."""
     _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Fin", c_int32),
                 ("M", c_int32), ("act", c_int32), ("p_batched", c_int32), ("x_planes_ready", c_int32),
-                ("reserved", c_int32), ("x_plane_stride", c_int64)]
+                ("x_batch_major", c_int32), ("x_plane_stride", c_int64)]
 
 
 class DecoderDims(ctypes.Structure):
@@ -36,8 +38,6 @@ _SIGNATURES = {
     "eeg_dcrnn_abi_version": (c_int, []),
     "eeg_dcrnn_is_device_build": (c_int, []),
     "eeg_dcrnn_supported": (c_int, [c_int, c_int, c_int, c_int]),
-    "eeg_dcrnn_set_seq_probe": (c_int, [_FP]),
-    "eeg_dcrnn_set_tuning": (c_int, [c_int, c_int]),
     "eeg_dcrnn_prof_enable": (c_int, [c_int]),
     "eeg_dcrnn_prof_report": (c_int, [ctypes.c_char_p, c_size_t]),
     "eeg_dcrnn_hop_polys": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, _FP, c_void_p]),
@@ -50,6 +50,8 @@ _SIGNATURES = {
     "eeg_dcrnn_diffuse_adj": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_dconv_fwd_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "eeg_dcrnn_dconv_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, _FP, _FP, c_int, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_dconv_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "eeg_dcrnn_dconv_bwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, _FP, c_int, _FP, _FP, _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_layer_fwd_ws_floats": (c_size_t, [POINTER(LayerDims)]),
     "eeg_dcrnn_batch_major_ok": (c_int, [POINTER(LayerDims)]),
     "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 14 + [c_void_p]),
@@ -76,6 +78,13 @@ _SIGNATURES = {
 }
 
 
+# include/eeg_dcrnn_dev.h: exported by the dev build (libeeg_dcrnn_hip_dev.so) and the test emulator only
+_SIGNATURES_DEV = {
+    "eeg_dcrnn_set_seq_probe": (c_int, [_FP]),
+    "eeg_dcrnn_set_tuning": (c_int, [c_int, c_int]),
+}
+
+
 class EegDcrnnError(RuntimeError):
     """Raised when a library call reports an error (shape/dtype/launch problems)."""
 
@@ -95,6 +104,11 @@ class EegDcrnnLib:
                 raise ImportError(f"{path} does not export {name} (declared in include/eeg_dcrnn.h)") from e
             fn.restype = res
             fn.argtypes = args
+        self.is_dev_build = hasattr(self._dll, "eeg_dcrnn_set_tuning")
+        if self.is_dev_build:
+            for name, (res, args) in _SIGNATURES_DEV.items():
+                fn = getattr(self._dll, name)
+                fn.restype, fn.argtypes = res, args
         if self._dll.eeg_dcrnn_abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self._dll.eeg_dcrnn_abi_version()} != {ABI_VERSION}; rebuild")
         self.is_device_build = bool(self._dll.eeg_dcrnn_is_device_build())
@@ -122,14 +136,5 @@ def get_lib() -> EegDcrnnLib:
         lib = EegDcrnnLib(HIP_LIB_PATH)
         if not lib.is_device_build:
             raise ImportError(f"{HIP_LIB_PATH} is not a device build")
-        for kv in filter(None, os.environ.get("EEG_DCRNN_TUNE", "").split(",")):   # development: "key=value,..."
-            k, v = kv.split("=")
-            lib.call("eeg_dcrnn_set_tuning", int(k), int(v))
         _LIB = lib
     return _LIB
-
-
-def _set_lib_for_testing(lib) -> None:
-    """tests/ only: install an explicitly constructed library object (e.g. the emulator build)."""
-    global _LIB
-    _LIB = lib

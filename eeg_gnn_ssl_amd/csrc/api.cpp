@@ -8,6 +8,8 @@
 #include <vector>
 
 #include "../../include/eeg_dcrnn.h"
+#include "../../include/eeg_dcrnn_dev.h"
+#include "../../include/eeg_dcrnn_prof.h"
 #include "kernels_diffuse.h"
 #include "kernels_feat.h"
 #include "kernels_gemm.h"
@@ -67,8 +69,15 @@ void prof_end(hipStream_t st) {
 namespace {
 
 thread_local char g_err[512] = "";
-long long* g_seq_probe = nullptr;  // development aid: see eeg_dcrnn_set_seq_probe
-int g_tune[16] = {0};               // development knobs, see eeg_dcrnn_set_tuning
+// Development aids exist only in the dev build (make dev / the test emulator: -DEEG_DEV, declared in
+// include/eeg_dcrnn_dev.h).  In the product build the knobs are compile-time zeros and there is no probe.
+#if defined(EEG_DEV)
+long long* g_seq_probe = nullptr;  // see eeg_dcrnn_set_seq_probe
+int g_tune[16] = {0};               // see eeg_dcrnn_set_tuning
+#else
+constexpr long long* g_seq_probe = nullptr;
+constexpr int g_tune[16] = {0};
+#endif
 
 int fail(const char* fmt, ...) {
     va_list ap;
@@ -106,48 +115,52 @@ int check_dims(int N, int H, int Fin, int M) {
 // ---- GEMM dispatch ---------------------------------------------------------------------------
 template <int NCTW, int KC>
 int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
-           float* C, int ldc, int O, hipStream_t st) {
+           float* C, int ldc, int O, hipStream_t st, const char* tag) {
     constexpr int KCS = lds_stride(KC), NB = 2 * NCTW;
     const size_t lds = 2 * (size_t)(128 * KCS + (KC / 4) * NB * 64) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_nn_kernel<NCTW, KC>), lds);
     dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
-    EEG_LAUNCH_P("gemm_nn", (gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
+    EEG_LAUNCH_P(tag, (gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn");
 }
+// segment 0 of a GEMM is batch-major (B clips x T steps x N nodes): the DMA kernels read it through a row map
+struct BtMap { int T = 0, B = 0, N = 0; };
 template <int NCTW, int KC, int MINB = 2>
 int run_nn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
-               float* C, int ldc, int O, hipStream_t st) {
+               float* C, int ldc, int O, hipStream_t st, const char* tag, BtMap bt) {
     constexpr int NB = 2 * NCTW;
     const size_t lds = 2 * (size_t)(128 * KC + (KC / 4) * NB * 64) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_nn_dma_kernel<NCTW, KC, MINB>), lds);
     dim3 grid(ceil_div(R, 128), ceil_div(nct_total, NB));
-    EEG_LAUNCH_P("gemm_nn", (gemm_nn_dma_kernel<NCTW, KC, MINB>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
+    EEG_LAUNCH_P(tag, (gemm_nn_dma_kernel<NCTW, KC, MINB>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, bt.T, bt.B, bt.N);
     return check_launch("gemm_nn_dma");
 }
+bool nn_dma_ok(int F, int R, int ldc) { return g_tune[0] == 0 && ldc % 4 == 0 && (double)R * F < 4.0e9 && (F % 16 == 0 || F % 20 == 0); }
 template <int NCTW>
 int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
-              float* C, int ldc, int O, hipStream_t st) {
-    if (g_tune[0] == 0 && ldc % 4 == 0 && (double)R * F < 4.0e9) {   // LDS-DMA staging (default)
-        if (F % 16 == 0) return run_nn_dma<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-        if (F % 20 == 0) return run_nn_dma<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+              float* C, int ldc, int O, hipStream_t st, const char* tag, BtMap bt) {
+    if (nn_dma_ok(F, R, ldc)) {                                      // LDS-DMA staging (default)
+        if (F % 16 == 0) return run_nn_dma<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
+        if (F % 20 == 0) return run_nn_dma<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
     }
-    if (F % 32 == 0) return run_nn<NCTW, 32>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-    if (F % 20 == 0) return run_nn<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-    if (F % 16 == 0) return run_nn<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-    return run_nn<NCTW, 4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+    if (bt.T > 0) return fail("gemm_nn: a batch-major segment needs the LDS-DMA kernel (F=%d)", F);
+    if (F % 32 == 0) return run_nn<NCTW, 32>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag);
+    if (F % 20 == 0) return run_nn<NCTW, 20>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag);
+    if (F % 16 == 0) return run_nn<NCTW, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag);
+    return run_nn<NCTW, 4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag);
 }
 // C[R x O] = [segments] @ packed B (nct_total col tiles) + bias
 int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
-            float* C, int ldc, int O, hipStream_t st) {
+            float* C, int ldc, int O, hipStream_t st, const char* tag = "gemm_nn", BtMap bt = BtMap()) {
     // few row blocks (per-step decoder GEMMs): narrower column blocks fill more CUs
     if (nct_total <= 4 || ceil_div(R, 128) * ceil_div(nct_total, 12) < 160)
-        return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
-    return run_nn_kc<6>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st);
+        return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
+    return run_nn_kc<6>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
 }
 
 template <int NCTW>
 int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
-           float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+           float* partial, int nsplit, int rows_per_split, hipStream_t st, const char* tag) {
     constexpr int OT = 2 * NCTW * 16;
     constexpr int YS = OT + ((16 - (OT % 32)) + 32) % 32;
     const size_t lds = 2 * (size_t)(32 * 80 + 32 * YS) * sizeof(float);
@@ -157,7 +170,7 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     // per step) -- the default round-robin spread already serves the shared dY rows from the Infinity Cache and
     // keeps eight L2s busy; the remap stays available as knob 4 for re-measurement on other shapes.
     const int remap = (g_tune[4] == 1 && nsplit % 8 == 0 && grid.x > 1) ? 1 : 0;
-    EEG_LAUNCH_P("gemm_tn", (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, remap);
+    EEG_LAUNCH_P(tag, (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, remap);
     return check_launch("gemm_tn");
 }
 // k-block width of the DMA TN kernel.  128-wide blocks halve the re-reads of dY (PMC: 862 -> ~600 MB per
@@ -166,17 +179,18 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
 constexpr int kTnKbw = 64;
 template <int KTW, int NCTW, int RC>
 int run_tn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
-               float* partial, int nsplit, int rows_per_split, hipStream_t st) {
+               float* partial, int nsplit, int rows_per_split, hipStream_t st, const char* tag, BtMap bt) {
     constexpr int OT = 2 * NCTW * 16, KBW = 32 * KTW;
     static_assert(KBW == kTnKbw, "tn_split assumes this k-block width");
     const size_t lds = 2 * (size_t)(RC * KBW + RC * OT) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_tn_dma_kernel<KTW, NCTW, RC>), lds);
     dim3 grid(ceil_div(nseg * F, KBW), nsplit);
-    EEG_LAUNCH_P("gemm_tn", (gemm_tn_dma_kernel<KTW, NCTW, RC>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split);
+    EEG_LAUNCH_P(tag, (gemm_tn_dma_kernel<KTW, NCTW, RC>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, bt.T, bt.B, bt.N);
     return check_launch("gemm_tn_dma");
 }
+bool tn_dma_ok(int F, int O) { return g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0; }
 int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
-    const bool dma = g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0;
+    const bool dma = tn_dma_ok(F, O);
     const int blocks = dma ? ceil_div(nseg * F, kTnKbw) : nseg * ceil_div(F, 64);
     int nsplit = ceil_div(768, blocks);             // ~3 workgroups per CU; more splits only add partial-sum traffic (measured)
     int rps = round_up(ceil_div(R, nsplit), 32);
@@ -188,9 +202,9 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
 }
 // partial[nsplit][nseg*F][O] = per-split A^T dY[:, ycol0:ycol0+O]
 int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
-            float* partial, int nsplit, int rows_per_split, hipStream_t st) {
-    if (g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0 && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
-#define EEG_TN(NCTW, RC) run_tn_dma<2, NCTW, RC>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st)
+            float* partial, int nsplit, int rows_per_split, hipStream_t st, const char* tag = "gemm_tn", BtMap bt = BtMap()) {
+    if (tn_dma_ok(F, O) && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
+#define EEG_TN(NCTW, RC) run_tn_dma<2, NCTW, RC>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag, bt)
         // row-chunk depth: the 192-column tile stages 16 rows at a time (32 KB of LDS per workgroup -> 4 workgroups
         // per CU instead of 2 with 32-row stages: -3.5 % on that shape); the narrower tiles are better off with 32
         // rows (measured both ways); 8-row stages are 15 % slower
@@ -199,10 +213,11 @@ int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
         return EEG_TN(2, 32);
 #undef EEG_TN
     }
-    if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-    if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-    if (O <= 128) return run_tn<4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
-    if (O <= 192) return run_tn<6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st);
+    if (bt.T > 0) return fail("gemm_tn: a batch-major segment needs the LDS-DMA kernel (O=%d)", O);
+    if (O <= 32) return run_tn<1>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag);
+    if (O <= 64) return run_tn<2>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag);
+    if (O <= 128) return run_tn<4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag);
+    if (O <= 192) return run_tn<6>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag);
     return fail("gemm_tn: O=%d unsupported", O);
 }
 
@@ -332,14 +347,14 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
 int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* planes, size_t x_stride, const float* Hprev,
                       const float* RHs, const float* dXW, const float* P, const float* hpl_in, const float* rpl_in,
                       size_t h_stride, float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate,
-                      float* dWg, float* dWc, hipStream_t st) {
+                      float* dWg, float* dWc, hipStream_t st, BtMap bt = BtMap()) {
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const int acc = accumulate ? 8 : 0;
     SegPtrs sx;
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
     float* part_g = part + (w.part_g - w.partial);
     float* part_c = part + (w.part_c - w.partial);
-    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st)) return 1;
+    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt)) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
     size_t hs = h_stride;
@@ -350,7 +365,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * hs : nullptr);
-    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st)) return 1;
+    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st, "gemm_tn_hg")) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     const float* rpl = rpl_in;
     size_t rs = h_stride;
@@ -361,7 +376,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * rs : nullptr);
-    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st)) return 1;
+    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st, "gemm_tn_hc")) return 1;
     //   one fixed-order reduction of the three sets of split-K partials into the reference's gradient layout
     ReduceJobs jobs;
     const int Ks[3] = {M * Fin, M * H, M * H}, Os[3] = {3 * H, 2 * H, H}, ns[3] = {w.nsplit_x, w.nsplit_hg, w.nsplit_hc};
@@ -466,7 +481,7 @@ int copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
 extern "C" {
 
 const char* eeg_dcrnn_last_error(void) { return g_err; }
-int eeg_dcrnn_abi_version(void) { return 1; }
+int eeg_dcrnn_abi_version(void) { return 2; }
 int eeg_dcrnn_is_device_build(void) {
 #if defined(EEG_SIMT_EMU)
     return 0;
@@ -474,6 +489,7 @@ int eeg_dcrnn_is_device_build(void) {
     return 1;
 #endif
 }
+#if defined(EEG_DEV)
 int eeg_dcrnn_set_tuning(int key, int value) {
     if (key < 0 || key >= 16) return fail("set_tuning: key %d out of range", key);
     g_tune[key] = value;
@@ -483,6 +499,7 @@ int eeg_dcrnn_set_seq_probe(int64_t* probe) {
     g_seq_probe = reinterpret_cast<long long*>(probe);
     return 0;
 }
+#endif
 int eeg_dcrnn_prof_enable(int on) {
 #if !defined(EEG_SIMT_EMU)
     eeg::g_prof_on = on != 0;
@@ -558,7 +575,11 @@ int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, 
 size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return (size_t)d->T * d->B * d->N * 3 * d->H; }
 
 int eeg_dcrnn_batch_major_ok(const eeg_layer_dims* d) {
-    return diffuse_streams(d->p_batched, d->T * d->B, d->B, d->N, d->Fin) ? 1 : 0;
+    if (!diffuse_streams(d->p_batched, d->T * d->B, d->B, d->N, d->Fin)) return 0;
+    // 2: the GEMMs read the batch-major input through a row map (d->x_batch_major = 1, no copy); 1: only with the
+    // time-major copy Xtm
+    const int R = d->T * d->B * d->N;
+    return (nn_dma_ok(d->Fin, R, 3 * d->H) && tn_dma_ok(d->Fin, 3 * d->H)) ? 2 : 1;
 }
 
 int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, const float* h0, const float* P,
@@ -579,17 +600,23 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     //    receives the time-major copy that everything after this point reads) -- unless the previous layer's
     //    recurrent kernel already left these planes behind (x_planes_ready)
     const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
+    BtMap bt;
+    if (d->x_batch_major) {
+        if (Xtm != nullptr || d->x_planes_ready) return fail("layer_fwd: x_batch_major excludes Xtm and x_planes_ready");
+        if (eeg_dcrnn_batch_major_ok(d) != 2) return fail("layer_fwd: x_batch_major is not available for this shape (eeg_dcrnn_batch_major_ok)");
+        bt.T = d->T; bt.B = d->B; bt.N = d->N;
+    }
     if (d->x_planes_ready) {
         if (Xtm != nullptr) return fail("layer_fwd: x_planes_ready excludes a batch-major input");
     } else {
-        if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, xs, Xtm != nullptr ? 1 : 0, Xtm)) return 1;
+        if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, xs, (Xtm != nullptr || d->x_batch_major) ? 1 : 0, Xtm)) return 1;
         if (Xtm != nullptr) X = Xtm;
     }
     // 2. hoisted x-part GEMM: XW = [X | planes] @ Bx + [bg|bc]
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * xs : nullptr);
     float* XW = ws;
-    if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st)) return 1;
+    if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt)) return 1;
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
@@ -623,14 +650,19 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     if (check_launch("reduce_bias")) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction)
     const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
+    BtMap bt;
+    if (d->x_batch_major) {
+        if (eeg_dcrnn_batch_major_ok(d) != 2) return fail("layer_bwd: x_batch_major is not available for this shape");
+        bt.T = d->T; bt.B = d->B; bt.N = N;
+    }
     if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
-                          ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st)) return 1;
+                          ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, bt)) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {
         float* Z = ws + w.z;
         SegPtrs sd;
         for (int m = 0; m < kMaxM; ++m) sd.p[m] = m == 0 ? dXW : nullptr;
-        if (gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st)) return 1;
+        if (gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st, "gemm_nn_dx")) return 1;
         if (diffuse_adj(Z, P, d->p_batched, S, d->B, N, Fin, M, dX, st)) return 1;
     }
     return 0;
@@ -850,6 +882,47 @@ int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, in
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * B * N * F : nullptr);
     return gemm_nn(segs, M, F, B * N, pack, O / 16, bias, out, O, O, st);
+}
+size_t eeg_dcrnn_dconv_bwd_ws_floats(int B, int N, int F, int M, int O) {
+    const int R = B * N;
+    int rps;
+    const int nsplit = tn_split(M, F, R, O, &rps);
+    return (size_t)(M - 1) * R * F + align64((size_t)nsplit * M * F * O) + align64((size_t)(O / 4) * (round_up(M * F, 16) / 16) * 64)
+           + (size_t)R * M * F + align64(colsum_ws(R, O));
+}
+int eeg_dcrnn_dconv_bwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M, const float* W, int O,
+                        const float* dOut, float* dX, float* dW, float* dbias, float* ws, void* stream) {
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("dconv_bwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (O % 16 != 0 || O > 192) return fail("dconv_bwd: output_dim=%d must be a multiple of 16 (<= 192)", O);
+    hipStream_t st = S_(stream);
+    const int R = B * N;
+    int rps;
+    const int nsplit = tn_split(M, F, R, O, &rps);
+    float* planes = ws;
+    float* part = planes + (size_t)(M - 1) * R * F;
+    float* tpack = part + align64((size_t)nsplit * M * F * O);
+    float* Z = tpack + align64((size_t)(O / 4) * (round_up(M * F, 16) / 16) * 64);
+    float* cws = Z + (size_t)R * M * F;
+    // dW[f*M+m][o] = sum_rows (P_m X)[row][f] dOut[row][o]: the hop planes are re-formed here (nothing is kept by the forward)
+    if (dW != nullptr) {
+        if (diffuse_fwd(X, P, p_batched, B, B, N, F, M, planes, st)) return 1;
+        SegPtrs sx;
+        for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * R * F : nullptr);
+        if (gemm_tn(sx, M, F, R, dOut, O, 0, O, part, nsplit, rps, st)) return 1;
+        EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(M * F * O, 64)), dim3(256), 256 * sizeof(float4), st, part, nsplit, M * F, O, 4, F, 0, M, dW, dW);
+        if (check_launch("reduce_unpack(dconv)")) return 1;
+    }
+    if (dbias != nullptr && colsum(dOut, R, O, O, cws, dbias, nullptr, st)) return 1;
+    // dX = Z_0 + sum_m P_m^T Z_m with Z = dOut W^T (R x M*F, hop-major)
+    if (dX != nullptr) {
+        EEG_LAUNCH_P("pack_dense", pack_dense_t_kernel, dim3(256), dim3(256), 0, st, W, F, M, O, tpack);
+        if (check_launch("pack_dense_t")) return 1;
+        SegPtrs sd;
+        for (int m = 0; m < kMaxM; ++m) sd.p[m] = m == 0 ? dOut : nullptr;
+        if (gemm_nn(sd, 1, O, R, tpack, round_up(M * F, 16) / 16, nullptr, Z, M * F, M * F, st)) return 1;
+        if (diffuse_adj(Z, P, p_batched, B, B, N, F, M, dX, st)) return 1;
+    }
+    return 0;
 }
 int eeg_dcrnn_bce_logits(const float* logits, const float* y, int B, float* loss, float* dlogits, void* stream) {
     if (B < 1) return fail("bce_logits: empty batch");

@@ -140,7 +140,8 @@ template <int NCTW, int KC, int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm_nn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
                                                                 const float* __restrict__ Bp, int nct_total,
                                                                 const float* __restrict__ bias,
-                                                                float* __restrict__ C, int ldc, int O) {
+                                                                float* __restrict__ C, int ldc, int O,
+                                                                int btT, int btB, int btN) {
     constexpr int NB = 2 * NCTW, KSC = KC / 4, Q = KC / 4;              // Q = 16-byte pieces per A row
     constexpr int A_FLOATS = 128 * KC, B_FLOATS = KSC * NB * 64;
     constexpr int A_INS = A_FLOATS / 256, B_INS = B_FLOATS / 256, INS = A_INS + B_INS;   // wave-DMAs per chunk
@@ -153,15 +154,23 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn_dma_kernel(SegPtrs segs, in
     const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
 
     // per-lane source offsets of this wave's DMAs (chunk-independent part), in floats
-    unsigned src[NI];
+    // btT > 0: segment 0 is BATCH-major (btB clips x btT steps x btN nodes x F): the time-major row
+    // r = (t*B + b)*N + n that everything else uses lives at row (b*T + t)*N + n of that segment (the model input as
+    // the trainer holds it, model.py:253 -- no time-major copy is made)
+    unsigned src[NI], src0[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = wave + 4 * i;                                     // DMA index inside the chunk
+        src0[i] = 0;
         if (j < A_INS) {
             const int s4 = j * 64 + lane, row = s4 / Q, piece = s4 % Q;
             const int grow = row0 + row < R ? row0 + row : R - 1;
             const int c4 = Q == 4 ? (piece ^ ((row >> 2) & 3)) : piece;
             src[i] = (unsigned)grow * F + 4 * c4;
+            if (btT > 0) {
+                const int sm_ = grow / btN, n = grow - sm_ * btN, t = sm_ / btB, b = sm_ - t * btB;
+                src0[i] = (unsigned)((b * btT + t) * btN + n) * F + 4 * c4;
+            }
         } else {
             const int s4 = (j - A_INS) * 64 + lane;                     // float4 index in [KSC][NB][16]
             const int ks = s4 / (NB * 16), rem = s4 % (NB * 16), ct = rem / 16, l4 = rem % 16;
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn_dma_kernel(SegPtrs segs, in
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int j = wave + 4 * i;
-            if (j < INS) lds_dma16(base + j * 256, (j < A_INS ? Ab : Bb) + src[i]);
+            if (j < INS) lds_dma16(base + j * 256, j < A_INS ? Ab + ((btT > 0 && seg == 0) ? src0[i] : src[i]) : Bb + src[i]);
         }
     };
 
@@ -375,7 +384,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
 template <int KTW, int NCTW, int RC>
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
                                                           const float* __restrict__ dY, int ldy, int ycol0, int Ov,
-                                                          float* __restrict__ partial, int rows_per_split) {
+                                                          float* __restrict__ partial, int rows_per_split,
+                                                          int btT, int btB, int btN) {
     constexpr int KBW = 32 * KTW, KQ = KBW / 4, O = 2 * NCTW * 16, OQ = O / 4;
     constexpr int A_FLOATS = RC * KBW, Y_FLOATS = RC * O;
     constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, INS = A_INS + Y_INS, NI = (INS + 3) / 4;
@@ -388,12 +398,18 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
 
     // this wave's DMAs: tile row, source base (plane of the lane's k column / dY) and (clamped) column
+    // btT > 0: segment 0 is BATCH-major (see gemm_nn_dma_kernel): lanes whose k column lies in segment 0 walk the
+    // rows of their split through (b, t, n) counters instead of a linear row index (no division in the loop)
     int drow[NI];
     const float* dsrc[NI];
     int dld[NI];
+    int mb[NI], mt[NI], mn[NI];
+    bool m0[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = wave + 4 * i;
+        m0[i] = false;
+        mb[i] = mt[i] = mn[i] = 0;
         if (j < A_INS) {
             const int s4 = j * 64 + lane, row = s4 / KQ, piece = (s4 % KQ) ^ (4 * (row & 3));
             int k = k0 + 4 * piece;
@@ -401,6 +417,13 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
             drow[i] = row;
             dsrc[i] = segs.p[k / F] + k % F;
             dld[i] = F;
+            if (btT > 0 && k < F) {
+                const int r = rbeg + row, sm_ = r / btN;
+                m0[i] = true;
+                mn[i] = r - sm_ * btN;
+                mt[i] = sm_ / btB;
+                mb[i] = sm_ - mt[i] * btB;
+            }
         } else {
             const int s4 = (j - A_INS) * 64 + lane, row = s4 / OQ, piece = (s4 % OQ) ^ (4 * (row & 3));
             drow[i] = row;
@@ -416,7 +439,17 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
             const int j = wave + 4 * i;
             if (j >= INS) continue;
             int row = r0 + drow[i];
-            if (tail && row >= R) row = R - 1;
+            if (m0[i]) {                                    // chunks are requested in row order: advance by RC rows per call
+                const int mapped = (mb[i] * btT + mt[i]) * btN + mn[i];
+                mn[i] += RC;
+                while (mn[i] >= btN) {
+                    mn[i] -= btN;
+                    if (++mb[i] == btB) { mb[i] = 0; ++mt[i]; }
+                }
+                row = row < R ? mapped : R - 1;            // (the last row maps to itself)
+            } else if (tail && row >= R) {
+                row = R - 1;
+            }
             lds_dma16(base + j * 256, dsrc[i] + (size_t)row * dld[i]);
         }
     };

@@ -118,6 +118,20 @@ __global__ void pack_dense_kernel(const float* __restrict__ W, int F, int M, int
     }
 }
 
+// The same weight transposed, for dX of the stand-alone dconv: right-hand side (K = O) x (J = M*F, hop-major,
+// zero-padded to whole column tiles): B[o][m*F + f] = W[f*M + m][o].
+__global__ void pack_dense_t_kernel(const float* __restrict__ W, int F, int M, int O, float* __restrict__ out) {
+    const int nct = round_up(M * F, 16) / 16;
+    const size_t total = (size_t)(O / 4) * nct * 64;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int lane = e & 63, ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+        const int o = 4 * ks + (lane >> 4), j = 16 * ct + (lane & 15);
+        float v = 0.f;
+        if (j < M * F) v = W[((size_t)(j % F) * M + j / F) * O + o];
+        out[e] = v;
+    }
+}
+
 // nn.Linear weight W (Out x In) -> fragment pack of a (K x O) right-hand side with zero-padded
 // column tiles: transposed = 1: K = In, O = Out (y = x W^T);  transposed = 0: K = Out, O = In (dx = dy W).
 __global__ void pack_linear_kernel(const float* __restrict__ W, int Out, int In, int transposed, float* __restrict__ out) {
@@ -135,7 +149,7 @@ __global__ void pack_linear_kernel(const float* __restrict__ W, int Out, int In,
 
 // Sum split-K partials [nsplit][K][O] in fixed order (deterministic) and scatter into the
 // reference-layout gradient tensors.  kind 0: x-part (K = M*Fin, O = 3H); 1: h-gate (K = M*H,
-// O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f); 3: dWg = plain (K x O).
+// O = 2H -> dWg rows Fin+f); 2: h-cand (K = M*H, O = H -> dWc rows Fin+f); 3: dWg = plain (K x O); 4: stand-alone dconv weight (K = M*F -> rows f*M+m).
 // Block = 16 split groups x 16 float4 columns (64 consecutive elements of the K x O matrix): group g sums
 // splits g, g+16, g+32, ... in that order (all its loads independent and in flight together -- the partials
 // are read once from HBM, so the launch lives on memory-level parallelism), the 16 group sums are then added
@@ -179,6 +193,8 @@ __device__ __forceinline__ void reduce_unpack_block(int block, const float* __re
             dst = &dWg[((size_t)(Fin + k % H) * M + k / H) * (2 * H) + o];
         } else if (kind == 3) {                       // plain (K x O) matrix
             dst = &dWg[idx];
+        } else if (kind == 4) {                       // stand-alone dconv: K = M*F hop-major -> row f*M + m of ((F*M) x O); F passed as Fin
+            dst = &dWg[((size_t)(k % Fin) * M + k / Fin) * O + o];
         } else {
             dst = &dWc[((size_t)(Fin + k % H) * M + k / H) * H + o];
         }

@@ -566,7 +566,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     __syncthreads();                                                // previous clip: the bias reduction has read EG
     for (int e = tid; e < ROWS * (KAP + KGP); e += 256) EC[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
-    const int t_len = (d_at_len != nullptr) ? (lengths != nullptr ? (int)lengths[b] - 1 : T - 1) : -1;
+    // same clamp as gather_last_kernel: forward and backward agree on which step an out-of-range length selects
+    int t_len = -1;
+    if (d_at_len != nullptr) {
+        t_len = lengths != nullptr ? (int)lengths[b] - 1 : T - 1;
+        t_len = t_len < 0 ? 0 : (t_len >= T ? T - 1 : t_len);
+    }
     __syncthreads();
     float pf[poly_chains<M, NKS>()][NKS];
     load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);

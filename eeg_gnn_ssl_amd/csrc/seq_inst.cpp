@@ -19,6 +19,7 @@ template <int H, int M, int NKS>
 int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeom<H, M>::fwd_lds_floats() * sizeof(float);
     if (lds > kMaxLdsBytes) return 3;
+#if defined(EEG_DEV)   // cycle-probe instantiations: dev build only
     if constexpr (H == 64 && M == 3 && NKS == 5) {
         if (a.probe != nullptr && a.variant != 1) {
             EEG_SET_MAX_LDS((seq_fwd_kernel<H, M, NKS, true>), lds);
@@ -27,9 +28,11 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
+#endif
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // M >= 4: the r + c weights of a wave no longer fit in 256 registers
         if (a.variant == 1) {
             const size_t lds2 = lds + 20 * (H + 4) * sizeof(float);
+#if defined(EEG_DEV)
             if constexpr (M == 3) {
                 if (a.probe != nullptr) {
                     EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, true>), lds2);
@@ -38,6 +41,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
                     return hipGetLastError() == hipSuccess ? 0 : 2;
                 }
             }
+#endif
             EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS>), lds2);
             EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
                          a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
@@ -57,6 +61,7 @@ template <int H, int M, int NKS>
 int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
     const size_t lds = SeqGeom<H, M>::bwd_lds_floats(SeqGeom<H, M>::bwd_rows(NKS)) * sizeof(float);
     if (lds > kMaxLdsBytes) return 3;
+#if defined(EEG_DEV)
     if constexpr (H == 64 && M == 3 && NKS == 5) {
         if (a.probe != nullptr) {
             EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS, true>), lds);
@@ -66,6 +71,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
+#endif
     EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS>), lds);
     EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                  a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,

@@ -14,7 +14,7 @@ from .. import ops
 
 
 class DiffusionGraphConv(nn.Module):
-    """Parameter holder for one diffusion convolution (reference: cell.py:17-48).
+    """One diffusion convolution (reference: cell.py:17-48).
 
     weight rows are ordered f*M + m (feature-major, hop-minor; cell.py:98-116).  Initialisation
     follows the reference: xavier-normal with gain 1.414 and constant `bias_start` biases.
@@ -39,16 +39,18 @@ class DiffusionGraphConv(nn.Module):
     def forward(self, supports, inputs, state, output_size, bias_start=0.0):
         """(B, N*Din), (B, N*H) -> (B, N*output_size); reference cell.py:66-118.
 
-        Forward-only convenience (no autograd): the training path never calls it.  HIP diffusion
-        kernel + fp32-MFMA GEMM on the reference's weight layout (eeg_dcrnn_dconv_fwd)."""
+        HIP diffusion kernel + fp32-MFMA GEMM on the reference's weight layout (`torch.ops.eeg_dcrnn.dconv`);
+        differentiable w.r.t. inputs, state, weight and biases like the reference module (the fused training
+        path never calls it: gate and candidate convolutions share the diffused input there)."""
         b = inputs.shape[0]
         n, f = self._num_nodes, self._input_size
         if f % 4 != 0:
             raise RuntimeError(f"DiffusionGraphConv: input_dim + hid_dim = {f} must be a multiple of 4")
+        if self._max_diffusion_step < 1:
+            raise NotImplementedError("max_diffusion_step must be >= 1")
         x = torch.cat([inputs.reshape(b, n, -1), state.reshape(b, n, -1)], dim=2)
-        with torch.no_grad():
-            p, p_batched = ops.hop_polys(supports, self._max_diffusion_step, b)
-            out = ops.dconv_forward(x, p, p_batched, self.weight, self.biases)
+        p, p_batched = ops.hop_polys(supports, self._max_diffusion_step, b)
+        out = ops.dconv(x, p, p_batched, self.weight, self.biases)
         return out.reshape(b, n * output_size)
 
 
@@ -93,20 +95,20 @@ class DCGRUCell(nn.Module):
             raise RuntimeError(f"filter_type={self._filter_type!r} expects {self._num_supports} support(s), "
                                f"got {len(supports)}")
 
-    def run_sequence(self, x, h0, p, p_batched, lengths=None):
-        """x (T,B,N,Din) -> (hseq (T,B,N*H), hsel (B,N*H)); used by the encoder/decoder loops."""
-        return ops.dcgru_layer(x, h0, p, p_batched, self.dconv_gate.weight, self.dconv_gate.biases,
-                               self.dconv_candidate.weight, self.dconv_candidate.biases,
-                               self._num_nodes, self._num_units, self.num_matrices,
-                               self._activation_name, lengths)
+    def run_sequence(self, x, h0, p, p_batched, lengths=None, x_off=0, x_planes=None):
+        """x (T + x_off, B, N, Din) -> ops.LayerOut (hext (T+1,B,N*H), hsel (B,N*H), hpl); used by the encoder /
+        decoder loops.  x_off = 1 with x_planes: x is the `hext` of the layer below and x_planes its `hpl`."""
+        return ops.dcgru_layer_ex(x, x_off, h0, p, p_batched, self.dconv_gate.weight, self.dconv_gate.biases,
+                                  self.dconv_candidate.weight, self.dconv_candidate.biases,
+                                  self._num_nodes, self._num_units, self.num_matrices,
+                                  self._activation_name, lengths, x_planes)
 
     def forward(self, supports, inputs, state):
         self._check_supports(supports)
         b = inputs.shape[0]
         p, p_batched = ops.hop_polys(supports, self._max_diffusion_step, b)
         x = inputs.reshape(1, b, self._num_nodes, self._input_dim)
-        hseq, _ = self.run_sequence(x, state, p, p_batched)
-        new_state = hseq[0]
+        new_state = self.run_sequence(x, state, p, p_batched).hsel      # T = 1: h at the last (only) step
         return new_state, new_state
 
     def init_hidden(self, batch_size):

@@ -41,21 +41,21 @@ class DCRNNEncoder(nn.Module):
         top state at t = lengths-1 (B,N*H) or None)."""
         t_len, b = inputs.shape[0], inputs.shape[1]
         self.encoding_cells[0]._check_supports(supports)
-        ops.new_forward_scope()
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
-        cur = inputs.reshape(t_len, b, self.num_nodes, -1)
-        finals, top_sel = [], None
+        cur, x_off, planes = inputs.reshape(t_len, b, self.num_nodes, -1), 0, None
+        finals, top_sel, out = [], None, None
         for layer, cell in enumerate(self.encoding_cells):
             h0 = None if initial_hidden_state is None else initial_hidden_state[layer]
             is_top = layer == self.num_rnn_layers - 1
+            # layers >= 1 read the `hext` of the layer below (slots 1..T) and take its hop planes as their own
+            out = cell.run_sequence(cur, h0, p, p_batched, lengths if is_top else None, x_off, planes)
             if is_top and lengths is not None:
-                hseq, top_sel = cell.run_sequence(cur, h0, p, p_batched, lengths)
-                finals.append(hseq[t_len - 1])
+                top_sel = out.hsel
+                finals.append(out.hext[t_len] if want_finals else None)
             else:
-                hseq, hfin = cell.run_sequence(cur, h0, p, p_batched)
-                finals.append(hfin)
-            cur = hseq.view(t_len, b, self.num_nodes, self.hid_dim)
-        return (torch.stack(finals, dim=0) if want_finals else None), cur.reshape(t_len, b, -1), top_sel
+                finals.append(out.hsel)
+            cur, x_off, planes = out.hext.view(t_len + 1, b, self.num_nodes, self.hid_dim), 1, out.hpl
+        return (torch.stack(finals, dim=0) if want_finals else None), out.hseq, top_sel
 
     def forward(self, inputs, initial_hidden_state, supports):
         """inputs (T,B,N,Din), initial_hidden_state (L,B,N*H) ->
@@ -97,7 +97,6 @@ class DCGRUDecoder(nn.Module):
         `random.random()` per step) are drawn here, in the reference's order."""
         t_len, b = inputs.shape[0], inputs.shape[1]
         self.decoding_cells[0]._check_supports(supports)
-        ops.new_forward_scope()
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
         if self.training and self.dropout.p > 0:
             return self._forward_stepwise(inputs, initial_hidden_state, p, p_batched, teacher_forcing_ratio)
@@ -125,8 +124,7 @@ class DCGRUDecoder(nn.Module):
             x = cur
             for layer, cell in enumerate(self.decoding_cells):
                 xin = x.reshape(1, b, self.num_nodes, -1)
-                hseq, _ = cell.run_sequence(xin, hidden[layer], p, p_batched)
-                hidden[layer] = hseq[0]
+                hidden[layer] = cell.run_sequence(xin, hidden[layer], p, p_batched).hsel
                 x = hidden[layer]
             proj = self.projection_layer(self.dropout(x.reshape(b, self.num_nodes, self.hid_dim)))
             proj = proj.reshape(b, self.num_nodes * self.output_dim)

@@ -1,8 +1,19 @@
-"""torch-facing operators over the C ABI (include/eeg_dcrnn.h): tensors in, tensors out, autograd.
+"""The `torch.ops.eeg_dcrnn.*` operator library over the C ABI (include/eeg_dcrnn.h).
 
-PyTorch is plumbing here — device memory, streams, autograd bookkeeping; all arithmetic of the
-DCRNN path runs in the HIP kernels of libeeg_dcrnn_hip.so.  Every function raises if its
-tensors are not on the GPU the library was built for: this package has no CPU path.
+Every operator of the DCRNN hot path is registered with the PyTorch dispatcher (`torch.library`):
+schema, device implementation (tensors in -> C-ABI launch on torch's current stream -> tensors out),
+a fake (meta) implementation for tracing, and — for the differentiable ones — the autograd formula,
+which calls the matching `*_bwd` operator.  PyTorch is plumbing here (device memory, streams, autograd
+bookkeeping); all arithmetic runs in the HIP kernels of libeeg_dcrnn_hip.so.  The implementations are
+registered for the CUDA (= HIP on ROCm) key; the same functions are also installed for the CPU key so
+that tests/ can drive the emulator build of the kernel sources — with the product library every
+operator raises on a non-GPU tensor: this package has no CPU path.
+
+Operators (namespace `eeg_dcrnn`):
+    hop_polys, pack_cell, diffusion_hops, dconv (+ dconv_bwd), dcgru_layer (+ dcgru_layer_bwd),
+    dcgru_decoder (+ dcgru_decoder_bwd), cls_head (+ cls_head_bwd), gather_last, corr_graph,
+    fft_features, bce_logits, ce_logits, masked_loss, clip_adam_.
+The functions below them are the Python conveniences the modules in model/ and train_step.py call.
 """
 from __future__ import annotations
 
@@ -15,6 +26,8 @@ from . import _lib
 from ._lib import DecoderDims, LayerDims
 
 ACT_CODES = {"tanh": 0, "relu": 1, None: 1}   # the reference maps anything but 'tanh' to relu (cell.py:146)
+NS = "eeg_dcrnn"
+_libdef = torch.library.Library(NS, "DEF")
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -37,38 +50,164 @@ def _check(lib, t: torch.Tensor, name: str, dtype=torch.float32):
         raise RuntimeError(f"{name}: tensor must be contiguous")
 
 
+def _new(shape, like: torch.Tensor, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _none_if_empty(t: Optional[torch.Tensor]):
+    return None if (t is None or t.numel() == 0) else t
+
+
+def _define(name: str, schema: str, impl, fake):
+    """schema + device implementation (CUDA key = HIP; CPU key only ever reaches the emulator in tests/)
+    + fake implementation."""
+    _libdef.define(f"{name}{schema}")
+    _libdef.impl(name, impl, "CUDA")
+    _libdef.impl(name, impl, "CPU")
+    torch.library.register_fake(f"{NS}::{name}", fake, lib=_libdef)
+
+
 def num_matrices(filter_type: str, max_diffusion_step: int) -> int:
     """cell.py:35,151-158."""
     return (2 if filter_type == "dual_random_walk" else 1) * max_diffusion_step + 1
 
 
-# ---------------------------------------------------------------------------------------------
-# small memo so that per-step cell calls (decoder) do not rebuild hop polynomials / weight packs
-# ---------------------------------------------------------------------------------------------
-class _Memo:
-    def __init__(self, cap=8):
-        self.cap, self.items = cap, []
+# =============================================================================================
+# hop polynomials, weight packs, the diffusion step
+# =============================================================================================
+def _hop_polys_impl(supports: List[torch.Tensor], max_diffusion_step: int, batch: int) -> torch.Tensor:
+    lib = _lib.get_lib()
+    sups = list(supports)
+    if len(sups) == 0:
+        raise RuntimeError("hop_polys: empty supports list")
+    batched = any(s.dim() == 3 for s in sups)
+    n = sups[0].shape[-1]
+    norm = []
+    for i, s in enumerate(sups):
+        if s.shape[-1] != n or s.shape[-2] != n:
+            raise RuntimeError(f"supports[{i}] has shape {tuple(s.shape)}, expected (..., {n}, {n})")
+        if s.dim() == 3 and s.shape[0] != batch:
+            raise RuntimeError(f"supports[{i}] batch {s.shape[0]} != input batch {batch}")
+        if batched and s.dim() == 2:
+            s = s.unsqueeze(0).expand(batch, n, n)
+        s = s.to(torch.float32).contiguous()
+        _check(lib, s, f"supports[{i}]")
+        norm.append(s)
+    g = batch if batched else 1
+    out = _new((g, len(norm) * max_diffusion_step, n, n), norm[0])
+    arr = (ctypes.c_void_p * len(norm))(*[s.data_ptr() for s in norm])
+    lib.call("eeg_dcrnn_hop_polys", arr, len(norm), g, n, max_diffusion_step, _p(out), _stream(out))
+    return out
 
-    @staticmethod
-    def key(tensors, extra=()):
-        return tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors) + tuple(extra)
 
-    def get(self, k):
-        for kk, v in self.items:
-            if kk == k:
-                return v
-        return None
-
-    def put(self, k, v):
-        self.items.append((k, v))
-        if len(self.items) > self.cap:
-            self.items.pop(0)
+def _hop_polys_fake(supports, max_diffusion_step, batch):
+    g = batch if any(s.dim() == 3 for s in supports) else 1
+    n = supports[0].shape[-1]
+    return supports[0].new_empty((g, len(supports) * max_diffusion_step, n, n), dtype=torch.float32)
 
 
-_poly_memo = _Memo()
-_pack_memo = _Memo(16)
+_define("hop_polys", "(Tensor[] supports, int max_diffusion_step, int batch) -> Tensor", _hop_polys_impl, _hop_polys_fake)
 
 
+def _pack_cell_impl(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
+    lib = _lib.get_lib()
+    tensors = [wg.detach(), bg.detach(), wc.detach(), bc.detach()]
+    for t, nm in zip(tensors, ("dconv_gate.weight", "dconv_gate.biases", "dconv_candidate.weight", "dconv_candidate.biases")):
+        _check(lib, t, nm)
+    rows = (fin + h) * m
+    if tuple(wg.shape) != (rows, 2 * h) or tuple(wc.shape) != (rows, h) or tuple(bg.shape) != (2 * h,) or tuple(bc.shape) != (h,):
+        raise RuntimeError(f"cell parameter shapes {tuple(wg.shape)}, {tuple(bg.shape)}, {tuple(wc.shape)}, {tuple(bc.shape)} "
+                           f"do not match input_dim={fin}, num_units={h}, num_matrices={m}")
+    pack = _new((lib.query("eeg_dcrnn_pack_floats", fin, h, m),), wg)
+    lib.call("eeg_dcrnn_pack_cell", _p(tensors[0]), _p(tensors[1]), _p(tensors[2]), _p(tensors[3]), fin, h, m, _p(pack), _stream(pack))
+    return pack
+
+
+def _pack_floats(fin, h, m):
+    """mirror of make_cell_pack (csrc/kernels_pack.h) for shape inference"""
+    r16 = lambda a: (a + 15) // 16 * 16   # noqa: E731
+    return m * fin * 3 * h + (3 * h + 63) // 64 * 64 + m * h * 2 * h + 2 * m * h * h + m * 2 * h * h + 3 * h * r16(m * fin)
+
+
+_define("pack_cell", "(Tensor wg, Tensor bg, Tensor wc, Tensor bc, int fin, int h, int m) -> Tensor", _pack_cell_impl,
+        lambda wg, bg, wc, bc, fin, h, m: wg.new_empty((_pack_floats(fin, h, m),)))
+
+
+def _diffusion_hops_impl(x, p, p_batched: int, batch: int) -> torch.Tensor:
+    lib = _lib.get_lib()
+    _check(lib, x, "x")
+    _check(lib, p, "P")
+    s, n, f = x.shape
+    m = p.shape[1] + 1
+    out = _new((m - 1, s, n, f), x)
+    lib.call("eeg_dcrnn_diffuse_fwd", _p(x), _p(p), p_batched, s, batch, n, f, m, _p(out), _stream(x))
+    return out
+
+
+_define("diffusion_hops", "(Tensor x, Tensor P, int p_batched, int batch) -> Tensor", _diffusion_hops_impl,
+        lambda x, p, p_batched, batch: x.new_empty((p.shape[1],) + tuple(x.shape)))
+
+
+# =============================================================================================
+# DiffusionGraphConv (cell.py:66-118), differentiable
+# =============================================================================================
+def _dconv_impl(x, p, p_batched: int, weight, biases) -> torch.Tensor:
+    lib = _lib.get_lib()
+    x = x.contiguous()
+    w, bvec = weight.detach().contiguous(), biases.detach().contiguous()
+    for t, nm in ((x, "inputs_and_state"), (p, "P"), (w, "weight"), (bvec, "biases")):
+        _check(lib, t, nm)
+    b, n, f = x.shape
+    m, o = p.shape[1] + 1, w.shape[1]
+    if w.shape[0] != f * m:
+        raise RuntimeError(f"weight has {w.shape[0]} rows, expected (input_dim+hid_dim)*num_matrices = {f * m}")
+    out = _new((b, n, o), x)
+    ws = _new((lib.query("eeg_dcrnn_dconv_fwd_ws_floats", b, n, f, m, o),), x)
+    lib.call("eeg_dcrnn_dconv_fwd", _p(x), _p(p), p_batched, b, n, f, m, _p(w), _p(bvec), o, _p(out), _p(ws), _stream(x))
+    return out
+
+
+def _dconv_bwd_impl(dout, x, p, p_batched: int, weight, need_dx: bool):
+    lib = _lib.get_lib()
+    dout, x, w = dout.contiguous(), x.contiguous(), weight.detach().contiguous()
+    for t, nm in ((dout, "grad_output"), (x, "inputs_and_state"), (p, "P"), (w, "weight")):
+        _check(lib, t, nm)
+    b, n, f = x.shape
+    m, o = p.shape[1] + 1, w.shape[1]
+    dx = _new((b, n, f), x) if need_dx else _new((0,), x)
+    dw, db = _new((f * m, o), x), _new((o,), x)
+    ws = _new((lib.query("eeg_dcrnn_dconv_bwd_ws_floats", b, n, f, m, o),), x)
+    lib.call("eeg_dcrnn_dconv_bwd", _p(x), _p(p), p_batched, b, n, f, m, _p(w), o, _p(dout), _p(dx) if need_dx else None,
+             _p(dw), _p(db), _p(ws), _stream(x))
+    return dx, dw, db
+
+
+_define("dconv", "(Tensor x, Tensor P, int p_batched, Tensor weight, Tensor biases) -> Tensor", _dconv_impl,
+        lambda x, p, p_batched, weight, biases: x.new_empty((x.shape[0], x.shape[1], weight.shape[1])))
+_define("dconv_bwd", "(Tensor dout, Tensor x, Tensor P, int p_batched, Tensor weight, bool need_dx) -> (Tensor, Tensor, Tensor)",
+        _dconv_bwd_impl,
+        lambda dout, x, p, p_batched, weight, need_dx: (x.new_empty(x.shape if need_dx else (0,)), torch.empty_like(weight),
+                                                        x.new_empty((weight.shape[1],))))
+
+
+def _dconv_setup(ctx, inputs, output):
+    x, p, p_batched, weight, _ = inputs
+    ctx.save_for_backward(x, p, weight)
+    ctx.p_batched = p_batched
+
+
+def _dconv_backward(ctx, dout):
+    x, p, weight = ctx.saved_tensors
+    dx, dw, db = torch.ops.eeg_dcrnn.dconv_bwd(dout, x, p, ctx.p_batched, weight, ctx.needs_input_grad[0])
+    return (dx if ctx.needs_input_grad[0] else None), None, None, dw, db
+
+
+torch.library.register_autograd(f"{NS}::dconv", _dconv_backward, setup_context=_dconv_setup, lib=_libdef)
+
+
+# =============================================================================================
+# one DCGRU layer over a whole sequence (model.py:93-96 around cell.py:182-210)
+# =============================================================================================
 class GradSink:
     """Lets the backward operators write parameter gradients straight into caller-owned buffers
     (TrainStep's flat gradient bucket) instead of returning fresh tensors that autograd then adds into
@@ -104,23 +243,486 @@ class GradSink:
         return tgt
 
 
-def new_forward_scope():
-    """Drop the memoised hop polynomials / weight packs.  Called at the start of every encoder /
-    decoder forward, so the memo only ever serves repeated cell calls INSIDE one forward (the
-    decoder's time loop) and can never hand out packs of stale weights (e.g. after an optimiser
-    that updates parameters through an aliased flat buffer, which does not bump `_version`)."""
-    _poly_memo.items.clear()
-    _pack_memo.items.clear()
-    _hop_planes.clear()
+def _layer_dims(t_len, b, n, h, fin, m, act, p_batched, planes_ready):
+    dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
+    if planes_ready:           # the layer below's Hplanes (M-1, T+1, B, N, Fin): slots 1..T are P_m x
+        dims.x_planes_ready = 1
+        dims.x_plane_stride = (t_len + 1) * b * n * fin
+    return dims
 
 
-# hop planes P_m h_t that a layer's recurrent kernel left behind (slots 1..T of its Hplanes), keyed by the
-# data pointer of the hidden sequence they belong to: the next layer, fed that very tensor and the same
-# hop polynomials, takes them as its input planes instead of diffusing again.  The entry keeps the hidden
-# sequence's storage alive (no pointer reuse inside a scope); cleared by new_forward_scope().
-_hop_planes: dict = {}
-hop_plane_handovers = 0            # diagnostics: how often a layer took its input planes from the layer below
-hop_plane_handover_enabled = True  # tests switch it off to compare against the separately diffused planes
+def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, lengths, x_planes, n: int, h: int, m: int,
+                      act: int, save: bool):
+    """x: (T + x_off, B, N, Fin) — x_off = 1 when x is the `hext` of the layer below (its slot 0 is that layer's
+    initial state), whose `hpl` output is then passed as x_planes.  Returns hext (T+1, B, N*H) (slot 0 = initial
+    state, slot t+1 = h_t), hsel (B, N*H) = h at t = lengths-1 (T-1 without lengths) and the tensors the backward
+    needs: [xtm, pack, planes, rs, us, cs, rhs, hpl, rhpl] (numel-0 placeholders where nothing is kept)."""
+    lib = _lib.get_lib()
+    t_len, b, fin = x.shape[0] - x_off, x.shape[1], x.shape[3]
+    if not lib.query("eeg_dcrnn_supported", n, h, fin, m):
+        raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
+    ready = x_planes is not None
+    dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, ready)
+    empty = _new((0,), p)
+    # a transposed view of a contiguous batch-major (B,T,N,Fin) tensor (what model.py:253 produces) is consumed
+    # as it is: the diffusion kernel emits the time-major copy as a by-product
+    xsrc, xtm = None, None
+    bm = 0
+    if not x.is_contiguous() and x_off == 0 and not ready and x.transpose(0, 1).is_contiguous():
+        bm = lib.query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims))
+    if bm:
+        xsrc = x.transpose(0, 1)
+        _check(lib, xsrc, "inputs")
+        if bm == 2:                       # no copy at all: diffusion kernel and GEMMs read (b,t) rows through a map
+            dims.x_batch_major = 1
+            xk = xsrc
+        else:
+            xtm = _new((t_len, b, n, fin), x)
+            xk = xtm
+    else:
+        if not x.is_contiguous():
+            xtm = x.contiguous()
+            x = xtm
+        _check(lib, x, "inputs")
+        xk = x[x_off:] if x_off else x
+    if h0 is not None:
+        h0 = h0.contiguous()
+        _check(lib, h0, "initial_hidden_state")
+    _check(lib, p, "P")
+    pack = torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
+    s = t_len * b
+    if ready:
+        _check(lib, x_planes, "x_planes")
+        if tuple(x_planes.shape) != (m - 1, t_len + 1, b, n, fin):
+            raise RuntimeError(f"x_planes has shape {tuple(x_planes.shape)}, expected {(m - 1, t_len + 1, b, n, fin)}")
+        planes, planes_ptr = empty, x_planes.data_ptr() + 4 * b * n * fin
+    else:
+        planes = _new((m - 1, s, n, fin), x)
+        planes_ptr = planes.data_ptr()
+    hext = _new((t_len + 1, b, n * h), x)
+    if save:
+        rs, us, cs, rhs = (_new((t_len, b, n * h), x) for _ in range(4))
+        hpl, rhpl = (_new((m - 1, t_len + 1, b, n, h), x) for _ in range(2))
+    else:
+        rs = us = cs = rhs = hpl = rhpl = None
+    ws = _new((lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)),), x)
+    lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(xsrc if xsrc is not None else xk), _p(xtm) if (xsrc is not None and bm != 2) else None,
+             _p(h0), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
+    if lengths is not None:
+        lengths = lengths.to(device=x.device, dtype=torch.int64).contiguous()
+        hsel = _new((b, n * h), x)
+        lib.call("eeg_dcrnn_gather_last", _p(hext[1:]), _p(lengths), t_len, b, n * h, _p(hsel), _stream(x))
+    else:
+        hsel = hext[t_len].clone()
+    if not save:
+        return hext, hsel, []
+    return hext, hsel, [xtm if xtm is not None else empty, pack, planes, rs, us, cs, rhs, hpl, rhpl]
+
+
+def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save):
+    t_len, b, fin = x.shape[0] - x_off, x.shape[1], x.shape[3]
+    ne = lambda *shape: x.new_empty(shape)   # noqa: E731
+    hext, hsel = ne(t_len + 1, b, n * h), ne(b, n * h)
+    if not save:
+        return hext, hsel, []
+    xtm = ne(t_len, b, n, fin) if not x.is_contiguous() else ne(0)
+    planes = ne(0) if x_planes is not None else ne(m - 1, t_len * b, n, fin)
+    return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + \
+        [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)]
+
+
+def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack, planes, x_planes, hext, rs, us, cs, rhs,
+                          hpl, rhpl, lengths, has_h0: bool, n: int, h: int, m: int, act: int, need_dx: bool, need_dh0: bool,
+                          dwg, dbg, dwc, dbc):
+    """BPTT + all parameter gradients of one layer.  d_hext (T+1,B,N*H) w.r.t. hext (slot 0 is ignored), d_hsel
+    (B,N*H) w.r.t. hsel.  dwg/dbg/dwc/dbc are overwritten.  Returns (dx (T + x_off, B, N, Fin) with the step
+    gradients in slots x_off.., dh0 (B,N*H)) — numel-0 tensors where not requested."""
+    lib = _lib.get_lib()
+    t_len, b, fin = hext.shape[0] - 1, hext.shape[1], x.shape[3]
+    ready = x_planes is not None
+    dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, ready)
+    if not x.is_contiguous():             # the forward consumed the batch-major input through the row map (saved as the view)
+        if not x.transpose(0, 1).is_contiguous():
+            raise RuntimeError("dcgru_layer_bwd: x must be contiguous or the transposed view of a batch-major tensor")
+        dims.x_batch_major = 1
+    planes_ptr = x_planes.data_ptr() + 4 * b * n * fin if ready else planes.data_ptr()
+    state = b * n * h
+    if d_hext is not None:
+        d_hext = d_hext.contiguous()
+        _check(lib, d_hext, "grad of hext")
+    if d_hsel is not None:
+        d_hsel = d_hsel.contiguous()
+    d_hseq_ptr = ctypes.c_void_p(d_hext.data_ptr() + 4 * state) if d_hext is not None else None
+    d_at_end = d_hsel if lengths is None else None
+    d_at_len = d_hsel if lengths is not None else None
+    xk_ptr = ctypes.c_void_p(x.data_ptr() + 4 * x_off * b * n * fin)
+    dx = _new((t_len + x_off, b, n, fin), hext) if need_dx else _new((0,), hext)
+    dx_ptr = ctypes.c_void_p(dx.data_ptr() + 4 * x_off * b * n * fin) if need_dx else None
+    dh0 = _new((b, n * h), hext) if (need_dh0 and has_h0) else _new((0,), hext)
+    ws = _new((lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),), hext)
+    lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), xk_ptr, _p(p), _p(pack), planes_ptr, _p(hext), _p(rs),
+             _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), d_hseq_ptr, _p(d_at_end), _p(d_at_len), _p(lengths), dx_ptr,
+             _p(dh0) if dh0.numel() else None, _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(hext))
+    return dx, dh0
+
+
+def _dcgru_layer_bwd_fake(d_hext, d_hsel, x, x_off, p, p_batched, pack, planes, x_planes, hext, rs, us, cs, rhs, hpl, rhpl,
+                          lengths, has_h0, n, h, m, act, need_dx, need_dh0, dwg, dbg, dwc, dbc):
+    t_len, b, fin = hext.shape[0] - 1, hext.shape[1], x.shape[3]
+    return (hext.new_empty((t_len + x_off, b, n, fin) if need_dx else (0,)),
+            hext.new_empty((b, n * h) if (need_dh0 and has_h0) else (0,)))
+
+
+_define("dcgru_layer",
+        "(Tensor x, int x_off, Tensor? h0, Tensor P, int p_batched, Tensor wg, Tensor bg, Tensor wc, Tensor bc, Tensor? lengths, "
+        "Tensor? x_planes, int n, int h, int m, int act, bool save) -> (Tensor hext, Tensor hsel, Tensor[] saved)",
+        _dcgru_layer_impl, _dcgru_layer_fake)
+_define("dcgru_layer_bwd",
+        "(Tensor? d_hext, Tensor? d_hsel, Tensor x, int x_off, Tensor P, int p_batched, Tensor pack, Tensor planes, Tensor? x_planes, "
+        "Tensor hext, Tensor rs, Tensor us, Tensor cs, Tensor rhs, Tensor hpl, Tensor rhpl, Tensor? lengths, bool has_h0, int n, int h, "
+        "int m, int act, bool need_dx, bool need_dh0, Tensor(a!) dwg, Tensor(b!) dbg, Tensor(c!) dwc, Tensor(d!) dbc) -> (Tensor, Tensor)",
+        _dcgru_layer_bwd_impl, _dcgru_layer_bwd_fake)
+
+
+def _dcgru_layer_setup(ctx, inputs, output):
+    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save) = inputs
+    hext, _, saved = output
+    ctx.set_materialize_grads(False)
+    ctx.saved_ok = bool(save) and len(saved) == 9
+    ctx.meta = (x_off, p_batched, n, h, m, act, h0 is not None)
+    ctx.params = (wg, bg, wc, bc)
+    if ctx.saved_ok:
+        xtm = saved[0]
+        lens = None if lengths is None else lengths.to(device=x.device, dtype=torch.int64).contiguous()
+        ctx.save_for_backward(xtm if xtm.numel() else x, p, x_planes, lens, hext, *saved[1:])
+
+
+def _dcgru_layer_backward(ctx, d_hext, d_hsel, d_saved):
+    if not ctx.saved_ok:
+        raise RuntimeError("eeg_dcrnn::dcgru_layer was run with save=False: nothing was kept for the backward pass")
+    xk, p, x_planes, lens, hext, pack, planes, rs, us, cs, rhs, hpl, rhpl = ctx.saved_tensors
+    x_off, p_batched, n, h, m, act, has_h0 = ctx.meta
+    need_dx, need_dh0 = ctx.needs_input_grad[0], has_h0 and ctx.needs_input_grad[2]
+    fin = xk.shape[3]
+    rows = (fin + h) * m
+    shapes = ((rows, 2 * h), (2 * h,), (rows, h), (h,))
+    sunk = [GradSink.take(q) for q in ctx.params]           # written in place -> nothing for autograd to add
+    bufs = [t if t is not None else _new(sh, hext) for t, sh in zip(sunk, shapes)]
+    dx, dh0 = torch.ops.eeg_dcrnn.dcgru_layer_bwd(d_hext, d_hsel, xk, x_off, p, p_batched, pack, planes, x_planes, hext,
+                                                  rs, us, cs, rhs, hpl, rhpl, lens, has_h0, n, h, m, act, need_dx, need_dh0, *bufs)
+    ret = [None if t is not None else g for t, g in zip(sunk, bufs)]
+    return (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None)
+
+
+torch.library.register_autograd(f"{NS}::dcgru_layer", _dcgru_layer_backward, setup_context=_dcgru_layer_setup, lib=_libdef)
+
+
+# =============================================================================================
+# decoder (model.py:160-204) as one operator
+# =============================================================================================
+def _dec_dims(meta):
+    t_len, b, n, h, dout, m, n_layers, act, p_batched = meta
+    return DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched)
+
+
+def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher: List[int],
+                        t_len: int, n: int, h: int, dout: int, m: int, n_layers: int, act: int):
+    """T autoregressive steps through L cells + the projection.  teacher: T ints (1 = feed targets[t] to step t+1,
+    all 0 = fully autoregressive); returns out (T,B,N*Dout) and [saved, pack0, pack1]."""
+    lib = _lib.get_lib()
+    for fin in (dout, h):
+        if not lib.query("eeg_dcrnn_supported", n, h, fin, m):
+            raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
+    h0 = h0.contiguous()
+    b = h0.shape[1]
+    wp, bp = wp.detach().contiguous(), bp.detach().contiguous()
+    for t, nm in ((h0, "initial_hidden_state"), (p, "P"), (wp, "projection_layer.weight"), (bp, "projection_layer.bias")):
+        _check(lib, t, nm)
+    if tuple(wp.shape) != (dout, h) or tuple(bp.shape) != (dout,):
+        raise RuntimeError(f"projection_layer shapes {tuple(wp.shape)}, {tuple(bp.shape)} do not match ({dout}, {h})")
+    use_tf = len(teacher) > 0 and any(teacher)
+    if use_tf:
+        if targets is None:
+            raise RuntimeError("teacher forcing needs the target sequence")
+        targets = targets.contiguous()
+        _check(lib, targets, "inputs (teacher-forcing targets)")
+    pack0 = torch.ops.eeg_dcrnn.pack_cell(wg0, bg0, wc0, bc0, dout, h, m)
+    pack1 = torch.ops.eeg_dcrnn.pack_cell(wg1, bg1, wc1, bc1, h, h, m) if n_layers > 1 else _new((0,), h0)
+    packs = [pack0] + [pack1] * (n_layers - 1)
+    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched))
+    out = _new((t_len, b, n * dout), h0)
+    saved = _new((lib.query("eeg_dcrnn_decoder_saved_floats", ctypes.byref(dims)),), h0)
+    ws = _new((lib.query("eeg_dcrnn_decoder_fwd_ws_floats", ctypes.byref(dims)),), h0)
+    tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if use_tf else None
+    pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
+    lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_arr, _p(h0), _p(p), pk_arr,
+             _p(wp), _p(bp), _p(out), _p(saved), _p(ws), _stream(h0))
+    return out, [saved, pack0, pack1]
+
+
+def _dcgru_decoder_bwd_impl(d_out, p, p_batched: int, saved, pack0, pack1, wp, teacher: List[int], t_len: int, n: int, h: int,
+                            dout: int, m: int, n_layers: int, act: int, dwg0, dbg0, dwc0, dbc0, dwg1, dbg1, dwc1, dbc1, dwp, dbp):
+    lib = _lib.get_lib()
+    d_out = d_out.contiguous()
+    _check(lib, d_out, "grad of the decoder output")
+    b = d_out.shape[1]
+    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched))
+    packs = [pack0] + [pack1] * (n_layers - 1)
+    g0, g1 = (dwg0, dbg0, dwc0, dbc0), (dwg1, dbg1, dwc1, dbc1)
+    dh0 = _new((n_layers, b, n * h), saved)
+    ws = _new((lib.query("eeg_dcrnn_decoder_bwd_ws_floats", ctypes.byref(dims)),), saved)
+    use_tf = len(teacher) > 0 and any(teacher)
+    tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if use_tf else None
+    arr = lambda k: (ctypes.c_void_p * n_layers)(*[(g0 if l == 0 else g1)[k].data_ptr() for l in range(n_layers)])  # noqa: E731
+    pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
+    lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_arr, _p(p), pk_arr, _p(wp.detach().contiguous()), _p(saved), _p(d_out),
+             _p(dh0), arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
+    return dh0
+
+
+def _dec_saved_floats_fake(h0, t_len, n, h, dout, m, n_layers):
+    return h0.new_empty((1,))        # opaque block: only the device implementation knows its size
+
+
+_define("dcgru_decoder",
+        "(Tensor? targets, Tensor h0, Tensor P, int p_batched, Tensor wg0, Tensor bg0, Tensor wc0, Tensor bc0, Tensor? wg1, Tensor? bg1, "
+        "Tensor? wc1, Tensor? bc1, Tensor wp, Tensor bp, int[] teacher, int t_len, int n, int h, int dout, int m, int n_layers, int act) "
+        "-> (Tensor out, Tensor[] saved)",
+        _dcgru_decoder_impl,
+        lambda targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act:
+        (h0.new_empty((t_len, h0.shape[1], n * dout)),
+         [_dec_saved_floats_fake(h0, t_len, n, h, dout, m, n_layers), h0.new_empty((_pack_floats(dout, h, m),)),
+          h0.new_empty((_pack_floats(h, h, m) if n_layers > 1 else 0,))]))
+_define("dcgru_decoder_bwd",
+        "(Tensor d_out, Tensor P, int p_batched, Tensor saved, Tensor pack0, Tensor pack1, Tensor wp, int[] teacher, int t_len, int n, "
+        "int h, int dout, int m, int n_layers, int act, Tensor(a!) dwg0, Tensor(b!) dbg0, Tensor(c!) dwc0, Tensor(d!) dbc0, "
+        "Tensor(e!)? dwg1, Tensor(f!)? dbg1, Tensor(g!)? dwc1, Tensor(h!)? dbc1, Tensor(i!) dwp, Tensor(j!) dbp) -> Tensor",
+        _dcgru_decoder_bwd_impl,
+        lambda d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m, n_layers, act, *grads:
+        d_out.new_empty((n_layers, d_out.shape[1], n * h)))
+
+
+def _dcgru_decoder_setup(ctx, inputs, output):
+    (targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act) = inputs
+    _, saved = output
+    ctx.set_materialize_grads(False)
+    ctx.save_for_backward(p, wp, *saved)
+    ctx.params = (wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp)
+    ctx.meta = (p_batched, list(teacher), t_len, n, h, dout, m, n_layers, act)
+
+
+def _dcgru_decoder_backward(ctx, d_out, d_saved):
+    p, wp, saved, pack0, pack1 = ctx.saved_tensors
+    p_batched, teacher, t_len, n, h, dout, m, n_layers, act = ctx.meta
+    if d_out is None:
+        return (None,) * 22
+    shapes = [None if q is None else tuple(q.shape) for q in ctx.params]
+    sunk = [GradSink.take(q) if q is not None else None for q in ctx.params]
+    bufs = [t if t is not None else (_new(sh, saved) if sh is not None else None) for t, sh in zip(sunk, shapes)]
+    dh0 = torch.ops.eeg_dcrnn.dcgru_decoder_bwd(d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m,
+                                                n_layers, act, *bufs)
+    ret = [None if (t is not None or g is None) else g for t, g in zip(sunk, bufs)]   # sunk: already in the caller's buffer
+    return (None, dh0, None, None, *ret, None, None, None, None, None, None, None, None)
+
+
+torch.library.register_autograd(f"{NS}::dcgru_decoder", _dcgru_decoder_backward, setup_context=_dcgru_decoder_setup, lib=_libdef)
+
+
+# =============================================================================================
+# heads, gather, graph construction, featurisation
+# =============================================================================================
+def _cls_head_impl(z, w, bias):
+    lib = _lib.get_lib()
+    z, w, bias = z.contiguous(), w.detach().contiguous(), bias.detach().contiguous()
+    for t, nm in ((z, "last_out"), (w, "fc.weight"), (bias, "fc.bias")):
+        _check(lib, t, nm)
+    b, n, h = z.shape
+    c = w.shape[0]
+    logits = _new((b, c), z)
+    arg = _new((b, c), z, torch.int32)
+    lib.call("eeg_dcrnn_cls_head_fwd", _p(z), _p(w), _p(bias), b, n, h, c, _p(logits), _p(arg), _stream(z))
+    return logits, arg
+
+
+def _cls_head_bwd_impl(z, w, dlogits, arg, dw, db):
+    lib = _lib.get_lib()
+    z, w, dlogits = z.contiguous(), w.detach().contiguous(), dlogits.contiguous()
+    b, n, h = z.shape
+    dz = torch.empty_like(z)
+    lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, w.shape[0], _p(dz), _p(dw), _p(db), _stream(z))
+    return dz
+
+
+_define("cls_head", "(Tensor z, Tensor w, Tensor bias) -> (Tensor logits, Tensor arg)", _cls_head_impl,
+        lambda z, w, bias: (z.new_empty((z.shape[0], w.shape[0])), z.new_empty((z.shape[0], w.shape[0]), dtype=torch.int32)))
+_define("cls_head_bwd", "(Tensor z, Tensor w, Tensor dlogits, Tensor arg, Tensor(a!) dw, Tensor(b!) db) -> Tensor", _cls_head_bwd_impl,
+        lambda z, w, dlogits, arg, dw, db: torch.empty_like(z))
+
+
+def _cls_head_setup(ctx, inputs, output):
+    z, w, bias = inputs
+    ctx.save_for_backward(z, w, output[1])
+    ctx.params = (w, bias)
+    ctx.set_materialize_grads(False)
+
+
+def _cls_head_backward(ctx, dlogits, _darg):
+    z, w, arg = ctx.saved_tensors
+    if dlogits is None:
+        return None, None, None
+    sunk = [GradSink.take(q) for q in ctx.params]
+    dw = sunk[0] if sunk[0] is not None else torch.empty_like(w)
+    db = sunk[1] if sunk[1] is not None else _new((w.shape[0],), z)
+    dz = torch.ops.eeg_dcrnn.cls_head_bwd(z, w, dlogits, arg, dw, db)
+    return dz, (None if sunk[0] is not None else dw), (None if sunk[1] is not None else db)
+
+
+torch.library.register_autograd(f"{NS}::cls_head", _cls_head_backward, setup_context=_cls_head_setup, lib=_libdef)
+
+
+def _gather_last_impl(htop, lengths):
+    lib = _lib.get_lib()
+    htop = htop.contiguous()
+    _check(lib, htop, "output")
+    t_len, b, d = htop.shape
+    lengths = lengths.to(device=htop.device, dtype=torch.int64).contiguous()
+    out = _new((b, d), htop)
+    lib.call("eeg_dcrnn_gather_last", _p(htop), _p(lengths), t_len, b, d, _p(out), _stream(htop))
+    return out
+
+
+_define("gather_last", "(Tensor htop, Tensor lengths) -> Tensor", _gather_last_impl,
+        lambda htop, lengths: htop.new_empty((htop.shape[1], htop.shape[2])))
+
+
+def _corr_graph_impl(x, top_k: int):
+    lib = _lib.get_lib()
+    x = x.contiguous()
+    _check(lib, x, "clips")
+    if x.dim() != 4:
+        raise RuntimeError(f"clips must be (B,T,N,D), got {tuple(x.shape)}")
+    b, t_len, n, d = x.shape
+    adj, s1, s2 = (_new((b, n, n), x) for _ in range(3))
+    ws = _new((lib.query("eeg_dcrnn_corr_graph_ws_floats", b, t_len),), x)
+    lib.call("eeg_dcrnn_corr_graph", _p(x), b, t_len, n, d, int(top_k), _p(adj), _p(s1), _p(s2), _p(ws), _stream(x))
+    return adj, s1, s2
+
+
+_define("corr_graph", "(Tensor x, int top_k) -> (Tensor adj, Tensor s1, Tensor s2)", _corr_graph_impl,
+        lambda x, top_k: tuple(x.new_empty((x.shape[0], x.shape[2], x.shape[2])) for _ in range(3)))
+
+
+def _fft_features_impl(raw, window: int, mean: float, std: float, standardise: bool, perm, log_scale):
+    lib = _lib.get_lib()
+    raw = raw.contiguous()
+    _check(lib, raw, "raw signals")
+    if raw.dim() != 3 or raw.shape[2] % window != 0:
+        raise RuntimeError(f"raw signals must be (B, N, T*{window}), got {tuple(raw.shape)}")
+    b, n, total = raw.shape
+    t_len = total // window
+    feat_raw = _new((b, t_len, n, window // 2), raw)
+    feat_std = torch.empty_like(feat_raw) if standardise else _new((0,), raw)
+    if perm is not None:
+        perm = perm.to(device=raw.device, dtype=torch.int32).contiguous()
+    if log_scale is not None:
+        log_scale = log_scale.to(device=raw.device, dtype=torch.float32).contiguous()
+    lib.call("eeg_dcrnn_fft_features", _p(raw), b, n, t_len, window, _p(perm), _p(log_scale), float(mean), float(std),
+             _p(feat_raw), _p(feat_std) if standardise else None, _stream(raw))
+    return feat_raw, feat_std
+
+
+def _fft_features_fake(raw, window, mean, std, standardise, perm, log_scale):
+    shape = (raw.shape[0], raw.shape[2] // window, raw.shape[1], window // 2)
+    return raw.new_empty(shape), raw.new_empty(shape if standardise else (0,))
+
+
+_define("fft_features", "(Tensor raw, int window, float mean, float std, bool standardise, Tensor? perm, Tensor? log_scale) -> (Tensor, Tensor)",
+        _fft_features_impl, _fft_features_fake)
+
+
+# =============================================================================================
+# losses that seed backward, optimiser tail
+# =============================================================================================
+def _bce_logits_impl(logits, y):
+    lib = _lib.get_lib()
+    x = logits.contiguous().view(-1)
+    yy = y.to(torch.float32).contiguous().view(-1)
+    _check(lib, x, "logits")
+    _check(lib, yy, "targets")
+    loss, dx = _new((1,), x), torch.empty_like(x)
+    lib.call("eeg_dcrnn_bce_logits", _p(x), _p(yy), x.numel(), _p(loss), _p(dx), _stream(x))
+    return loss[0], dx.view(logits.shape)
+
+
+def _ce_logits_impl(logits, y):
+    lib = _lib.get_lib()
+    x = logits.contiguous()
+    yy = y.to(torch.int64).contiguous()
+    _check(lib, x, "logits")
+    _check(lib, yy, "targets", torch.int64)
+    loss, dx = _new((1,), x), torch.empty_like(x)
+    lib.call("eeg_dcrnn_ce_logits", _p(x), _p(yy), x.shape[0], x.shape[1], _p(loss), _p(dx), _stream(x))
+    return loss[0], dx
+
+
+def _masked_loss_impl(pred, y, use_scaler: bool, mean: float, std: float, mask_val: float, kind: int):
+    lib = _lib.get_lib()
+    pr = pred.contiguous()
+    t = y.to(torch.float32).contiguous()
+    _check(lib, pr, "y_predicted")
+    _check(lib, t, "y_true")
+    if pr.shape != t.shape:
+        raise RuntimeError(f"y_predicted {tuple(pr.shape)} and y_true {tuple(t.shape)} differ in shape")
+    loss, dp = _new((1,), pr), torch.empty_like(pr)
+    ws = _new((lib.query("eeg_dcrnn_masked_loss_ws_floats"),), pr)
+    lib.call("eeg_dcrnn_masked_loss", _p(pr), _p(t), pr.numel(), 1 if use_scaler else 0, float(mean), float(std),
+             float(mask_val), int(kind), _p(loss), _p(dp), _p(ws), _stream(pr))
+    return loss[0], dp
+
+
+_loss_fake = lambda x, *a: (x.new_empty(()), torch.empty_like(x))   # noqa: E731
+_define("bce_logits", "(Tensor logits, Tensor y) -> (Tensor loss, Tensor dlogits)", _bce_logits_impl, _loss_fake)
+_define("ce_logits", "(Tensor logits, Tensor y) -> (Tensor loss, Tensor dlogits)", _ce_logits_impl, _loss_fake)
+_define("masked_loss", "(Tensor pred, Tensor y, bool use_scaler, float mean, float std, float mask_val, int kind) -> (Tensor loss, Tensor dpred)",
+        _masked_loss_impl, _loss_fake)
+
+
+def _loss_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.n_in = len(inputs)
+
+
+def _loss_backward(ctx, dloss, _dgrad):
+    (dx,) = ctx.saved_tensors
+    return (dx * dloss,) + (None,) * (ctx.n_in - 1)
+
+
+for _name in ("bce_logits", "ce_logits", "masked_loss"):
+    torch.library.register_autograd(f"{NS}::{_name}", _loss_backward, setup_context=_loss_setup, lib=_libdef)
+
+
+def _clip_adam_impl(params, grads, exp_avg, exp_avg_sq, step: int, lr: float, beta1: float, beta2: float, eps: float,
+                    weight_decay: float, max_norm: float, grad_scale: float, ws, norm_out):
+    lib = _lib.get_lib()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _check(lib, t, nm)
+    lib.call("eeg_dcrnn_clip_adam", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), float(max_norm),
+             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+             _p(ws), _p(norm_out), _stream(params))
+
+
+_define("clip_adam_",
+        "(Tensor(a!) params, Tensor(b!) grads, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, int step, float lr, float beta1, float beta2, "
+        "float eps, float weight_decay, float max_norm, float grad_scale, Tensor(e!) ws, Tensor(f!)? norm_out) -> ()",
+        _clip_adam_impl, lambda *a: None)
+
+
+# =============================================================================================
+# Python conveniences used by model/, utils.py and train_step.py
+# =============================================================================================
+# diagnostics: how often a layer took its input hop planes from the recurrent kernel of the layer below
+hop_plane_handovers = 0
+hop_plane_handover_enabled = True   # tests switch it off to compare against separately diffused planes
 
 
 def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: int) -> Tuple[torch.Tensor, int]:
@@ -128,35 +730,11 @@ def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: 
 
     supports: list of (N,N) or (B,N,N) tensors (torch.matmul broadcast semantics of cell.py:85).
     Returns (P (G, M-1, N, N), p_batched) with G = B if any support is batched else 1."""
-    lib = _lib.get_lib()
     sups = list(supports)
     if len(sups) == 0:
         raise RuntimeError("hop_polys: empty supports list")
-    k = _Memo.key(sups, (max_diffusion_step, batch))
-    hit = _poly_memo.get(k)
-    if hit is not None:
-        return hit[0], hit[1]
-    batched = any(s.dim() == 3 for s in sups)
-    n = sups[0].shape[-1]
-    norm = []
-    for i, s in enumerate(sups):
-        if s.shape[-1] != n or s.shape[-2] != n:
-            raise RuntimeError(f"supports[{i}] has shape {tuple(s.shape)}, expected (..., {n}, {n})")
-        if s.dim() == 3 and s.shape[0] != batch:
-            raise RuntimeError(f"supports[{i}] batch {s.shape[0]} != input batch {batch}")
-        if batched and s.dim() == 2:
-            s = s.unsqueeze(0).expand(batch, n, n)
-        s = s.to(torch.float32).contiguous()
-        _check(lib, s, f"supports[{i}]")
-        norm.append(s)
-    g = batch if batched else 1
-    m1 = len(norm) * max_diffusion_step
-    out = torch.empty((g, m1, n, n), dtype=torch.float32, device=norm[0].device)
-    arr = (ctypes.c_void_p * len(norm))(*[s.data_ptr() for s in norm])
-    lib.call("eeg_dcrnn_hop_polys", arr, len(norm), g, n, max_diffusion_step, _p(out), _stream(out))
-    flag = 1 if batched else 0
-    _poly_memo.put(k, (out, flag, norm, sups))   # keep the keyed tensors alive with the cache entry
-    return out, flag
+    flag = 1 if any(s.dim() == 3 for s in sups) else 0
+    return torch.ops.eeg_dcrnn.hop_polys(sups, int(max_diffusion_step), int(batch)), flag
 
 
 def fft_features(raw: torch.Tensor, window: int = 200, mean: Optional[float] = None, std: Optional[float] = None,
@@ -168,23 +746,10 @@ def fft_features(raw: torch.Tensor, window: int = 200, mean: Optional[float] = N
     Replaces `computeFFT` per step (data_utils.py:13-35, dataloader_detection.py:57-71), the reflection /
     amplitude-jitter augmentation (perm (B,N) int32 source channel per node, log_scale (B);
     dataloader_detection.py:233-256) and `StandardScaler.transform` (utils.py:393-428)."""
-    lib = _lib.get_lib()
-    raw = raw.contiguous()
-    _check(lib, raw, "raw signals")
-    if raw.dim() != 3 or raw.shape[2] % window != 0:
-        raise RuntimeError(f"raw signals must be (B, N, T*{window}), got {tuple(raw.shape)}")
-    b, n, total = raw.shape
-    t_len = total // window
-    feat_raw = torch.empty((b, t_len, n, window // 2), dtype=torch.float32, device=raw.device)
-    feat_std = torch.empty_like(feat_raw) if mean is not None else None
-    if perm is not None:
-        perm = perm.to(device=raw.device, dtype=torch.int32).contiguous()
-    if log_scale is not None:
-        log_scale = log_scale.to(device=raw.device, dtype=torch.float32).contiguous()
-    lib.call("eeg_dcrnn_fft_features", _p(raw), b, n, t_len, window, _p(perm), _p(log_scale),
-             float(mean) if mean is not None else 0.0, float(std) if std is not None else 1.0,
-             _p(feat_raw), _p(feat_std), _stream(raw))
-    return feat_raw, feat_std
+    std_on = mean is not None
+    fr, fs = torch.ops.eeg_dcrnn.fft_features(raw, int(window), float(mean) if std_on else 0.0,
+                                              float(std) if std is not None else 1.0, std_on, perm, log_scale)
+    return fr, (fs if std_on else None)
 
 
 def correlation_supports(x: torch.Tensor, top_k: int = 3, return_adj: bool = False):
@@ -193,416 +758,111 @@ def correlation_supports(x: torch.Tensor, top_k: int = 3, return_adj: bool = Fal
     x (B,T,N,D) clips (the model input).  Replaces the DataLoader-side `_get_indiv_graphs` +
     `keep_topk` + `_compute_supports('dual_random_walk')` (dataloader_detection.py:258-307,335-354).
     Returns [S1 (B,N,N), S2 (B,N,N)] (and the sparsified adjacency (B,N,N) if return_adj)."""
-    lib = _lib.get_lib()
-    x = x.contiguous()
-    _check(lib, x, "clips")
-    if x.dim() != 4:
-        raise RuntimeError(f"clips must be (B,T,N,D), got {tuple(x.shape)}")
-    b, t_len, n, d = x.shape
-    s1 = torch.empty((b, n, n), dtype=torch.float32, device=x.device)
-    s2 = torch.empty_like(s1)
-    adj = torch.empty_like(s1) if return_adj else None
-    ws = torch.empty(lib.query("eeg_dcrnn_corr_graph_ws_floats", b, t_len), dtype=torch.float32, device=x.device)
-    lib.call("eeg_dcrnn_corr_graph", _p(x), b, t_len, n, d, int(top_k), _p(adj), _p(s1), _p(s2), _p(ws), _stream(x))
+    adj, s1, s2 = torch.ops.eeg_dcrnn.corr_graph(x, int(top_k))
     return ([s1, s2], adj) if return_adj else [s1, s2]
 
 
 def pack_cell(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
     """Reference-layout cell parameters -> MFMA-fragment-ordered device block (kernels_pack.h)."""
-    lib = _lib.get_lib()
-    tensors = [wg.detach(), bg.detach(), wc.detach(), bc.detach()]
-    k = _Memo.key(tensors, (fin, h, m))
-    hit = _pack_memo.get(k)
-    if hit is not None:
-        return hit
-    for t, nm in zip(tensors, ("dconv_gate.weight", "dconv_gate.biases", "dconv_candidate.weight", "dconv_candidate.biases")):
-        _check(lib, t, nm)
-    rows = (fin + h) * m
-    if tuple(wg.shape) != (rows, 2 * h) or tuple(wc.shape) != (rows, h) or tuple(bg.shape) != (2 * h,) or tuple(bc.shape) != (h,):
-        raise RuntimeError(f"cell parameter shapes {tuple(wg.shape)}, {tuple(bg.shape)}, {tuple(wc.shape)}, {tuple(bc.shape)} "
-                           f"do not match input_dim={fin}, num_units={h}, num_matrices={m}")
-    n = lib.query("eeg_dcrnn_pack_floats", fin, h, m)
-    pack = torch.empty(n, dtype=torch.float32, device=wg.device)
-    lib.call("eeg_dcrnn_pack_cell", _p(tensors[0]), _p(tensors[1]), _p(tensors[2]), _p(tensors[3]), fin, h, m, _p(pack), _stream(pack))
-    _pack_memo.put(k, pack)
-    return pack
+    return torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
 
 
 def diffusion_hops(x: torch.Tensor, p: torch.Tensor, p_batched: int, batch: int) -> torch.Tensor:
     """The diffusion step alone: x (S,N,F) -> (M-1,S,N,F) hop planes P_m x (micro-benchmark entry;
     north_star's HBM-bound kernel)."""
-    lib = _lib.get_lib()
-    _check(lib, x, "x")
-    _check(lib, p, "P")
-    s, n, f = x.shape
-    m = p.shape[1] + 1
-    out = torch.empty((m - 1, s, n, f), dtype=torch.float32, device=x.device)
-    lib.call("eeg_dcrnn_diffuse_fwd", _p(x), _p(p), p_batched, s, batch, n, f, m, _p(out), _stream(x))
-    return out
+    return torch.ops.eeg_dcrnn.diffusion_hops(x, p, int(p_batched), int(batch))
 
 
-def dconv_forward(x, p, p_batched, weight, biases):
+def dconv(x, p, p_batched, weight, biases):
     """DiffusionGraphConv.forward (cell.py:66-118) on x (B,N,F): HIP diffusion + fp32-MFMA GEMM with
-    the reference-layout weight ((F*M), O).  Forward only."""
-    lib = _lib.get_lib()
-    x = x.contiguous()
-    w = weight.detach().contiguous()
-    bvec = biases.detach().contiguous()
-    for t, nm in ((x, "inputs_and_state"), (p, "P"), (w, "weight"), (bvec, "biases")):
-        _check(lib, t, nm)
-    b, n, f = x.shape
-    m, o = p.shape[1] + 1, w.shape[1]
-    if w.shape[0] != f * m:
-        raise RuntimeError(f"weight has {w.shape[0]} rows, expected (input_dim+hid_dim)*num_matrices = {f * m}")
-    out = torch.empty((b, n, o), dtype=torch.float32, device=x.device)
-    ws = torch.empty(lib.query("eeg_dcrnn_dconv_fwd_ws_floats", b, n, f, m, o), dtype=torch.float32, device=x.device)
-    lib.call("eeg_dcrnn_dconv_fwd", _p(x), _p(p), p_batched, b, n, f, m, _p(w), _p(bvec), o, _p(out), _p(ws), _stream(x))
-    return out
+    the reference-layout weight ((F*M), O); differentiable w.r.t. x, weight and biases."""
+    return torch.ops.eeg_dcrnn.dconv(x, p, int(p_batched), weight, biases)
 
 
-class _DCGRULayerFn(torch.autograd.Function):
-    """One DCGRU layer over a whole sequence (the `for t` loop of model.py:93-96 around
-    DCGRUCell.forward, cell.py:182-210), fwd + explicit BPTT backward in HIP.
+class LayerOut:
+    """what one layer hands on: hext (T+1,B,N*H) with hseq = hext[1:], hsel (B,N*H) and — when the backward
+    pass will run — the hop planes hpl (M-1,T+1,B,N,H) whose slots 1..T are the next layer's input planes"""
+    __slots__ = ("hext", "hsel", "hpl")
 
-    inputs : x (T,B,N,Fin), h0 (B,N*H) or None, P, wg, bg, wc, bc, lengths (int64 (B,) or None)
-    outputs: hseq (T,B,N*H), hsel (B,N*H) = h at t = lengths-1 (or T-1 when lengths is None)."""
+    def __init__(self, hext, hsel, hpl):
+        self.hext, self.hsel, self.hpl = hext, hsel, hpl
 
-    @staticmethod
-    def forward(ctx, x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act, track):
-        lib = _lib.get_lib()
-        t_len, b = x.shape[0], x.shape[1]
-        fin = x.shape[3]
-        dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
-        # input = the hidden sequence of the layer below, whose kernel already formed P_m x: take its planes
-        ready = _hop_planes.get(x.data_ptr()) if (x.is_contiguous() and hop_plane_handover_enabled) else None
-        if ready is not None and (ready["key"] != (t_len, b, n, fin, m, p.data_ptr(), p_batched)
-                                  or ready["hext"]._version != ready["version"]):
-            ready = None
-        if ready is not None:
+    @property
+    def hseq(self):
+        return self.hext[1:]
+
+
+def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None, x_planes=None) -> LayerOut:
+    """One DCGRU layer over x (T + x_off, B, N, Fin).  x_off = 1 / x_planes: x is the `hext` of the layer below and
+    x_planes its `hpl` (the layer then skips its own diffusion pass)."""
+    act = ACT_CODES.get(activation, 1)
+    save = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, h0, wg, bg, wc, bc))
+    if x_planes is not None:
+        if not hop_plane_handover_enabled:
+            x_planes = None
+        else:
             global hop_plane_handovers
             hop_plane_handovers += 1
-            dims.x_planes_ready = 1
-            dims.x_plane_stride = (t_len + 1) * b * n * fin
-        # a transposed view of a contiguous batch-major (B,T,N,Fin) tensor (what model.py:253 produces) is
-        # consumed as it is: the diffusion kernel emits the time-major copy as a by-product
-        xsrc, xtm = None, None
-        if not x.is_contiguous() and x.transpose(0, 1).is_contiguous() and lib.query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)):
-            xsrc = x.transpose(0, 1)
-            _check(lib, xsrc, "inputs")
-            xtm = torch.empty((t_len, b, n, fin), dtype=torch.float32, device=x.device)
-            x = xtm
-        else:
-            x = x.contiguous()
-            _check(lib, x, "inputs")
-        if h0 is not None:
-            h0 = h0.contiguous()
-            _check(lib, h0, "initial_hidden_state")
-        need_grad = track and any(ctx.needs_input_grad)      # track: grad mode of the caller (off inside forward)
-        pack = pack_cell(wg, bg, wc, bc, fin, h, m)
-        ctx.params = (wg, bg, wc, bc)
-        dev = x.device
-        s = t_len * b
-        if ready is not None:
-            planes = ready["hpl"]                               # (M-1, T+1, B, N, Fin): slots 1..T are P_m x
-            planes_ptr = planes.data_ptr() + 4 * b * n * fin
-        else:
-            planes = torch.empty((m - 1, s, n, fin), dtype=torch.float32, device=dev)
-            planes_ptr = planes.data_ptr()
-        hext = torch.empty((t_len + 1, b, n * h), dtype=torch.float32, device=dev)
-        if need_grad:
-            rs, us, cs, rhs = (torch.empty((t_len, b, n * h), dtype=torch.float32, device=dev) for _ in range(4))
-            hpl, rhpl = (torch.empty((m - 1, t_len + 1, b, n, h), dtype=torch.float32, device=dev) for _ in range(2))
-        else:
-            rs = us = cs = rhs = hpl = rhpl = None
-        ws = torch.empty(lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
-        lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(xsrc if xsrc is not None else x), _p(xtm), _p(h0), _p(p),
-                 _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
-        hseq = hext[1:]
-        if hpl is not None:
-            _hop_planes[hseq.data_ptr()] = {"key": (t_len, b, n, h, m, p.data_ptr(), p_batched), "hpl": hpl,
-                                            "hext": hext, "version": hext._version}
-        if lengths is not None:
-            lengths = lengths.to(device=dev, dtype=torch.int64).contiguous()
-            hsel = torch.empty((b, n * h), dtype=torch.float32, device=dev)
-            lib.call("eeg_dcrnn_gather_last", _p(hseq), _p(lengths), t_len, b, n * h, _p(hsel), _stream(x))
-        else:
-            hsel = hseq[t_len - 1].clone()
-        if need_grad:
-            ctx.save_for_backward(x, p, pack, planes, hext, rs, us, cs, rhs, hpl, rhpl, lengths)
-            ctx.meta = (t_len, b, n, h, fin, m, act, p_batched, h0 is not None, ready is not None)
-            ctx.set_materialize_grads(False)
-        return hseq, hsel
-
-    @staticmethod
-    def backward(ctx, d_hseq, d_hsel):
-        lib = _lib.get_lib()
-        x, p, pack, planes, hext, rs, us, cs, rhs, hpl, rhpl, lengths = ctx.saved_tensors
-        t_len, b, n, h, fin, m, act, p_batched, has_h0, planes_ready = ctx.meta
-        dims = LayerDims(t_len, b, n, h, fin, m, act, p_batched)
-        planes_ptr = planes.data_ptr()
-        if planes_ready:                                        # the layer below's Hplanes, slots 1..T
-            dims.x_planes_ready = 1
-            dims.x_plane_stride = (t_len + 1) * b * n * fin
-            planes_ptr += 4 * b * n * fin
-        dev = x.device
-        need_dx = ctx.needs_input_grad[0]
-        need_dh0 = has_h0 and ctx.needs_input_grad[1]
-        if d_hseq is not None:
-            d_hseq = d_hseq.contiguous()
-        if d_hsel is not None:
-            d_hsel = d_hsel.contiguous()
-        d_at_end = d_hsel if lengths is None else None
-        d_at_len = d_hsel if lengths is not None else None
-        dx = torch.empty_like(x) if need_dx else None
-        dh0 = torch.empty((b, n * h), dtype=torch.float32, device=dev) if need_dh0 else None
-        rows = (fin + h) * m
-        shapes = ((rows, 2 * h), (2 * h,), (rows, h), (h,))
-        sunk = [GradSink.take(q) for q in ctx.params]           # written in place -> nothing for autograd to add
-        dwg, dbg, dwc, dbc = (t if t is not None else torch.empty(sh, dtype=torch.float32, device=dev)
-                              for t, sh in zip(sunk, shapes))
-        ws = torch.empty(lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),
-                         dtype=torch.float32, device=dev)
-        lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), _p(x), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs),
-                 _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(d_hseq), _p(d_at_end), _p(d_at_len), _p(lengths), _p(dx), _p(dh0),
-                 _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(x))
-        ret = [None if t is not None else g for t, g in zip(sunk, (dwg, dbg, dwc, dbc))]
-        return (dx, dh0, None, *ret, None, None, None, None, None, None, None)
+    hext, hsel, saved = torch.ops.eeg_dcrnn.dcgru_layer(x, int(x_off), h0, p, int(p_batched), wg, bg, wc, bc, lengths, x_planes,
+                                                        n, h, m, act, save)
+    return LayerOut(hext, hsel, saved[7].detach() if save else None)
 
 
 def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None):
     """Run one DCGRU layer over x (T,B,N,Fin).  Returns (hseq (T,B,N*H), hsel (B,N*H))."""
-    act = ACT_CODES.get(activation, 1)
-    lib = _lib.get_lib()
-    if not lib.query("eeg_dcrnn_supported", n, h, x.shape[3], m):
-        raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
-    return _DCGRULayerFn.apply(x, h0, p, wg, bg, wc, bc, lengths, p_batched, n, h, m, act, torch.is_grad_enabled())
-
-
-class _DecoderFn(torch.autograd.Function):
-    """DCGRUDecoder.forward (model.py:160-204) as one operator: T autoregressive steps through L cells
-    and the projection; explicit BPTT backward with all parameter gradients hoisted over the T steps.
-
-    inputs : targets (T,B,N*Dout) or None, h0 (L,B,N*H), P, teacher (tuple of T bools or None),
-             first cell (wg,bg,wc,bc), shared cell (wg,bg,wc,bc) or Nones when L == 1, Wp (Dout,H), bp (Dout)
-    output : (T,B,N*Dout)"""
-
-    @staticmethod
-    def forward(ctx, targets, h0, p, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, meta):
-        lib = _lib.get_lib()
-        t_len, b, n, h, dout, m, n_layers, act, p_batched = meta
-        dev = h0.device
-        h0 = h0.contiguous()
-        wp, bp = wp.detach().contiguous(), bp.detach().contiguous()
-        for t, nm in ((h0, "initial_hidden_state"), (p, "P"), (wp, "projection_layer.weight"), (bp, "projection_layer.bias")):
-            _check(lib, t, nm)
-        if tuple(wp.shape) != (dout, h) or tuple(bp.shape) != (dout,):
-            raise RuntimeError(f"projection_layer shapes {tuple(wp.shape)}, {tuple(bp.shape)} do not match ({dout}, {h})")
-        use_tf = teacher is not None and any(teacher)
-        if use_tf:
-            targets = targets.contiguous()
-            _check(lib, targets, "inputs (teacher-forcing targets)")
-        packs = [pack_cell(wg0, bg0, wc0, bc0, dout, h, m)]
-        if n_layers > 1:
-            packs += [pack_cell(wg1, bg1, wc1, bc1, h, h, m)] * (n_layers - 1)
-        dims = DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched)
-        out = torch.empty((t_len, b, n * dout), dtype=torch.float32, device=dev)
-        saved = torch.empty(lib.query("eeg_dcrnn_decoder_saved_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.query("eeg_dcrnn_decoder_fwd_ws_floats", ctypes.byref(dims)), dtype=torch.float32, device=dev)
-        tf_arr = (ctypes.c_int32 * t_len)(*[1 if (use_tf and teacher[i]) else 0 for i in range(t_len)]) if use_tf else None
-        pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
-        lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_arr, _p(h0), _p(p), pk_arr,
-                 _p(wp), _p(bp), _p(out), _p(saved), _p(ws), _stream(h0))
-        ctx.save_for_backward(p, saved, wp, *packs[:2])
-        ctx.params = (wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp)
-        ctx.meta, ctx.teacher = meta, (tuple(bool(v) for v in teacher) if use_tf else None)
-        ctx.shapes = (wg0.shape, bg0.shape, wc0.shape, bc0.shape,
-                      None if wg1 is None else (wg1.shape, bg1.shape, wc1.shape, bc1.shape))
-        return out
-
-    @staticmethod
-    def backward(ctx, d_out):
-        lib = _lib.get_lib()
-        p, saved, wp, *packs = ctx.saved_tensors
-        t_len, b, n, h, dout, m, n_layers, act, p_batched = ctx.meta
-        dev = saved.device
-        d_out = d_out.contiguous()
-        dims = DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched)
-        packs = [packs[0]] + ([packs[1]] * (n_layers - 1) if n_layers > 1 else [])
-        new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)   # noqa: E731
-        s0 = ctx.shapes
-        shapes = list(s0[:4]) + (list(s0[4]) if n_layers > 1 else [None] * 4) + [(dout, h), (dout,)]
-        sunk = [GradSink.take(q) if (q is not None and sh is not None) else None for q, sh in zip(ctx.params, shapes)]
-        bufs = [t if t is not None else (new(sh) if sh is not None else None) for t, sh in zip(sunk, shapes)]
-        g0, g1, dwp, dbp = bufs[0:4], bufs[4:8], bufs[8], bufs[9]
-        dh0 = new((n_layers, b, n * h))
-        ws = new((lib.query("eeg_dcrnn_decoder_bwd_ws_floats", ctypes.byref(dims)),))
-        teacher = ctx.teacher
-        tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if teacher else None
-        arr = lambda k: (ctypes.c_void_p * n_layers)(*[(g0 if l == 0 else g1)[k].data_ptr() for l in range(n_layers)])  # noqa: E731
-        pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
-        lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_arr, _p(p), pk_arr, _p(wp), _p(saved), _p(d_out), _p(dh0),
-                 arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
-        ret = [None if t is not None else g for t, g in zip(sunk, bufs)]        # sunk: already in the caller's buffer
-        return (None, dh0, None, *ret, None, None)
+    out = dcgru_layer_ex(x, 0, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation, lengths)
+    return out.hseq, out.hsel
 
 
 def dcgru_decoder(targets, h0, p, p_batched, first_cell, shared_cell, wp, bp, n, h, dout, m, n_layers,
                   activation="tanh", teacher=None):
     """Run the whole decoder: returns (T,B,N*Dout).  first_cell / shared_cell = (wg, bg, wc, bc)."""
-    lib = _lib.get_lib()
     act = ACT_CODES.get(activation, 1)
-    for fin in (dout, h):
-        if not lib.query("eeg_dcrnn_supported", n, h, fin, m):
-            raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
-    t_len, b = targets.shape[0], targets.shape[1]
-    meta = (t_len, b, n, h, dout, m, n_layers, act, p_batched)
+    t_len = targets.shape[0]
     sc = shared_cell if shared_cell is not None else (None, None, None, None)
-    return _DecoderFn.apply(targets, h0, p, *first_cell, *sc, wp, bp, teacher, meta)
-
-
-class _ClsHeadFn(torch.autograd.Function):
-    """model.py:267-270 after dropout: per-node Linear(H->C) on relu(z), max over nodes."""
-
-    @staticmethod
-    def forward(ctx, z, w, bias):
-        lib = _lib.get_lib()
-        z = z.contiguous()
-        w = w.contiguous()
-        bias = bias.contiguous()
-        for t, nm in ((z, "last_out"), (w, "fc.weight"), (bias, "fc.bias")):
-            _check(lib, t, nm)
-        b, n, h = z.shape
-        c = w.shape[0]
-        logits = torch.empty((b, c), dtype=torch.float32, device=z.device)
-        arg = torch.empty((b, c), dtype=torch.int32, device=z.device)
-        lib.call("eeg_dcrnn_cls_head_fwd", _p(z), _p(w), _p(bias), b, n, h, c, _p(logits), _p(arg), _stream(z))
-        ctx.save_for_backward(z, w, arg)
-        ctx.params = (w, bias)
-        return logits
-
-    @staticmethod
-    def backward(ctx, dlogits):
-        lib = _lib.get_lib()
-        z, w, arg = ctx.saved_tensors
-        b, n, h = z.shape
-        c = w.shape[0]
-        dlogits = dlogits.contiguous()
-        dz = torch.empty_like(z)
-        sunk = [GradSink.take(q) for q in ctx.params]
-        dw = sunk[0] if sunk[0] is not None else torch.empty_like(w)
-        db = sunk[1] if sunk[1] is not None else torch.empty((c,), dtype=torch.float32, device=z.device)
-        lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, c, _p(dz), _p(dw), _p(db), _stream(z))
-        return dz, (None if sunk[0] is not None else dw), (None if sunk[1] is not None else db)
+    use_tf = teacher is not None and any(teacher)
+    tf = [1 if v else 0 for v in teacher] if use_tf else [0] * t_len     # never an empty list: pytree leaf of the autograd glue
+    out, _ = torch.ops.eeg_dcrnn.dcgru_decoder(targets if use_tf else None, h0, p, int(p_batched), *first_cell, *sc, wp, bp, tf,
+                                               int(t_len), n, h, dout, m, n_layers, act)
+    return out
 
 
 def cls_head(z, w, bias):
-    return _ClsHeadFn.apply(z, w, bias)
+    """model.py:267-270 after dropout: per-node Linear(H->C) on relu(z), max over nodes."""
+    return torch.ops.eeg_dcrnn.cls_head(z, w, bias)[0]
 
 
 def gather_last(htop: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
     """utils.last_relevant_pytorch on a time-major (T,B,D) tensor, no host sync (forward only)."""
-    lib = _lib.get_lib()
-    htop = htop.contiguous()
-    _check(lib, htop, "output")
-    t_len, b, d = htop.shape
-    lengths = lengths.to(device=htop.device, dtype=torch.int64).contiguous()
-    out = torch.empty((b, d), dtype=torch.float32, device=htop.device)
-    lib.call("eeg_dcrnn_gather_last", _p(htop), _p(lengths), t_len, b, d, _p(out), _stream(htop))
-    return out
-
-
-class _BCELogitsFn(torch.autograd.Function):
-    """nn.BCEWithLogitsLoss() (mean): value and dlogits from one HIP launch (train.py:203-204)."""
-
-    @staticmethod
-    def forward(ctx, logits, y):
-        lib = _lib.get_lib()
-        x = logits.contiguous().view(-1)
-        yy = y.to(torch.float32).contiguous().view(-1)
-        _check(lib, x, "logits")
-        _check(lib, yy, "targets")
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
-        lib.call("eeg_dcrnn_bce_logits", _p(x), _p(yy), x.numel(), _p(loss), _p(dx), _stream(x))
-        ctx.save_for_backward(dx)
-        ctx.shape = logits.shape
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, dloss):
-        (dx,) = ctx.saved_tensors
-        return (dx * dloss).view(ctx.shape), None
-
-
-class _CELogitsFn(torch.autograd.Function):
-    """nn.CrossEntropyLoss() (mean) on (B,C) logits and int64 class targets (train.py:205-206)."""
-
-    @staticmethod
-    def forward(ctx, logits, y):
-        lib = _lib.get_lib()
-        x = logits.contiguous()
-        yy = y.to(torch.int64).contiguous()
-        _check(lib, x, "logits")
-        _check(lib, yy, "targets", torch.int64)
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
-        dx = torch.empty_like(x)
-        lib.call("eeg_dcrnn_ce_logits", _p(x), _p(yy), x.shape[0], x.shape[1], _p(loss), _p(dx), _stream(x))
-        ctx.save_for_backward(dx)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, dloss):
-        (dx,) = ctx.saved_tensors
-        return dx * dloss, None
-
-
-class _MaskedLossFn(torch.autograd.Function):
-    """utils.compute_regression_loss (utils.py:431-495): masked MAE / masked RMSE with an optional
-    scalar StandardScaler inverse transform; value and gradient from three small HIP launches."""
-
-    @staticmethod
-    def forward(ctx, pred, y, mean, std, mask_val, kind):
-        lib = _lib.get_lib()
-        p = pred.contiguous()
-        t = y.to(torch.float32).contiguous()
-        _check(lib, p, "y_predicted")
-        _check(lib, t, "y_true")
-        if p.shape != t.shape:
-            raise RuntimeError(f"y_predicted {tuple(p.shape)} and y_true {tuple(t.shape)} differ in shape")
-        loss = torch.empty(1, dtype=torch.float32, device=p.device)
-        dp = torch.empty_like(p)
-        ws = torch.empty(lib.query("eeg_dcrnn_masked_loss_ws_floats"), dtype=torch.float32, device=p.device)
-        scaled = mean is not None
-        lib.call("eeg_dcrnn_masked_loss", _p(p), _p(t), p.numel(), 1 if scaled else 0, float(mean) if scaled else 0.0,
-                 float(std) if scaled else 1.0, float(mask_val), int(kind), _p(loss), _p(dp), _p(ws), _stream(p))
-        ctx.save_for_backward(dp)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, dloss):
-        (dp,) = ctx.saved_tensors
-        return dp * dloss, None, None, None, None, None
+    return torch.ops.eeg_dcrnn.gather_last(htop, lengths)
 
 
 def masked_regression_loss(y_predicted, y_true, mean=None, std=None, loss_fn="mae", mask_val=0.0):
-    """Only the exact string 'mae' selects the MAE (utils.py:489-495); anything else is the masked RMSE."""
-    return _MaskedLossFn.apply(y_predicted, y_true, mean, std, mask_val, 0 if loss_fn == "mae" else 1)
+    """utils.compute_regression_loss (utils.py:431-495).  Only the exact string 'mae' selects the MAE
+    (utils.py:489-495); anything else is the masked RMSE."""
+    scaled = mean is not None
+    return torch.ops.eeg_dcrnn.masked_loss(y_predicted, y_true, scaled, float(mean) if scaled else 0.0,
+                                           float(std) if scaled else 1.0, float(mask_val), 0 if loss_fn == "mae" else 1)[0]
 
 
 def bce_with_logits(logits, y):
-    return _BCELogitsFn.apply(logits, y)
+    """nn.BCEWithLogitsLoss() (mean): value and dlogits from one HIP launch (train.py:203-204)."""
+    return torch.ops.eeg_dcrnn.bce_logits(logits, y)[0]
 
 
 def cross_entropy(logits, y):
-    return _CELogitsFn.apply(logits, y)
+    """nn.CrossEntropyLoss() (mean) on (B,C) logits and int64 class targets (train.py:205-206)."""
+    return torch.ops.eeg_dcrnn.ce_logits(logits, y)[0]
 
 
 def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, max_norm, grad_scale, ws,
                    norm_out=None):
     """Fused clip_grad_norm_ + Adam (coupled L2) over flat fp32 buffers (train.py:273-275)."""
-    lib = _lib.get_lib()
-    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
-        _check(lib, t, nm)
-    lib.call("eeg_dcrnn_clip_adam", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), float(max_norm),
-             float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale),
-             _p(ws), _p(norm_out), _stream(params))
+    torch.ops.eeg_dcrnn.clip_adam_(params, grads, exp_avg, exp_avg_sq, int(step), float(lr), float(betas[0]), float(betas[1]),
+                                   float(eps), float(weight_decay), float(max_norm), float(grad_scale), ws, norm_out)
+
+
+def new_forward_scope():
+    """Kept for callers of the round-1 API: the operators hold no caches any more (hop polynomials and weight
+    packs are built by explicit operators once per forward; hop planes are handed from layer to layer as
+    tensors), so there is nothing to drop."""

@@ -64,6 +64,9 @@ class TrainStep:
         self.ws = torch.zeros(64, device=self.fp.flat.device, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=self.fp.flat.device, dtype=torch.float32)
         self.step_count = 0
+        # samples seen so far = the reference's `step += batch_size` (train_ssl.py:163,178): drives the scheduled-
+        # sampling threshold of the SSL model under curriculum learning (global batch: every rank advances alike)
+        self.samples_seen = 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
 
@@ -91,7 +94,7 @@ class TrainStep:
         if supports is None:
             supports = ops.correlation_supports(x, top_k=3)
         if self.task == "ssl":
-            out = self.model(x, y, supports)
+            out = self.model(x, y, supports, batches_seen=self.samples_seen)    # train_ssl.py:163
         else:
             out = self.model(x, seq_lengths, supports)
         loss = self.loss(out, y)
@@ -107,6 +110,11 @@ class TrainStep:
         graph launch).  The exchange + optimiser tail stay outside the graph: the RCCL all-reduce is
         issued eagerly between the replay and the fused clip+Adam kernel.  New data is fed by
         copying into the captured tensors (`x.copy_(batch)`)."""
+        if self.task == "ssl" and getattr(self.model, "use_curriculum_learning", False):
+            # the teacher-forcing coin flips (model.py:194-200) are host-side `random.random()` draws that select
+            # which launches are issued: a captured graph would freeze one draw for ever
+            raise RuntimeError("TrainStep.capture: curriculum learning draws teacher-forcing flags on the host every "
+                               "step; use step() (eager launches) for this configuration")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -123,6 +131,7 @@ class TrainStep:
     def replay_step(self):
         """One optimisation step on the captured tensors: graph replay + all-reduce + clip/Adam."""
         self._graph.replay()
+        self.samples_seen += self._graph_inputs[0].shape[0] * self.world
         self.reduce_and_update()
         return self._graph_loss
 
@@ -134,20 +143,21 @@ class TrainStep:
         # mean over ranks (grad_scale), clip_grad_norm_(max_norm) and Adam in one pass over the buffers
         ops.clip_adam_step(self.fp.flat, g, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas,
                            self.eps, self.weight_decay, self.max_grad_norm, 1.0 / self.world, self.ws, self.grad_norm)
-        ops.new_forward_scope()          # parameters changed through the flat alias: drop weight packs
         return self.grad_norm
 
     def step(self, x, y, seq_lengths, supports):
         loss = self.forward_backward(x, y, seq_lengths, supports)
+        self.samples_seen += x.shape[0] * self.world
         self.reduce_and_update()
         return loss
 
     # -- checkpointing (utils.CheckpointSaver / load_model_checkpoint use these like an optimizer's) -------
     def state_dict(self):
-        return {"step": self.step_count, "lr": self.lr, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
+        return {"step": self.step_count, "samples_seen": self.samples_seen, "lr": self.lr, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone()}
 
     def load_state_dict(self, state):
         self.step_count, self.lr = int(state["step"]), float(state["lr"])
+        self.samples_seen = int(state.get("samples_seen", 0))
         self.exp_avg.copy_(state["exp_avg"])
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
 

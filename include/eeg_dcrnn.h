@@ -36,7 +36,9 @@ typedef struct eeg_layer_dims {
     int32_t act;        /* 0 = tanh, 1 = relu  (cell.py:146 `nonlinearity`) */
     int32_t p_batched;  /* 1: P holds one graph per clip (B graphs); 0: one shared graph */
     int32_t x_planes_ready;  /* 1: `planes` already holds P_m X (the previous layer's Hplanes, slots 1..T) */
-    int32_t reserved;
+    int32_t x_batch_major;   /* 1: X is the BATCH-major (B,T,N,Fin) model input and is consumed as it is: the diffusion
+                                kernel and the hoisted GEMMs address it through a (b,t) row map, no time-major copy is
+                                written (only where eeg_dcrnn_batch_major_ok() returns 2; pass the same X to layer_bwd) */
     int64_t x_plane_stride;  /* floats between two hop planes of `planes`; 0 = T*B*N*Fin (contiguous) */
 } eeg_layer_dims;
 
@@ -53,20 +55,6 @@ const char* eeg_dcrnn_last_error(void);
 int eeg_dcrnn_abi_version(void);
 /* 1 if the library was built for the GPU (always, for the product build), 0 for the test emulator. */
 int eeg_dcrnn_is_device_build(void);
-/* Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline):
- * enable(1) starts recording, report() synchronises and writes "name launches total_ms" lines
- * into buf (and clears the records). */
-int eeg_dcrnn_prof_enable(int on);
-int eeg_dcrnn_prof_report(char* buf, size_t cap);
-/* Development aid: when set to a device buffer of B*4*32 int64, the recurrent kernels store the
- * shader-clock cycles each wave spent per phase (slots 0-5 forward, 8-13 backward); NULL disables.  Only the H=64, M=3 instantiations carry the probe. */
-int eeg_dcrnn_set_seq_probe(int64_t* probe);
-/* Development aid: integer knobs selecting kernel variants for A/B timing.  key 0 = 1: register-staged NN
- * GEMM; key 1 = 1: register-staged TN GEMM;
- * key 4 = 1: XCD-aware placement of the TN k-blocks; key 9 = 1: LDS/MFMA adjoint diffusion;
- * key 12 = 1: single-wave-per-SIMD forward recurrent kernel also where the two-wave one exists (64 units, M <= 3).
- * Defaults (all 0) are the shipped configuration. */
-int eeg_dcrnn_set_tuning(int key, int value);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
 int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 
@@ -112,10 +100,17 @@ int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, 
                           int M, float* dX, void* stream);
 
 /* DiffusionGraphConv.forward (cell.py:66-118) on its own: X (B,N,F) = [inputs | state] per node,
- * W ((F*M), O) and bias (O) in reference layout, out (B,N,O).  Forward only. */
+ * W ((F*M), O) and bias (O) in reference layout, out (B,N,O). */
 size_t eeg_dcrnn_dconv_fwd_ws_floats(int B, int N, int F, int M, int O);
 int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M,
                         const float* W, const float* bias, int O, float* out, float* ws, void* stream);
+
+/* Backward of the same convolution (autograd's replay of cell.py:66-118): dOut (B,N,O) ->
+ * dX (B,N,F), dW ((F*M), O) and dbias (O) in reference layout (each output may be NULL).  O <= 192. */
+size_t eeg_dcrnn_dconv_bwd_ws_floats(int B, int N, int F, int M, int O);
+int eeg_dcrnn_dconv_bwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M,
+                        const float* W, int O, const float* dOut, float* dX, float* dW, float* dbias,
+                        float* ws, void* stream);
 
 /* One DCGRU layer over a whole sequence = the `for t` loop of model.py:93-96 around
  * DCGRUCell.forward (cell.py:182-210).  h0 may be NULL (zeros).  Rs/Us/Cs/RHs may all be NULL
@@ -127,7 +122,8 @@ int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, in
  * Xtm (nullable): when given, X is BATCH-major (B,T,N,Fin) -- the trainer's `input_seq` before
  * model.py:253's transpose -- and Xtm (T,B,N,Fin) receives its time-major copy as a by-product of
  * the diffusion kernel (pass Xtm as X to eeg_dcrnn_layer_bwd); only where
- * eeg_dcrnn_batch_major_ok() returns 1. */
+ * eeg_dcrnn_batch_major_ok() returns >= 1.  Where it returns 2, d->x_batch_major = 1 (with Xtm = NULL) consumes
+ * the batch-major input without any copy (the diffusion step then moves exactly 4*S*N*F*M bytes). */
 size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d);
 int eeg_dcrnn_batch_major_ok(const eeg_layer_dims* d);
 int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, const float* h0, const float* P,

@@ -1,0 +1,29 @@
+/*
+ * eeg_dcrnn_dev.h — DEVELOPMENT entry points, exported only by the dev build of the library
+ * (`make -C eeg_gnn_ssl_amd/csrc dev` -> libeeg_dcrnn_hip_dev.so, compiled with -DEEG_DEV) and by the
+ * test emulator.  The product library libeeg_dcrnn_hip.so does not export them: its kernel-variant
+ * choices are compile-time constants and it carries no process-global mutable tuning state.
+ * Users: tools/ (A/B timing, cycle probe) and `bench.py --tune`.
+ */
+#ifndef EEG_DCRNN_DEV_H
+#define EEG_DCRNN_DEV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* When set to a device buffer of B*4*32 int64, the recurrent kernels store the shader-clock cycles each
+ * wave spent per phase (slots 0-7 forward, 8-15 backward); NULL disables.  Only the H=64, M=3
+ * instantiations carry the probe. */
+int eeg_dcrnn_set_seq_probe(int64_t* probe);
+/* Integer knobs selecting kernel variants for A/B timing.  key 0 = 1: register-staged NN GEMM;
+ * key 1 = 1: register-staged TN GEMM; key 4 = 1: XCD-aware placement of the TN k-blocks;
+ * key 9 = 1: LDS/MFMA adjoint diffusion; key 12 = 1: single-wave-per-SIMD forward recurrent kernel also
+ * where the two-wave one exists (64 units, M <= 3).  Defaults (all 0) = the product configuration. */
+int eeg_dcrnn_set_tuning(int key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEG_DCRNN_DEV_H */

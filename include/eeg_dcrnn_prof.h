@@ -1,0 +1,24 @@
+/*
+ * eeg_dcrnn_prof.h — measurement hook of libeeg_dcrnn_hip.so: per-kernel HIP-event timing on the
+ * launch stream, which bench.py needs for its live `roofline` figures (a C-ABI call launches several
+ * kernels, so the caller cannot bracket them itself).  Off by default and free when off; the recorder
+ * is the only process-global state of the library and is never touched by the compute entry points
+ * unless enabled.
+ */
+#ifndef EEG_DCRNN_PROF_H
+#define EEG_DCRNN_PROF_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enable(1) starts recording an event pair around every kernel launch; enable(0) stops. */
+int eeg_dcrnn_prof_enable(int on);
+/* Synchronises on the recorded events and writes "name launches total_ms" lines into buf (clears the records). */
+int eeg_dcrnn_prof_report(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEG_DCRNN_PROF_H */

@@ -14,10 +14,10 @@ def install_emulator():
     path = build_emu.build()
     lib = _lib.EegDcrnnLib(path)
     assert not lib.is_device_build
-    _lib._set_lib_for_testing(lib)
+    _lib._LIB = lib
     return lib
 
 
 def uninstall():
     from eeg_gnn_ssl_amd import _lib
-    _lib._set_lib_for_testing(None)
+    _lib._LIB = None

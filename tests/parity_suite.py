@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 import cases
-from closed_form import sample_view
+from closed_form import cf, sample_view
 from oracle import dcrnn_oracle as orc
 
 TOL = 2e-5          # asserted (relative to the tensor's max magnitude); north_star bar is 1e-4
@@ -159,8 +159,14 @@ def check_dconv_case(tag, golden, adj3d, device):
     ns = 2 if c["filt"] == "dual_random_walk" else 1
     mod = DiffusionGraphConv(ns, c["din"], c["h"], 19, 2, c["o"], filter_type=c["filt"])
     load(mod, {"weight": c["weight"], "biases": c["biases"]}, device)
-    out = mod([t.to(device) for t in c["sup"]], c["x"].to(device), c["s"].to(device), c["o"])
-    assert_close(out.cpu().numpy(), golden[f"dconv/{tag}/out"], f"dconv/{tag}/out")
+    x, s = c["x"].to(device).requires_grad_(True), c["s"].to(device).requires_grad_(True)
+    out = mod([t.to(device) for t in c["sup"]], x, s, c["o"])
+    assert_close(out.detach().cpu().numpy(), golden[f"dconv/{tag}/out"], f"dconv/{tag}/out")
+    # the module is differentiable like the reference's (cell.py:66-118): gradients w.r.t. inputs, state, weight, biases
+    up = cases.T(cf((c["b"], 19 * c["o"]), scale=1.0, freq=0.291, phase=0.4)).to(device)
+    (out * up).sum().backward()
+    for got, key in ((x.grad, "dx"), (s.grad, "ds"), (mod.weight.grad, "d_weight"), (mod.biases.grad, "d_biases")):
+        assert_close_scaled(got.cpu().numpy(), golden[f"dconv/{tag}/{key}"], f"dconv/{tag}/{key}")
 
 
 def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3d, seed=0, lengths=None, act="tanh", k=2):
@@ -464,7 +470,9 @@ def check_training_trajectory(device, golden_train, adj3d, steps=None):
         with torch.no_grad():
             prob = torch.sigmoid(model(x, seq, sup)).view(-1).cpu().numpy()
         assert np.abs(prob - golden_train["train/final_prob"]).max() <= 2e-3
-        from closed_form import sample_view
+        from sklearn.metrics import roc_auc_score         # north_star: "parity AUROC on synthetic labels"
+        assert abs(roc_auc_score(c["y"].numpy(), prob) - float(golden_train["train/auroc"])) <= 1e-3
+        from closed_form import cf, sample_view
         for k, v in model.state_dict().items():
             key = f"train/final/{k}"
             if key in golden_train:
@@ -475,7 +483,7 @@ def check_training_trajectory(device, golden_train, adj3d, steps=None):
 def check_ssl_training_trajectory(device, golden_train, steps=None):
     """TrainStep(task="ssl") (native decoder operator, masked-RMSE kernel, fused clip/Adam) follows the
     genuine reference's SSL training trajectory (train_ssl.py recipe, shared decoder cell)."""
-    from closed_form import sample_view
+    from closed_form import cf, sample_view
     from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
     from eeg_gnn_ssl_amd.train_step import TrainStep
     c = cases.ssl_train_inputs(golden_train)
@@ -582,3 +590,114 @@ def check_fft_features(device, golden_fft):
         for i in (0, b - 1):
             ref = orc.fft_features(rawb[i].numpy().astype(np.float64), window=w)
             assert np.abs(fr[i].cpu().numpy() - ref).max() <= 5e-6, (b, n, w, nwin)
+
+
+def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_registration", "test_faketensor")):
+    """The operators are registered with the PyTorch dispatcher (north_star: "exposed as a torch.ops extension"):
+    `torch.ops.eeg_dcrnn.*` called DIRECTLY (no module, no Python wrapper) against the oracle, and run through
+    `torch.library.opcheck` (schema / aliasing, autograd registration, fake-tensor implementation)."""
+    import torch.library
+    from eeg_gnn_ssl_amd import ops  # noqa: F401  (registers the library)
+    E = torch.ops.eeg_dcrnn
+    g = torch.Generator().manual_seed(17)
+    n, h, din, t_len, b, k = 19, 16, 8, 4, 3, 2
+    cfg = orc.DCRNNConfig(filter_type="dual_random_walk", input_dim=din, rnn_units=h, num_rnn_layers=1, num_classes=1,
+                          max_diffusion_step=k)
+    params = orc.init_params(cfg, "classification", seed=3)
+    pre = "encoder.encoding_cells.0."
+    wg, bg, wc, bc = (params[pre + s].clone() for s in ("dconv_gate.weight", "dconv_gate.biases", "dconv_candidate.weight",
+                                                         "dconv_candidate.biases"))
+    bg, bc = bg + 0.1, bc - 0.05
+    sup = cases.supports_for("dual_random_walk", adj3d, b)
+    x = torch.randn(t_len, b, n, din, generator=g)
+    h0 = 0.3 * torch.randn(b, n * h, generator=g)
+    up = torch.randn(t_len, b, n * h, generator=g)
+    # oracle: one encoder layer with an initial state, gradients of sum(hseq * up)
+    po = {pre + "dconv_gate.weight": wg, pre + "dconv_gate.biases": bg, pre + "dconv_candidate.weight": wc,
+          pre + "dconv_candidate.biases": bc}
+    po = {kk: v.clone().requires_grad_(True) for kk, v in po.items()}
+    xo, h0o = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+    _, top = orc.encoder_forward(po, cfg, xo, h0o.unsqueeze(0), sup)
+    (top * up).sum().backward()
+    # the operators, directly
+    d = lambda t: t.to(device)   # noqa: E731
+    P = E.hop_polys([d(s) for s in sup], k, b)
+    assert tuple(P.shape) == (b, 2 * k, n, n)
+    leaf = [d(t).clone().requires_grad_(True) for t in (x, h0, wg, bg, wc, bc)]
+    xd, h0d, wgd, bgd, wcd, bcd = leaf
+    hext, hsel, saved = E.dcgru_layer(xd, 0, h0d, P, 1, wgd, bgd, wcd, bcd, None, None, n, h, 2 * k + 1, 0, True)
+    assert tuple(hext.shape) == (t_len + 1, b, n * h) and len(saved) == 9
+    assert_close(hext[1:].detach().cpu().numpy(), top.detach().numpy(), "torch.ops dcgru_layer hseq")
+    assert_close(hsel.detach().cpu().numpy(), top[-1].detach().numpy(), "torch.ops dcgru_layer hsel")
+    assert_close(hext[0].detach().cpu().numpy(), h0.numpy(), "hext slot 0 = initial state", tol=1e-7)
+    (hext[1:] * d(up)).sum().backward()
+    for got, ref, nm in ((xd.grad, xo.grad, "dx"), (h0d.grad, h0o.grad, "dh0"), (wgd.grad, po[pre + "dconv_gate.weight"].grad, "dWg"),
+                         (bgd.grad, po[pre + "dconv_gate.biases"].grad, "dbg"), (wcd.grad, po[pre + "dconv_candidate.weight"].grad, "dWc"),
+                         (bcd.grad, po[pre + "dconv_candidate.biases"].grad, "dbc")):
+        assert_close_scaled(got.cpu().numpy(), ref.numpy(), f"torch.ops dcgru_layer {nm}")
+    # hop planes handed to a second layer == that layer diffusing its input itself
+    w2 = [d(t) for t in (0.1 * torch.randn((h + h) * 5, 2 * h, generator=g), torch.zeros(2 * h),
+                         0.1 * torch.randn((h + h) * 5, h, generator=g), torch.zeros(h))]
+    xin = hext.detach().view(t_len + 1, b, n, h)
+    a1 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, saved[7].detach(), n, h, 5, 0, False)[0]
+    a2 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, None, n, h, 5, 0, False)[0]
+    assert_close(a1.cpu().numpy(), a2.cpu().numpy(), "x_planes hand-over", tol=1e-6)
+    # opcheck: schema + aliasing annotations, autograd registration, fake (meta) implementations
+    nog = [t.detach() for t in leaf]
+    samples = [
+        (E.hop_polys.default, ([d(s) for s in sup], k, b)),
+        (E.pack_cell.default, (nog[2], nog[3], nog[4], nog[5], din, h, 5)),
+        (E.diffusion_hops.default, (nog[0].reshape(t_len * b, n, din), P, 1, b)),
+        (E.dcgru_layer.default, (xd.detach().requires_grad_(True), 0, h0d.detach().requires_grad_(True), P, 1,
+                                 *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True)),
+        (E.dconv.default, (torch.randn(b, n, din + h, generator=g).to(device).requires_grad_(True), P, 1,
+                           nog[2].clone().requires_grad_(True), nog[3].clone().requires_grad_(True))),
+        (E.cls_head.default, (torch.randn(b, n, h, generator=g).to(device).requires_grad_(True),
+                              torch.randn(4, h, generator=g).to(device).requires_grad_(True),
+                              torch.randn(4, generator=g).to(device).requires_grad_(True))),
+        (E.bce_logits.default, (torch.randn(b, generator=g).to(device).requires_grad_(True), d(torch.tensor([1.0, 0.0, 1.0])))),
+        (E.ce_logits.default, (torch.randn(b, 4, generator=g).to(device).requires_grad_(True), d(torch.tensor([1, 0, 3])))),
+        (E.masked_loss.default, (torch.randn(b, 7, generator=g).to(device).requires_grad_(True), d(torch.randn(b, 7, generator=g)),
+                                 True, 0.5, 2.0, 0.0, 1)),
+        (E.corr_graph.default, (d(torch.randn(b, t_len, n, 8, generator=g)), 3)),
+        (E.gather_last.default, (d(torch.randn(t_len, b, 5, generator=g)), d(torch.tensor([4, 1, 2])))),
+        (E.clip_adam_.default, (d(torch.randn(64, generator=g)), d(torch.randn(64, generator=g)), d(torch.zeros(64)), d(torch.zeros(64)),
+                                1, 1e-3, 0.9, 0.999, 1e-8, 5e-4, 5.0, 1.0, d(torch.zeros(64)), d(torch.zeros(1)))),
+    ]
+    for op, args in samples:
+        res = torch.library.opcheck(op, args, test_utils=list(opcheck_utils), raise_exception=True)
+        assert all(v == "SUCCESS" for v in res.values()), (str(op), res)
+
+
+def check_batch_major_input(device, adj3d):
+    """The batch-major (B,T,N,Din) model input is consumed WITHOUT a time-major copy where the library allows it
+    (eeg_dcrnn_batch_major_ok == 2: diffusion kernel and hoisted GEMMs address it through a (b,t) row map):
+    same logits and gradients, bit for bit, as when the encoder is handed a contiguous time-major tensor."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib
+    from eeg_gnn_ssl_amd._lib import LayerDims
+    import ctypes
+    g = torch.Generator().manual_seed(8)
+    for filt, b, t_len, m in (("laplacian", 3, 5, 3), ("dual_random_walk", 2, 9, 5)):
+        dims = LayerDims(t_len, b, 19, 64, 100, m, 0, 1)
+        assert _lib.get_lib().query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)) == 2
+        cfg = orc.DCRNNConfig(filter_type=filt, num_classes=4)
+        torch.manual_seed(4)
+        model = DCRNNModel_classification(make_args(cfg), 4, device=device).to(device).train()
+        x = torch.randn(b, t_len, 19, 100, generator=g).to(device)
+        lengths = torch.tensor([t_len, 2, 4][:b]).to(device)
+        sup = [s.to(device) for s in cases.supports_for(filt, adj3d, b)]
+        res = []
+        for mode in ("batch_major", "time_major"):
+            model.zero_grad()
+            if mode == "batch_major":
+                out = model(x, lengths, sup)                     # model.py:253: the encoder sees x.transpose(0, 1)
+            else:
+                xt = x.transpose(0, 1).contiguous()
+                _, _, last = model.encoder.run(xt, None, sup, lengths=lengths, want_finals=False)
+                from eeg_gnn_ssl_amd import ops
+                out = ops.cls_head(last.view(b, 19, 64), model.fc.weight, model.fc.bias)
+            out.square().sum().backward()
+            res.append((out.detach().clone(), [q.grad.clone() for q in model.parameters()]))
+        assert torch.equal(res[0][0], res[1][0]), filt
+        for a, b_, (nm, _) in zip(res[0][1], res[1][1], model.named_parameters()):
+            assert torch.equal(a, b_), (filt, nm, (a - b_).abs().max().item())

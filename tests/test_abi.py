@@ -6,14 +6,19 @@ import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HDR = os.path.join(ROOT, "include", "eeg_dcrnn.h")
+INC = os.path.join(ROOT, "include")
 LIB = os.path.join(ROOT, "eeg_gnn_ssl_amd", "libeeg_dcrnn_hip.so")
+DEV_LIB = os.path.join(ROOT, "eeg_gnn_ssl_amd", "libeeg_dcrnn_hip_dev.so")
+PRODUCT_HEADERS = ("eeg_dcrnn.h", "eeg_dcrnn_prof.h")     # what libeeg_dcrnn_hip.so exports
+DEV_HEADERS = ("eeg_dcrnn_dev.h",)                         # extra entry points of the dev build / test emulator only
 
 
-def declared_symbols():
-    text = open(HDR).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(eeg_dcrnn_\w+)\s*\(", text)))
+def declared_symbols(headers=PRODUCT_HEADERS):
+    out = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(INC, h)).read(), flags=re.S)
+        out |= set(re.findall(r"\b(eeg_dcrnn_\w+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_declares_the_expected_surface():
@@ -24,14 +29,17 @@ def test_header_declares_the_expected_surface():
 
 
 def test_library_builds_loads_and_exports_every_declared_symbol():
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc"), "-j", "8"],
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc"), "-j", "8", "all", "dev"],
                           stdout=subprocess.DEVNULL)
     dll = ctypes.CDLL(LIB)
     for s in declared_symbols():
-        assert hasattr(dll, s), f"{s} declared in include/eeg_dcrnn.h but not exported by {LIB}"
+        assert hasattr(dll, s), f"{s} declared in include/ but not exported by {LIB}"
+    for s in declared_symbols(DEV_HEADERS):      # the product carries no tuning knobs / probes (no global mutable state)
+        assert not hasattr(dll, s), f"development entry point {s} leaked into the product library"
+        assert hasattr(ctypes.CDLL(DEV_LIB), s)
     dll.eeg_dcrnn_is_device_build.restype = ctypes.c_int
     assert dll.eeg_dcrnn_is_device_build() == 1
-    assert dll.eeg_dcrnn_abi_version() == 1
+    assert dll.eeg_dcrnn_abi_version() == 2
     assert dll.eeg_dcrnn_supported(19, 64, 100, 3) == 1
     assert dll.eeg_dcrnn_supported(19, 48, 100, 3) == 0
     dll.eeg_dcrnn_last_error.restype = ctypes.c_char_p
@@ -41,6 +49,20 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 def test_python_binding_matches_header():
     from eeg_gnn_ssl_amd import _lib
     assert sorted(_lib._SIGNATURES) == declared_symbols()
+    assert sorted(_lib._SIGNATURES_DEV) == declared_symbols(DEV_HEADERS)
+
+
+def test_operators_are_registered_with_the_dispatcher():
+    """north_star: 'exposed as a torch.ops extension' — every operator of the path has a schema in the
+    `eeg_dcrnn` namespace (implementations: eeg_gnn_ssl_amd/ops.py over the C ABI)."""
+    import torch
+    import eeg_gnn_ssl_amd  # noqa: F401  (registers the library)
+    for name in ("hop_polys", "pack_cell", "diffusion_hops", "dconv", "dconv_bwd", "dcgru_layer", "dcgru_layer_bwd",
+                 "dcgru_decoder", "dcgru_decoder_bwd", "cls_head", "cls_head_bwd", "gather_last", "corr_graph", "fft_features",
+                 "bce_logits", "ce_logits", "masked_loss", "clip_adam_"):
+        op = getattr(torch.ops.eeg_dcrnn, name)
+        assert op.default._schema.name == f"eeg_dcrnn::{name}"
+    assert torch.ops.eeg_dcrnn.clip_adam_.default._schema.is_mutable
 
 
 def test_product_has_no_cpu_path():
@@ -48,7 +70,7 @@ def test_product_has_no_cpu_path():
     import pytest
     import torch
     from eeg_gnn_ssl_amd import DCGRUCell, _lib
-    _lib._set_lib_for_testing(None)
+    _lib._LIB = None
     cell = DCGRUCell(100, 64, 2, 19)
     with pytest.raises(RuntimeError, match="no CPU path"):
         cell([torch.eye(19)], torch.zeros(2, 1900), torch.zeros(2, 19 * 64))

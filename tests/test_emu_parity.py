@@ -100,3 +100,11 @@ def test_evaluation_driver(adj3d):
 
 def test_fft_features(golden_fft):
     ps.check_fft_features("cpu", golden_fft)
+
+
+def test_torch_ops_direct_and_opcheck(adj3d):
+    ps.check_torch_ops("cpu", adj3d)
+
+
+def test_batch_major_input_without_copy(adj3d):
+    ps.check_batch_major_input("cpu", adj3d)

@@ -17,7 +17,7 @@ DEV = "cuda"
 @pytest.fixture(scope="module", autouse=True)
 def hip_library():
     from eeg_gnn_ssl_amd import _lib
-    _lib._set_lib_for_testing(None)
+    _lib._LIB = None
     lib = _lib.get_lib()                  # ImportError if the HIP library is missing: no fallback
     assert lib.is_device_build and os.path.basename(lib.path) == "libeeg_dcrnn_hip.so"
     assert torch.cuda.is_available()
@@ -179,24 +179,26 @@ def test_beyond_benchmark_sizes(filt, batch, t_len, adj3d):
     assert err < 1e-4, f"logits of clips {pick} differ from the oracle by {err:.2e}"
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "cfg4"])
 def test_full_size_gradients_vs_oracle(workload, adj3d):
-    """BASELINE cfg2 / cfg3 at FULL size (B=256, T=60, ragged lengths; cfg3: one correlation graph per clip):
-    logits of every clip and every parameter gradient of the whole batch against the oracle run on the host on
-    the same batch (fp32 tolerance 1e-4 of each tensor's largest entry, the bar north_star states)."""
+    """BASELINE cfg2 / cfg3 / cfg4 at FULL per-GPU size (B=256, T=60, ragged lengths; cfg3: one correlation graph per
+    clip; cfg4: the 4-class model under cross-entropy): logits of every clip and every parameter gradient of the whole
+    batch against the oracle run on the host on the same batch (fp32 tolerance 1e-4 of each tensor's largest entry,
+    the bar north_star states)."""
     import bench
     from oracle import dcrnn_oracle as orc
     task, filt, t_len, batch, classes = bench.WORKLOADS[workload]
     x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=77)
     lengths = torch.randint(t_len // 2, t_len + 1, (batch,), generator=torch.Generator().manual_seed(3))
     model = _full_size_model(filt, classes)
+    from eeg_gnn_ssl_amd import ops
     lg = model(x.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup])
-    torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), y.to(DEV)).backward()
+    (ops.bce_with_logits(lg.view(-1), y.to(DEV)) if classes == 1 else ops.cross_entropy(lg, y.to(DEV))).backward()
     cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
     po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     torch.set_num_threads(16)
     lo = orc.classification_forward(po, cfg, x, lengths, sup)
-    orc.bce_with_logits(lo, y).backward()
+    (orc.bce_with_logits(lo, y) if classes == 1 else orc.cross_entropy(lo, y)).backward()
     assert (lg.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
     for k, p in model.named_parameters():
         ref = po[k].grad
@@ -381,3 +383,31 @@ def test_evaluation_driver(adj3d):
 
 def test_fft_features(golden_fft):
     ps.check_fft_features(DEV, golden_fft)
+
+
+def test_torch_ops_direct_and_opcheck(adj3d):
+    """`torch.ops.eeg_dcrnn.*` on the MI355X: direct operator calls vs the oracle + torch.library.opcheck."""
+    ps.check_torch_ops(DEV, adj3d)
+
+
+def test_lengths_out_of_range_agree_between_forward_and_backward():
+    """seq_lengths outside 1..T: forward (gather) and backward (BPTT injection point) clamp alike, so the
+    gradient of such a clip is that of the clamped step (the reference would raise an index error)."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    x, y, _, sup = bench.synthetic_batch("detection", "laplacian", 6, 4, 1, seed=2)
+    torch.manual_seed(1)
+    model = DCRNNModel_classification(bench.make_args("laplacian"), 1, device=DEV).to(DEV).train()
+    res = []
+    for lengths in ([6, 9, 0, 3], [6, 6, 1, 3]):
+        model.zero_grad()
+        lg = model(x.to(DEV), torch.tensor(lengths).to(DEV), [s.to(DEV) for s in sup])
+        lg.sum().backward()
+        res.append((lg.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+
+
+def test_batch_major_input_without_copy(adj3d):
+    ps.check_batch_major_input(DEV, adj3d)

@@ -51,8 +51,14 @@ def test_correlation_graph_pipeline(golden):
 @pytest.mark.parametrize("tag", list(cases.DCONV_CASES))
 def test_diffusion_conv(tag, golden, adj3d):
     c = cases.dconv_inputs(tag, adj3d)
-    out = orc.diffusion_conv(c["sup"], c["x"], c["s"], c["weight"], c["biases"], 19, 2)
-    close(out.numpy(), golden[f"dconv/{tag}/out"])
+    x, s_, w, bvec = (t.clone().requires_grad_(True) for t in (c["x"], c["s"], c["weight"], c["biases"]))
+    out = orc.diffusion_conv(c["sup"], x, s_, w, bvec, 19, 2)
+    close(out.detach().numpy(), golden[f"dconv/{tag}/out"])
+    from closed_form import cf
+    (out * cases.T(cf((c["b"], 19 * c["o"]), scale=1.0, freq=0.291, phase=0.4))).sum().backward()
+    for got, key in ((x.grad, "dx"), (s_.grad, "ds"), (w.grad, "d_weight"), (bvec.grad, "d_biases")):
+        ref = golden[f"dconv/{tag}/{key}"]
+        close(got.numpy(), ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
 
 
 @pytest.mark.parametrize("tag", list(cases.CELL_CASES) + list(cases.CELL_K_CASES))
@@ -155,6 +161,8 @@ def test_training_trajectory_matches_reference(golden_train, adj3d):
     with torch.no_grad():
         prob = torch.sigmoid(orc.classification_forward(p, c["cfg"], c["x"], c["seq"], c["sup"])).view(-1).numpy()
     assert np.abs(prob - golden_train["train/final_prob"]).max() <= 2e-3
+    from sklearn.metrics import roc_auc_score
+    assert abs(roc_auc_score(c["y"].numpy(), prob) - float(golden_train["train/auroc"])) <= 1e-3     # parity AUROC
 
 
 def test_ssl_training_trajectory_matches_reference(golden_train):

@@ -8,7 +8,7 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
   ( cd /tmp && timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/sq_$i" -o sq -- \
-      python "$OLDPWD/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph "$@" > "$OLDPWD/gpurun_out/sq_$i.log" 2>&1 )
+      python "$OLDPWD/bench.py" --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-prof --no-graph --no-stream-inputs "$@" > "$OLDPWD/gpurun_out/sq_$i.log" 2>&1 )
 done
 python - <<'PY'
 import csv, glob, collections

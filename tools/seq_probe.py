@@ -18,6 +18,7 @@ dev = torch.device("cuda", 0)
 x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123)
 model = DCRNNModel_classification(bench.make_args(filt), classes, device=dev).to(dev).train()
 x, y, lengths, sup = x.to(dev), y.to(dev), lengths.to(dev), [s.to(dev) for s in sup]
+_lib._LIB = _lib.EegDcrnnLib(_lib.DEV_LIB_PATH)   # cycle probe: dev build only
 lib = _lib.get_lib()
 
 
