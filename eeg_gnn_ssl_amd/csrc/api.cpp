@@ -123,7 +123,7 @@ int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct
     EEG_LAUNCH_P(tag, (gemm_nn_kernel<NCTW, KC>), grid, dim3(256), lds, st, segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O);
     return check_launch("gemm_nn");
 }
-// segment 0 of a GEMM is batch-major (B clips x T steps x N nodes): the DMA kernels read it through a row map
+// the A segments of a GEMM are batch-major (B clips x T steps x N nodes): the DMA kernels read them through a row map
 struct BtMap { int T = 0, B = 0, N = 0; };
 template <int NCTW, int KC, int MINB = 2>
 int run_nn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
@@ -237,7 +237,11 @@ int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int
         while (threads > 64 && (threads / 2) / F4 >= T && (threads / 2) >= F4) threads /= 2;
         const int SPW = threads / F4;
         int ny = ceil_div(T, SPW);
-        const int want = ceil_div(4096, sB);     // ~16 workgroups per CU in total
+        // ~4 workgroups per CU in total, each walking >= 2 passes of consecutive samples: measured on MI355X (cfg2, F=100,
+        // profiles/r02_b_diffuse_sweep.txt) 64 us against 75 us with 6 single-pass workgroups per CU and 68 / 85 us with 2 / 1
+        // (fewer, longer sequential streams suit the DRAM pages better than more parallelism); prefetching the next
+        // sample's rows ahead of the stores was slower (71 us).  dev knob 5 overrides the target.
+        const int want = ceil_div(g_tune[5] > 0 ? g_tune[5] : 1024, sB);
         if (ny > want) ny = want;
         if (ny < 1) ny = 1;
         EEG_LAUNCH_P("diffuse_fwd", diffuse_fwd_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, X, P, p_batched, S, B, F, M, planes, plane_stride, x_bt, xcopy);
@@ -275,7 +279,7 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
         while (threads > 64 && (threads / 2) / F4 >= T && (threads / 2) >= F4) threads /= 2;
         const int SPW = threads / F4;
         int ny = ceil_div(T, SPW);
-        const int want = ceil_div(4096, sB);
+        const int want = ceil_div(g_tune[6] > 0 ? g_tune[6] : 4096, sB);   // dev knob 6 (512 .. 4096 measured alike)
         if (ny > want) ny = want;
         if (ny < 1) ny = 1;
         EEG_LAUNCH_P("diffuse_adj", diffuse_adj_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, M, add, dX);
@@ -609,7 +613,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     if (d->x_planes_ready) {
         if (Xtm != nullptr) return fail("layer_fwd: x_planes_ready excludes a batch-major input");
     } else {
-        if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, xs, (Xtm != nullptr || d->x_batch_major) ? 1 : 0, Xtm)) return 1;
+        if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, xs, d->x_batch_major ? 2 : (Xtm != nullptr ? 1 : 0), Xtm)) return 1;
         if (Xtm != nullptr) X = Xtm;
     }
     // 2. hoisted x-part GEMM: XW = [X | planes] @ Bx + [bg|bc]
@@ -685,7 +689,7 @@ int eeg_dcrnn_fft_features(const float* raw, int B, int N, int T, int W, const i
 
 /* ---- per-clip correlation graph -> supports --------------------------------------------------- */
 static int corr_nsplit(int B, int T) {
-    int ns = ceil_div(1024, B);
+    int ns = ceil_div(g_tune[7] > 0 ? g_tune[7] : 1024, B);         // dev knob 7: target number of workgroups
     const int cap = ceil_div(T, 4);
     if (ns > cap) ns = cap;
     return ns < 1 ? 1 : ns;

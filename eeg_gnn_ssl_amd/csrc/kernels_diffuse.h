@@ -89,9 +89,10 @@ __global__ __launch_bounds__(256) void diffuse_fwd_kernel(const float* __restric
 // work on samples of ONE graph (g = blockIdx.x), so the polynomial coefficients are wave-uniform:
 // the compiler keeps them in SGPRs (scalar loads), there is no LDS and no barrier.
 // Algorithmic bytes per sample: 4*N*F*M; VALU work 2*(M-1)*N*N*F flop is ~4x below the HBM time.
-// x_bt != 0: X is batch-major (B, S/B, N, F) (the model input as the trainer holds it) and xcopy
-// receives its time-major copy as a by-product (the GEMMs read time-major rows): the separate
-// transpose pass (117 MB in + out at cfg2) disappears.
+// x_bt != 0: X is batch-major (B, S/B, N, F) (the model input as the trainer holds it).  x_bt == 1: the planes
+// are written time-major and xcopy (optional) receives the time-major copy of X as a by-product; x_bt == 2: the
+// planes keep X's batch-major order (every workgroup then reads AND writes one contiguous stretch per clip; the
+// GEMMs that consume X and the planes address their rows through a (b,t) map) -- exactly 4*N*F*M bytes per sample.
 template <int N>
 __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __restrict__ X,
                                                                  const float* __restrict__ P, int p_batched,
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __
     for (int t = blockIdx.y * SPW + tl; t < T; t += gridDim.y * SPW) {
         const size_t s = (size_t)t * sB + g;         // time-major sample index (t_clip * B + b)
         const size_t ssrc = x_bt ? (s % B) * Tc + s / B : s;
+        const size_t sdst = x_bt == 2 ? ssrc : s;   // x_bt == 2: the planes keep the batch-major sample order of X
         float4 x[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) x[n] = X4[(ssrc * N + n) * F4 + c4];
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void diffuse_fwd_stream_kernel(const float* __
         }
         for (int m1 = 0; m1 < M - 1; ++m1) {
             const float* __restrict__ Pm = Pg + m1 * N * N;
-            float4* out = O4 + (size_t)m1 * (plane_stride / 4) + (s * N) * F4 + c4;
+            float4* out = O4 + (size_t)m1 * (plane_stride / 4) + (sdst * N) * F4 + c4;
 #pragma unroll
             for (int n = 0; n < N; ++n) {
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);

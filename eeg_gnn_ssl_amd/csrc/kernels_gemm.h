@@ -154,23 +154,22 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn_dma_kernel(SegPtrs segs, in
     const int nchunk_seg = F / KC, nchunks = nseg * nchunk_seg;
 
     // per-lane source offsets of this wave's DMAs (chunk-independent part), in floats
-    // btT > 0: segment 0 is BATCH-major (btB clips x btT steps x btN nodes x F): the time-major row
-    // r = (t*B + b)*N + n that everything else uses lives at row (b*T + t)*N + n of that segment (the model input as
-    // the trainer holds it, model.py:253 -- no time-major copy is made)
-    unsigned src[NI], src0[NI];
+    // btT > 0: the A segments are BATCH-major (btB clips x btT steps x btN nodes x F): the time-major row
+    // r = (t*B + b)*N + n that C uses lives at row (b*T + t)*N + n of every segment (the model input as the trainer
+    // holds it, model.py:253, and its hop planes in the same order -- no time-major copy is made)
+    unsigned src[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int j = wave + 4 * i;                                     // DMA index inside the chunk
-        src0[i] = 0;
         if (j < A_INS) {
             const int s4 = j * 64 + lane, row = s4 / Q, piece = s4 % Q;
-            const int grow = row0 + row < R ? row0 + row : R - 1;
+            int grow = row0 + row < R ? row0 + row : R - 1;
             const int c4 = Q == 4 ? (piece ^ ((row >> 2) & 3)) : piece;
-            src[i] = (unsigned)grow * F + 4 * c4;
             if (btT > 0) {
                 const int sm_ = grow / btN, n = grow - sm_ * btN, t = sm_ / btB, b = sm_ - t * btB;
-                src0[i] = (unsigned)((b * btT + t) * btN + n) * F + 4 * c4;
+                grow = (b * btT + t) * btN + n;
             }
+            src[i] = (unsigned)grow * F + 4 * c4;
         } else {
             const int s4 = (j - A_INS) * 64 + lane;                     // float4 index in [KSC][NB][16]
             const int ks = s4 / (NB * 16), rem = s4 % (NB * 16), ct = rem / 16, l4 = rem % 16;
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nn_dma_kernel(SegPtrs segs, in
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int j = wave + 4 * i;
-            if (j < INS) lds_dma16(base + j * 256, j < A_INS ? Ab + ((btT > 0 && seg == 0) ? src0[i] : src[i]) : Bb + src[i]);
+            if (j < INS) lds_dma16(base + j * 256, (j < A_INS ? Ab : Bb) + src[i]);
         }
     };
 
@@ -398,8 +397,8 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
 
     // this wave's DMAs: tile row, source base (plane of the lane's k column / dY) and (clamped) column
-    // btT > 0: segment 0 is BATCH-major (see gemm_nn_dma_kernel): lanes whose k column lies in segment 0 walk the
-    // rows of their split through (b, t, n) counters instead of a linear row index (no division in the loop)
+    // btT > 0: the A segments are BATCH-major (see gemm_nn_dma_kernel): their lanes walk the rows of the split
+    // through (b, t, n) counters instead of a linear row index (no division in the loop); dY stays time-major
     int drow[NI];
     const float* dsrc[NI];
     int dld[NI];
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
             drow[i] = row;
             dsrc[i] = segs.p[k / F] + k % F;
             dld[i] = F;
-            if (btT > 0 && k < F) {
+            if (btT > 0) {
                 const int r = rbeg + row, sm_ = r / btN;
                 m0[i] = true;
                 mn[i] = r - sm_ * btN;

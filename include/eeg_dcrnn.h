@@ -36,9 +36,10 @@ typedef struct eeg_layer_dims {
     int32_t act;        /* 0 = tanh, 1 = relu  (cell.py:146 `nonlinearity`) */
     int32_t p_batched;  /* 1: P holds one graph per clip (B graphs); 0: one shared graph */
     int32_t x_planes_ready;  /* 1: `planes` already holds P_m X (the previous layer's Hplanes, slots 1..T) */
-    int32_t x_batch_major;   /* 1: X is the BATCH-major (B,T,N,Fin) model input and is consumed as it is: the diffusion
-                                kernel and the hoisted GEMMs address it through a (b,t) row map, no time-major copy is
-                                written (only where eeg_dcrnn_batch_major_ok() returns 2; pass the same X to layer_bwd) */
+    int32_t x_batch_major;   /* 1: X is the BATCH-major (B,T,N,Fin) model input and is consumed as it is; `planes` then
+                                holds P_m X in the same (b,t) order and the hoisted GEMMs address both through a row
+                                map: no time-major copy is written (only where eeg_dcrnn_batch_major_ok() returns 2;
+                                pass the same X and planes to layer_bwd) */
     int64_t x_plane_stride;  /* floats between two hop planes of `planes`; 0 = T*B*N*Fin (contiguous) */
 } eeg_layer_dims;
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B timing of tuning-knob sets: ab.sh [--workload W] "k=v,k=v" "k=v" ...   ("-" = defaults)
+# A/B timing of tuning-knob sets (dev build): ab.sh [--workload W] "k=v,k=v" "k=v" ...   ("-" = product defaults)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; mkdir -p gpurun_out
 WL=cfg2; if [ "$1" == "--workload" ]; then WL=$2; shift 2; fi
 for t in "$@"; do
@@ -7,5 +7,5 @@ for t in "$@"; do
   python bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-stream-inputs $args 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['kernels']
-print('$t'.ljust(14), d['value'], d['ms_per_step'], 'loss', d['config']['final_loss'], ' '.join(f\"{n}={k[n]['ms_per_step']:.3f}\" for n in ('gemm_tn_x','gemm_tn_hg','gemm_tn_hc','gemm_nn_xw','gemm_nn_dx','seq_fwd','seq_bwd','reduce_unpack','diffuse_fwd','diffuse_adj') if n in k))"
+print('$t'.ljust(14), d['value'], d['ms_per_step'], ' '.join(f\"{n}={k[n]['ms_per_step']:.4f}\" for n in ('gemm_tn_x','gemm_tn_hg','gemm_tn_hc','gemm_nn_xw','gemm_nn_dx','seq_fwd','seq_bwd','reduce_unpack','diffuse_fwd','diffuse_adj','corr_gram') if n in k))"
 done
