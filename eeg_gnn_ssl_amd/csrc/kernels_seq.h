@@ -34,11 +34,11 @@ namespace eeg {
 
 template <int H, int M>
 struct SeqGeom {
-    static constexpr int KA = M * H, KAP = lds_stride_q(KA), KS = KA / 4;        // h-wide hop tile
-    static constexpr int KG = M * 2 * H, KGP = lds_stride_q(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
+    static constexpr int KA = M * H, KAP = lds_stride_x(KA), KS = KA / 4;        // h-wide hop tile (swizzled, common.h)
+    static constexpr int KG = M * 2 * H, KGP = lds_stride_x(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
     static constexpr int NGT = 2 * H / 16, NCT = H / 16;                         // gate / cand col tiles
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
-    static constexpr int kRemScratch = 4 * 2 * CT * 256;                         // 4 waves x up to 2*CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
+    static constexpr int kRemScratch = 4 * 2 * CT * kRemTile;                    // 4 waves x up to 2*CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
     static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + kRemScratch; }
     // Node rows of the backward kernel's LDS tiles: 32 (two MFMA node tiles), or -- where 32 rows exceed the
     // 160 KB of a CU (H=64, M=7) and the montage has at most 20 nodes, so that the second tile runs on the
@@ -71,22 +71,27 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
     static_assert(MODE == 0 || REM4, "split modes exist for the 4x4x1 remainder only");
     constexpr bool DO16 = MODE != 2, DO4 = REM4 && MODE != 1;
-    const float* p0 = X + lr * stride + 4 * lg;
-    const float* p1 = REM4 ? X + (16 + (lane & 3)) * stride + 4 * lg : p0 + 16 * stride;
+    // swizzled tile (common.h): quad q of row r is the 16-byte piece 16*(q>>2) + ((4*(q&3) + lg) ^ sigma4(r))
+    const int s0 = lg ^ sigma4(lr), s1 = REM4 ? (lg ^ sigma4(lane & 3)) : s0;
+    const float* p0 = X + lr * stride;
+    const float* p1 = X + (REM4 ? 16 + (lane & 3) : 16 + lr) * stride;
+    auto frag = [&](const float* rowp, int sx, int q) {
+        return *reinterpret_cast<const float4*>(rowp + 64 * (q >> 2) + 4 * ((4 * (q & 3)) ^ sx));
+    };
     f32x4 rem[NT][4];           // one chain per k-step of the quad: consecutive 4x4x1 MFMAs are independent
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    if (DO16) a0 = *reinterpret_cast<const float4*>(p0);
-    if (!REM4 || DO4) a1 = *reinterpret_cast<const float4*>(p1);
+    if (DO16) a0 = frag(p0, s0, 0);
+    if (!REM4 || DO4) a1 = frag(p1, s1, 0);
 #pragma unroll
     for (int q = 0; q < NKS / 4; ++q) {
         float4 n0 = a0, n1 = a1;
         if (q + 1 < NKS / 4) {
-            if (DO16) n0 = *reinterpret_cast<const float4*>(p0 + 16 * (q + 1));
-            if (!REM4 || DO4) n1 = *reinterpret_cast<const float4*>(p1 + 16 * (q + 1));
+            if (DO16) n0 = frag(p0, s0, q + 1);
+            if (!REM4 || DO4) n1 = frag(p1, s1, q + 1);
         }
         EEG_SCHED_FENCE();      // next quad's fragments are in flight while this quad's MFMAs issue
         const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
@@ -110,18 +115,18 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
         a1 = n1;
     }
     if (DO4) {
-        // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr);  reader (lr < 4, lg): sum over the 4 groups
-        // of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
+        // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr) (lane groups 80 floats apart);  reader (lr < 4, lg):
+        // sum over the 4 groups of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                scratch[((i * 4 + lg) * 4 + r) * 16 + lr] = (rem[i][0][r] + rem[i][1][r]) + (rem[i][2][r] + rem[i][3][r]);
+                scratch[i * kRemTile + lg * 80 + r * 16 + lr] = (rem[i][0][r] + rem[i][1][r]) + (rem[i][2][r] + rem[i][3][r]);
         EEG_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const float* q = scratch + (i * 16 + (lr & 3)) * 16 + 4 * lg;
-            const f32x4 s = (ld4(q) + ld4(q + 64)) + (ld4(q + 128) + ld4(q + 192));
+            const float* q = scratch + i * kRemTile + (lr & 3) * 16 + 4 * lg;
+            const f32x4 s = (ld4(q) + ld4(q + 80)) + (ld4(q + 160) + ld4(q + 240));
             if (lr < 4) acc[i][1] += s;
         }
         EEG_WAVE_SYNC();        // the next call may overwrite the scratch
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
     constexpr bool REM4 = NKS == 5;         // at most 20 nodes: the second node tile runs as 4x4x1 MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = A2 + 32 * KAP + wave * (2 * CT * 256);   // this wave's REM4 hand-over scratch
+    float* RS = A2 + 32 * KAP + wave * (2 * CT * kRemTile);   // this wave's REM4 hand-over scratch
     const bool save = Rs != nullptr;
 
     // Wave w owns column tiles ct = w + 4*i of r, u, c and h (so gate tiles ct and NCT+ct): the
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float pf[poly_chains<M, NKS>()][NKS];
     load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
     if (h0 != nullptr) {
-        for (int e = tid; e < N * H; e += 256) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
+        for (int e = tid; e < N * H; e += 256) A[lds_sw(e / H, e % H, KAP)] = h0[(size_t)b * N * H + e];
     } else {      // zero initial state: clear this clip's row of the slot in front of Hseq (= Hext slot 0, read by the backward)
         for (int e = tid; e < N * H; e += 256) (Hseq - (size_t)B * N * H)[(size_t)b * N * H + e] = 0.f;
     }
@@ -287,9 +292,9 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                         u[r] = sigmoidf_(ag[CT + i][nt][r] + xu[i][nt][r]);
                     }
                     ug[i][nt] = u;
-                    f32x4 rh = rg * ld4(A + node[nt] * KAP + col);
+                    f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
                     rh = valid[nt] ? rh : zero4;
-                    st4(A2 + node[nt] * KAP + col, rh);
+                    st4(A2 + lds_sw(node[nt], col, KAP), rh);
                     if (save && valid[nt]) {
                         st4(r_t + oh[i][nt], rg);
                         st4(rh_t + oh[i][nt], rh);
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                 const int col = ct * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 u = ug[i][nt], h = ld4(A + node[nt] * KAP + col);
+                    const f32x4 u = ug[i][nt], h = ld4(A + lds_sw(node[nt], col, KAP));
                     f32x4 c, hn;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                         hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                     }
                     hn = valid[nt] ? hn : zero4;
-                    st4(A + node[nt] * KAP + col, hn);
+                    st4(A + lds_sw(node[nt], col, KAP), hn);
                     if (valid[nt]) {
                         st4(h_t + oh[i][nt], hn);
                         if (save) st4(c_t + oh[i][nt], c);
@@ -364,15 +369,15 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     PhaseProbe<PROBE> pp;
     pp.start();
     static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
-    constexpr int KAP = G::KAP, KS = G::KS, NGT = G::NGT, NCT = G::NCT, UST = H + 4;
+    constexpr int KAP = G::KAP, KS = G::KS, NGT = G::NGT, NCT = G::NCT, UST = 64;    // U: swizzled like the big tiles
     EEG_DYN_SMEM(sm);
     float* Pl = sm;
     float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, wave = wave8 & 3;
     const int lr = lane & 15, lg = lane >> 4;
-    float* RS = A2 + 32 * KAP + wave8 * 256;          // this wave's hand-over scratch (one column tile)
-    float* U = A2 + 32 * KAP + 8 * 256;               // [16][UST] update gate of nodes 0..15 of the current step
+    float* RS = A2 + 32 * KAP + wave8 * kRemTile;     // this wave's hand-over scratch (one column tile)
+    float* U = A2 + 32 * KAP + 8 * kRemTile;          // [16][UST] update gate of nodes 0..15 of the current step
     const bool save = Rs != nullptr;
     const int ct = wave;                               // NCT == 4 == waves per role
 
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
     if (h0 != nullptr) {
-        for (int e = tid; e < N * H; e += 512) A[(e / H) * KAP + (e % H)] = h0[(size_t)b * N * H + e];
+        for (int e = tid; e < N * H; e += 512) A[lds_sw(e / H, e % H, KAP)] = h0[(size_t)b * N * H + e];
     } else {
         for (int e = tid; e < N * H; e += 512) (Hseq - (size_t)B * N * H)[(size_t)b * N * H + e] = 0.f;
     }
@@ -436,9 +441,9 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 f32x4 rg;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rg[r] = sigmoidf_(ar[0][nt][r] + xr[nt][r]);
-                f32x4 rh = rg * ld4(A + node[nt] * KAP + col);
+                f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
                 rh = valid[nt] ? rh : zero4;
-                st4(A2 + node[nt] * KAP + col, rh);
+                st4(A2 + lds_sw(node[nt], col, KAP), rh);
                 if (save && valid[nt]) {
                     st4(Rs + s * N * H + oh[nt], rg);
                     st4(RHs + s * N * H + oh[nt], rh);
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac, RS);
             pp.mark(4);
             {
-                const f32x4 u = ld4(U + lr * UST + col), h = ld4(A + lr * KAP + col);
+                const f32x4 u = ld4(U + lds_sw(lr, col, UST)), h = ld4(A + lds_sw(lr, col, KAP));
                 f32x4 c, hn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                 }
                 hn = valid[0] ? hn : zero4;
-                st4(A + lr * KAP + col, hn);
+                st4(A + lds_sw(lr, col, KAP), hn);
                 if (valid[0]) {
                     st4(Hseq + s * N * H + oh[0], hn);
                     if (save) st4(Cs + s * N * H + oh[0], c);
@@ -497,14 +502,14 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     u0[r] = sigmoidf_(au[0][0][r] + xu[0][r]);
                     u[r] = sigmoidf_(au[0][1][r] + xu[1][r]);
                 }
-                st4(U + lr * UST + col, u0);                        // nodes >= N: finite, never used
+                st4(U + lds_sw(lr, col, UST), u0);                        // nodes >= N: finite, never used
                 if (save && valid[0]) st4(Us + s * N * H + oh[0], u0);
             }
             __syncthreads();                                        // (2)
             // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend
             mfma_nodes32<1, KS, true, 2>(A2, KAP, lane, lr, lg, w1, ac, RS);
             {
-                const f32x4 h = ld4(A + node[1] * KAP + col);
+                const f32x4 h = ld4(A + lds_sw(node[1], col, KAP));
                 f32x4 c, hn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                 }
                 hn = valid[1] ? hn : zero4;
-                if (lr < 4) st4(A + node[1] * KAP + col, hn);       // rows 16..19 (the others belong to nobody here)
+                if (lr < 4) st4(A + lds_sw(node[1], col, KAP), hn);       // rows 16..19 (the others belong to nobody here)
                 if (valid[1]) {
                     st4(Hseq + s * N * H + oh[1], hn);
                     if (save) {
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float* EG = EC + ROWS * KAP;            // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
     constexpr bool REM4 = NKS == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = EG + ROWS * KGP + wave * (2 * CT * 256);
+    float* RS = EG + ROWS * KGP + wave * (2 * CT * kRemTile);
 
     // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
     // the 2H-wide gate gradient): all elementwise -> diffusion hand-offs are wave-local.
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
                     du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
                 }
-                if (own[i] && (ROWS == 32 || node[nt] < ROWS)) st4(EC + node[nt] * KAP + col, dC);   // zeros on padding nodes
+                if (own[i] && (ROWS == 32 || node[nt] < ROWS)) st4(EC + lds_sw(node[nt], col, KAP), dC);   // zeros on padding nodes
                 if (ok) {
                     st4(dxw + oxw[i][nt] + 2 * H, dC);
                     st4(dxw + oxw[i][nt] + H, du_);
@@ -691,8 +696,8 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                     const f32x4 dR = drh * hp[i][nt] * rg * (1.f - rg);
                     dhn[i][nt] += drh * rg;
                     if (ROWS == 32 || node[nt] < ROWS) {
-                        st4(EG + node[nt] * KGP + col, dR);
-                        st4(EG + node[nt] * KGP + H + col, dU[i][nt]);
+                        st4(EG + lds_sw(node[nt], col, KGP), dR);
+                        st4(EG + lds_sw(node[nt], H + col, KGP), dU[i][nt]);
                     }
                     if (valid[nt]) st4(dxw + oxw[i][nt], dR);
                     sb_r[i] += dR;

@@ -116,6 +116,7 @@ __device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[pol
 // m = 1..M-1 at columns src_col + m*slot_w.  The wave reads the NKS feature fragments once and runs
 // all chains (see above) on them.  Issued transposed (features as A operand, polynomial as B operand) so
 // that a lane ends up with 4 consecutive columns of one node row: one ds_write_b128 per chain.
+// `buf` is an XOR-swizzled tile (common.h lds_sw; stride % 64 == 0, slot_w % 16 == 0).
 // Wave-local use: when the source tile was written by this same wave, only EEG_WAVE_SYNC() (no
 // workgroup barrier) is needed before the call.
 // gout != nullptr: the hop rows are also stored to global planes (forward by-product kept for the
@@ -129,7 +130,7 @@ __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src
     constexpr int NC = poly_chains<M, NKS>();
     float b[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + src_col + lr];
+    for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[lds_sw(4 * ks + lg, src_col + lr, stride)];
     f32x4 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -149,7 +150,7 @@ __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src
         }
         const float4 v = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
         if (live && (ROWS == 32 || node < ROWS))
-            *reinterpret_cast<float4*>(buf + node * stride + (hop + 1) * slot_w + src_col + 4 * lg) = v;
+            *reinterpret_cast<float4*>(buf + lds_sw(node, (hop + 1) * slot_w + src_col + 4 * lg, stride)) = v;
         if (gout != nullptr && live && node < n_nodes)
             *reinterpret_cast<float4*>(gout + (size_t)hop * gplane + node * slot_w + src_col + 4 * lg) = v;
     }

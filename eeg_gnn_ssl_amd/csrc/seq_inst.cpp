@@ -31,7 +31,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
 #endif
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // M >= 4: the r + c weights of a wave no longer fit in 256 registers
         if (a.variant == 1) {
-            const size_t lds2 = lds + 20 * (H + 4) * sizeof(float);
+            const size_t lds2 = lds + 16 * 64 * sizeof(float);      // + the update-gate tile U [16][64]
 #if defined(EEG_DEV)
             if constexpr (M == 3) {
                 if (a.probe != nullptr) {
