@@ -649,6 +649,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     SeqBwdArgs a{Hext + state, Hext, Rs, Us, Cs, dHseq, d_at_end, d_at_len,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
                  dXW, dh0, dbias, d->T, d->B, N, d->act, g_seq_probe};
+    a.variant = g_tune[13] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 13 = 1: off)
     if (seq_bwd(H, M, a, st)) return 1;
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
     if (check_launch("reduce_bias")) return 1;
@@ -815,6 +816,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
                          t == T - 1 ? nullptr : dhn_in, nullptr, nullptr, P, d->p_batched, pack + p.b1, pack + p.b2,
                          dXW, t == 0 ? dh0 + (size_t)l * state : dhn_out, ws + y.dbias[l] + (size_t)t * B * 3 * H,
                          1, B, N, d->act, nullptr};
+            a.variant = g_tune[13] == 0 ? 1 : 0;
             if (seq_bwd(H, M, a, st)) return 1;
             const bool need_dx = l > 0 || (t > 0 && feeds_back(t - 1));
             if (need_dx) {

@@ -22,6 +22,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::
 #define EEG_SCHED_FENCE() ((void)0)
 #define EEG_WAVE_SYNC() emu::wave_sync()
 #define EEG_SETPRIO(p) ((void)0)
+#define EEG_LDS_BARRIER() __syncthreads()
 __device__ __forceinline__ long long cycle_now() { return 0; }
 #else
 #include <hip/hip_runtime.h>
@@ -42,6 +43,14 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // is visible to its own later LDS reads; this only stops the compiler from reordering across it.
 #define EEG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define EEG_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier, and the
+// fence makes the compiler drain the vector-memory counter (s_waitcnt vmcnt(0)) in front of every s_barrier: a wave
+// with global loads or stores in flight -- the recurrent kernels prefetch their operands a step ahead and stream
+// their results out -- then sits at the barrier for a full HBM round trip, every step (measured: ~2200 cycles per
+// barrier that follows a prefetch).  The waves of these kernels exchange data through LDS only (no wave reads global
+// memory another wave of its workgroup wrote in the same launch), so waiting for the LDS counter is sufficient; the
+// compiler still tracks the outstanding loads and waits where their registers are first used.
+#define EEG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 #endif
 

@@ -65,7 +65,10 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float
 // tile layout (lane (lr < 4, lg): node 16 + lr, columns 4*lg..4*lg+3), which also sums the 4 groups.
 // MODE (REM4 only): 0 = both node tiles; 1 = only the 16-node tile (acc[.][0]); 2 = only the 4x4x1 remainder
 // (acc[.][1]) -- the two-wave forward kernel splits a GEMM between its waves that way.
-template <int NT, int NKS, bool REM4, int MODE = 0>
+// QM (the two-role BPTT kernel splits its K = M*2H gate GEMM by column half): 0: weight quad q' reads tile quad q';
+// 1 / 2: the quads of the dR / dU halves of every 2H-wide hop slot (tile quad 8*(q'/4) + q'%4 [+ 4]).
+// WQ: `w` holds ALL k-steps and is indexed by the mapped quad too (only half of the quads are visited).
+template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false>
 __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
                                              const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
@@ -75,7 +78,10 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     const int s0 = lg ^ sigma4(lr), s1 = REM4 ? (lg ^ sigma4(lane & 3)) : s0;
     const float* p0 = X + lr * stride;
     const float* p1 = X + (REM4 ? 16 + (lane & 3) : 16 + lr) * stride;
-    auto frag = [&](const float* rowp, int sx, int q) {
+    constexpr int NQ = WQ ? NKS / 8 : NKS / 4;                       // quads visited
+    auto qmap = [](int qw) { return QM == 0 ? qw : 8 * (qw >> 2) + (qw & 3) + (QM == 2 ? 4 : 0); };
+    auto frag = [&](const float* rowp, int sx, int qw) {
+        const int q = qmap(qw);
         return *reinterpret_cast<const float4*>(rowp + 64 * (q >> 2) + 4 * ((4 * (q & 3)) ^ sx));
     };
     f32x4 rem[NT][4];           // one chain per k-step of the quad: consecutive 4x4x1 MFMAs are independent
@@ -87,9 +93,10 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     if (DO16) a0 = frag(p0, s0, 0);
     if (!REM4 || DO4) a1 = frag(p1, s1, 0);
 #pragma unroll
-    for (int q = 0; q < NKS / 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
+        const int qw4 = 4 * (WQ ? qmap(q) : q);                      // first weight k-step of this quad
         float4 n0 = a0, n1 = a1;
-        if (q + 1 < NKS / 4) {
+        if (q + 1 < NQ) {
             if (DO16) n0 = frag(p0, s0, q + 1);
             if (!REM4 || DO4) n1 = frag(p1, s1, q + 1);
         }
@@ -100,15 +107,15 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    acc[i][0] = mfma16(w[i][4 * q + j], x0[j], acc[i][0]);
-                    if (!REM4) acc[i][1] = mfma16(w[i][4 * q + j], x1[j], acc[i][1]);
+                    acc[i][0] = mfma16(w[i][qw4 + j], x0[j], acc[i][0]);
+                    if (!REM4) acc[i][1] = mfma16(w[i][qw4 + j], x1[j], acc[i][1]);
                 }
         }
         if (DO4) {                  // the quad's 4x4x1 MFMAs as one group (fewer switches between MFMA shapes)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < NT; ++i) rem[i][j] = mfma4(x1[j], w[i][4 * q + j], rem[i][j]);
+                for (int i = 0; i < NT; ++i) rem[i][j] = mfma4(x1[j], w[i][qw4 + j], rem[i][j]);
         }
         EEG_SCHED_FENCE();
         a0 = n0;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                 ag[i][nt] = zero4; ag[CT + i][nt] = zero4; ac[i][nt] = zero4;
                 xr[i][nt] = nxr[i][nt]; xu[i][nt] = nxu[i][nt]; xc[i][nt] = nxc[i][nt];
             }
-        __syncthreads();                                            // (1) hops(h) complete
+        EEG_LDS_BARRIER();                                            // (1) hops(h) complete
         pp.mark(0);
 
         // gate GEMM: (2H cols) x (32 nodes), K = M*H
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         pp.mark(2);
         diffuse_own(A2, RHpl, t);                                   // own column tiles: no barrier needed
         pp.mark(7);
-        __syncthreads();                                            // (2) hops(r*h) complete
+        EEG_LDS_BARRIER();                                            // (2) hops(r*h) complete
         pp.mark(3);
         if (t + 1 < T) fetch_xw(t + 1);
 
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             const size_t s = (size_t)t * B + b;
             f32x4 ar[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
             const f32x4 xr[2] = {nxr[0], nxr[1]}, xc = nxc;
-            __syncthreads();                                        // (1) hops(h) complete
+            EEG_LDS_BARRIER();                                        // (1) hops(h) complete
             pp.mark(0);
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, ar, RS);
             pp.mark(1);
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             pp.mark(2);
             diffuse_own(A2, RHpl, t);
             pp.mark(7);
-            __syncthreads();                                        // (2) hops(r*h) and u of nodes 0..15 complete
+            EEG_LDS_BARRIER();                                        // (2) hops(r*h) and u of nodes 0..15 complete
             pp.mark(3);
             if (t + 1 < T) fetch_xw(t + 1);
             mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac, RS);
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 }
             }
             pp.mark(5);
-            __syncthreads();                                        // (3) h' complete (rows 16..19 come from role B)
+            EEG_LDS_BARRIER();                                        // (3) h' complete (rows 16..19 come from role B)
             if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);
             pp.mark(6);
         }
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             const size_t s = (size_t)t * B + b;
             f32x4 au[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
             const f32x4 xu[2] = {nxu[0], nxu[1]}, xc = nxc;
-            __syncthreads();                                        // (1)
+            EEG_LDS_BARRIER();                                        // (1)
             if (t + 1 < T) fetch_x(t + 1);
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, au, RS);
             f32x4 u;                                                // nodes 16..19: stays in registers for the blend
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 st4(U + lds_sw(lr, col, UST), u0);                        // nodes >= N: finite, never used
                 if (save && valid[0]) st4(Us + s * N * H + oh[0], u0);
             }
-            __syncthreads();                                        // (2)
+            EEG_LDS_BARRIER();                                        // (2)
             // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend
             mfma_nodes32<1, KS, true, 2>(A2, KAP, lane, lr, lg, w1, ac, RS);
             {
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     }
                 }
             }
-            __syncthreads();                                        // (3)
+            EEG_LDS_BARRIER();                                        // (3)
         }
     }
     }   // clips of this workgroup
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         for (int i = 0; i < CT; ++i)
             if (own[i]) lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, (wave + 4 * i) * 16, H, pf, lr, lg);
         pp.mark(7);
-        __syncthreads();                                            // (1) P_m^T dC complete
+        EEG_LDS_BARRIER();                                            // (1) P_m^T dC complete
         pp.mark(1);
 
         // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T (M*H x H)
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                 lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
                 lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + (wave + 4 * i) * 16, 2 * H, pf, lr, lg);
             }
-        __syncthreads();                                            // (2) P_m^T [dR|dU] complete
+        EEG_LDS_BARRIER();                                            // (2) P_m^T [dR|dU] complete
         pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
@@ -752,6 +759,246 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
         dbias_part[(size_t)b * 3 * H + j] = sacc;
     }
+    }   // clips of this workgroup
+    pp.dump(probe, 8);
+}
+
+// ---- two waves per SIMD in the BPTT kernel (rnn_units = 64, at most 20 nodes, M <= 3) ---------------------------
+// The BPTT step is a latency chain as well (dh -> dC,dU -> P^T dC -> GEMM1 -> dR -> P^T dR -> GEMM2 -> dh), but a good
+// part of a step does not sit on it:
+//   * HALF of its largest GEMM: GEMM2 contracts [P_m^T dR | P_m^T dU] with Wg^h^T, and dU is known right after the
+//     blend backward (E1) -- it does not depend on GEMM1;
+//   * everything of the elementwise steps that does not depend on the incoming gradient g: with
+//     kC = (1-u) act'(c), kU = (h-c) u (1-u), hr1 = h r (1-r) the step is dC = g kC, dU = g kU, dh_part = g u,
+//     dR = d(rh) hr1, dh_part += d(rh) r;
+//   * the operand traffic (h_{t-1}, r, u, c, external gradient of the next step) and the per-clip bias sums.
+// So 8 waves: wave w (role A, the chain, raised priority) owns column tile w of every H-wide quantity like
+// seq_bwd_kernel -- the g-dependent multiplies, the three node mixes, GEMM1 -- and keeps only w1 (48 registers) and no
+// operand loads at all; wave 4+w (role B, same SIMD) owns GEMM2 of column tile w (w2: 96 registers; the dU half runs
+// while A does GEMM1 / dR / P^T dR, only the dR half is on the chain), fetches the operands of the NEXT step a step
+// ahead, turns them into the five coefficient vectors and leaves them in a lane-linear LDS block that A reads with
+// conflict-free 16-byte reads, adds the external gradient to its GEMM2 result before handing it to A (tile DP), and
+// gathers the bias sums from the slot-0 tiles.  No register spills in either role: a scratch reload queues behind
+// the outstanding prefetches in the memory pipe (keeping half of w2 in A spilled 105 registers and ran 2x slower;
+// 15-30 spills cost 10-25 %).  The matrix pipe is shared, so no MFMA capacity is gained: the chain gets shorter and
+// B's work fills A's waits.  M >= 4: w2 alone exceeds the 256 registers of a two-wave SIMD.
+//   window 0 (after barrier 3 of step t+1)  A: g = dh_part + DP, dC, dU, P^T dC, P^T dU; takes hr1, r    B: sums dR(t+1)
+//   window 1 (after barrier 1)               A: GEMM1, dR, P^T dR       B: coefficients(t-1) -> LDS, requests operands(t-2); GEMM2 dU half; sums dC, dU
+//   window 2 (after barrier 2)               A: -                       B: GEMM2 dR half; DP = result + external gradient(t-1)
+template <int H, int M, int NKS, bool PROBE = false>
+__global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
+    const float* __restrict__ Hseq, const float* __restrict__ h0, const float* __restrict__ Rs,
+    const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
+    const float* __restrict__ d_at_end, const float* __restrict__ d_at_len, const long long* __restrict__ lengths,
+    const float* __restrict__ P, int p_batched, const float* __restrict__ b1p, const float* __restrict__ b2p,
+    float* __restrict__ dXW, float* __restrict__ dh0, float* __restrict__ dbias_part, int T, int B, int N, int act,
+    long long* probe) {
+    using G = SeqGeom<H, M>;
+    static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
+    constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, NCT = G::NCT, ROWS = 32, DPS = 20;
+    constexpr int kCoefTile = 5 * 2 * 256;                             // [kC, kU, u, hr1, r][node tile][64 lanes x 4]
+    PhaseProbe<PROBE> pp;
+    pp.start();
+    EEG_DYN_SMEM(sm);
+    float* Pl = sm;
+    float* EC = Pl + (M - 1) * kPFloats;    // [32][KAP]  slot 0 = dC, slots m = P_m^T dC
+    float* EG = EC + ROWS * KAP;            // [32][KGP]  slot m = [P_m^T dR | P_m^T dU]
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, ct = wave8 & 3;
+    const int lr = lane & 15, lg = lane >> 4;
+    float* RS = EG + ROWS * KGP + wave8 * kRemTile;                    // this wave's 4x4x1 hand-over scratch
+    float* DP = EG + ROWS * KGP + 8 * kRemTile + ct * (20 * DPS);      // [20][DPS] GEMM2 result + external gradient, tile ct
+    float* CF = EG + ROWS * KGP + 8 * kRemTile + 4 * 20 * DPS + ct * kCoefTile + 4 * lane;   // this lane's coefficient slots
+    constexpr int kZero = ROWS * (KAP + KGP) + 8 * kRemTile + 4 * 20 * DPS + 4 * kCoefTile;   // floats cleared per clip
+    const int node[2] = {lr, 16 + lr};
+    const bool valid[2] = {lr < N, 16 + lr < N};
+    const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int col = ct * 16 + 4 * lg;
+    const int odp[2] = {lr * DPS + 4 * lg, (16 + (lr & 3)) * DPS + 4 * lg};   // lane <-> lane hand-over
+
+    if (role == 1) {
+        // ================= role B =================
+        float w2[1][KSG];
+#pragma unroll
+        for (int ks = 0; ks < KSG; ++ks) w2[0][ks] = b2p[((size_t)ks * NCT + ct) * 64 + lane];
+        const int oh[2] = {nodec[0] * H + col, nodec[1] * H + col};
+        const int orow[2] = {lr, valid[1] ? 16 + lr : 16};             // bias sums, nt = 1: only lanes with a real node add
+        for (int b = blockIdx.x; b < B; b += gridDim.x) {
+            __syncthreads();
+            for (int e = tid; e < kZero; e += 512) EC[e] = 0.f;
+            lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
+            int t_len = -1;                                             // same clamp as gather_last_kernel
+            if (d_at_len != nullptr) {
+                t_len = lengths != nullptr ? (int)lengths[b] - 1 : T - 1;
+                t_len = t_len < 0 ? 0 : (t_len >= T ? T - 1 : t_len);
+            }
+            const size_t tstride = (size_t)B * N * H, boff = (size_t)b * N * H;
+            f32x4 nh[2], nr[2], nu[2], nc[2], ng[2];
+            auto fetch = [&](int t) {
+                const size_t so = (size_t)t * tstride + boff;
+                const float* hs = t > 0 ? Hseq + (so - tstride) : (h0 != nullptr ? h0 + boff : nullptr);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int o = oh[nt];
+                    nh[nt] = hs != nullptr ? ld4(hs + o) : zero4;
+                    nr[nt] = ld4(Rs + so + o);
+                    nu[nt] = ld4(Us + so + o);
+                    nc[nt] = ld4(Cs + so + o);
+                    f32x4 g = dHseq != nullptr ? ld4(dHseq + so + o) : zero4;
+                    if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + boff + o);
+                    if (t == t_len) g += ld4(d_at_len + boff + o);
+                    ng[nt] = g;
+                }
+            };
+            // the five coefficient vectors of one step from its operands -> this lane's LDS slots; the external gradient
+            // of that step is kept (gx) and added to the GEMM2 result that becomes its incoming gradient
+            f32x4 gx[2];
+            auto coef = [&]() {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 h = nh[nt], u = nu[nt], c = nc[nt], r = nr[nt];
+                    f32x4 kC, kU, hr1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float one_u = 1.f - u[e];
+                        kC[e] = act == 0 ? one_u * (1.f - c[e] * c[e]) : (c[e] > 0.f ? one_u : 0.f);
+                        kU[e] = (h[e] - c[e]) * u[e] * one_u;
+                        hr1[e] = h[e] * r[e] * (1.f - r[e]);
+                    }
+                    st4(CF + (0 * 2 + nt) * 256, kC);
+                    st4(CF + (1 * 2 + nt) * 256, kU);
+                    st4(CF + (2 * 2 + nt) * 256, u);
+                    st4(CF + (3 * 2 + nt) * 256, hr1);
+                    st4(CF + (4 * 2 + nt) * 256, r);
+                    gx[nt] = ng[nt];
+                }
+            };
+            fetch(T - 1);
+            __syncthreads();                                            // tiles cleared
+            coef();                                                     // first step: its coefficients, DP = external gradient
+            if (T > 1) fetch(T - 2);
+            st4(DP + odp[0], gx[0]);
+            if (lr < 4) st4(DP + odp[1], gx[1]);
+            f32x4 sb_r = zero4, sb_u = zero4, sb_c = zero4;
+            EEG_LDS_BARRIER();                                          // (3) of an imaginary step T
+            for (int t = T - 1; t >= 0; --t) {
+                if (t < T - 1) {                                        // window 0: dR of the step before is still in place
+                    sb_r += ld4(EG + lds_sw(orow[0], col, KGP));
+                    if (valid[1]) sb_r += ld4(EG + lds_sw(orow[1], col, KGP));
+                }
+                EEG_LDS_BARRIER();                                      // (1) P_m^T dC and P_m^T dU complete; A has read its coefficients
+                if (t > 0) {
+                    coef();                                             // coefficients of step t-1 (operands requested a step ago)
+                    if (t > 1) fetch(t - 2);                            // ... and the same registers request step t-2
+                }
+                f32x4 acc[1][2] = {{zero4, zero4}};
+                mfma_nodes32<1, KSG, true, 0, 2, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
+                sb_c += ld4(EC + lds_sw(orow[0], col, KAP));
+                sb_u += ld4(EG + lds_sw(orow[0], H + col, KGP));
+                if (valid[1]) {
+                    sb_c += ld4(EC + lds_sw(orow[1], col, KAP));
+                    sb_u += ld4(EG + lds_sw(orow[1], H + col, KGP));
+                }
+                EEG_LDS_BARRIER();                                      // (2) P_m^T dR complete
+                EEG_SETPRIO(3);                                         // the dR half is on the chain
+                mfma_nodes32<1, KSG, true, 0, 1, true>(EG, KGP, lane, lr, lg, w2, acc, RS);
+                EEG_SETPRIO(0);
+                if (t > 0) { acc[0][0] += gx[0]; acc[0][1] += gx[1]; }
+                st4(DP + odp[0], acc[0][0]);
+                if (lr < 4) st4(DP + odp[1], acc[0][1]);
+                EEG_LDS_BARRIER();                                      // (3) DP and the coefficients of step t-1 complete
+            }
+            sb_r += ld4(EG + lds_sw(orow[0], col, KGP));                // dR of the last step (t = 0)
+            if (valid[1]) sb_r += ld4(EG + lds_sw(orow[1], col, KGP));
+            __syncthreads();                                            // all waves done with EG
+            float* red = EG;                                            // [3H][16]: fixed-order node reduction
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                red[(0 * H + col + r) * 16 + lr] = sb_r[r];
+                red[(1 * H + col + r) * 16 + lr] = sb_u[r];
+                red[(2 * H + col + r) * 16 + lr] = sb_c[r];
+            }
+            __syncthreads();
+            for (int j = tid - 256; j < 3 * H; j += 256) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
+                dbias_part[(size_t)b * 3 * H + j] = sacc;
+            }
+        }
+        return;
+    }
+    // ================= role A =================
+    float w1[1][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) w1[0][ks] = b1p[((size_t)ks * NCT + ct) * 64 + lane];
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {               // clips of this workgroup (see seq_fwd_kernel)
+    __syncthreads();                                                // previous clip: the bias reduction has read EG
+    for (int e = tid; e < kZero; e += 512) EC[e] = 0.f;
+    lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
+    __syncthreads();                                                // tiles cleared
+    EEG_SETPRIO(3);                                                 // windows 0 and 1: the chain issues first
+    float pf[poly_chains<M, NKS>()][NKS];
+    load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
+    const int oxw[2] = {node[0] * (3 * H) + col, node[1] * (3 * H) + col};
+    const size_t boff = (size_t)b * N * H;
+    f32x4 dhn[2] = {zero4, zero4};                                  // A's elementwise part of dh
+    EEG_LDS_BARRIER();                                              // (3) of an imaginary step T: first coefficients, DP
+    for (int t = T - 1; t >= 0; --t) {
+        float* dxw = dXW + ((size_t)t * B + b) * N * (3 * H);
+        // ---- E1: g = A's elementwise part + role B's GEMM2 of the step before (+ external gradient, added by B)
+        f32x4 hr1[2], rg[2];                                        // taken now: role B refills the slots in window 1
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 g = valid[nt] ? dhn[nt] + ld4(DP + odp[nt]) : zero4;
+            const f32x4 dC = g * ld4(CF + (0 * 2 + nt) * 256), du_ = g * ld4(CF + (1 * 2 + nt) * 256);
+            st4(EC + lds_sw(node[nt], col, KAP), dC);               // zeros on padding nodes
+            st4(EG + lds_sw(node[nt], H + col, KGP), du_);
+            if (valid[nt]) {
+                st4(dxw + oxw[nt] + 2 * H, dC);
+                st4(dxw + oxw[nt] + H, du_);
+            }
+            dhn[nt] = g * ld4(CF + (2 * 2 + nt) * 256);
+            hr1[nt] = ld4(CF + (3 * 2 + nt) * 256);
+            rg[nt] = ld4(CF + (4 * 2 + nt) * 256);
+        }
+        pp.mark(0);
+        EEG_WAVE_SYNC();
+        lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
+        lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
+        pp.mark(7);
+        EEG_LDS_BARRIER();                                          // (1) P_m^T dC and P_m^T dU complete
+        pp.mark(1);
+        // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T
+        f32x4 acc[1][2] = {{zero4, zero4}};
+        mfma_nodes32<1, KS, true>(EC, KAP, lane, lr, lg, w1, acc, RS);
+        pp.mark(2);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 drh = acc[0][nt];                           // exact 0 on padding nodes
+            const f32x4 dR = drh * hr1[nt];
+            dhn[nt] += drh * rg[nt];
+            st4(EG + lds_sw(node[nt], col, KGP), dR);
+            if (valid[nt]) st4(dxw + oxw[nt], dR);
+        }
+        pp.mark(3);
+        EEG_WAVE_SYNC();
+        lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
+        EEG_LDS_BARRIER();                                          // (2) P_m^T dR complete
+        pp.mark(4);
+        EEG_SETPRIO(0);                                             // window 2 belongs to role B's half GEMM
+        EEG_LDS_BARRIER();                                          // (3) role B's GEMM2 is in DP
+        EEG_SETPRIO(3);
+        pp.mark(6);
+    }
+    // ---- epilogue: dh0; role B reduces the bias sums
+    __syncthreads();                                                // all waves done with EG
+    if (dh0 != nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (valid[nt]) st4(dh0 + boff + node[nt] * H + col, dhn[nt] + ld4(DP + odp[nt]));
+    }
+    __syncthreads();
     }   // clips of this workgroup
     pp.dump(probe, 8);
 }

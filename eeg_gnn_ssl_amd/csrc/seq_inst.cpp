@@ -63,7 +63,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
     if (lds > kMaxLdsBytes) return 3;
 #if defined(EEG_DEV)
     if constexpr (H == 64 && M == 3 && NKS == 5) {
-        if (a.probe != nullptr) {
+        if (a.probe != nullptr && a.variant != 1) {
             EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS, true>), lds);
             EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us,
                          a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
@@ -72,6 +72,27 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
         }
     }
 #endif
+    if constexpr (H == 64 && NKS == 5 && M <= 3) {   // two waves per SIMD: role A holds w1 + half of w2 (M >= 4: > 256 registers)
+        if (a.variant == 1) {
+            const size_t lds2 = ((size_t)(M - 1) * kPFloats + 32 * (SeqGeom<H, M>::KAP + SeqGeom<H, M>::KGP) + 8 * kRemTile + 4 * 20 * 20 + 4 * 5 * 2 * 256) * sizeof(float);
+#if defined(EEG_DEV)
+            if constexpr (M == 3) {
+                if (a.probe != nullptr) {
+                    EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, true>), lds2);
+                    EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us,
+                                 a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
+                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
+                    return hipGetLastError() == hipSuccess ? 0 : 2;
+                }
+            }
+#endif
+            EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS>), lds2);
+            EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
+                         a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
+                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
+            return hipGetLastError() == hipSuccess ? 0 : 2;
+        }
+    }
     EEG_SET_MAX_LDS((seq_bwd_kernel<H, M, NKS>), lds);
     EEG_LAUNCH_P("seq_bwd", (seq_bwd_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(256), lds, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                  a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,

@@ -26,6 +26,7 @@ struct SeqBwdArgs {
     float *dXW, *dh0, *dbias_part;
     int T, B, N, act;
     long long* probe;
+    int variant = 0;        // 1: two waves per SIMD (seq_bwd2_kernel) where it exists
 };
 
 // return 0 ok, 1 unsupported M for this H, 2 launch error
