@@ -704,9 +704,20 @@ int eeg_dcrnn_corr_graph(const float* X, int B, int T, int N, int D, int top_k, 
     if (top_k < 0 || top_k >= N) return fail("corr_graph: top_k=%d unsupported (0..%d)", top_k, N - 1);
     hipStream_t st = S_(stream);
     const int ns = corr_nsplit(B, T);
-    const size_t lds = 4 * kGramFloats * sizeof(float);
+    const int step_floats = round_up(N * D, 256);          // one time step, in whole 1-KB wave-DMAs
+    const size_t lds = 4 * (size_t)(step_floats > kGramFloats ? step_floats : kGramFloats) * sizeof(float);
+    if (lds > 64 * 1024) return fail("corr_graph: N*D=%d too large for the per-wave staging buffers", N * D);
     switch (ceil_div(D, 16)) {
-#define EEG_GRAM(NQ) case NQ: EEG_LAUNCH_P("corr_gram", corr_gram_kernel<NQ>, dim3(B, ns), dim3(256), lds, st, X, T, N, D, ws); break;
+#define EEG_GRAM(NQ)                                                                                                          \
+    case NQ:                                                                                                                  \
+        if (N <= 20) {                                                                                                        \
+            EEG_SET_MAX_LDS((corr_gram_kernel<NQ, true>), lds);                                                               \
+            EEG_LAUNCH_P("corr_gram", (corr_gram_kernel<NQ, true>), dim3(B, ns), dim3(256), lds, st, X, T, N, D, ws, step_floats);  \
+        } else {                                                                                                              \
+            EEG_SET_MAX_LDS((corr_gram_kernel<NQ, false>), lds);                                                              \
+            EEG_LAUNCH_P("corr_gram", (corr_gram_kernel<NQ, false>), dim3(B, ns), dim3(256), lds, st, X, T, N, D, ws, step_floats); \
+        }                                                                                                                     \
+        break;
         EEG_GRAM(1) EEG_GRAM(2) EEG_GRAM(3) EEG_GRAM(4) EEG_GRAM(5) EEG_GRAM(6) EEG_GRAM(7) EEG_GRAM(8)
 #undef EEG_GRAM
         default: return fail("corr_graph: feature dim=%d unsupported (<= 128)", D);
