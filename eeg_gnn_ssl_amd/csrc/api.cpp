@@ -177,22 +177,25 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
 // launch) but measured SLOWER (gemm_tn 1.08-1.15 vs 0.92 ms/step, cfg2): the re-reads are served by the
 // Infinity Cache, and the wider tile costs occupancy.
 constexpr int kTnKbw = 64;
-template <int KTW, int NCTW, int RC>
+template <int KTW, int NCTW, int RC, int WK = 2>
 int run_tn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
                float* partial, int nsplit, int rows_per_split, hipStream_t st, const char* tag, BtMap bt) {
-    constexpr int OT = 2 * NCTW * 16, KBW = 32 * KTW;
-    static_assert(KBW == kTnKbw, "tn_split assumes this k-block width");
+    constexpr int OT = 2 * NCTW * 16, KBW = 16 * KTW * WK;
     const size_t lds = 2 * (size_t)(RC * KBW + RC * OT) * sizeof(float);
-    EEG_SET_MAX_LDS((gemm_tn_dma_kernel<KTW, NCTW, RC>), lds);
+    EEG_SET_MAX_LDS((gemm_tn_dma_kernel<KTW, NCTW, RC, WK>), lds);
     dim3 grid(ceil_div(nseg * F, KBW), nsplit);
-    EEG_LAUNCH_P(tag, (gemm_tn_dma_kernel<KTW, NCTW, RC>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, bt.T, bt.B, bt.N);
+    EEG_LAUNCH_P(tag, (gemm_tn_dma_kernel<KTW, NCTW, RC, WK>), grid, dim3(128 * WK), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, bt.T, bt.B, bt.N);
     return check_launch("gemm_tn_dma");
 }
+
+// dev knob 14: 8-wave / 128-column k-blocks for dY tiles of this width and up (0 = never); knob 15: their workgroup target
+int tn_wide_from() { return g_tune[14]; }
 bool tn_dma_ok(int F, int O) { return g_tune[1] == 0 && O > 32 && O % 4 == 0 && F % 4 == 0; }
 int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
     const bool dma = tn_dma_ok(F, O);
-    const int blocks = dma ? ceil_div(nseg * F, kTnKbw) : nseg * ceil_div(F, 64);
-    int nsplit = ceil_div(768, blocks);             // ~3 workgroups per CU; more splits only add partial-sum traffic (measured)
+    const bool wide = dma && tn_wide_from() > 0 && O >= tn_wide_from();
+    const int blocks = dma ? ceil_div(nseg * F, wide ? 2 * kTnKbw : kTnKbw) : nseg * ceil_div(F, 64);
+    int nsplit = ceil_div(wide ? (g_tune[15] > 0 ? g_tune[15] : 512) : 768, blocks);   // ~3 (wide: 2) workgroups per CU; more splits only add partial-sum traffic (measured)
     int rps = round_up(ceil_div(R, nsplit), 32);
     if (rps < 128) rps = 128;
     nsplit = ceil_div(R, rps);
@@ -208,9 +211,12 @@ int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ld
         // row-chunk depth: the 192-column tile stages 16 rows at a time (32 KB of LDS per workgroup -> 4 workgroups
         // per CU instead of 2 with 32-row stages: -3.5 % on that shape); the narrower tiles are better off with 32
         // rows (measured both ways); 8-row stages are 15 % slower
-        if (O > 128 && O <= 192) return EEG_TN(6, 16);
-        if (O > 64 && O <= 128) return EEG_TN(4, 32);
-        return EEG_TN(2, 32);
+#define EEG_TNW(NCTW, RC) run_tn_dma<2, NCTW, RC, 4>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag, bt)
+        const bool wide = tn_wide_from() > 0 && O >= tn_wide_from();
+        if (O > 128 && O <= 192) return wide ? EEG_TNW(6, 16) : EEG_TN(6, 16);
+        if (O > 64 && O <= 128) return wide ? EEG_TNW(4, 32) : EEG_TN(4, 32);
+        return wide ? EEG_TNW(2, 32) : EEG_TN(2, 32);
+#undef EEG_TNW
 #undef EEG_TN
     }
     if (bt.T > 0) return fail("gemm_tn: a batch-major segment needs the LDS-DMA kernel (O=%d)", O);

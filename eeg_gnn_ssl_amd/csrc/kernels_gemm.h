@@ -380,14 +380,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(SegPtrs segs, int nseg, in
 // rows are zeroed in LDS before the last chunk is multiplied).
 // 4 waves = 2 (k) x 2 (cols), each KTW k-tiles x NCTW col tiles.  grid = (ceil(K / KBW), nsplit).
 // Requires O % 64 == 0 (NCTW in {2,4,6}), F % 4 == 0, Ov % 4 == 0, rows_per_split % RC == 0.
-template <int KTW, int NCTW, int RC>
-__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
+// WK = waves along k: 2 (4 waves, 64-column k-block, the default) or 4 (8 waves, 128-column k-block: every dY chunk is
+// multiplied with twice as many A columns, i.e. half the dY re-reads per flop, at 2 waves per SIMD and workgroup).
+template <int KTW, int NCTW, int RC, int WK = 2>
+__global__ __launch_bounds__(128 * WK) void gemm_tn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
                                                           const float* __restrict__ dY, int ldy, int ycol0, int Ov,
                                                           float* __restrict__ partial, int rows_per_split,
                                                           int btT, int btB, int btN) {
-    constexpr int KBW = 32 * KTW, KQ = KBW / 4, O = 2 * NCTW * 16, OQ = O / 4;
+    constexpr int NW = 2 * WK, KBW = 16 * KTW * WK, KQ = KBW / 4, O = 2 * NCTW * 16, OQ = O / 4;
     constexpr int A_FLOATS = RC * KBW, Y_FLOATS = RC * O;
-    constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, INS = A_INS + Y_INS, NI = (INS + 3) / 4;
+    constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, INS = A_INS + Y_INS, NI = (INS + NW - 1) / NW;
     static_assert(A_FLOATS % 256 == 0 && Y_FLOATS % 256 == 0 && RC % 4 == 0, "chunk must be whole wave-DMAs");
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
     bool m0[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int j = wave + 4 * i;
+        const int j = wave + NW * i;
         m0[i] = false;
         mb[i] = mt[i] = mn[i] = 0;
         if (j < A_INS) {
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
         const bool tail = r0 + RC > R;                      // only the last chunk of the last split
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int j = wave + 4 * i;
+            const int j = wave + NW * i;
             if (j >= INS) continue;
             int row = r0 + drow[i];
             if (m0[i]) {                                    // chunks are requested in row order: advance by RC rows per call
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(SegPtrs segs, int nseg
         float* Ys = At + A_FLOATS;
         if (r0 + RC > rend) {                               // partial last chunk: rows past the end contribute zero
             const int valid = rend - r0;
-            for (int e = tid; e < (RC - valid) * OQ; e += 256)
+            for (int e = tid; e < (RC - valid) * OQ; e += 64 * NW)
                 *reinterpret_cast<float4*>(Ys + valid * O + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
         }
