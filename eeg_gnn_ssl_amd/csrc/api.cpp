@@ -96,13 +96,13 @@ inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 using namespace eeg;
 
 bool h_supported(int H) { return H == 16 || H == 32 || H == 64; }
-bool m_supported(int M) { return M == 2 || M == 3 || M == 4 || M == 5 || M == 7; }
+bool m_supported(int M) { return M == 1 || M == 2 || M == 3 || M == 4 || M == 5 || M == 7; }
 
 int check_dims(int N, int H, int Fin, int M) {
     if (N < 1 || N > kMaxNodes) return fail("num_nodes=%d unsupported (1..%d)", N, kMaxNodes);
     if (!h_supported(H)) return fail("rnn_units=%d unsupported (16, 32 or 64)", H);
     if (Fin < 4 || Fin % 4 != 0) return fail("per-node input dim=%d unsupported (must be a positive multiple of 4)", Fin);
-    if (!m_supported(M)) return fail("num hop matrices M=%d unsupported (2,3,4,5,7)", M);
+    if (!m_supported(M)) return fail("num hop matrices M=%d unsupported (1,2,3,4,5,7)", M);
     // LDS of the BPTT kernel (SeqGeom::bwd_lds_floats): the widest case (H=64, M=7) only fits montages of <= 20 nodes
     const int ka = M * H, rows = N <= 20 ? 20 : 32, ct = ceil_div(H / 16, 4);
     const size_t bwd = ((size_t)(M - 1) * kPFloats + (size_t)rows * (lds_stride_x(ka) + lds_stride_x(2 * ka)) + 4 * 2 * ct * kRemTile) * sizeof(float);
@@ -234,6 +234,7 @@ bool diffuse_streams(int p_batched, int S, int B, int N, int F) { return N == 19
 int diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M, float* planes,
                 hipStream_t st, size_t plane_stride = 0, int x_bt = 0, float* xcopy = nullptr) {
     if (plane_stride == 0) plane_stride = (size_t)S * N * F;
+    if (M == 1 && xcopy == nullptr) return 0;         // max_diffusion_step = 0: no planes (a requested copy still runs below)
     if (x_bt && !diffuse_streams(p_batched, S, B, N, F)) return fail("diffuse_fwd: batch-major input needs the streaming kernel");
     // the EEG montage: streaming kernel (no LDS); launches with < 4 samples per graph (decoder steps) leave most of its
     // lanes idle and are faster through the LDS/MFMA kernel below
@@ -551,7 +552,8 @@ int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_grap
                         void* stream) {
     if (n_supports < 1 || n_supports > 4) return fail("hop_polys: n_supports=%d unsupported (1..4)", n_supports);
     if (N < 1 || N > kMaxNodes) return fail("hop_polys: num_nodes=%d unsupported", N);
-    if (K < 1) return fail("hop_polys: max_diffusion_step=%d unsupported (>= 1)", K);
+    if (K < 0) return fail("hop_polys: max_diffusion_step=%d unsupported (>= 0)", K);
+    if (K == 0) return 0;                            // cell.py:80-81: no hop matrices beyond the identity, P_out is empty
     if (n_supports * K + 1 > kMaxM) return fail("hop_polys: %d supports x K=%d exceeds %d hop matrices", n_supports, K, kMaxM);
     SupPtrs sp;
     for (int i = 0; i < 4; ++i) sp.p[i] = i < n_supports ? supports[i] : nullptr;
@@ -573,12 +575,12 @@ int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const
 
 int eeg_dcrnn_diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M,
                           float* planes, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("diffuse_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("diffuse_fwd: bad dims N=%d F=%d M=%d", N, F, M);
     return diffuse_fwd(X, P, p_batched, S, B, N, F, M, planes, S_(stream));
 }
 int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M,
                           float* dX, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("diffuse_adj: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("diffuse_adj: bad dims N=%d F=%d M=%d", N, F, M);
     return diffuse_adj(Z, P, p_batched, S, B, N, F, M, dX, S_(stream));
 }
 
@@ -894,7 +896,7 @@ size_t eeg_dcrnn_dconv_fwd_ws_floats(int B, int N, int F, int M, int O) {
 }
 int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M,
                         const float* W, const float* bias, int O, float* out, float* ws, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("dconv_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("dconv_fwd: bad dims N=%d F=%d M=%d", N, F, M);
     if (O % 16 != 0) return fail("dconv_fwd: output_dim=%d must be a multiple of 16", O);
     hipStream_t st = S_(stream);
     float* planes = ws;
@@ -915,7 +917,7 @@ size_t eeg_dcrnn_dconv_bwd_ws_floats(int B, int N, int F, int M, int O) {
 }
 int eeg_dcrnn_dconv_bwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M, const float* W, int O,
                         const float* dOut, float* dX, float* dW, float* dbias, float* ws, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 2 || M > kMaxM) return fail("dconv_bwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("dconv_bwd: bad dims N=%d F=%d M=%d", N, F, M);
     if (O % 16 != 0 || O > 192) return fail("dconv_bwd: output_dim=%d must be a multiple of 16 (<= 192)", O);
     hipStream_t st = S_(stream);
     const int R = B * N;

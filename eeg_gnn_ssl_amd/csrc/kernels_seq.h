@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     for (int e = tid; e < 2 * 32 * KAP; e += 256) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();
-    float pf[poly_chains<M, NKS>()][NKS];
+    float pf[poly_slots<M, NKS>()][NKS];
     load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
     if (h0 != nullptr) {
         for (int e = tid; e < N * H; e += 256) A[lds_sw(e / H, e % H, KAP)] = h0[(size_t)b * N * H + e];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     }
     if (role == 0) {
         EEG_SETPRIO(3);         // the r -> r*h -> c chain is the critical path: its instructions issue first
-        float pf[poly_chains<M, NKS>()][NKS];
+        float pf[poly_slots<M, NKS>()][NKS];
         load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
         auto diffuse_own = [&](float* buf, float* planes, int t) {
             EEG_WAVE_SYNC();
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         t_len = t_len < 0 ? 0 : (t_len >= T ? T - 1 : t_len);
     }
     __syncthreads();
-    float pf[poly_chains<M, NKS>()][NKS];
+    float pf[poly_slots<M, NKS>()][NKS];
     load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
 
     const int node[2] = {lr, 16 + lr};
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
     __syncthreads();                                                // tiles cleared
     EEG_SETPRIO(3);                                                 // windows 0 and 1: the chain issues first
-    float pf[poly_chains<M, NKS>()][NKS];
+    float pf[poly_slots<M, NKS>()][NKS];
     load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
     const int oxw[2] = {node[0] * (3 * H) + col, node[1] * (3 * H) + col};
     const size_t boff = (size_t)b * N * H;

@@ -81,9 +81,12 @@ __device__ __forceinline__ void lds_diffuse_tiles(float* buf, int stride, int sr
 //     (hop, node) row, so its result goes out as one 16-byte write like every other.
 template <int M, int NKS>
 constexpr int poly_chains() { return NKS == 5 ? (M - 1) + (M - 1 + 3) / 4 : (M - 1) * 2; }
+// array extent for the fragment registers (M = 1, i.e. max_diffusion_step = 0, has no chain at all)
+template <int M, int NKS>
+constexpr int poly_slots() { return poly_chains<M, NKS>() > 0 ? poly_chains<M, NKS>() : 1; }
 
 template <int M, int NKS, bool ADJ>
-__device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[poly_chains<M, NKS>()][NKS], int lr, int lg) {
+__device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[poly_slots<M, NKS>()][NKS], int lr, int lg) {
     if constexpr (NKS == 5) {
 #pragma unroll
         for (int c = 0; c < M - 1; ++c)
@@ -125,13 +128,15 @@ __device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[pol
 // (NKS == 5: rows 20..31 of the hop slots are never written -- nothing reads them in that regime.)
 template <int M, int NKS, int ROWS = 32>
 __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src_col, int slot_w,
-                                                 const float (&pf)[poly_chains<M, NKS>()][NKS], int lr, int lg,
+                                                 const float (&pf)[poly_slots<M, NKS>()][NKS], int lr, int lg,
                                                  float* __restrict__ gout = nullptr, size_t gplane = 0, int n_nodes = 0) {
     constexpr int NC = poly_chains<M, NKS>();
+    if constexpr (NC == 0) return;                       // max_diffusion_step = 0: nothing to mix
+    constexpr int NA = NC > 0 ? NC : 1;
     float b[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[lds_sw(4 * ks + lg, src_col + lr, stride)];
-    f32x4 acc[NC];
+    f32x4 acc[NA];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -108,6 +108,7 @@ int bwd_one(const SeqBwdArgs& a, hipStream_t st) {
 
 int EEG_CAT(launch_seq_fwd_h, EEG_SEQ_H)(int M, const SeqFwdArgs& a, hipStream_t st) {
     switch (M) {
+        case 1: return fwd_one<EEG_SEQ_H, 1>(a, st);
         case 2: return fwd_one<EEG_SEQ_H, 2>(a, st);
         case 3: return fwd_one<EEG_SEQ_H, 3>(a, st);
         case 4: return fwd_one<EEG_SEQ_H, 4>(a, st);
@@ -118,6 +119,7 @@ int EEG_CAT(launch_seq_fwd_h, EEG_SEQ_H)(int M, const SeqFwdArgs& a, hipStream_t
 }
 int EEG_CAT(launch_seq_bwd_h, EEG_SEQ_H)(int M, const SeqBwdArgs& a, hipStream_t st) {
     switch (M) {
+        case 1: return bwd_one<EEG_SEQ_H, 1>(a, st);
         case 2: return bwd_one<EEG_SEQ_H, 2>(a, st);
         case 3: return bwd_one<EEG_SEQ_H, 3>(a, st);
         case 4: return bwd_one<EEG_SEQ_H, 4>(a, st);

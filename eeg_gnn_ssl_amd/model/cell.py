@@ -46,8 +46,6 @@ class DiffusionGraphConv(nn.Module):
         n, f = self._num_nodes, self._input_size
         if f % 4 != 0:
             raise RuntimeError(f"DiffusionGraphConv: input_dim + hid_dim = {f} must be a multiple of 4")
-        if self._max_diffusion_step < 1:
-            raise NotImplementedError("max_diffusion_step must be >= 1")
         x = torch.cat([inputs.reshape(b, n, -1), state.reshape(b, n, -1)], dim=2)
         p, p_batched = ops.hop_polys(supports, self._max_diffusion_step, b)
         out = ops.dconv(x, p, p_batched, self.weight, self.biases)
@@ -73,8 +71,8 @@ class DCGRUCell(nn.Module):
         self._use_gc_for_ru = use_gc_for_ru
         if not use_gc_for_ru:
             raise NotImplementedError("use_gc_for_ru=False is a stub (`_fc` is `pass`) in the reference as well")
-        if max_diffusion_step < 1:
-            raise NotImplementedError("max_diffusion_step must be >= 1")
+        if max_diffusion_step < 0:
+            raise ValueError("max_diffusion_step must be >= 0")
         self._num_supports = 2 if filter_type == "dual_random_walk" else 1     # cell.py:151-158
         self._filter_type = filter_type
         common = dict(num_supports=self._num_supports, input_dim=input_dim, hid_dim=num_units,

@@ -73,6 +73,9 @@ CELL_K_CASES = {
     "dual_k1": ("dual_random_walk", 8, 16, 3, "tanh", 1),
     "dual_k3": ("dual_random_walk", 8, 16, 3, "relu", 3),
     "rw_k2": ("random_walk", 12, 32, 2, "tanh", 2),
+    # max_diffusion_step = 0 (tests/golden/make_golden_k0.py): one "hop matrix" = the identity, no graph mixing
+    "lap_k0": ("laplacian", 8, 16, 3, "tanh", 0),
+    "dual_k0_h64": ("dual_random_walk", 100, 64, 2, "tanh", 0),
 }
 
 

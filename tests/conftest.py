@@ -17,7 +17,7 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden():
     out = {}
-    for name in ("golden_v1.npz", "golden_k_v1.npz", "golden_dconv_grad_v1.npz"):     # model / cell goldens, other diffusion orders, dconv gradients
+    for name in ("golden_v1.npz", "golden_k_v1.npz", "golden_k0_v1.npz", "golden_dconv_grad_v1.npz"):     # model / cell goldens, other diffusion orders, dconv gradients
         with np.load(os.path.join(ROOT, "tests", "golden", name)) as z:
             out.update({k: z[k] for k in z.files})
     return out

@@ -108,3 +108,23 @@ def test_torch_ops_direct_and_opcheck(adj3d):
 
 def test_batch_major_input_without_copy(adj3d):
     ps.check_batch_major_input("cpu", adj3d)
+
+
+def test_zero_diffusion_steps_model_and_dconv(adj3d):
+    """max_diffusion_step = 0 (the reference's `pass` branch, cell.py:80-81): one hop matrix = the identity.  Whole
+    classification model vs the oracle, and the stand-alone DiffusionGraphConv forward + backward."""
+    import torch
+    from eeg_gnn_ssl_amd import DiffusionGraphConv
+    from oracle import dcrnn_oracle as orc
+    import cases
+    ps.check_vs_oracle_random("cpu", "dual_random_walk", 8, 16, 2, 3, 2, 4, adj3d, seed=2, lengths=[3, 1], k=0)
+    g = torch.Generator().manual_seed(1)
+    mod = DiffusionGraphConv(1, 8, 16, 19, 0, 32, filter_type="laplacian")
+    x = torch.randn(2, 19 * 8, generator=g, requires_grad=True)
+    s = torch.randn(2, 19 * 16, generator=g, requires_grad=True)
+    sup = cases.supports_for("laplacian", adj3d, 2)
+    out = mod(sup, x, s, 32)
+    ref = orc.diffusion_conv(sup, x.detach(), s.detach(), mod.weight.detach(), mod.biases.detach(), 19, 0)
+    ps.assert_close(out.detach().numpy(), ref.numpy(), "dconv K=0")
+    out.sum().backward()
+    assert x.grad is not None and mod.weight.grad is not None and tuple(mod.weight.shape) == (24, 32)

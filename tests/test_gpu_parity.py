@@ -56,6 +56,8 @@ def test_random_vs_oracle(filt, din, h, layers, t_len, b, classes, lengths, act,
 
 
 @pytest.mark.parametrize("filt,k,din,h,layers,t_len,b,classes,lengths", [
+    ("laplacian", 0, 100, 64, 2, 6, 3, 1, None),                        # M = 1: max_diffusion_step = 0 (cell.py:80-81)
+    ("dual_random_walk", 0, 20, 32, 3, 5, 3, 4, [5, 2, 4]),             # M = 1 with two (unused) supports
     ("laplacian", 1, 100, 64, 2, 6, 3, 1, None),                        # M = 2
     ("laplacian", 3, 100, 64, 2, 5, 3, 4, [5, 1, 3]),                   # M = 4
     ("dual_random_walk", 1, 100, 64, 2, 6, 2, 1, None),                 # M = 3 with two supports
