@@ -10,6 +10,7 @@
 #include "../../include/eeg_dcrnn.h"
 #include "../../include/eeg_dcrnn_dev.h"
 #include "../../include/eeg_dcrnn_prof.h"
+#include "kernels_decoder.h"
 #include "kernels_diffuse.h"
 #include "kernels_feat.h"
 #include "kernels_gemm.h"
@@ -760,6 +761,35 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
     if (hipMemsetAsync(xin, 0, xstep * sizeof(float), st) != hipSuccess) return fail("decoder_fwd: memset failed");   // GO symbol
     for (int l = 0; l < L; ++l)
         if (copy_floats(saved + y.hext[l], h0 + (size_t)l * state, state, st)) return 1;
+    // ---- persistent path: ONE launch for all T steps, layers and the projection (kernels_decoder.h); where it does not
+    //      apply (hidden size, montage > 20 nodes, LDS) the per-step launches below run
+    {
+        const int q4 = Dout / 4;
+        int dx = q4 % 25 == 0 ? 25 : (q4 % 16 == 0 ? 16 : (q4 % 5 == 0 ? 5 : (q4 % 4 == 0 ? 4 : 0)));
+        if (g_tune[8] > 0 && q4 % g_tune[8] == 0) dx = g_tune[8];   // dev knob 8: weight-group size of the layer-0 x-part
+        const size_t lds = dec_fwd_lds_floats(M, L, Dout) * sizeof(float);
+        if (g_tune[11] == 0 && H == 64 && N <= kDecRows && L <= 4 && d->T <= 64 && dx != 0 && lds <= kMaxLdsBytes) {
+            DecFwdArgs a;
+            for (int l = 0; l < L; ++l) {
+                const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);
+                a.l[l] = DecLayerPtrs{packs[l] + p.bx, packs[l] + p.bias, packs[l] + p.bhg, packs[l] + p.bhc,
+                                      saved + y.hext[l], saved + y.rs[l], saved + y.us[l], saved + y.cs[l], saved + y.rhs[l],
+                                      saved + y.hpl[l], saved + y.rpl[l]};
+            }
+            for (int l = L; l < 4; ++l) a.l[l] = a.l[0];
+            a.P = P; a.targets = targets; a.ppack = ppack; a.pbias = pbias;
+            a.out = out; a.xin = xin; a.planes0 = saved + y.planes[0];
+            a.planes0_stride = (size_t)d->T * RB * Dout;
+            a.hplane_stride = (size_t)(d->T + 1) * state;
+            a.teacher_mask = 0;
+            for (int t = 0; t < d->T; ++t)
+                if (teacher != nullptr && teacher[t] != 0) a.teacher_mask |= 1ull << t;
+            a.p_batched = d->p_batched; a.T = d->T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
+            const int rc = launch_dec_fwd_persist(M, dx, a, lds, st);
+            if (rc == 0) return 0;
+            if (rc == 2) return fail("decoder_fwd: persistent kernel launch failed");
+        }
+    }
     float* XW = ws;
     for (int t = 0; t < d->T; ++t) {
         for (int l = 0; l < L; ++l) {

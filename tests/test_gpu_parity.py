@@ -343,7 +343,10 @@ def test_hip_graph_replay_equals_eager_steps():
     ("laplacian", 8, 16, 2, 5, 3, 0.5, "tanh"),            # teacher forcing on some steps
     ("dual_random_walk", 12, 32, 3, 4, 2, 0.6, "relu"),    # shared cell used by two layers + teacher forcing
     ("laplacian", 20, 16, 1, 3, 2, None, "tanh"),          # single layer, fully autoregressive
-    ("dual_random_walk", 100, 64, 2, 12, 6, None, "tanh"),
+    ("dual_random_walk", 100, 64, 2, 12, 6, None, "tanh"),  # cfg5's decoder: the persistent kernel (kernels_decoder.h)
+    ("dual_random_walk", 20, 64, 2, 3, 2, 0.5, "tanh"),     # persistent kernel with teacher forcing
+    ("laplacian", 16, 64, 3, 3, 2, None, "relu"),           # persistent kernel, 3 layers (shared cell), Dout % 16 == 0
+    ("laplacian", 8, 64, 2, 2, 2, None, "tanh"),            # 64 units but Dout/4 not a multiple of 4 or 5: per-step launches
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
