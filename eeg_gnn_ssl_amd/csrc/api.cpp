@@ -468,8 +468,9 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
     part = pp > part ? pp : part;
     y.partial = o; o += align64(part);
     y.projt_pack = o; o += align64((size_t)(d->Dout / 4) * nct_h * 64);
-    const size_t c1 = colsum_ws((int)R, d->Dout), c2 = colsum_ws(d->L * d->T * d->B, 3 * d->H);
-    y.colsum = o; o += align64(c1 > c2 ? c1 : c2);
+    // bias column sums: over the per-clip partial sums (per-step path) or over dXW itself (persistent path)
+    const size_t c1 = colsum_ws((int)R, d->Dout), c2 = colsum_ws(d->L * d->T * d->B, 3 * d->H), c3 = colsum_ws(d->L * (int)R, 3 * d->H);
+    y.colsum = o; o += align64(c1 > c2 ? (c1 > c3 ? c1 : c3) : (c2 > c3 ? c2 : c3));
     y.bwd_total = o;
     return y;
 }
@@ -844,7 +845,32 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
     float* dA = ws + y.da;
     float* Z = ws + y.z;
     auto feeds_back = [&](int t) { return t + 1 < T && !(teacher != nullptr && teacher[t] != 0); };   // out_t is step t+1's input
-    for (int t = T - 1; t >= 0; --t) {
+    // ---- persistent path: ONE launch walks the T steps backwards (kernels_decoder.h); it leaves dXW of every
+    //      (layer, step), dOtot and dh0 -- the hoisted parameter gradients below are common to both paths
+    bool persistent = false;
+    {
+        const int q4 = Dout / 4;
+        const int dt = q4 % 5 == 0 ? 5 : (q4 % 4 == 0 ? 4 : 0);
+        const size_t lds = dec_bwd_lds_floats(M, L, Dout) * sizeof(float);
+        if (g_tune[10] == 0 && H == 64 && N <= kDecRows && L <= 4 && T <= 64 && dt != 0 && lds <= kMaxLdsBytes) {
+            DecBwdArgs a;
+            for (int l = 0; l < L; ++l) {
+                const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);
+                a.l[l] = DecBwdLayerPtrs{packs[l] + p.b1, packs[l] + p.b2, packs[l] + p.bxt, saved + y.hext[l], saved + y.rs[l],
+                                         saved + y.us[l], saved + y.cs[l], ws + y.dxw[l]};
+            }
+            for (int l = L; l < 4; ++l) a.l[l] = a.l[0];
+            a.P = P; a.tpack = tpack; a.dOut = dOut; a.dOtot = dOtot; a.dh0 = dh0;
+            a.feeds_mask = 0;
+            for (int t = 0; t < T; ++t)
+                if (feeds_back(t)) a.feeds_mask |= 1ull << t;
+            a.p_batched = d->p_batched; a.T = T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
+            const int rc = launch_dec_bwd_persist(M, dt, a, lds, st);
+            if (rc == 2) return fail("decoder_bwd: persistent kernel launch failed");
+            persistent = rc == 0;
+        }
+    }
+    for (int t = persistent ? -1 : T - 1; t >= 0; --t) {
         // total gradient of out_t: the loss term, plus (autoregressive feedback) dx of layer 0 at step t+1, which
         // the adjoint diffusion of that step has already added into dOtot[t]
         const float* dO = feeds_back(t) ? dOtot + (size_t)t * xstep : dOut + (size_t)t * xstep;
@@ -891,8 +917,13 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
                               ws + y.dxw[l], P, saved + y.hpl[l], saved + y.rpl[l], hstride, nullptr, nullptr,
                               ws + y.partial, y.lw[l], !first_use, dWg[l], dWc[l], st)) return 1;
     }
-    if (colsum(ws + y.dbias[0], T * B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
-    if (L > 1 && colsum(ws + y.dbias[1], (L - 1) * T * B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
+    if (persistent) {   // bias gradients = column sums of dXW (layers >= 1 share a cell; their dXW regions are contiguous)
+        if (colsum(ws + y.dxw[0], (int)Rall, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
+        if (L > 1 && colsum(ws + y.dxw[1], (L - 1) * (int)Rall, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
+    } else {
+        if (colsum(ws + y.dbias[0], T * B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
+        if (L > 1 && colsum(ws + y.dbias[1], (L - 1) * T * B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
+    }
     // projection: dW_p (Dout x H) = sum_rows dOtot^T h_top ;  db_p = column sums of dOtot
     SegPtrs so;
     for (int m = 0; m < kMaxM; ++m) so.p[m] = m == 0 ? dOtot : nullptr;

@@ -349,3 +349,260 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
 }
 
 }  // namespace eeg
+
+namespace eeg {
+
+// ---- persistent decoder backward ---------------------------------------------------------------------------------
+// The BPTT mirror of dec_fwd_persist_kernel: ONE launch walks the T_out steps backwards for the clips it owns -- per
+// step the projection transpose, every layer's cell backward (the step of seq_bwd_kernel: blend backward, P^T dC,
+// GEMM1, dR, P^T [dR|dU], GEMM2), the input gradient of the layer (dXW x W^x^T, then the adjoint node mix) which feeds
+// the layer below or, through the autoregressive feedback, the previous step's output gradient -- with every weight
+// streamed from L2 (packs b1, b2, bxt of kernels_pack.h and the transposed projection pack).  On chip per clip: the
+// dC / [dR|dU] tiles with their adjoint hop rows (the dead hop slots of the [dR|dU] tile hold Z = dXW W^x^T between
+// GEMM2 and the adjoint mix), the output-gradient tile, the recurrent gradients dh^l (lane-linear LDS slots).  It emits
+// dXW of every (layer, step) -- the hoisted parameter-gradient GEMMs, the bias column sums and the projection gradients
+// stay as they are -- the total output gradients dOtot and dh0.  At most 20 nodes, 64 units.
+struct DecBwdLayerPtrs {
+    const float *b1, *b2, *bxt;                      // weight packs
+    const float *hext, *rs, *us, *cs;                // saved by the forward
+    float* dxw;                                      // (T,B,N,3H) out
+};
+struct DecBwdArgs {
+    DecBwdLayerPtrs l[4];
+    const float* P;
+    const float* tpack;           // projection, transposed role: K = Dout, H/16 column tiles
+    const float* dOut;            // (T,B,N,Dout) loss gradient
+    float* dOtot;                 // (T,B,N,Dout) total gradient of out_t (loss + feedback)
+    float* dh0;                   // (L,B,N,H)
+    unsigned long long feeds_mask;     // bit t: out_t is the input of step t+1 (no teacher forcing there, t+1 < T)
+    int p_batched, T, B, N, Dout, L, act;
+};
+
+// Z (M*Fin columns, Fin = Dout for layer 0, H above) lives in the hop slots of the [dR|dU] tile when they are wide enough
+// (M = 5, Dout = 100: 512 of 512 columns), else in a tile of its own.
+__host__ __device__ constexpr int dec_bwd_z_cols(int M, int L, int Dout) {
+    const int H = 64, z0 = round_up(M * Dout, 16), z1 = L > 1 ? M * H : 0;
+    return z0 > z1 ? z0 : z1;
+}
+__host__ __device__ constexpr bool dec_bwd_z_aliased(int M, int L, int Dout) { return dec_bwd_z_cols(M, L, Dout) <= (M - 1) * 2 * 64; }
+__host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) {
+    const int H = 64, FP = round_up(Dout, 16);
+    return (size_t)(M - 1) * kPFloats + (size_t)kDecRows * (M * H + M * 2 * H) + 2 * (size_t)kDecRows * FP + (size_t)kDecRows * (H + 4)
+           + (size_t)L * 4 * 2 * 256 + 4 * 4 * kRemTile
+           + (dec_bwd_z_aliased(M, L, Dout) ? 0 : (size_t)kDecRows * lds_stride_x(dec_bwd_z_cols(M, L, Dout)));
+}
+
+template <int H, int M, int DT>
+__global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
+    static_assert(H == 64, "one column tile per wave");
+    constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, KGP = M * 2 * H, NCT = H / 16, NQ = M * H / 16, DAS = H + 4;
+    EEG_DYN_SMEM(sm);
+    const int T = a.T, B = a.B, N = a.N, Dout = a.Dout, L = a.L, act = a.act;
+    const int FP = round_up(Dout, 16);
+    float* Pl = sm;
+    float* EC = Pl + (M - 1) * kPFloats;     // [ROWS][KAP]  slot 0 = dC, slots m = P_m^T dC
+    float* EG = EC + ROWS * KAP;             // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]; cols 2H.. double as Z
+    float* DO = EG + ROWS * KGP;             // [ROWS][FP]   total gradient of out_t
+    float* DX = DO + ROWS * FP;              // [ROWS][FP]   input gradient of layer 0 at step t (feeds dO_{t-1})
+    float* DA = DX + ROWS * FP;              // [ROWS][DAS]  input gradient of layer l > 0 = gradient of h^{l-1}_t
+    float* DH = DA + ROWS * DAS;             // [L][4 waves][2][64 lanes] float4: recurrent gradients dh^l, lane-linear
+    float* RS0 = DH + L * 4 * 2 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
+    float* RS = RS0 + wave * (4 * kRemTile);
+    const bool z_alias = dec_bwd_z_aliased(M, L, Dout);
+    float* ZT = z_alias ? EG : RS0 + 4 * 4 * kRemTile;           // Z = dXW W^x^T, swizzled like the state tiles
+    const int ZS = z_alias ? KGP : lds_stride_x(dec_bwd_z_cols(M, L, Dout)), zc0 = z_alias ? 2 * H : 0;
+    const int ct = wave, col = ct * 16 + 4 * lg;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const size_t state = (size_t)B * N * H;
+    const int nct_h = H / 16;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < (int)(ROWS * (KAP + KGP) + 2 * ROWS * FP + ROWS * DAS + L * 4 * 2 * 256); e += 256) EC[e] = 0.f;
+        if (!z_alias)
+            for (int e = tid; e < ROWS * ZS; e += 256) ZT[e] = 0.f;
+        lds_load_polys(Pl, a.P, a.p_batched ? b : 0, M, N);
+        __syncthreads();
+        float pf[poly_slots<M, NKS>()][NKS];
+        load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
+        const int node[2] = {lr, 16 + lr};
+        const int rowt[2] = {lr, 16 + (lr & 3)};                       // tile rows (second node tile: 4 rows)
+        const bool valid[2] = {lr < N, 16 + lr < N};
+        const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
+        const int oh[2] = {nodec[0] * H + col, nodec[1] * H + col};
+        const int oxw[2] = {node[0] * (3 * H) + col, node[1] * (3 * H) + col};
+        float* dhl = DH + (wave * 2) * 256 + 4 * lane;                 // + l * 2048 + nt * 256
+        const size_t boff = (size_t)b * N * H;
+        // operands of one (layer, step) pair; the next pair's are requested while the current one is processed
+        f32x4 nh[2], nr[2], nu[2], nc[2];
+        auto fetch = [&](int l, int t) {
+            const DecBwdLayerPtrs& lp = a.l[l];
+            const size_t so = (size_t)t * state + boff;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                nh[nt] = ld4(lp.hext + so + oh[nt]);                   // hext slot t = h_{t-1}
+                nr[nt] = ld4(lp.rs + so + oh[nt]);
+                nu[nt] = ld4(lp.us + so + oh[nt]);
+                nc[nt] = ld4(lp.cs + so + oh[nt]);
+            }
+        };
+        fetch(L - 1, T - 1);
+        for (int t = T - 1; t >= 0; --t) {
+            const size_t s = (size_t)t * B + b;
+            const bool fb = ((a.feeds_mask >> t) & 1ull) != 0;       // out_t feeds step t+1: its gradient gets DX of that step
+            // ---- S0: total gradient of out_t -> DO tile and dOtot
+            for (int e = tid; e < N * (Dout / 4); e += 256) {
+                const int n = e / (Dout / 4), c4 = e % (Dout / 4);
+                f32x4 g = ld4(a.dOut + (s * N + n) * Dout + 4 * c4);
+                if (fb) g += ld4(DX + n * FP + 4 * c4);
+                st4(DO + n * FP + 4 * c4, g);
+                st4(a.dOtot + (s * N + n) * Dout + 4 * c4, g);
+            }
+            __syncthreads();
+            // ---- gradient of h^{L-1}_t through the projection (model.py:188-190): dA = dO W_p
+            f32x4 gext[2];
+            {
+                f32x4 pa[1][2] = {{zero4, zero4}};
+                const int wt1[1] = {ct};
+                gemm_stream_plain<1, DT, false>(DO, FP, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS);
+                gext[0] = pa[0][0];
+                gext[1] = pa[0][1];
+            }
+            for (int l = L - 1; l >= 0; --l) {
+                const DecBwdLayerPtrs& lp = a.l[l];
+                const int Fin = l == 0 ? Dout : H;
+                float* dxw = lp.dxw + s * N * (3 * H);
+                f32x4 hp[2], rr[2], uu[2], cc[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) { hp[nt] = nh[nt]; rr[nt] = nr[nt]; uu[nt] = nu[nt]; cc[nt] = nc[nt]; }
+                if (l > 0) fetch(l - 1, t); else if (t > 0) fetch(L - 1, t - 1);
+                // ---- E1: blend backward (cell.py:182-210 reversed)
+                f32x4 dU[2], dhn[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 h = hp[nt], u = uu[nt], c = cc[nt];
+                    const f32x4 g = valid[nt] ? ld4(dhl + l * 2048 + nt * 256) + gext[nt] : zero4;
+                    f32x4 dC, du_;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dc = g[r] * (1.f - u[r]);
+                        dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
+                        du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
+                    }
+                    if (nt == 0 || lr < 4) st4(EC + lds_sw(rowt[nt], col, KAP), dC);      // zeros on padding nodes
+                    if (valid[nt]) {
+                        st4(dxw + oxw[nt] + 2 * H, dC);
+                        st4(dxw + oxw[nt] + H, du_);
+                    }
+                    dU[nt] = du_;
+                    dhn[nt] = g * u;
+                }
+                EEG_WAVE_SYNC();
+                lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
+                __syncthreads();                                         // (1) P_m^T dC complete
+                // ---- GEMM1: d(r*h) = [P_m^T dC]_m @ Wc^h^T
+                f32x4 acc1[1][2] = {{zero4, zero4}};
+                {
+                    const int wt1[1] = {ct};
+                    gemm_stream_quad<1, NQ, (NQ < 10 ? NQ : 10)>(EC, KAP, lp.b1, NCT, wt1, lane, lr, lg, acc1, RS);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 drh = acc1[0][nt], rg = rr[nt];          // exact 0 on padding nodes
+                    const f32x4 dR = drh * hp[nt] * rg * (1.f - rg);
+                    dhn[nt] += drh * rg;
+                    if (nt == 0 || lr < 4) {
+                        st4(EG + lds_sw(rowt[nt], col, KGP), dR);
+                        st4(EG + lds_sw(rowt[nt], H + col, KGP), dU[nt]);
+                    }
+                    if (valid[nt]) st4(dxw + oxw[nt], dR);
+                }
+                EEG_WAVE_SYNC();
+                lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
+                lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
+                __syncthreads();                                         // (2) P_m^T [dR|dU] complete
+                // ---- GEMM2: dh = dhn + [P_m^T dG]_m @ Wg^h^T  -> recurrent gradient of this layer for step t-1
+                {
+                    f32x4 acc2[1][2] = {{dhn[0], dhn[1]}};
+                    const int wt1[1] = {ct};
+                    gemm_stream_quad<1, 2 * NQ, (2 * NQ < 10 ? 2 * NQ : 10)>(EG, KGP, lp.b2, NCT, wt1, lane, lr, lg, acc2, RS);
+                    st4(dhl + l * 2048 + 0 * 256, acc2[0][0]);
+                    st4(dhl + l * 2048 + 1 * 256, acc2[0][1]);
+                }
+                const bool need_dx = l > 0 || (t > 0 && ((a.feeds_mask >> (t - 1)) & 1ull) != 0);
+                if (!need_dx) {
+                    __syncthreads();                                     // tiles free for the next pair
+                    continue;
+                }
+                __syncthreads();                                         // (3) every wave is done with the hop slots of EG
+                // ---- Z = dXW_t @ W^x^T (K = 3H: [dR|dU] from EG slot 0, dC from EC slot 0) -> EG columns 2H.. (M*Fin wide)
+                {
+                    const int nct_x = round_up(M * Fin, 16) / 16;
+                    for (int j0 = wave; j0 < nct_x; j0 += 16) {          // this wave's tiles j0, j0+4, j0+8, j0+12
+                        f32x4 z[4][2];
+                        int wt4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            wt4[i] = j0 + 4 * i < nct_x ? j0 + 4 * i : j0;
+                            z[i][0] = zero4;
+                            z[i][1] = zero4;
+                        }
+                        gemm_stream_plain<4, 8, true>(EG, KGP, 2 * H, 2 * H / 4, 1, lp.bxt, nct_x, wt4, lane, lr, lg, z, RS);
+                        gemm_stream_plain<4, 8, true>(EC, KAP, H, H / 4, 1, lp.bxt + (size_t)(2 * H / 4) * nct_x * 64, nct_x, wt4, lane, lr, lg, z, RS);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (j0 + 4 * i >= nct_x) continue;
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+                                if (nt == 0 || lr < 4) st4(ZT + lds_sw(rowt[nt], zc0 + wt4[i] * 16 + 4 * lg, ZS), z[i][nt]);
+                        }
+                    }
+                }
+                __syncthreads();                                         // (4) Z complete
+                // ---- adjoint node mix: dX[n][f] = Z_0[n][f] + sum_{m>=1} sum_q P_m[q][n] Z_m[q][f]
+                {
+                    const int nctf = round_up(Fin, 16) / 16, nks = ceil_div(N, 4);
+                    float* dst = l == 0 ? DX : DA;
+                    const int dss = l == 0 ? FP : DAS;
+                    for (int tix = wave; tix < 2 * nctf; tix += 4) {
+                        const int cti = tix % nctf, rt = tix / nctf;
+                        f32x4 acc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = rt * 16 + 4 * lg + r;
+                            acc[r] = n < ROWS ? ZT[lds_sw(n, zc0 + cti * 16 + lr, ZS)] : 0.f;
+                        }
+                        for (int m1 = 0; m1 < M - 1; ++m1) {
+                            const float* Pm = Pl + m1 * kPFloats;
+                            for (int ks = 0; ks < nks; ++ks) {
+                                const int kk = 4 * ks + lg;
+                                acc = mfma16(Pm[kk * kPStride + rt * 16 + lr], ZT[lds_sw(kk, zc0 + (m1 + 1) * Fin + cti * 16 + lr, ZS)], acc);
+                            }
+                        }
+                        const int c = cti * 16 + lr;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = rt * 16 + 4 * lg + r;
+                            if (n < ROWS && c < Fin) dst[n * dss + c] = n < N ? acc[r] : 0.f;
+                        }
+                    }
+                }
+                __syncthreads();                                         // (5) DA / DX complete; tiles free for the next pair
+                if (l > 0) {
+                    gext[0] = ld4(DA + rowt[0] * DAS + col);
+                    gext[1] = ld4(DA + rowt[1] * DAS + col);
+                }
+            }
+        }
+        // ---- gradients of the initial states (the encoder's final states)
+        if (a.dh0 != nullptr) {
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    if (valid[nt]) st4(a.dh0 + (size_t)l * state + boff + node[nt] * H + col, ld4(dhl + l * 2048 + nt * 256));
+        }
+    }
+}
+
+}  // namespace eeg

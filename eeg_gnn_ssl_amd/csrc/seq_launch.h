@@ -38,7 +38,9 @@ int launch_seq_bwd_h32(int M, const SeqBwdArgs& a, hipStream_t st);
 int launch_seq_bwd_h64(int M, const SeqBwdArgs& a, hipStream_t st);
 bool seq_m_supported(int M);
 struct DecFwdArgs;
+struct DecBwdArgs;
 int launch_dec_fwd_persist(int M, int dx, const DecFwdArgs& a, size_t lds, hipStream_t st);
+int launch_dec_bwd_persist(int M, int dt, const DecBwdArgs& a, size_t lds, hipStream_t st);
 
 #if defined(EEG_SIMT_EMU)
 #define EEG_SET_MAX_LDS(kern, bytes) ((void)0)

@@ -79,6 +79,7 @@ def test_training_tail_kernels():
     ("laplacian", 8, 64, 2, 2, 2, None, "tanh"),           # 64 units, M = 3: single-step launches of the two-wave kernel
     ("dual_random_walk", 20, 64, 2, 3, 2, 0.5, "tanh"),    # 64 units, Dout % 20 == 0: the persistent decoder kernel (M = 5), teacher forcing
     ("laplacian", 16, 64, 3, 3, 2, None, "relu"),          # persistent kernel, 3 layers (shared cell), Dout % 16 == 0
+    ("laplacian", 100, 64, 2, 3, 2, 0.5, "tanh"),          # persistent backward with a Z tile of its own (M = 3, Dout = 100)
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle("cpu", filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)

@@ -346,6 +346,7 @@ def test_hip_graph_replay_equals_eager_steps():
     ("dual_random_walk", 100, 64, 2, 12, 6, None, "tanh"),  # cfg5's decoder: the persistent kernel (kernels_decoder.h)
     ("dual_random_walk", 20, 64, 2, 3, 2, 0.5, "tanh"),     # persistent kernel with teacher forcing
     ("laplacian", 16, 64, 3, 3, 2, None, "relu"),           # persistent kernel, 3 layers (shared cell), Dout % 16 == 0
+    ("laplacian", 100, 64, 2, 3, 2, 0.5, "tanh"),           # persistent backward with a Z tile of its own (M = 3, Dout = 100)
     ("laplacian", 8, 64, 2, 2, 2, None, "tanh"),            # 64 units but Dout/4 not a multiple of 4 or 5: per-step launches
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):

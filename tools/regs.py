@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """dev aid: register / LDS / spill counts of the gfx950 kernels of one translation unit.
-usage: python tools/regs.py [api|seq64|seq32|seq16] [name filter ...]"""
+usage: python tools/regs.py [api|dec|decb|seq64|seq32|seq16] [name filter ...]"""
 import os
 import re
 import subprocess
@@ -10,7 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc")
 unit = sys.argv[1] if len(sys.argv) > 1 else "api"
 filt = sys.argv[2:]
-src, extra = ("api.cpp", []) if unit == "api" else ("seq_inst.cpp", ["-fno-slp-vectorize", f"-DEEG_SEQ_H={unit[3:]}"])
+if unit == "api":
+    src, extra = "api.cpp", []
+elif unit in ("dec", "decb"):
+    src, extra = unit + "_inst.cpp", ["-fno-slp-vectorize"]
+else:
+    src, extra = "seq_inst.cpp", ["-fno-slp-vectorize", f"-DEEG_SEQ_H={unit[3:]}"]
 out = f"/tmp/regs_{unit}.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-w",
                        *extra, os.path.join(CSRC, src), "-o", out])
