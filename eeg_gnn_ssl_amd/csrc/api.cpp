@@ -852,11 +852,11 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
         const int q4 = Dout / 4;
         const int dt = q4 % 5 == 0 ? 5 : (q4 % 4 == 0 ? 4 : 0);
         const size_t lds = dec_bwd_lds_floats(M, L, Dout) * sizeof(float);
-        if (g_tune[10] == 0 && H == 64 && N <= kDecRows && L <= 4 && T <= 64 && dt != 0 && lds <= kMaxLdsBytes) {
+        if (g_tune[10] == 0 && H == 64 && N <= kDecRows && L <= 4 && T <= 64 && Dout <= 128 && dt != 0 && lds <= kMaxLdsBytes) {
             DecBwdArgs a;
             for (int l = 0; l < L; ++l) {
                 const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);
-                a.l[l] = DecBwdLayerPtrs{packs[l] + p.b1, packs[l] + p.b2, packs[l] + p.bxt, saved + y.hext[l], saved + y.rs[l],
+                a.l[l] = DecBwdLayerPtrs{packs[l] + p.c1, packs[l] + p.c2, saved + y.hext[l], saved + y.rs[l],
                                          saved + y.us[l], saved + y.cs[l], ws + y.dxw[l]};
             }
             for (int l = L; l < 4; ++l) a.l[l] = a.l[0];

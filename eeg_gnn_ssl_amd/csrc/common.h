@@ -71,6 +71,26 @@ __device__ __forceinline__ void lds_dma16(float* lds_wave_base, const float* g) 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
+// Streamed weight packs (kernels_decoder.h) are read through a buffer descriptor: the address of a load is
+// descriptor base (SGPRs) + a per-lane 32-bit offset (ONE VGPR for all loads of a tile) + a wave-uniform offset
+// (SGPR / literal).  With flat loads every k-step row further than 4 KB from the previous one needs its own 64-bit VGPR
+// address, which the compiler hoists out of the time loop -- hundreds of registers.  Offsets in floats.
+#if defined(EEG_SIMT_EMU)
+struct wbuf_t { const float* p; };
+__device__ __forceinline__ wbuf_t make_wbuf(const float* p) { return wbuf_t{p}; }
+__device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) { return b.p[(size_t)voff + soff]; }
+#else
+typedef __amdgpu_buffer_rsrc_t wbuf_t;
+__device__ __forceinline__ wbuf_t make_wbuf(const float* p) {              // p must be wave-uniform
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4u * voff, 4u * soff, 0));
+}
+#endif
+
 namespace eeg {
 
 constexpr int kWave = 64;
@@ -113,6 +133,10 @@ __host__ __device__ constexpr int lds_sw(int row, int col, int stride) {
 // per-tile stride of the 4x4x1 remainder hand-over scratch: [4 lane groups][4 nodes][16 cols] with the lane groups
 // 80 floats apart (80 = 16 mod 32: the two lane groups of a half-wave write different bank halves)
 constexpr int kRemTile = 4 * 80;
+
+// columns of the packs c1 / c2 (kernels_pack.h): hidden units, then input features padded so that the decoder's
+// layers (Fin <= 128, 64 units) all have the SAME column-tile count, a literal in kernels_decoder.h
+__host__ __device__ constexpr int cell_pack_cx_cols(int Fin, int H) { return H + (Fin <= 128 ? 128 : round_up(Fin, 64)); }
 
 // Quad-permuted K order of the recurrent-kernel weight packs: MFMA number `ks` consumes, on lane
 // group g = lane>>4, the logical k index 16*(ks/4) + 4*g + (ks%4), so that one ds_read_b128 of

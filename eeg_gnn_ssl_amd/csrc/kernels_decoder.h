@@ -18,6 +18,8 @@
 //     backward operator is unchanged.
 // Wave w of 4 owns column tile w of r, u, c and h (64 units).  At most 20 nodes (second node tile on v_mfma_f32_4x4x1).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "kernels_seq.h"
 #include "lds_diffuse.h"
@@ -47,10 +49,24 @@ struct DecFwdArgs {
 // which the first 4*KPP are real; SWZ: the tile is an XOR-swizzled state tile (lds_sw), else a plain [rows][stride] one.
 // The weights of group g+1 (D k-steps x NT tiles, one coalesced dword per lane each) are requested before the MFMAs
 // of group g.  KPP % D == 0.
-template <int NT, int D, bool SWZ>
+// The first weight group can be requested by the caller long before the call (plain_wload into `wa`, then PRE = true):
+// between two GEMMs of a step there is elementwise work, a node mix and a barrier for the L2 latency to hide behind.
+// The last hop slot may come from a second tile (tile_last != nullptr: columns 0.. of that tile).
+template <int NT, int D>
+__device__ __forceinline__ void plain_wload(const float* __restrict__ wp, int nct_total, const int (&wt)[NT], int lane, int g,
+                                            float (&w)[D][NT]) {
+    const wbuf_t wb = make_wbuf(wp);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) w[d][i] = wbuf_ld(wb, wt[i] * 64 + lane, (g * D + d) * nct_total * 64);
+}
+template <int NT, int D, bool SWZ, bool PRE = false, bool XP = true>
 __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile, int stride, int slotw, int kpp, int nslots,
                                                   const float* __restrict__ wp, int nct_total, const int (&wt)[NT],
-                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2], float* scratch) {
+                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2], float* scratch,
+                                                  float (&wa)[D][NT], const float* __restrict__ tile_last = nullptr,
+                                                  int stride_last = 0) {
     const int ngroups = nslots * kpp / D;
     const int row1 = 16 + (lane & 3);
     f32x4 rem[NT][4];
@@ -58,20 +74,19 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wl = wp + lane;
-    auto wload = [&](int g, float (&w)[D][NT]) {
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int i = 0; i < NT; ++i) w[d][i] = wl[((size_t)(g * D + d) * nct_total + wt[i]) * 64];
-    };
-    auto xload = [&](int slot, int f0, float (&x0)[D], float (&x1)[D]) {
+    int slot = 0, f0 = 0;
+    auto xload = [&](float (&x0)[D], float (&x1)[D]) {            // fragments of the next group; advances (slot, f0)
+        const bool last = tile_last != nullptr && slot == nslots - 1;
+        const float* tp = last ? tile_last : tile;
+        const int st = last ? stride_last : stride, cb = last ? 0 : slot * slotw;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int col = slot * slotw + 4 * (f0 + d) + lg;
-            x0[d] = tile[SWZ ? lds_sw(lr, col, stride) : lr * stride + col];
-            x1[d] = tile[SWZ ? lds_sw(row1, col, stride) : row1 * stride + col];
+            const int col = cb + 4 * (f0 + d) + lg;
+            x0[d] = tp[SWZ ? lds_sw(lr, col, st) : lr * st + col];
+            x1[d] = tp[SWZ ? lds_sw(row1, col, st) : row1 * st + col];
         }
+        f0 += D;
+        if (f0 == kpp) { f0 = 0; ++slot; }
     };
     auto mac = [&](const float (&w)[D][NT], const float (&x0)[D], const float (&x1)[D]) {
 #pragma unroll
@@ -82,23 +97,39 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
                 rem[i][d & 3] = mfma4(x1[d], w[d][i], rem[i][d & 3]);
             }
     };
-    float wa[D][NT], wb[D][NT], x0[D], x1[D];
-    int slot = 0, f0 = 0;
-    wload(0, wa);
-    for (int g = 0; g < ngroups; g += 2) {
-        if (g + 1 < ngroups) wload(g + 1, wb);
-        xload(slot, f0, x0, x1);
-        EEG_SCHED_FENCE();
-        mac(wa, x0, x1);
-        f0 += D;
-        if (f0 == kpp) { f0 = 0; ++slot; }
-        if (g + 1 < ngroups) {
-            if (g + 2 < ngroups) wload(g + 2, wa);
-            xload(slot, f0, x0, x1);
+    float wb[D][NT], xa0[D], xa1[D];
+    if (!PRE) plain_wload<NT, D>(wp, nct_total, wt, lane, 0, wa);
+    if constexpr (XP) {                                            // operand fragments one group ahead of their MFMAs
+        float xb0[D], xb1[D];
+        xload(xa0, xa1);
+        for (int g = 0; g < ngroups; g += 2) {
+            if (g + 1 < ngroups) {
+                plain_wload<NT, D>(wp, nct_total, wt, lane, g + 1, wb);
+                xload(xb0, xb1);
+            }
             EEG_SCHED_FENCE();
-            mac(wb, x0, x1);
-            f0 += D;
-            if (f0 == kpp) { f0 = 0; ++slot; }
+            mac(wa, xa0, xa1);
+            if (g + 1 < ngroups) {
+                if (g + 2 < ngroups) {
+                    plain_wload<NT, D>(wp, nct_total, wt, lane, g + 2, wa);
+                    xload(xa0, xa1);
+                }
+                EEG_SCHED_FENCE();
+                mac(wb, xb0, xb1);
+            }
+        }
+    } else {
+        for (int g = 0; g < ngroups; g += 2) {
+            if (g + 1 < ngroups) plain_wload<NT, D>(wp, nct_total, wt, lane, g + 1, wb);
+            xload(xa0, xa1);
+            EEG_SCHED_FENCE();
+            mac(wa, xa0, xa1);
+            if (g + 1 < ngroups) {
+                if (g + 2 < ngroups) plain_wload<NT, D>(wp, nct_total, wt, lane, g + 2, wa);
+                xload(xa0, xa1);
+                EEG_SCHED_FENCE();
+                mac(wb, xa0, xa1);
+            }
         }
     }
     // remainder hand-over (see mfma_nodes32)
@@ -116,38 +147,60 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
     }
     EEG_WAVE_SYNC();
 }
+template <int NT, int D, bool SWZ>
+__device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile, int stride, int slotw, int kpp, int nslots,
+                                                  const float* __restrict__ wp, int nct_total, const int (&wt)[NT],
+                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2], float* scratch) {
+    float wa[D][NT];
+    gemm_stream_plain<NT, D, SWZ, false, false>(tile, stride, slotw, kpp, nslots, wp, nct_total, wt, lane, lr, lg, acc, scratch, wa);
+}
 
 // Same for the recurrent packs (quad-permuted K order, ds_read_b128 fragments of a swizzled state tile): NQ quads
-// (compile time), weights requested PD quads ahead.
-template <int NT, int NQ, int PD>
+// (compile time), weights requested PD quads ahead; the operand fragments one quad ahead.  PRE: the caller has already
+// requested the first PD quads (quad_prefetch into `w`).
+template <int NT, int NQ, int PD, int NTW = NT>
+__device__ __forceinline__ void quad_prefetch(const float* __restrict__ wp, int nct_total, const int (&wt)[NT], int lane,
+                                              float (&w)[PD + 1][4][NTW]) {
+    const wbuf_t wb = make_wbuf(wp);
+#pragma unroll
+    for (int q = 0; q < PD && q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) w[q % (PD + 1)][j][i] = wbuf_ld(wb, wt[i] * 64 + lane, (4 * q + j) * nct_total * 64);
+}
+template <int NT, int NQ, int PD, bool PRE = false, int NTW = NT>
 __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile, int stride, const float* __restrict__ wp,
                                                  int nct_total, const int (&wt)[NT], int lane, int lr, int lg,
-                                                 f32x4 (&acc)[NT][2], float* scratch) {
+                                                 f32x4 (&acc)[NT][2], float* scratch, float (&w)[PD + 1][4][NTW]) {
     const int s0 = lg ^ sigma4(lr), s1 = lg ^ sigma4(lane & 3);
     const float* p0 = tile + lr * stride;
     const float* p1 = tile + (16 + (lane & 3)) * stride;
     auto frag = [&](const float* rowp, int sx, int q) {
         return *reinterpret_cast<const float4*>(rowp + 64 * (q >> 2) + 4 * ((4 * (q & 3)) ^ sx));
     };
-    const float* wl = wp + lane;
-    float w[PD + 1][4][NT];
-    auto wload = [&](int q, float (&dst)[4][NT]) {
+    const wbuf_t wb = make_wbuf(wp);
+    auto wload = [&](int q, float (&dst)[4][NTW]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < NT; ++i) dst[j][i] = wl[((size_t)(4 * q + j) * nct_total + wt[i]) * 64];
+            for (int i = 0; i < NT; ++i) dst[j][i] = wbuf_ld(wb, wt[i] * 64 + lane, (4 * q + j) * nct_total * 64);
     };
     f32x4 rem[NT][4];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < PD && q < NQ; ++q) wload(q, w[q % (PD + 1)]);
+    if (!PRE) quad_prefetch<NT, NQ, PD, NTW>(wp, nct_total, wt, lane, w);
+    float4 a0 = frag(p0, s0, 0), a1 = frag(p1, s1, 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (q + PD < NQ) wload(q + PD, w[(q + PD) % (PD + 1)]);
-        const float4 a0 = frag(p0, s0, q), a1 = frag(p1, s1, q);
+        float4 n0 = a0, n1 = a1;
+        if (q + 1 < NQ) {
+            n0 = frag(p0, s0, q + 1);
+            n1 = frag(p1, s1, q + 1);
+        }
         const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
         EEG_SCHED_FENCE();
 #pragma unroll
@@ -157,6 +210,8 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
                 acc[i][0] = mfma16(w[q % (PD + 1)][j][i], x0[j], acc[i][0]);
                 rem[i][j] = mfma4(x1[j], w[q % (PD + 1)][j][i], rem[i][j]);
             }
+        a0 = n0;
+        a1 = n1;
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -171,6 +226,13 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
         if (lr < 4) acc[i][1] += s;
     }
     EEG_WAVE_SYNC();
+}
+template <int NT, int NQ, int PD>
+__device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile, int stride, const float* __restrict__ wp,
+                                                 int nct_total, const int (&wt)[NT], int lane, int lr, int lg,
+                                                 f32x4 (&acc)[NT][2], float* scratch) {
+    float w[PD + 1][4][NT];
+    gemm_stream_quad<NT, NQ, PD, false>(tile, stride, wp, nct_total, wt, lane, lr, lg, acc, scratch, w);
 }
 
 constexpr int kDecRows = 20;     // node rows of the LDS tiles (montages of at most 20 nodes)
@@ -354,16 +416,19 @@ namespace eeg {
 
 // ---- persistent decoder backward ---------------------------------------------------------------------------------
 // The BPTT mirror of dec_fwd_persist_kernel: ONE launch walks the T_out steps backwards for the clips it owns -- per
-// step the projection transpose, every layer's cell backward (the step of seq_bwd_kernel: blend backward, P^T dC,
-// GEMM1, dR, P^T [dR|dU], GEMM2), the input gradient of the layer (dXW x W^x^T, then the adjoint node mix) which feeds
-// the layer below or, through the autoregressive feedback, the previous step's output gradient -- with every weight
-// streamed from L2 (packs b1, b2, bxt of kernels_pack.h and the transposed projection pack).  On chip per clip: the
-// dC / [dR|dU] tiles with their adjoint hop rows (the dead hop slots of the [dR|dU] tile hold Z = dXW W^x^T between
-// GEMM2 and the adjoint mix), the output-gradient tile, the recurrent gradients dh^l (lane-linear LDS slots).  It emits
-// dXW of every (layer, step) -- the hoisted parameter-gradient GEMMs, the bias column sums and the projection gradients
-// stay as they are -- the total output gradients dOtot and dh0.  At most 20 nodes, 64 units.
+// step the projection transpose and every layer's cell backward (the step of seq_bwd_kernel: blend backward, P^T dC,
+// GEMM1, dR, P^T [dR|dU], GEMM2) -- with every weight streamed from L2.  The input gradient of a layer needs no GEMM
+// of its own and no adjoint node mix: dX = sum_m P_m^T (dXW W^x_m^T) = sum_m (P_m^T dXW) W^x_m^T, and the adjoint hop
+// rows P_m^T dC / P_m^T [dR|dU] are exactly what GEMM1 / GEMM2 consume -- so the packs c1 / c2 (kernels_pack.h) carry
+// the input-feature columns next to the hidden ones and the two GEMMs accumulate dX as extra column tiles from the same
+// operand fragments.  For a layer above the first, dX (64 columns, tile w on wave w) IS the next cell's external
+// gradient, in registers; for the first layer it goes to an LDS tile and, through the autoregressive feedback, into the
+// previous step's output gradient.  On chip per clip: the dC / [dR|dU] tiles with their adjoint hop rows, the
+// output-gradient tiles, the recurrent gradients dh^l (lane-linear LDS slots).  It emits dXW of every (layer, step) --
+// the hoisted parameter-gradient GEMMs, the bias column sums and the projection gradients stay as they are -- the total
+// output gradients dOtot and dh0.  At most 20 nodes, 64 units, Dout <= 128 (packs of 8 or 12 column tiles).
 struct DecBwdLayerPtrs {
-    const float *b1, *b2, *bxt;                      // weight packs
+    const float *c1, *c2;                            // weight packs [hidden | input] (kernels_pack.h)
     const float *hext, *rs, *us, *cs;                // saved by the forward
     float* dxw;                                      // (T,B,N,3H) out
 };
@@ -378,50 +443,42 @@ struct DecBwdArgs {
     int p_batched, T, B, N, Dout, L, act;
 };
 
-// Z (M*Fin columns, Fin = Dout for layer 0, H above) lives in the hop slots of the [dR|dU] tile when they are wide enough
-// (M = 5, Dout = 100: 512 of 512 columns), else in a tile of its own.
-__host__ __device__ constexpr int dec_bwd_z_cols(int M, int L, int Dout) {
-    const int H = 64, z0 = round_up(M * Dout, 16), z1 = L > 1 ? M * H : 0;
-    return z0 > z1 ? z0 : z1;
-}
-__host__ __device__ constexpr bool dec_bwd_z_aliased(int M, int L, int Dout) { return dec_bwd_z_cols(M, L, Dout) <= (M - 1) * 2 * 64; }
 __host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) {
     const int H = 64, FP = round_up(Dout, 16);
-    return (size_t)(M - 1) * kPFloats + (size_t)kDecRows * (M * H + M * 2 * H) + 2 * (size_t)kDecRows * FP + (size_t)kDecRows * (H + 4)
-           + (size_t)L * 4 * 2 * 256 + 4 * 4 * kRemTile
-           + (dec_bwd_z_aliased(M, L, Dout) ? 0 : (size_t)kDecRows * lds_stride_x(dec_bwd_z_cols(M, L, Dout)));
+    return (size_t)(M - 1) * kPFloats + (size_t)kDecRows * (M * H + M * 2 * H) + 2 * (size_t)kDecRows * FP
+           + (size_t)L * 4 * 2 * 256 + 4 * 3 * kRemTile;
 }
 
 template <int H, int M, int DT>
 __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
     static_assert(H == 64, "one column tile per wave");
-    constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, KGP = M * 2 * H, NCT = H / 16, NQ = M * H / 16, DAS = H + 4;
+    constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, KGP = M * 2 * H, NCT = H / 16, NQ = M * H / 16;
+    constexpr int PD = NQ < 6 ? NQ : 6;              // quads of weights in flight ahead of the MFMAs
+    constexpr int kCx = cell_pack_cx_cols(H, H) / 16;     // column tiles of the c1 / c2 packs (12)
     EEG_DYN_SMEM(sm);
     const int T = a.T, B = a.B, N = a.N, Dout = a.Dout, L = a.L, act = a.act;
     const int FP = round_up(Dout, 16);
     float* Pl = sm;
     float* EC = Pl + (M - 1) * kPFloats;     // [ROWS][KAP]  slot 0 = dC, slots m = P_m^T dC
-    float* EG = EC + ROWS * KAP;             // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]; cols 2H.. double as Z
+    float* EG = EC + ROWS * KAP;             // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
     float* DO = EG + ROWS * KGP;             // [ROWS][FP]   total gradient of out_t
     float* DX = DO + ROWS * FP;              // [ROWS][FP]   input gradient of layer 0 at step t (feeds dO_{t-1})
-    float* DA = DX + ROWS * FP;              // [ROWS][DAS]  input gradient of layer l > 0 = gradient of h^{l-1}_t
-    float* DH = DA + ROWS * DAS;             // [L][4 waves][2][64 lanes] float4: recurrent gradients dh^l, lane-linear
+    float* DH = DX + ROWS * FP;              // [L][4 waves][2][64 lanes] float4: recurrent gradients dh^l, lane-linear
     float* RS0 = DH + L * 4 * 2 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
-    float* RS = RS0 + wave * (4 * kRemTile);
-    const bool z_alias = dec_bwd_z_aliased(M, L, Dout);
-    float* ZT = z_alias ? EG : RS0 + 4 * 4 * kRemTile;           // Z = dXW W^x^T, swizzled like the state tiles
-    const int ZS = z_alias ? KGP : lds_stride_x(dec_bwd_z_cols(M, L, Dout)), zc0 = z_alias ? 2 * H : 0;
+    float* RS = RS0 + wave * (3 * kRemTile);
     const int ct = wave, col = ct * 16 + 4 * lg;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const size_t state = (size_t)B * N * H;
-    const int nct_h = H / 16;
+    const int nct_h = H / 16, nct_o = FP / 16;
+    // column tiles of c1 / c2 this wave accumulates: its hidden tile, then the input-feature tiles wave, wave + 4
+    const int nx0 = (nct_o + 3) / 4;                                // input tiles per wave, layer 0 (1 or 2)
+    const int wt0[3] = {ct, NCT + (wave < nct_o ? wave : 0), NCT + (wave + 4 < nct_o ? wave + 4 : 0)};
+    const int wtu[3] = {ct, NCT + ct, NCT + ct};                    // layers above: input = 64 hidden units of the layer below
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        for (int e = tid; e < (int)(ROWS * (KAP + KGP) + 2 * ROWS * FP + ROWS * DAS + L * 4 * 2 * 256); e += 256) EC[e] = 0.f;
-        if (!z_alias)
-            for (int e = tid; e < ROWS * ZS; e += 256) ZT[e] = 0.f;
+        for (int e = tid; e < (int)(ROWS * (KAP + KGP) + 2 * ROWS * FP + L * 4 * 2 * 256); e += 256) EC[e] = 0.f;
         lds_load_polys(Pl, a.P, a.p_batched ? b : 0, M, N);
         __syncthreads();
         float pf[poly_slots<M, NKS>()][NKS];
@@ -447,7 +504,38 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 nc[nt] = ld4(lp.cs + so + oh[nt]);
             }
         };
+        // column tiles of a pair: 1 (no input gradient wanted), 2 (layers above the first / narrow outputs) or 3
+        auto pair_nt = [&](int l, int t) {
+            if (l > 0) return 2;
+            return t > 0 && ((a.feeds_mask >> (t - 1)) & 1ull) != 0 ? 1 + nx0 : 1;
+        };
+        // weights requested ahead of their GEMM: the first group of the projection transpose, the first PD quads of GEMM1 / GEMM2
+        const int wt1[1] = {ct};
+        float wpt[DT][1], wq1[PD + 1][4][3], wq2[PD + 1][4][3];
+        // (kCx column tiles in every c1 / c2 pack: the weight addresses are base + immediate; narrower pairs skip tiles)
+        auto prefetch1 = [&](int l, int nt_) {
+            const int(&wt)[3] = l == 0 ? wt0 : wtu;
+            const wbuf_t wb = make_wbuf(a.l[l].c1);
+            const unsigned v0 = wt[0] * 64 + lane, v1 = wt[1] * 64 + lane, v2 = wt[2] * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < PD; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wq1[q][j][0] = wbuf_ld(wb, v0, (4 * q + j) * kCx * 64);
+            if (nt_ > 1) {
+#pragma unroll
+                for (int q = 0; q < PD; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wq1[q][j][1] = wbuf_ld(wb, v1, (4 * q + j) * kCx * 64);
+            }
+            if (nt_ > 2) {
+#pragma unroll
+                for (int q = 0; q < PD; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wq1[q][j][2] = wbuf_ld(wb, v2, (4 * q + j) * kCx * 64);
+            }
+        };
         fetch(L - 1, T - 1);
+        plain_wload<1, DT>(a.tpack, nct_h, wt1, lane, 0, wpt);
         for (int t = T - 1; t >= 0; --t) {
             const size_t s = (size_t)t * B + b;
             const bool fb = ((a.feeds_mask >> t) & 1ull) != 0;       // out_t feeds step t+1: its gradient gets DX of that step
@@ -464,15 +552,15 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
             f32x4 gext[2];
             {
                 f32x4 pa[1][2] = {{zero4, zero4}};
-                const int wt1[1] = {ct};
-                gemm_stream_plain<1, DT, false>(DO, FP, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS);
+                gemm_stream_plain<1, DT, false, true>(DO, FP, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS, wpt);
                 gext[0] = pa[0][0];
                 gext[1] = pa[0][1];
             }
+            prefetch1(L - 1, pair_nt(L - 1, t));
             for (int l = L - 1; l >= 0; --l) {
                 const DecBwdLayerPtrs& lp = a.l[l];
-                const int Fin = l == 0 ? Dout : H;
                 float* dxw = lp.dxw + s * N * (3 * H);
+                const int(&wt)[3] = l == 0 ? wt0 : wtu;
                 f32x4 hp[2], rr[2], uu[2], cc[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) { hp[nt] = nh[nt]; rr[nt] = nr[nt]; uu[nt] = nu[nt]; cc[nt] = nc[nt]; }
@@ -501,98 +589,62 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 EEG_WAVE_SYNC();
                 lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
                 __syncthreads();                                         // (1) P_m^T dC complete
-                // ---- GEMM1: d(r*h) = [P_m^T dC]_m @ Wc^h^T
-                f32x4 acc1[1][2] = {{zero4, zero4}};
-                {
-                    const int wt1[1] = {ct};
-                    gemm_stream_quad<1, NQ, (NQ < 10 ? NQ : 10)>(EC, KAP, lp.b1, NCT, wt1, lane, lr, lg, acc1, RS);
-                }
+                const int ntp = pair_nt(l, t);
+                f32x4 dx[2][2] = {{zero4, zero4}, {zero4, zero4}};      // this wave's input-gradient tiles
+                auto cell = [&](auto ntag) {
+                    constexpr int NT = decltype(ntag)::value, nct = kCx;
+                    int wtn[NT];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 drh = acc1[0][nt], rg = rr[nt];          // exact 0 on padding nodes
-                    const f32x4 dR = drh * hp[nt] * rg * (1.f - rg);
-                    dhn[nt] += drh * rg;
-                    if (nt == 0 || lr < 4) {
-                        st4(EG + lds_sw(rowt[nt], col, KGP), dR);
-                        st4(EG + lds_sw(rowt[nt], H + col, KGP), dU[nt]);
+                    for (int i = 0; i < NT; ++i) wtn[i] = wt[i];
+                    // ---- GEMM1: [d(r*h) | dX part] = [P_m^T dC]_m @ [Wc^h | Wc^x]^T
+                    f32x4 acc[NT][2];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
+                    gemm_stream_quad<NT, NQ, PD, true, 3>(EC, KAP, lp.c1, nct, wtn, lane, lr, lg, acc, RS, wq1);
+                    quad_prefetch<NT, 2 * NQ, PD, 3>(lp.c2, nct, wtn, lane, wq2);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const f32x4 drh = acc[0][nt], rg = rr[nt];       // exact 0 on padding nodes
+                        const f32x4 dR = drh * hp[nt] * rg * (1.f - rg);
+                        dhn[nt] += drh * rg;
+                        if (nt == 0 || lr < 4) {
+                            st4(EG + lds_sw(rowt[nt], col, KGP), dR);
+                            st4(EG + lds_sw(rowt[nt], H + col, KGP), dU[nt]);
+                        }
+                        if (valid[nt]) st4(dxw + oxw[nt], dR);
+                        acc[0][nt] = dhn[nt];
                     }
-                    if (valid[nt]) st4(dxw + oxw[nt], dR);
-                }
-                EEG_WAVE_SYNC();
-                lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
-                lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
-                __syncthreads();                                         // (2) P_m^T [dR|dU] complete
-                // ---- GEMM2: dh = dhn + [P_m^T dG]_m @ Wg^h^T  -> recurrent gradient of this layer for step t-1
-                {
-                    f32x4 acc2[1][2] = {{dhn[0], dhn[1]}};
-                    const int wt1[1] = {ct};
-                    gemm_stream_quad<1, 2 * NQ, (2 * NQ < 10 ? 2 * NQ : 10)>(EG, KGP, lp.b2, NCT, wt1, lane, lr, lg, acc2, RS);
-                    st4(dhl + l * 2048 + 0 * 256, acc2[0][0]);
-                    st4(dhl + l * 2048 + 1 * 256, acc2[0][1]);
-                }
-                const bool need_dx = l > 0 || (t > 0 && ((a.feeds_mask >> (t - 1)) & 1ull) != 0);
-                if (!need_dx) {
-                    __syncthreads();                                     // tiles free for the next pair
-                    continue;
-                }
-                __syncthreads();                                         // (3) every wave is done with the hop slots of EG
-                // ---- Z = dXW_t @ W^x^T (K = 3H: [dR|dU] from EG slot 0, dC from EC slot 0) -> EG columns 2H.. (M*Fin wide)
-                {
-                    const int nct_x = round_up(M * Fin, 16) / 16;
-                    for (int j0 = wave; j0 < nct_x; j0 += 16) {          // this wave's tiles j0, j0+4, j0+8, j0+12
-                        f32x4 z[4][2];
-                        int wt4[4];
+                    EEG_WAVE_SYNC();
+                    lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
+                    lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
+                    __syncthreads();                                     // (2) P_m^T [dR|dU] complete
+                    // ---- GEMM2: [dh | dX] += [P_m^T dG]_m @ [Wg^h | Wg^x]^T -> recurrent gradient for step t-1, input gradient
+                    gemm_stream_quad<NT, 2 * NQ, PD, true, 3>(EG, KGP, lp.c2, nct, wtn, lane, lr, lg, acc, RS, wq2);
+                    st4(dhl + l * 2048 + 0 * 256, acc[0][0]);
+                    st4(dhl + l * 2048 + 1 * 256, acc[0][1]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            wt4[i] = j0 + 4 * i < nct_x ? j0 + 4 * i : j0;
-                            z[i][0] = zero4;
-                            z[i][1] = zero4;
-                        }
-                        gemm_stream_plain<4, 8, true>(EG, KGP, 2 * H, 2 * H / 4, 1, lp.bxt, nct_x, wt4, lane, lr, lg, z, RS);
-                        gemm_stream_plain<4, 8, true>(EC, KAP, H, H / 4, 1, lp.bxt + (size_t)(2 * H / 4) * nct_x * 64, nct_x, wt4, lane, lr, lg, z, RS);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (j0 + 4 * i >= nct_x) continue;
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-                                if (nt == 0 || lr < 4) st4(ZT + lds_sw(rowt[nt], zc0 + wt4[i] * 16 + 4 * lg, ZS), z[i][nt]);
-                        }
-                    }
-                }
-                __syncthreads();                                         // (4) Z complete
-                // ---- adjoint node mix: dX[n][f] = Z_0[n][f] + sum_{m>=1} sum_q P_m[q][n] Z_m[q][f]
-                {
-                    const int nctf = round_up(Fin, 16) / 16, nks = ceil_div(N, 4);
-                    float* dst = l == 0 ? DX : DA;
-                    const int dss = l == 0 ? FP : DAS;
-                    for (int tix = wave; tix < 2 * nctf; tix += 4) {
-                        const int cti = tix % nctf, rt = tix / nctf;
-                        f32x4 acc;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = rt * 16 + 4 * lg + r;
-                            acc[r] = n < ROWS ? ZT[lds_sw(n, zc0 + cti * 16 + lr, ZS)] : 0.f;
-                        }
-                        for (int m1 = 0; m1 < M - 1; ++m1) {
-                            const float* Pm = Pl + m1 * kPFloats;
-                            for (int ks = 0; ks < nks; ++ks) {
-                                const int kk = 4 * ks + lg;
-                                acc = mfma16(Pm[kk * kPStride + rt * 16 + lr], ZT[lds_sw(kk, zc0 + (m1 + 1) * Fin + cti * 16 + lr, ZS)], acc);
-                            }
-                        }
-                        const int c = cti * 16 + lr;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = rt * 16 + 4 * lg + r;
-                            if (n < ROWS && c < Fin) dst[n * dss + c] = n < N ? acc[r] : 0.f;
-                        }
-                    }
-                }
-                __syncthreads();                                         // (5) DA / DX complete; tiles free for the next pair
+                    for (int i = 1; i < NT; ++i) { dx[i - 1][0] = acc[i][0]; dx[i - 1][1] = acc[i][1]; }
+                };
+                if (ntp == 3) cell(std::integral_constant<int, 3>{});
+                else if (ntp == 2) cell(std::integral_constant<int, 2>{});
+                else cell(std::integral_constant<int, 1>{});
+                // the next pair's first weights fly across the barrier
+                if (l > 0) prefetch1(l - 1, pair_nt(l - 1, t));
+                else if (t > 0) plain_wload<1, DT>(a.tpack, nct_h, wt1, lane, 0, wpt);
                 if (l > 0) {
-                    gext[0] = ld4(DA + rowt[0] * DAS + col);
-                    gext[1] = ld4(DA + rowt[1] * DAS + col);
+                    gext[0] = dx[0][0];                                  // gradient of h^{l-1}_t, already in this wave's registers
+                    gext[1] = dx[0][1];
+                } else if (ntp > 1) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int j = wave + 4 * i;
+                        if (j >= nct_o || i + 1 >= ntp) continue;
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            if (nt == 0 || lr < 4) st4(DX + rowt[nt] * FP + j * 16 + 4 * lg, dx[i][nt]);
+                    }
                 }
+                __syncthreads();                                         // (3) tiles free for the next pair; DX complete
             }
         }
         // ---- gradients of the initial states (the encoder's final states)

@@ -24,6 +24,12 @@ struct CellPack {
     size_t b1;     // bwd cand:  K = M*H  (k = m*H + o),  O = H (f)   = Wc^h transposed
     size_t b2;     // bwd gate:  K = M*2H (k = m*2H + o), O = H (f)   = Wg^h transposed
     size_t bxt;    // bwd dx:    K = 3H (k = o), O = round_up(M*Fin,16)  = Bx transposed
+    // persistent decoder backward (kernels_decoder.h): b1 / b2 widened by the input-feature columns, so that the
+    // recurrent GEMMs also produce dX = sum_m (P_m^T dXW) W^x_m^T from the SAME adjoint hop rows
+    // (O = cell_pack_cx_cols: 12 column tiles for 64 units and up to 128 input features -- ONE literal tile count for every
+    //  layer of the decoder, so the streamed-weight addresses are base + immediate)
+    size_t c1;     // K = M*H  (k = m*H + o),  O columns: [Wc^h | Wc^x | 0] transposed, quad-permuted K
+    size_t c2;     // K = M*2H (k = m*2H + o), O columns: [Wg^h | Wg^x | 0] transposed, quad-permuted K
     size_t total;
 };
 
@@ -38,6 +44,8 @@ __host__ __device__ inline CellPack make_cell_pack(int Fin, int H, int M) {
     p.b1 = o;   o += (size_t)M * H * H;
     p.b2 = o;   o += (size_t)M * 2 * H * H;
     p.bxt = o;  o += (size_t)3 * H * round_up(M * Fin, 16);
+    p.c1 = o;   o += (size_t)M * H * cell_pack_cx_cols(Fin, H);
+    p.c2 = o;   o += (size_t)M * 2 * H * cell_pack_cx_cols(Fin, H);
     p.total = o;
     return p;
 }
@@ -91,7 +99,7 @@ __global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __re
             const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
             const int k = kperm(ks, lane >> 4), f = 16 * ct + (lane & 15);
             v = ref_wg(Wg, M, H, Fin + f, k / (2 * H), k % (2 * H));
-        } else {                                  // bxt[k = o][j = m*Fin + f]
+        } else if (idx < p.c1) {                  // bxt[k = o][j = m*Fin + f]
             const size_t e = idx - p.bxt;
             const int lane = e & 63, nct = round_up(M * Fin, 16) / 16;
             const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
@@ -100,6 +108,14 @@ __global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __re
                 const int m = j / Fin, f = j % Fin;
                 v = o < 2 * H ? ref_wg(Wg, M, H, f, m, o) : ref_wc(Wc, M, H, f, m, o - 2 * H);
             }
+        } else {                                  // c1 / c2 [k = m*W + o][j]: j < H hidden feature j, else input feature j - H
+            const bool gate = idx >= p.c2;
+            const size_t e = idx - (gate ? p.c2 : p.c1);
+            const int lane = e & 63, nct = cell_pack_cx_cols(Fin, H) / 16, W = gate ? 2 * H : H;
+            const int ct = (e >> 6) % nct, ks = (e >> 6) / nct;
+            const int k = kperm(ks, lane >> 4), j = 16 * ct + (lane & 15);
+            const int f_all = j < H ? Fin + j : j - H;
+            if (j < H + Fin) v = gate ? ref_wg(Wg, M, H, f_all, k / W, k % W) : ref_wc(Wc, M, H, f_all, k / W, k % W);
         }
         out[idx] = v;
     }
