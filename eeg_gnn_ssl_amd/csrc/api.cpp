@@ -408,7 +408,12 @@ int colsum_rows_per_chunk(int R) { int rpc = ceil_div(R, 512); return rpc < 64 ?
 size_t colsum_ws(int R, int C) { return (size_t)ceil_div(R, colsum_rows_per_chunk(R)) * C; }
 int colsum(const float* A, int R, int C, int split, float* ws, float* out0, float* out1, hipStream_t st) {
     const int rpc = colsum_rows_per_chunk(R), nchunk = ceil_div(R, rpc);
-    EEG_LAUNCH_P("reduce_bias", colsum_partial_kernel, dim3(nchunk, ceil_div(C, 128)), dim3(256), 256 * sizeof(float), st, A, R, C, rpc, ws);
+    if (C % 4 == 0 && C <= 1024) {
+        const int nrs = 256 / (C / 4);
+        EEG_LAUNCH_P("reduce_bias", colsum_partial4_kernel, dim3(nchunk), dim3(256), (size_t)nrs * C * sizeof(float), st, A, R, C, rpc, ws);
+    } else {
+        EEG_LAUNCH_P("reduce_bias", colsum_partial_kernel, dim3(nchunk, ceil_div(C, 128)), dim3(256), 256 * sizeof(float), st, A, R, C, rpc, ws);
+    }
     if (check_launch("colsum_partial")) return 1;
     EEG_LAUNCH_P("reduce_bias", colsum_final_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, ws, nchunk, C, split, out0, out1);
     return check_launch("colsum_final");
@@ -468,9 +473,8 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
     part = pp > part ? pp : part;
     y.partial = o; o += align64(part);
     y.projt_pack = o; o += align64((size_t)(d->Dout / 4) * nct_h * 64);
-    // bias column sums: over the per-clip partial sums (per-step path) or over dXW itself (persistent path)
-    const size_t c1 = colsum_ws((int)R, d->Dout), c2 = colsum_ws(d->L * d->T * d->B, 3 * d->H), c3 = colsum_ws(d->L * (int)R, 3 * d->H);
-    y.colsum = o; o += align64(c1 > c2 ? (c1 > c3 ? c1 : c3) : (c2 > c3 ? c2 : c3));
+    const size_t c1 = colsum_ws((int)R, d->Dout), c2 = colsum_ws(d->L * d->T * d->B, 3 * d->H);
+    y.colsum = o; o += align64(c1 > c2 ? c1 : c2);
     y.bwd_total = o;
     return y;
 }
@@ -861,6 +865,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
             }
             for (int l = L; l < 4; ++l) a.l[l] = a.l[0];
             a.P = P; a.tpack = tpack; a.dOut = dOut; a.dOtot = dOtot; a.dh0 = dh0;
+            a.dbias0 = ws + y.dbias[0]; a.dbias1 = ws + y.dbias[L > 1 ? 1 : 0];
             a.feeds_mask = 0;
             for (int t = 0; t < T; ++t)
                 if (feeds_back(t)) a.feeds_mask |= 1ull << t;
@@ -917,9 +922,9 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
                               ws + y.dxw[l], P, saved + y.hpl[l], saved + y.rpl[l], hstride, nullptr, nullptr,
                               ws + y.partial, y.lw[l], !first_use, dWg[l], dWc[l], st)) return 1;
     }
-    if (persistent) {   // bias gradients = column sums of dXW (layers >= 1 share a cell; their dXW regions are contiguous)
-        if (colsum(ws + y.dxw[0], (int)Rall, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
-        if (L > 1 && colsum(ws + y.dxw[1], (L - 1) * (int)Rall, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
+    if (persistent) {   // per-clip sums over steps and nodes (layers >= 1 share a cell: already added up)
+        if (colsum(ws + y.dbias[0], B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
+        if (L > 1 && colsum(ws + y.dbias[1], B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
     } else {
         if (colsum(ws + y.dbias[0], T * B, 3 * H, 2 * H, ws + y.colsum, dbg[0], dbc[0], st)) return 1;
         if (L > 1 && colsum(ws + y.dbias[1], (L - 1) * T * B, 3 * H, 2 * H, ws + y.colsum, dbg[1], dbc[1], st)) return 1;
@@ -1029,12 +1034,15 @@ int eeg_dcrnn_masked_loss(const float* pred, const float* y, size_t n, int use_s
     hipStream_t st = S_(stream);
     int nblk = (int)((n + 256 * 8 - 1) / (256 * 8));
     if (nblk > kLossBlocks) nblk = kLossBlocks;
+    // 16-byte accesses need 16-byte aligned tensors (torch allocations are; views with an odd offset are not)
+    if (((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dpred)) & 15) != 0)
+        return fail("masked_loss: tensors must be 16-byte aligned");
     EEG_LAUNCH_P("loss_masked", masked_loss_partial_kernel, dim3(nblk), dim3(256), 512 * sizeof(float), st, pred, y, n, mean, std_, use_scaler, mask_val, kind, ws);
     if (check_launch("masked_loss_partial")) return 1;
-    EEG_LAUNCH_P("loss_masked", masked_loss_finish_kernel, dim3(1), dim3(64), 0, st, ws, nblk, kind, loss);
+    EEG_LAUNCH_P("loss_masked", masked_loss_finish_kernel, dim3(1), dim3(256), 512 * sizeof(float), st, ws, nblk, kind, loss);
     if (check_launch("masked_loss_finish")) return 1;
     if (dpred != nullptr) {
-        EEG_LAUNCH_P("loss_masked", masked_loss_grad_kernel, dim3(nblk * 4), dim3(256), 0, st, pred, y, n, mean, std_, use_scaler, mask_val, kind, ws, dpred);
+        EEG_LAUNCH_P("loss_masked", masked_loss_grad_kernel, dim3(nblk * 2), dim3(256), 0, st, pred, y, n, mean, std_, use_scaler, mask_val, kind, ws, dpred);
         if (check_launch("masked_loss_grad")) return 1;
     }
     return 0;

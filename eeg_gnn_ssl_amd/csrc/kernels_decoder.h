@@ -439,6 +439,7 @@ struct DecBwdArgs {
     const float* dOut;            // (T,B,N,Dout) loss gradient
     float* dOtot;                 // (T,B,N,Dout) total gradient of out_t (loss + feedback)
     float* dh0;                   // (L,B,N,H)
+    float *dbias0, *dbias1;       // (B,3H) per-clip bias-gradient sums [r|u|c] over steps and nodes: layer 0, layers >= 1 (one shared cell)
     unsigned long long feeds_mask;     // bit t: out_t is the input of step t+1 (no teacher forcing there, t+1 < T)
     int p_batched, T, B, N, Dout, L, act;
 };
@@ -453,7 +454,7 @@ template <int H, int M, int DT>
 __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
     static_assert(H == 64, "one column tile per wave");
     constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, KGP = M * 2 * H, NCT = H / 16, NQ = M * H / 16;
-    constexpr int PD = NQ < 6 ? NQ : 6;              // quads of weights in flight ahead of the MFMAs
+    constexpr int PD = NQ < 3 ? NQ : 3;              // quads of weights in flight ahead of the MFMAs
     constexpr int kCx = cell_pack_cx_cols(H, H) / 16;     // column tiles of the c1 / c2 packs (12)
     EEG_DYN_SMEM(sm);
     const int T = a.T, B = a.B, N = a.N, Dout = a.Dout, L = a.L, act = a.act;
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     for (int j = 0; j < 4; ++j) wq1[q][j][2] = wbuf_ld(wb, v2, (4 * q + j) * kCx * 64);
             }
         };
+        f32x4 sb0[3] = {zero4, zero4, zero4}, sb1[3] = {zero4, zero4, zero4};   // bias-gradient sums [r, u, c]: layer 0, layers above
         fetch(L - 1, T - 1);
         plain_wload<1, DT>(a.tpack, nct_h, wt1, lane, 0, wpt);
         for (int t = T - 1; t >= 0; --t) {
@@ -585,6 +587,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     }
                     dU[nt] = du_;
                     dhn[nt] = g * u;
+                    if (l == 0) { sb0[1] += du_; sb0[2] += dC; } else { sb1[1] += du_; sb1[2] += dC; }
                 }
                 EEG_WAVE_SYNC();
                 lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
@@ -612,6 +615,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                             st4(EG + lds_sw(rowt[nt], H + col, KGP), dU[nt]);
                         }
                         if (valid[nt]) st4(dxw + oxw[nt], dR);
+                        if (l == 0) sb0[0] += dR; else sb1[0] += dR;
                         acc[0][nt] = dhn[nt];
                     }
                     EEG_WAVE_SYNC();
@@ -653,6 +657,23 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     if (valid[nt]) st4(a.dh0 + (size_t)l * state + boff + node[nt] * H + col, ld4(dhl + l * 2048 + nt * 256));
+        }
+        // ---- per-clip bias-gradient sums (fixed-order node reduction through the free dC / [dR|dU] tiles)
+        float* red = EC;                                             // [3H][16]
+        for (int set = 0; set < (L > 1 ? 2 : 1); ++set) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(k * H + col + r) * 16 + lr] = set == 0 ? sb0[k][r] : sb1[k][r];
+            __syncthreads();
+            float* dst = (set == 0 ? a.dbias0 : a.dbias1) + (size_t)b * 3 * H;
+            for (int j = tid; j < 3 * H; j += 256) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
+                dst[j] = sacc;
+            }
         }
     }
 }

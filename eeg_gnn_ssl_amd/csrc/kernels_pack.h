@@ -255,6 +255,34 @@ __global__ void colsum_partial_kernel(const float* __restrict__ A, int R, int C,
     __syncthreads();
     if (q == 0 && col < C) partial[(size_t)blockIdx.x * C + col] = sm[c] + sm[128 + c];
 }
+// The same for C % 4 == 0, C <= 1024: a thread owns 4 consecutive columns (16-byte loads, 4 in flight) of one of
+// 256 / (C/4) row slices; the slices are added in slice order through LDS.
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ A, int R, int C, int rpc,
+                                                              float* __restrict__ partial) {
+    EEG_DYN_SMEM(sm);                                 // [nrs][C]
+    const int c4n = C / 4, nrs = 256 / c4n;
+    const int cq = threadIdx.x % c4n, q = threadIdx.x / c4n;
+    const int r0 = blockIdx.x * rpc, r1 = (r0 + rpc < R) ? r0 + rpc : R;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (q < nrs) {
+        const float* p = A + 4 * cq;
+        int r = r0 + q;
+        for (; r + 3 * nrs < r1; r += 4 * nrs) {
+            a0 += ld4(p + (size_t)r * C);
+            a1 += ld4(p + (size_t)(r + nrs) * C);
+            a2 += ld4(p + (size_t)(r + 2 * nrs) * C);
+            a3 += ld4(p + (size_t)(r + 3 * nrs) * C);
+        }
+        for (; r < r1; r += nrs) a0 += ld4(p + (size_t)r * C);
+        st4(sm + q * C + 4 * cq, (a0 + a1) + (a2 + a3));
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < C; col += 256) {
+        float s = 0.f;
+        for (int i = 0; i < nrs; ++i) s += sm[i * C + col];
+        partial[(size_t)blockIdx.x * C + col] = s;
+    }
+}
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchunk, int C, int split,
                                     float* __restrict__ out0, float* __restrict__ out1) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;

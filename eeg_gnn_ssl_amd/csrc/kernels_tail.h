@@ -57,7 +57,7 @@ __global__ void ce_logits_kernel(const float* __restrict__ x, const long long* _
 // masked MAE) or d^2 followed by sqrt (kind 1: `masked_mse_loss`, really a masked RMSE).
 // stage 1: per-block partial sums [sum | count]; stage 2 (one block): loss value + gradient scale;
 // stage 3: dpred.  Fixed-order reductions.
-constexpr int kLossBlocks = 256;
+constexpr int kLossBlocks = 1024;
 __device__ __forceinline__ void masked_terms(float p, float y, float mean, float std_, int scaled, float mask_val,
                                              float& d, float& mk) {
     // two roundings like the reference's `data * std + mean` (no FMA contraction: the mask tests ys against mask_val)
@@ -65,17 +65,34 @@ __device__ __forceinline__ void masked_terms(float p, float y, float mean, float
     d = ps - ys;
     mk = ys != mask_val ? 1.f : 0.f;
 }
-__global__ void masked_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ y, size_t n,
-                                           float mean, float std_, int scaled, float mask_val, int kind,
-                                           float* __restrict__ part) {
+// 16-byte loads, two per operand in flight per thread; the n % 4 tail elements go to the last thread of the grid.
+__global__ __launch_bounds__(256) void masked_loss_partial_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                                  size_t n, float mean, float std_, int scaled,
+                                                                  float mask_val, int kind, float* __restrict__ part) {
     EEG_DYN_SMEM(sm);                                   // [2][256]
     float s = 0.f, c = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    auto term = [&](float p, float yv) {
         float d, mk;
-        masked_terms(pred[i], y[i], mean, std_, scaled, mask_val, d, mk);
+        masked_terms(p, yv, mean, std_, scaled, mask_val, d, mk);
         s += (kind == 0 ? fabsf(d) : d * d) * mk;
         c += mk;
+    };
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const f32x4 p0 = ld4(pred + 4 * i), y0 = ld4(y + 4 * i), p1 = ld4(pred + 4 * (i + stride)), y1 = ld4(y + 4 * (i + stride));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) term(p0[r], y0[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) term(p1[r], y1[r]);
     }
+    if (i < n4) {
+        const f32x4 p0 = ld4(pred + 4 * i), y0 = ld4(y + 4 * i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) term(p0[r], y0[r]);
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1)
+        for (size_t e = 4 * n4; e < n; ++e) term(pred[e], y[e]);
     sm[threadIdx.x] = s;
     sm[256 + threadIdx.x] = c;
     __syncthreads();
@@ -86,10 +103,21 @@ __global__ void masked_loss_partial_kernel(const float* __restrict__ pred, const
     if (threadIdx.x == 0) { part[blockIdx.x] = sm[0]; part[kLossBlocks + blockIdx.x] = sm[256]; }
 }
 // part[2*kLossBlocks] = loss, [+1] = gradient scale (MAE: 1/count; RMSE: 1/(count*loss)); 0 when count == 0
-__global__ void masked_loss_finish_kernel(float* __restrict__ part, int nblk, int kind, float* __restrict__ loss) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one block of 256 threads: thread i adds parts i, i + 256, ...; then a fixed tree.
+__global__ __launch_bounds__(256) void masked_loss_finish_kernel(float* __restrict__ part, int nblk, int kind, float* __restrict__ loss) {
+    EEG_DYN_SMEM(sm);                                   // [2][256]
     float s = 0.f, c = 0.f;
-    for (int i = 0; i < nblk; ++i) { s += part[i]; c += part[kLossBlocks + i]; }
+    for (int i = threadIdx.x; i < nblk; i += 256) { s += part[i]; c += part[kLossBlocks + i]; }
+    sm[threadIdx.x] = s;
+    sm[256 + threadIdx.x] = c;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { sm[threadIdx.x] += sm[threadIdx.x + k]; sm[256 + threadIdx.x] += sm[256 + threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    s = sm[0];
+    c = sm[256];
     float l = 0.f, sc = 0.f;
     if (c > 0.f) {
         l = kind == 0 ? s / c : sqrtf(s / c);
@@ -99,16 +127,26 @@ __global__ void masked_loss_finish_kernel(float* __restrict__ part, int nblk, in
     part[2 * kLossBlocks] = l;
     part[2 * kLossBlocks + 1] = sc;
 }
-__global__ void masked_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ y, size_t n,
-                                        float mean, float std_, int scaled, float mask_val, int kind,
-                                        const float* __restrict__ part, float* __restrict__ dpred) {
+__global__ __launch_bounds__(256) void masked_loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ y,
+                                                               size_t n, float mean, float std_, int scaled, float mask_val,
+                                                               int kind, const float* __restrict__ part, float* __restrict__ dpred) {
     const float sc = part[2 * kLossBlocks + 1] * (scaled ? std_ : 1.f);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    auto grad = [&](float p, float yv) {
         float d, mk;
-        masked_terms(pred[i], y[i], mean, std_, scaled, mask_val, d, mk);
+        masked_terms(p, yv, mean, std_, scaled, mask_val, d, mk);
         const float e = kind == 0 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : d;
-        dpred[i] = e * mk * sc;
+        return e * mk * sc;
+    };
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 p0 = ld4(pred + 4 * i), y0 = ld4(y + 4 * i);
+        f32x4 g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[r] = grad(p0[r], y0[r]);
+        st4(dpred + 4 * i, g);
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == blockDim.x - 1)
+        for (size_t e = 4 * n4; e < n; ++e) dpred[e] = grad(pred[e], y[e]);
 }
 
 // stage 1: per-block partial sums of g^2 (fixed assignment of elements to blocks/threads)

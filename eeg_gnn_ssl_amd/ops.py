@@ -126,7 +126,9 @@ def _pack_cell_impl(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
 def _pack_floats(fin, h, m):
     """mirror of make_cell_pack (csrc/kernels_pack.h) for shape inference"""
     r16 = lambda a: (a + 15) // 16 * 16   # noqa: E731
-    return m * fin * 3 * h + (3 * h + 63) // 64 * 64 + m * h * 2 * h + 2 * m * h * h + m * 2 * h * h + 3 * h * r16(m * fin)
+    cx = h + (128 if fin <= 128 else (fin + 63) // 64 * 64)     # cell_pack_cx_cols (csrc/common.h)
+    return (m * fin * 3 * h + (3 * h + 63) // 64 * 64 + m * h * 2 * h + 2 * m * h * h + m * 2 * h * h + 3 * h * r16(m * fin)
+            + 3 * m * h * cx)
 
 
 _define("pack_cell", "(Tensor wg, Tensor bg, Tensor wc, Tensor bc, int fin, int h, int m) -> Tensor", _pack_cell_impl,
