@@ -79,10 +79,21 @@ def test_training_tail_kernels():
     ("laplacian", 8, 64, 2, 2, 2, None, "tanh"),           # 64 units, M = 3: single-step launches of the two-wave kernel
     ("dual_random_walk", 20, 64, 2, 3, 2, 0.5, "tanh"),    # 64 units, Dout % 20 == 0: the persistent decoder kernel (M = 5), teacher forcing
     ("laplacian", 16, 64, 3, 3, 2, None, "relu"),          # persistent kernel, 3 layers (shared cell), Dout % 16 == 0
-    ("laplacian", 100, 64, 2, 3, 2, 0.5, "tanh"),          # persistent backward with a Z tile of its own (M = 3, Dout = 100)
+    ("laplacian", 100, 64, 2, 3, 2, 0.5, "tanh"),          # persistent kernels at M = 3, Dout = 100 (two input-gradient tiles per wave)
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle("cpu", filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
+
+
+@pytest.mark.parametrize("filt,dout,layers,t_out,b,ratio,n,order", [
+    ("laplacian", 16, 1, 1, 2, None, 12, 1),            # one layer, one step, 12 nodes (no remainder tile), M = 2
+    ("dual_random_walk", 20, 2, 2, 2, None, 20, 1),     # 20 nodes: the 4x4 remainder tile full, M = 3
+    ("laplacian", 16, 2, 3, 2, 0.5, 19, 0),             # max_diffusion_step = 0: M = 1, no hop slots
+    ("dual_random_walk", 20, 4, 2, 1, None, 5, 1),      # four layers (three uses of the shared cell), 5 nodes
+])
+def test_persistent_decoder_edge_shapes(filt, dout, layers, t_out, b, ratio, n, order, adj3d):
+    """the persistent decoder kernels (forward and BPTT, kernels_decoder.h) at the edges of their range"""
+    ps.check_decoder_vs_oracle("cpu", filt, dout, 64, layers, t_out, b, adj3d, seed=3, ratio=ratio, n=n, order=order)
 
 
 def test_correlation_graph_supports(golden):

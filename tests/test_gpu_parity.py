@@ -346,11 +346,24 @@ def test_hip_graph_replay_equals_eager_steps():
     ("dual_random_walk", 100, 64, 2, 12, 6, None, "tanh"),  # cfg5's decoder: the persistent kernel (kernels_decoder.h)
     ("dual_random_walk", 20, 64, 2, 3, 2, 0.5, "tanh"),     # persistent kernel with teacher forcing
     ("laplacian", 16, 64, 3, 3, 2, None, "relu"),           # persistent kernel, 3 layers (shared cell), Dout % 16 == 0
-    ("laplacian", 100, 64, 2, 3, 2, 0.5, "tanh"),           # persistent backward with a Z tile of its own (M = 3, Dout = 100)
+    ("laplacian", 100, 64, 2, 3, 2, 0.5, "tanh"),           # persistent kernels at M = 3, Dout = 100 (two input-gradient tiles per wave)
     ("laplacian", 8, 64, 2, 2, 2, None, "tanh"),            # 64 units but Dout/4 not a multiple of 4 or 5: per-step launches
 ])
 def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
+
+
+@pytest.mark.parametrize("filt,dout,layers,t_out,b,ratio,n,order", [
+    ("laplacian", 16, 1, 1, 2, None, 12, 1),            # one layer, one step, 12 nodes (no remainder tile), M = 2
+    ("dual_random_walk", 20, 2, 2, 2, None, 20, 1),     # 20 nodes: the 4x4 remainder tile full, M = 3
+    ("laplacian", 16, 2, 3, 2, 0.5, 19, 0),             # max_diffusion_step = 0: M = 1, no hop slots
+    ("dual_random_walk", 20, 4, 2, 1, None, 5, 1),      # four layers (three uses of the shared cell), 5 nodes
+    ("dual_random_walk", 100, 2, 2, 300, None, 19, 2),  # more clips than workgroups: the clip loop of a workgroup
+    ("laplacian", 128, 2, 4, 2, 0.5, 19, 2),            # widest output the persistent kernels take (Dout = 128)
+])
+def test_persistent_decoder_edge_shapes(filt, dout, layers, t_out, b, ratio, n, order, adj3d):
+    """the persistent decoder kernels (forward and BPTT, kernels_decoder.h) at the edges of their range"""
+    ps.check_decoder_vs_oracle(DEV, filt, dout, 64, layers, t_out, b, adj3d, seed=3, ratio=ratio, n=n, order=order)
 
 
 @pytest.mark.parametrize("n", [3, 20, 21, 32])
