@@ -316,7 +316,18 @@ int seq_fwd(int H, int M, const SeqFwdArgs& a, hipStream_t st) {
     if (rc == 3) return fail("seq_fwd: H=%d M=%d N=%d exceeds the LDS of a CU", H, M, a.N);
     return 0;
 }
+// BPTT with more clips than 1.5 x the CUs at hop counts the two-wave kernel does not cover: two streamed-weight
+// workgroups per CU (kernels_seq_stream.h; dev knob 3: 1 = wherever the kernel exists, 2 = never)
+bool seq_stream_wanted(int H, int M, int B, int N) {
+    if (H != 64 || N > kDecRows || M > 5 || g_tune[3] == 2) return false;
+    return g_tune[3] == 1 || (M >= 4 && B >= 384);
+}
 int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
+    if (a.variant != 0 && a.probe == nullptr && seq_stream_wanted(H, M, a.B, a.N)) {
+        const int rs = launch_seq_bwd_stream(M, a, st);
+        if (rs == 0) return 0;
+        if (rs == 2) return fail("seq_bwd: streamed kernel launch failed (M=%d)", M);
+    }
     int rc = H == 16 ? launch_seq_bwd_h16(M, a, st) : H == 32 ? launch_seq_bwd_h32(M, a, st) : launch_seq_bwd_h64(M, a, st);
     if (rc == 1) return fail("seq_bwd: no kernel for H=%d M=%d", H, M);
     if (rc == 2) return fail("seq_bwd: kernel launch failed (H=%d M=%d)", H, M);

@@ -79,6 +79,14 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 struct wbuf_t { const float* p; };
 __device__ __forceinline__ wbuf_t make_wbuf(const float* p) { return wbuf_t{p}; }
 __device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) { return b.p[(size_t)voff + soff]; }
+__device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff) {
+    const float* q = b.p + (size_t)voff + soff;
+    return f32x4{q[0], q[1], q[2], q[3]};
+}
+__device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
+    float* q = const_cast<float*>(b.p) + (size_t)voff + soff;
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+}
 #else
 typedef __amdgpu_buffer_rsrc_t wbuf_t;
 __device__ __forceinline__ wbuf_t make_wbuf(const float* p) {              // p must be wave-uniform
@@ -88,6 +96,14 @@ __device__ __forceinline__ wbuf_t make_wbuf(const float* p) {              // p 
 }
 __device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4u * voff, 4u * soff, 0));
+}
+// 16-byte accesses of activations through a descriptor (offsets in floats, < 2^29)
+__device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, 4u * voff, 4u * soff, 0));
+}
+__device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), b, 4u * voff, 4u * soff, 0);
 }
 #endif
 

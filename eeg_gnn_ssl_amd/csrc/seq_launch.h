@@ -26,7 +26,7 @@ struct SeqBwdArgs {
     float *dXW, *dh0, *dbias_part;
     int T, B, N, act;
     long long* probe;
-    int variant = 0;        // 1: two waves per SIMD (seq_bwd2_kernel) where it exists
+    int variant = 0;        // 1: two waves per SIMD (seq_bwd2_kernel) or two workgroups per CU (seq_bwd_stream_kernel) where they apply
 };
 
 // return 0 ok, 1 unsupported M for this H, 2 launch error
@@ -37,6 +37,8 @@ int launch_seq_bwd_h16(int M, const SeqBwdArgs& a, hipStream_t st);
 int launch_seq_bwd_h32(int M, const SeqBwdArgs& a, hipStream_t st);
 int launch_seq_bwd_h64(int M, const SeqBwdArgs& a, hipStream_t st);
 bool seq_m_supported(int M);
+// streamed weights, two workgroups per CU (kernels_seq_stream.h): 64 units, at most 20 nodes; 3 = does not fit
+int launch_seq_bwd_stream(int M, const SeqBwdArgs& a, hipStream_t st);
 struct DecFwdArgs;
 struct DecBwdArgs;
 int launch_dec_fwd_persist(int M, int dx, const DecFwdArgs& a, size_t lds, hipStream_t st);

@@ -39,6 +39,7 @@ def build(force=False):
              ("emu_impl", os.path.join(HERE, "emu_impl.cpp"), [])]
     units.append(("dec", os.path.join(CSRC, "dec_inst.cpp"), []))
     units.append(("decb", os.path.join(CSRC, "decb_inst.cpp"), []))
+    units.append(("seqs", os.path.join(CSRC, "seqs_inst.cpp"), []))
     for h in (16, 32, 64):
         units.append((f"seq_h{h}", os.path.join(CSRC, "seq_inst.cpp"), [f"-DEEG_SEQ_H={h}"]))
     for name, src, extra in units:

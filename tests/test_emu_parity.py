@@ -68,6 +68,18 @@ def test_single_wave_forward_kernel_at_default_width(emulator, adj3d, golden):
         emulator.call("eeg_dcrnn_set_tuning", 12, 0)
 
 
+@pytest.mark.parametrize("filt,k,lengths,act", [("dual_random_walk", 2, [3, 1, 2], "tanh"), ("laplacian", 2, None, "relu"),
+                                                ("dual_random_walk", 1, None, "tanh"), ("laplacian", 0, [2, 3, 3], "tanh")])
+def test_streamed_weight_bptt_kernel(emulator, adj3d, filt, k, lengths, act):
+    """kernels_seq_stream.h (BPTT with two workgroups per CU, weights streamed from L2; by default only for batches
+    beyond 1.5 clips per CU at M >= 4) forced on: whole model vs the oracle."""
+    emulator.call("eeg_dcrnn_set_tuning", 3, 1)
+    try:
+        ps.check_vs_oracle_random("cpu", filt, 8, 64, 2, 3, 3, 4, adj3d, seed=5, lengths=lengths, act=act, k=k)
+    finally:
+        emulator.call("eeg_dcrnn_set_tuning", 3, 0)
+
+
 def test_training_tail_kernels():
     ps.check_training_tail("cpu")
 

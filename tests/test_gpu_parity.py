@@ -353,6 +353,14 @@ def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ps.check_decoder_vs_oracle(DEV, filt, dout, h, layers, t_out, b, adj3d, seed=1, ratio=ratio, act=act)
 
 
+def test_streamed_weight_bptt_kernel_large_batch(adj3d):
+    """more than 1.5 clips per CU at M = 5: the BPTT of every layer runs as two streamed-weight workgroups per CU
+    (kernels_seq_stream.h); whole model vs the oracle, ragged lengths"""
+    b = 400
+    lengths = [1 + (i * 7) % 3 for i in range(b)]
+    ps.check_vs_oracle_random(DEV, "dual_random_walk", 8, 64, 2, 3, b, 4, adj3d, seed=5, lengths=lengths)
+
+
 @pytest.mark.parametrize("filt,dout,layers,t_out,b,ratio,n,order", [
     ("laplacian", 16, 1, 1, 2, None, 12, 1),            # one layer, one step, 12 nodes (no remainder tile), M = 2
     ("dual_random_walk", 20, 2, 2, 2, None, 20, 1),     # 20 nodes: the 4x4 remainder tile full, M = 3

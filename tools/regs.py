@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """dev aid: register / LDS / spill counts of the gfx950 kernels of one translation unit.
-usage: python tools/regs.py [api|dec|decb|seq64|seq32|seq16] [name filter ...]"""
+usage: python tools/regs.py [api|dec|decb|seqs|seq64|seq32|seq16] [name filter ...]"""
 import os
 import re
 import subprocess
@@ -12,7 +12,7 @@ unit = sys.argv[1] if len(sys.argv) > 1 else "api"
 filt = sys.argv[2:]
 if unit == "api":
     src, extra = "api.cpp", []
-elif unit in ("dec", "decb"):
+elif unit in ("dec", "decb", "seqs"):
     src, extra = unit + "_inst.cpp", ["-fno-slp-vectorize"]
 else:
     src, extra = "seq_inst.cpp", ["-fno-slp-vectorize", f"-DEEG_SEQ_H={unit[3:]}"]
