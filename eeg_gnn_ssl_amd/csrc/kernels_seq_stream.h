@@ -7,8 +7,8 @@
 // kernels_decoder.h), so a workgroup needs 256 registers and 80 KB of LDS, and the two independent chains of a CU fill
 // each other's stalls.  Same operands and outputs as seq_bwd_kernel.  Measured (cfg5, B = 512, M = 5): seq_bwd 2.08 ->
 // 1.91 ms.  The forward twin (same construction, gate + candidate GEMMs of 2 + 1 tiles) was 6 % SLOWER than the
-// register-resident seq_fwd_kernel (2.06 -> 2.18 ms) and is not kept: with 256 registers a wave can hold only 2-3
-// quads of weights in flight, less than the L2 latency for its short 1-2 tile k-steps.
+// register-resident seq_fwd_kernel and is not kept (2.06 -> 2.18 ms; with buffer-descriptor operand accesses and no
+// spill 2.13 ms at 3 / 4 quads of gate / candidate weights in flight, 2.17 ms at 5 / 8).
 #pragma once
 #include "kernels_decoder.h"
 
