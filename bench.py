@@ -138,6 +138,12 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
             w["dec_diffuse_adj"] += 4.0 * sd * n * fin * (m + 1)
         w["dec_gemm_nn"] += 2 * 2.0 * rd * h * D_IN          # projection forward + d h_top
         w["dec_gemm_tn"] += 2.0 * rd * h * D_IN              # projection weight gradient
+        # the persistent decoder kernels (kernels_decoder.h) do the work of the per-step roles in ONE launch each:
+        # forward = recurrence + x-part GEMMs + input hop mixes + projection; backward = BPTT + input gradients + d h_top.
+        # Priced for their own rows only (`*_persist` is left out of the whole-step sum: the roles above already hold it).
+        w["dec_fwd_persist"] = w["dec_seq_fwd"] + sum(2.0 * rd * (m * fin) * 3 * h for fin in fins) \
+            + sd * (m - 1) * 2.0 * n * n * D_IN + 2.0 * rd * h * D_IN
+        w["dec_bwd_persist"] = w["dec_seq_bwd"] + sum(2.0 * rd * (m * fin) * 3 * h for fin in fins) + 2.0 * rd * h * D_IN
     return w
 
 
@@ -421,7 +427,7 @@ def main():
         by_class = {k: {"ms_per_step": round(v["ms_per_step"], 4),
                         "frac": round(v["work"] / (v["ms_per_step"] * 1e-3) / (PEAK_HBM_GBS * 1e9 if v["bound"] == "hbm" else PEAK_MFMA_F32_TFLOPS * 1e12), 4)}
                     for k, v in classes_ms.items()}
-        flops = sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram")
+        flops = sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram" and not k.endswith("_persist"))
         roofline = {"kernel": dom, "symbol": d.get("symbol"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"],
                     "traffic": (traffic or {}).get(dom), "avg_launch_ms": d["avg_launch_ms"],

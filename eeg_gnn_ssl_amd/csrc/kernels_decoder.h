@@ -312,14 +312,19 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     gemm_stream_plain<3, DX, false>(XA, XS, FP, Dout / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag, RS);
                 else
                     gemm_stream_plain<3, 16, true>(A0 + (l - 1) * ROWS * KAP, KAP, H, H / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag, RS);
+                // the first quads of the gate / candidate weights are requested before the barrier / the epilogue in front of their GEMM
+                constexpr int PDG = NQ < 6 ? NQ : 6, PDC = NQ < 10 ? NQ : 10;
+                const int wt2[2] = {ct, NCT + ct}, wt1[1] = {ct};
+                float wqg[PDG + 1][4][2], wqc[PDC + 1][4][1];
+                quad_prefetch<2, NQ, PDG>(lp.bhg, NGT, wt2, lane, wqg);
                 __syncthreads();                                     // layer 0: every wave has read X0 (A2 aliases it)
                 // gate h-part: hops(h^l) x Wg^h
                 {
                     f32x4 g2[2][2] = {{ag[0][0], ag[0][1]}, {ag[1][0], ag[1][1]}};
-                    const int wt2[2] = {ct, NCT + ct};
-                    gemm_stream_quad<2, NQ, (NQ < 6 ? NQ : 6)>(Al, KAP, lp.bhg, NGT, wt2, lane, lr, lg, g2, RS);
+                    gemm_stream_quad<2, NQ, PDG, true>(Al, KAP, lp.bhg, NGT, wt2, lane, lr, lg, g2, RS, wqg);
                     ag[0][0] = g2[0][0]; ag[0][1] = g2[0][1]; ag[1][0] = g2[1][0]; ag[1][1] = g2[1][1];
                 }
+                quad_prefetch<1, NQ, PDC>(lp.bhc, NCT, wt1, lane, wqc);
                 f32x4 ug[2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
@@ -345,8 +350,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                 // candidate h-part: hops(r*h) x Wc^h
                 {
                     f32x4 c1[1][2] = {{ag[2][0], ag[2][1]}};
-                    const int wt1[1] = {ct};
-                    gemm_stream_quad<1, NQ, (NQ < 10 ? NQ : 10)>(A2, KAP, lp.bhc, NCT, wt1, lane, lr, lg, c1, RS);
+                    gemm_stream_quad<1, NQ, PDC, true>(A2, KAP, lp.bhc, NCT, wt1, lane, lr, lg, c1, RS, wqc);
                     ag[2][0] = c1[0][0]; ag[2][1] = c1[0][1];
                 }
 #pragma unroll
