@@ -149,7 +149,7 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
 
 # kernel symbol behind every role at the cfg2 shapes (64 units, M = 3, 19 nodes)
 ROLE_SYMBOLS = {
-    "seq_fwd": "seq_fwd2_kernel<64,3,5>", "seq_bwd": "seq_bwd_kernel<64,3,5>",
+    "seq_fwd": "seq_fwd2_kernel<64,3,5>", "seq_bwd": "seq_bwd2_kernel<64,3,5>",
     "gemm_nn_xw": "gemm_nn_dma_kernel<6,20,2> (layer 0, K=300) + gemm_nn_dma_kernel<6,16,2> (layer 1, K=192)",
     "gemm_nn_dx": "gemm_nn_dma_kernel<6,16,2>", "gemm_tn_x": "gemm_tn_dma_kernel<2,6,16>",
     "gemm_tn_hg": "gemm_tn_dma_kernel<2,4,32>", "gemm_tn_hc": "gemm_tn_dma_kernel<2,2,32>",
