@@ -239,7 +239,7 @@ constexpr int kDecRows = 20;     // node rows of the LDS tiles (montages of at m
 
 // LDS floats of dec_fwd_persist_kernel<64, M>
 __host__ __device__ constexpr size_t dec_fwd_lds_floats(int M, int L, int Dout) {
-    const int H = 64, KAP = M * H, XS = M * round_up(Dout, 16);
+    const int H = 64, KAP = M * H, XS = lds_stride_q(M * round_up(Dout, 16));
     return (size_t)(M - 1) * kPFloats + (size_t)L * kDecRows * KAP + (size_t)kDecRows * (XS > KAP ? XS : KAP) + 4 * 3 * kRemTile;
 }
 
@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
     constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, NCT = H / 16, NGT = 2 * NCT, NQ = M * H / 16;
     EEG_DYN_SMEM(sm);
     const int T = a.T, B = a.B, N = a.N, Dout = a.Dout, L = a.L, act = a.act;
-    const int FP = round_up(Dout, 16), XS = M * FP, XK = XS > KAP ? XS : KAP;
+    // X0 row stride = 4 mod 64 dwords: the ds_read_b32 fragment reads of the layer-0 input GEMM (lane (lr, lg): row lr,
+    // column c + lg) then cover the 64 banks exactly (M*FP = 560 gave 4-way conflicts: 7.8 % of the wave cycles)
+    const int FP = round_up(Dout, 16), XS = lds_stride_q(M * FP), XK = XS > KAP ? XS : KAP;
     float* Pl = sm;
     float* A0 = Pl + (M - 1) * kPFloats;            // L state tiles [ROWS][KAP]: slot 0 = h^l, slots m = P_m h^l
     float* XA = A0 + L * ROWS * KAP;                // step-input tile X0 [ROWS][XS] (plain)  |  r*h tile A2 [ROWS][KAP] (swizzled)
@@ -449,8 +451,8 @@ struct DecBwdArgs {
 };
 
 __host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) {
-    const int H = 64, FP = round_up(Dout, 16);
-    return (size_t)(M - 1) * kPFloats + (size_t)kDecRows * (M * H + M * 2 * H) + 2 * (size_t)kDecRows * FP
+    const int H = 64, FS = lds_stride_q(round_up(Dout, 16));
+    return (size_t)(M - 1) * kPFloats + (size_t)kDecRows * (M * H + M * 2 * H) + 2 * (size_t)kDecRows * FS
            + (size_t)L * 4 * 2 * 256 + 4 * 3 * kRemTile;
 }
 
@@ -462,13 +464,13 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
     constexpr int kCx = cell_pack_cx_cols(H, H) / 16;     // column tiles of the c1 / c2 packs (12)
     EEG_DYN_SMEM(sm);
     const int T = a.T, B = a.B, N = a.N, Dout = a.Dout, L = a.L, act = a.act;
-    const int FP = round_up(Dout, 16);
+    const int FP = round_up(Dout, 16), FS = lds_stride_q(FP);      // row stride of the output-gradient tiles: 4 mod 64 dwords (conflict-free fragment reads)
     float* Pl = sm;
     float* EC = Pl + (M - 1) * kPFloats;     // [ROWS][KAP]  slot 0 = dC, slots m = P_m^T dC
     float* EG = EC + ROWS * KAP;             // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
-    float* DO = EG + ROWS * KGP;             // [ROWS][FP]   total gradient of out_t
-    float* DX = DO + ROWS * FP;              // [ROWS][FP]   input gradient of layer 0 at step t (feeds dO_{t-1})
-    float* DH = DX + ROWS * FP;              // [L][4 waves][2][64 lanes] float4: recurrent gradients dh^l, lane-linear
+    float* DO = EG + ROWS * KGP;             // [ROWS][FS]   total gradient of out_t
+    float* DX = DO + ROWS * FS;              // [ROWS][FS]   input gradient of layer 0 at step t (feeds dO_{t-1})
+    float* DH = DX + ROWS * FS;              // [L][4 waves][2][64 lanes] float4: recurrent gradients dh^l, lane-linear
     float* RS0 = DH + L * 4 * 2 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
     float* RS = RS0 + wave * (3 * kRemTile);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
-        for (int e = tid; e < (int)(ROWS * (KAP + KGP) + 2 * ROWS * FP + L * 4 * 2 * 256); e += 256) EC[e] = 0.f;
+        for (int e = tid; e < (int)(ROWS * (KAP + KGP) + 2 * ROWS * FS + L * 4 * 2 * 256); e += 256) EC[e] = 0.f;
         lds_load_polys(Pl, a.P, a.p_batched ? b : 0, M, N);
         __syncthreads();
         float pf[poly_slots<M, NKS>()][NKS];
@@ -549,8 +551,8 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
             for (int e = tid; e < N * (Dout / 4); e += 256) {
                 const int n = e / (Dout / 4), c4 = e % (Dout / 4);
                 f32x4 g = ld4(a.dOut + (s * N + n) * Dout + 4 * c4);
-                if (fb) g += ld4(DX + n * FP + 4 * c4);
-                st4(DO + n * FP + 4 * c4, g);
+                if (fb) g += ld4(DX + n * FS + 4 * c4);
+                st4(DO + n * FS + 4 * c4, g);
                 st4(a.dOtot + (s * N + n) * Dout + 4 * c4, g);
             }
             __syncthreads();
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
             f32x4 gext[2];
             {
                 f32x4 pa[1][2] = {{zero4, zero4}};
-                gemm_stream_plain<1, DT, false, true>(DO, FP, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS, wpt);
+                gemm_stream_plain<1, DT, false, true>(DO, FS, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS, wpt);
                 gext[0] = pa[0][0];
                 gext[1] = pa[0][1];
             }
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                         if (j >= nct_o || i + 1 >= ntp) continue;
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
-                            if (nt == 0 || lr < 4) st4(DX + rowt[nt] * FP + j * 16 + 4 * lg, dx[i][nt]);
+                            if (nt == 0 || lr < 4) st4(DX + rowt[nt] * FS + j * 16 + 4 * lg, dx[i][nt]);
                     }
                 }
                 __syncthreads();                                         // (3) tiles free for the next pair; DX complete
