@@ -156,6 +156,12 @@ int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nc
     // few row blocks (per-step decoder GEMMs): narrower column blocks fill more CUs
     if (nct_total <= 4 || ceil_div(R, 128) * ceil_div(nct_total, 12) < 160)
         return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
+    // column block of 12, 10 or 8 tiles, whichever leaves the fewest padding tiles (20 tiles = dX at M = 5: 2 x 10
+    // instead of 2 x 12 with a sixth of the MFMAs on padding)
+    const int pad6 = round_up(nct_total, 12) - nct_total, pad5 = round_up(nct_total, 10) - nct_total, pad4 = round_up(nct_total, 8) - nct_total;
+    if (pad5 < pad6 && pad5 <= pad4 && F % 16 == 0 && nn_dma_ok(F, R, ldc))
+        return run_nn_dma<5, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
+    if (pad4 < pad6 && nn_dma_ok(F, R, ldc)) return run_nn_kc<4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
     return run_nn_kc<6>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
 }
 
