@@ -3,12 +3,12 @@
 # separate passes for FETCH_SIZE and WRITE_SIZE (counters only + kernel trace, no other trace domains);
 # read bytes = 2 * FETCH_SIZE * 1024 on gfx950 (wide coalesced reads are tallied at half their size),
 # write bytes = WRITE_SIZE * 1024.  Writes gpurun_out/pmc_traffic_<workload>.json (copy into profiles/).
-# usage: pmc_traffic.sh [workload]
-W="${1:-cfg2}"
+# usage: pmc_traffic.sh [workload] [extra bench args, e.g. --tune 14=64]
+W="${1:-cfg2}"; shift
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_${W}_$c" -o pmc -- \
-      python "$OLDPWD/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph --no-stream-inputs > "$OLDPWD/gpurun_out/pmc_${W}_$c.log" 2>&1 )
+      python "$OLDPWD/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph --no-stream-inputs "$@" > "$OLDPWD/gpurun_out/pmc_${W}_$c.log" 2>&1 )
 done
 python - "$W" <<'PY'
 import csv, glob, collections, json, sys
