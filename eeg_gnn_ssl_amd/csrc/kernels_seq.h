@@ -387,6 +387,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     float* U = A2 + 32 * KAP + 8 * kRemTile;          // [16][UST] update gate of nodes 0..15 of the current step
     const bool save = Rs != nullptr;
     const int ct = wave;                               // NCT == 4 == waves per role
+    // results leave through buffer descriptors (one VGPR offset per node tile, the step offset in an SGPR): the 64-bit
+    // per-lane address arithmetic of ~10 stores per step is VALU work, and VALU shares its ALUs with the fp32 MFMAs
+    const wbuf_t bH = make_wbuf(Hseq), bR = make_wbuf(save ? Rs : Hseq), bU = make_wbuf(save ? Us : Hseq),
+                 bC = make_wbuf(save ? Cs : Hseq), bRH = make_wbuf(save ? RHs : Hseq);
+    // (the launcher takes this kernel only while T*B*N*H floats stay below 2 GB: 32-bit buffer offsets)
 
     float w0[1][KS], w1[1][KS];                        // role A: r and c fragments; role B: u and c fragments
 #pragma unroll
@@ -437,8 +442,10 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         fetch_xw(0);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
-            f32x4 ar[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
-            const f32x4 xr[2] = {nxr[0], nxr[1]}, xc = nxc;
+            // the accumulators start from the hoisted pre-activations (no zero fill, no add behind the GEMM); the
+            // remainder tile's accumulator is read on lanes lr < 4 only
+            f32x4 ar[1][2] = {{nxr[0], lr < 4 ? nxr[1] : zero4}}, ac[1][2] = {{nxc, zero4}};
+            const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1) hops(h) complete
             pp.mark(0);
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, ar, RS);
@@ -447,13 +454,13 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 rg;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rg[r] = sigmoidf_(ar[0][nt][r] + xr[nt][r]);
+                for (int r = 0; r < 4; ++r) rg[r] = sigmoidf_(ar[0][nt][r]);
                 f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
                 rh = valid[nt] ? rh : zero4;
                 st4(A2 + lds_sw(node[nt], col, KAP), rh);
                 if (save && valid[nt]) {
-                    st4(Rs + s * N * H + oh[nt], rg);
-                    st4(RHs + s * N * H + oh[nt], rh);
+                    wbuf_st4(bR, oh[nt], so, rg);
+                    wbuf_st4(bRH, oh[nt], so, rh);
                 }
             }
             pp.mark(2);
@@ -469,15 +476,15 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 f32x4 c, hn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pre = ac[0][0][r] + xc[r];
+                    const float pre = ac[0][0][r];
                     c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
                     hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                 }
                 hn = valid[0] ? hn : zero4;
                 st4(A + lds_sw(lr, col, KAP), hn);
                 if (valid[0]) {
-                    st4(Hseq + s * N * H + oh[0], hn);
-                    if (save) st4(Cs + s * N * H + oh[0], c);
+                    wbuf_st4(bH, oh[0], so, hn);
+                    if (save) wbuf_st4(bC, oh[0], so, c);
                 }
             }
             pp.mark(5);
@@ -496,8 +503,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         fetch_x(0);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
-            f32x4 au[1][2] = {{zero4, zero4}}, ac[1][2] = {{zero4, zero4}};
-            const f32x4 xu[2] = {nxu[0], nxu[1]}, xc = nxc;
+            f32x4 au[1][2] = {{nxu[0], lr < 4 ? nxu[1] : zero4}}, ac[1][2] = {{zero4, lr < 4 ? nxc : zero4}};
+            const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1)
             if (t + 1 < T) fetch_x(t + 1);
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, au, RS);
@@ -506,11 +513,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 f32x4 u0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    u0[r] = sigmoidf_(au[0][0][r] + xu[0][r]);
-                    u[r] = sigmoidf_(au[0][1][r] + xu[1][r]);
+                    u0[r] = sigmoidf_(au[0][0][r]);
+                    u[r] = sigmoidf_(au[0][1][r]);
                 }
                 st4(U + lds_sw(lr, col, UST), u0);                        // nodes >= N: finite, never used
-                if (save && valid[0]) st4(Us + s * N * H + oh[0], u0);
+                if (save && valid[0]) wbuf_st4(bU, oh[0], so, u0);
             }
             EEG_LDS_BARRIER();                                        // (2)
             // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend
@@ -520,17 +527,17 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 f32x4 c, hn;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pre = ac[0][1][r] + xc[r];
+                    const float pre = ac[0][1][r];
                     c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
                     hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
                 }
                 hn = valid[1] ? hn : zero4;
                 if (lr < 4) st4(A + lds_sw(node[1], col, KAP), hn);       // rows 16..19 (the others belong to nobody here)
                 if (valid[1]) {
-                    st4(Hseq + s * N * H + oh[1], hn);
+                    wbuf_st4(bH, oh[1], so, hn);
                     if (save) {
-                        st4(Cs + s * N * H + oh[1], c);
-                        st4(Us + s * N * H + oh[1], u);
+                        wbuf_st4(bC, oh[1], so, c);
+                        wbuf_st4(bU, oh[1], so, u);
                     }
                 }
             }
@@ -834,17 +841,20 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             }
             const size_t tstride = (size_t)B * N * H, boff = (size_t)b * N * H;
             f32x4 nh[2], nr[2], nu[2], nc[2], ng[2];
+            // operands through buffer descriptors (one VGPR offset per node tile, the step offset in an SGPR): no 64-bit
+            // per-lane address arithmetic on the VALU, which shares its ALUs with the fp32 MFMAs of the other role
+            const wbuf_t bH = make_wbuf(Hseq), bH0 = make_wbuf(h0 != nullptr ? h0 : Hseq), bR = make_wbuf(Rs), bU = make_wbuf(Us),
+                         bC = make_wbuf(Cs), bG = make_wbuf(dHseq != nullptr ? dHseq : Hseq);
             auto fetch = [&](int t) {
-                const size_t so = (size_t)t * tstride + boff;
-                const float* hs = t > 0 ? Hseq + (so - tstride) : (h0 != nullptr ? h0 + boff : nullptr);
+                const unsigned so = (unsigned)((size_t)t * tstride + boff);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int o = oh[nt];
-                    nh[nt] = hs != nullptr ? ld4(hs + o) : zero4;
-                    nr[nt] = ld4(Rs + so + o);
-                    nu[nt] = ld4(Us + so + o);
-                    nc[nt] = ld4(Cs + so + o);
-                    f32x4 g = dHseq != nullptr ? ld4(dHseq + so + o) : zero4;
+                    const unsigned o = oh[nt];
+                    nh[nt] = t > 0 ? wbuf_ld4(bH, o, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld4(bH0, o, (unsigned)boff) : zero4);
+                    nr[nt] = wbuf_ld4(bR, o, so);
+                    nu[nt] = wbuf_ld4(bU, o, so);
+                    nc[nt] = wbuf_ld4(bC, o, so);
+                    f32x4 g = dHseq != nullptr ? wbuf_ld4(bG, o, so) : zero4;
                     if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + boff + o);
                     if (t == t_len) g += ld4(d_at_len + boff + o);
                     ng[nt] = g;
@@ -944,8 +954,9 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     const size_t boff = (size_t)b * N * H;
     f32x4 dhn[2] = {zero4, zero4};                                  // A's elementwise part of dh
     EEG_LDS_BARRIER();                                              // (3) of an imaginary step T: first coefficients, DP
+    const wbuf_t bX = make_wbuf(dXW);
     for (int t = T - 1; t >= 0; --t) {
-        float* dxw = dXW + ((size_t)t * B + b) * N * (3 * H);
+        const unsigned sx = (unsigned)(((size_t)t * B + b) * N * (3 * H));
         // ---- E1: g = A's elementwise part + role B's GEMM2 of the step before (+ external gradient, added by B)
         f32x4 hr1[2], rg[2];                                        // taken now: role B refills the slots in window 1
 #pragma unroll
@@ -955,8 +966,8 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             st4(EC + lds_sw(node[nt], col, KAP), dC);               // zeros on padding nodes
             st4(EG + lds_sw(node[nt], H + col, KGP), du_);
             if (valid[nt]) {
-                st4(dxw + oxw[nt] + 2 * H, dC);
-                st4(dxw + oxw[nt] + H, du_);
+                wbuf_st4(bX, oxw[nt] + 2 * H, sx, dC);
+                wbuf_st4(bX, oxw[nt] + H, sx, du_);
             }
             dhn[nt] = g * ld4(CF + (2 * 2 + nt) * 256);
             hr1[nt] = ld4(CF + (3 * 2 + nt) * 256);
@@ -979,7 +990,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             const f32x4 dR = drh * hr1[nt];
             dhn[nt] += drh * rg[nt];
             st4(EG + lds_sw(node[nt], col, KGP), dR);
-            if (valid[nt]) st4(dxw + oxw[nt], dR);
+            if (valid[nt]) wbuf_st4(bX, oxw[nt], sx, dR);
         }
         pp.mark(3);
         EEG_WAVE_SYNC();

@@ -30,7 +30,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
     }
 #endif
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // M >= 4: the r + c weights of a wave no longer fit in 256 registers
-        if (a.variant == 1) {
+        if (a.variant == 1 && (double)a.T * a.B * a.N * H * sizeof(float) < 2147483648.0) {      // (32-bit buffer offsets of its stores)
             const size_t lds2 = lds + 16 * 64 * sizeof(float);      // + the update-gate tile U [16][64]
 #if defined(EEG_DEV)
             if constexpr (M == 3) {
@@ -73,7 +73,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
     }
 #endif
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // two waves per SIMD: role A holds w1 + half of w2 (M >= 4: > 256 registers)
-        if (a.variant == 1) {
+        if (a.variant == 1 && (double)a.T * a.B * a.N * 3 * H * sizeof(float) < 2147483648.0) {   // (32-bit buffer offsets)
             const size_t lds2 = ((size_t)(M - 1) * kPFloats + 32 * (SeqGeom<H, M>::KAP + SeqGeom<H, M>::KGP) + 8 * kRemTile + 4 * 20 * 20 + 4 * 5 * 2 * 256) * sizeof(float);
 #if defined(EEG_DEV)
             if constexpr (M == 3) {
