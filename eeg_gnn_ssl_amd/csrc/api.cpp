@@ -173,10 +173,9 @@ int run_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy
     const size_t lds = 2 * (size_t)(32 * 80 + 32 * YS) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_tn_kernel<NCTW>), lds);
     dim3 grid(nseg * ceil_div(F, 64), nsplit);
-    // measured on MI355X (cfg2): co-locating the k-blocks of a split on one XCD is SLOWER (gemm_tn 1.19 vs 1.04 ms
-    // per step) -- the default round-robin spread already serves the shared dY rows from the Infinity Cache and
-    // keeps eight L2s busy; the remap stays available as knob 4 for re-measurement on other shapes.
-    const int remap = (g_tune[4] == 1 && nsplit % 8 == 0 && grid.x > 1) ? 1 : 0;
+    // same XCD-aware placement as the DMA kernel (run_tn_dma); in this register-staged kernel it measured slower in round 1
+    // (1.19 vs 1.04 ms per step), so here it stays a dev knob (4 = 2)
+    const int remap = (g_tune[4] == 2 && nsplit % 8 == 0 && grid.x > 1) ? 1 : 0;
     EEG_LAUNCH_P(tag, (gemm_tn_kernel<NCTW>), grid, dim3(256), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, remap);
     return check_launch("gemm_tn");
 }
@@ -191,7 +190,10 @@ int run_tn_dma(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int
     const size_t lds = 2 * (size_t)(RC * KBW + RC * OT) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_tn_dma_kernel<KTW, NCTW, RC, WK>), lds);
     dim3 grid(ceil_div(nseg * F, KBW), nsplit);
-    EEG_LAUNCH_P(tag, (gemm_tn_dma_kernel<KTW, NCTW, RC, WK>), grid, dim3(128 * WK), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, bt.T, bt.B, bt.N);
+    // all k-blocks of a row split on ONE XCD (they read the same dY rows): PMC traffic of the class 831 -> 432 MB per launch
+    // (1.93x -> 1.00x algorithmic) at unchanged time (dev knob 4 = 1 switches the placement off)
+    const int remap = (g_tune[4] == 0 && nsplit % 8 == 0 && grid.x > 1) ? 1 : 0;
+    EEG_LAUNCH_P(tag, (gemm_tn_dma_kernel<KTW, NCTW, RC, WK>), grid, dim3(128 * WK), lds, st, segs, nseg, F, R, dY, ldy, ycol0, O, partial, rows_per_split, bt.T, bt.B, bt.N, remap);
     return check_launch("gemm_tn_dma");
 }
 
@@ -202,7 +204,10 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
     const bool dma = tn_dma_ok(F, O);
     const bool wide = dma && tn_wide_from() > 0 && O >= tn_wide_from();
     const int blocks = dma ? ceil_div(nseg * F, wide ? 2 * kTnKbw : kTnKbw) : nseg * ceil_div(F, 64);
-    int nsplit = ceil_div(wide ? (g_tune[15] > 0 ? g_tune[15] : 512) : 768, blocks);   // ~3 (wide: 2) workgroups per CU; more splits only add partial-sum traffic (measured)
+    // ~3 workgroups per CU (wide: 2) per 400 k rows: measured, R = 291 840 rows (cfg2/3/4): 768 workgroups best (1152: +12 %,
+    // 1536: +1..10 %); R = 583 680 (cfg5): 1536 best (768: +4 %, and +20 % on the h-gate shape with the XCD placement)
+    const int target = (wide ? 512 : 768) * ceil_div(R, 400000);
+    int nsplit = ceil_div(g_tune[15] > 0 ? g_tune[15] : target, blocks);
     int rps = round_up(ceil_div(R, nsplit), 32);
     if (rps < 128) rps = 128;
     nsplit = ceil_div(R, rps);

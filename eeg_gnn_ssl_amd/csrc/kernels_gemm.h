@@ -386,7 +386,7 @@ template <int KTW, int NCTW, int RC, int WK = 2>
 __global__ __launch_bounds__(128 * WK) void gemm_tn_dma_kernel(SegPtrs segs, int nseg, int F, int R,
                                                           const float* __restrict__ dY, int ldy, int ycol0, int Ov,
                                                           float* __restrict__ partial, int rows_per_split,
-                                                          int btT, int btB, int btN) {
+                                                          int btT, int btB, int btN, int xcd_remap) {
     constexpr int NW = 2 * WK, KBW = 16 * KTW * WK, KQ = KBW / 4, O = 2 * NCTW * 16, OQ = O / 4;
     constexpr int A_FLOATS = RC * KBW, Y_FLOATS = RC * O;
     constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, INS = A_INS + Y_INS, NI = (INS + NW - 1) / NW;
@@ -394,7 +394,16 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn_dma_kernel(SegPtrs segs, int
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int wk = wave >> 1, wc = wave & 1, lr = lane & 15, lg = lane >> 4;
-    const int K = nseg * F, k0 = blockIdx.x * KBW, split = blockIdx.y;
+    // xcd_remap (default where gridDim.y % 8 == 0): workgroups go round-robin over the 8 XCDs by linear id; with the remap
+    // all k-blocks of one row split (they read the same dY rows) land on ONE XCD, i.e. behind one L2 -- the re-reads stop
+    // at that L2 instead of going out to the fabric (PMC FETCH_SIZE of the x-part GEMM 634 -> 263 MB-units per launch)
+    int kblock = blockIdx.x, split = blockIdx.y;
+    if (xcd_remap) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        split = xcd + 8 * (slot / (int)gridDim.x);
+        kblock = slot % (int)gridDim.x;
+    }
+    const int K = nseg * F, k0 = kblock * KBW;
     const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
 

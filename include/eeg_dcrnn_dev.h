@@ -18,7 +18,7 @@ extern "C" {
  * instantiations carry the probe. */
 int eeg_dcrnn_set_seq_probe(int64_t* probe);
 /* Integer knobs selecting kernel variants for A/B timing.  key 0 = 1: register-staged NN GEMM;
- * key 1 = 1: register-staged TN GEMM; key 4 = 1: XCD-aware placement of the TN k-blocks;
+ * key 1 = 1: register-staged TN GEMM; key 4 = 1: NO XCD-aware placement of the TN k-blocks in the LDS-DMA kernel (2: placement in the register-staged one);
  * key 9 = 1: LDS/MFMA adjoint diffusion; key 12 = 1: single-wave-per-SIMD forward recurrent kernel also
  * where the two-wave one exists (64 units, M <= 3); key 13 = 1: the same for the BPTT kernel; key 11 = 1: per-step
  * launches in the decoder forward instead of the persistent kernel, key 10 = 1: the same for the decoder backward;
