@@ -1,8 +1,8 @@
-// Times the product NN GEMM kernel (eeg-gnn-ssl_amd/csrc/kernels_gemm.h) in isolation at the cfg2 shapes.
+// Times the product NN GEMM kernel (eeg_gnn_ssl_amd/csrc/kernels_gemm.h) in isolation at the cfg2 shapes.
 // (Round-1 experiments with persistent / 64- and 96-row-tile register-staged variants: DESIGN.md section 4.2.)
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../eeg-gnn-ssl_amd/csrc/kernels_gemm.h"
+#include "../../eeg_gnn_ssl_amd/csrc/kernels_gemm.h"
 using namespace eeg;
 static float* A; static float* Bp; static float* C; static float* bias;
 template <typename K, typename... Args>
