@@ -47,24 +47,55 @@ __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
 }
 #define EEG_VM_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {   // offsets in floats
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2_){__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, b, 4u * voff, 4u * soff, 0);
+}
+__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), b, 4u * voff, 4u * soff, 0);
+}
 #else
+__device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {
+    float* q = const_cast<float*>(b.p) + (size_t)voff + soff; q[0] = x; q[1] = y;
+}
+__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) { const_cast<float*>(b.p)[(size_t)voff + soff] = x; }
 __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
     memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
 }
 #define EEG_VM_WAIT_BARRIER(n) __syncthreads()
 #endif
 
+#if defined(EEG_SIMT_EMU)
+struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+#else
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#endif
 template <int V> struct IntC { static constexpr int value = V; };
+// a value the optimiser cannot see through: keeps rare-path computations from being hoisted out of a hot loop (and
+// parked in registers the loop needs)
+__device__ __forceinline__ int opaque(int v) {
+#if !defined(EEG_SIMT_EMU)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 
-// ABL (lab only): 1 = no C stores, 2 = no DMA after the prologue, 3 = both.
+// ABL (lab only, bits): 1 = no C stores, 2 = no DMA after the prologue, 4 = A always fetched from the first rows / chunk
+// (cache-hot), 8 = B always fetched from chunk 0 (cache-hot), 16 = the DMAs of a chunk are issued between the row tiles
+// instead of all at the top, 32 = every tile is stored over the workgroup's first tile (cache-resident C), 64 = the
+// stores of a tile interleaved with the MFMAs of its last chunk instead of one burst behind it.  flags bits 0-1: which workgroups start with a HALF first tile (0 none, 1 the upper half of
+// the grid, 2 odd ids, 3 bit 3 of the id) -- the two workgroups of a CU then store their tiles half a tile apart.
 // Requires: O % 4 == 0, ldc % 4 == 0, F % 4 == 0, at most 2 tail chunks (make_nnq_order(nseg, F).ntail <= 2), every
 // segment and C smaller than 4 GB (32-bit buffer offsets).  LDS: NS stages of 20 KB.
 template <int NS, int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg, int F, int R,
                                                          const float* __restrict__ Bq, int nct_total,
                                                          const float* __restrict__ bias, float* __restrict__ C, int ldc, int O,
-                                                         int btT, int btB, int btN) {
+                                                         int btT, int btB, int btN, int flags, long long* __restrict__ probe = nullptr) {
     constexpr int NB = 12, AF = 128 * 16, ST = kNnqStageFloats, NST = 24;
+    constexpr bool PROBE = (ABL & 128) != 0;   // lab: cycle counters per workgroup (wave 0): probe[8]
+    const long long tk0 = PROBE ? cycle_now() : 0, tr0 = PROBE ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc6 = 0, pc7 = 0;   // waits after an epilogue (0, 1, 2 iterations), other waits, their count, iteration cycles, epilogue cycles, epilogues
     static_assert(NS >= 2 && NS <= 5, "ring depth");
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
@@ -72,9 +103,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
     const int nch = ko.nch;
     const int RT = ceil_div(R, 16);
     const int rt0 = (int)((long long)blockIdx.x * RT / gridDim.x), rt1 = (int)((long long)(blockIdx.x + 1) * RT / gridDim.x);
-    const int ntile = ceil_div(rt1 - rt0, 8);
-    if (ntile <= 0) return;
-    const int nrt_last = (rt1 - rt0) - 8 * (ntile - 1);
+    const int nrows = rt1 - rt0;                           // row tiles of this workgroup
+    if (nrows <= 0) return;
+    const int bid = blockIdx.x, pm = flags & 7;
+    const bool half_first = pm == 1 ? bid >= (int)gridDim.x / 2 : pm == 2 ? (bid & 1) : pm == 3 ? ((bid >> 3) & 1) : false;
+    int nrt_first = half_first ? 4 : 8;
+    if (pm == 4) nrt_first = 4 + bid % 5;                  // five phases: the C stores of the grid spread over the tile period
+    if (pm == 5) nrt_first = 1 + bid % 8;
+    if (pm == 6) nrt_first = 4 + (bid >> 3) % 5;
+    if (nrt_first > nrows) nrt_first = nrows;
+    const int ntile = 1 + ceil_div(nrows - nrt_first, 8);
+    // tile t covers row tiles [tile_rt(t), tile_rt(t) + tile_nrt(t))
+    auto tile_rt = [&](int t) __attribute__((always_inline)) { return rt0 + (t == 0 ? 0 : nrt_first + 8 * (t - 1)); };
+    auto tile_nrt = [&](int t) __attribute__((always_inline)) {
+        if (t == 0) return nrt_first;
+        const int left = nrows - nrt_first - 8 * (t - 1);
+        return left < 8 ? left : 8;
+    };
     const int ct0 = blockIdx.y * NB;
     const int Q = ntile * nch;
 
@@ -99,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
     int d_tile = 0, d_c = 0, d_seg = 0, d_kc = 0, d_stage = 0;
     unsigned a_voff[2];                                    // (row * F + 4 * piece) * 4 bytes of the two A rows this lane fetches
     auto tile_rows = [&](int tile) __attribute__((always_inline)) {
-        const int row0 = (rt0 + 8 * tile) * 16;
+        const int row0 = ((ABL & 4) ? rt0 : tile_rt(tile)) * 16;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int r = row0 + 16 * (w + 4 * i) + (lane >> 2);
@@ -112,28 +157,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
         }
     };
     tile_rows(0);
-    auto issue_dma = [&]() __attribute__((always_inline)) {
+    // the 5 DMAs of a chunk: part 0 = the two A pieces of this wave, parts 1..3 = its three weight column tiles (and the
+    // cursor advance with part 3)
+    auto issue_part = [&](int part) __attribute__((always_inline)) {
         float* base = sm + d_stage * ST;
-        if (d_c < ko.nmain) {
-            const wbuf_t ra = make_wbuf(segs.p[d_seg]);
-            wbuf_dma16(ra, base + w * 256, a_voff[0], (unsigned)d_kc * 4u);
-            wbuf_dma16(ra, base + (w + 4) * 256, a_voff[1], (unsigned)d_kc * 4u);
-            d_kc += 16;
-            if (d_kc == ko.a * 16) { d_kc = 0; ++d_seg; }
-        } else {
-            const char* p = reinterpret_cast<const char*>(d_c == ko.nmain ? tptr[0] : tptr[1]) - 16 * a_piece;
-            lds_dma16(base + w * 256, reinterpret_cast<const float*>(p + a_voff[0]));
-            lds_dma16(base + (w + 4) * 256, reinterpret_cast<const float*>(p + a_voff[1]));
+        if (part == 0) {
+            if (d_c < ko.nmain) {
+                const wbuf_t ra = make_wbuf(segs.p[d_seg]);
+                const unsigned so = (ABL & 4) ? 0u : (unsigned)d_kc * 4u;
+                wbuf_dma16(ra, base + w * 256, a_voff[0], so);
+                wbuf_dma16(ra, base + (w + 4) * 256, a_voff[1], so);
+                d_kc += 16;
+                if (d_kc == ko.a * 16) { d_kc = 0; ++d_seg; }
+            } else {
+                const char* p = reinterpret_cast<const char*>(d_c == ko.nmain ? tptr[0] : tptr[1]) - 16 * a_piece;
+                lds_dma16(base + w * 256, reinterpret_cast<const float*>(p + a_voff[0]));
+                lds_dma16(base + (w + 4) * 256, reinterpret_cast<const float*>(p + a_voff[1]));
+            }
+            return;
         }
-        const unsigned bso = (unsigned)(d_c * nct_total) * 1024u;
-        wbuf_dma16(rb, base + AF + w * 256, b_voff[0], bso);
-        wbuf_dma16(rb, base + AF + (w + 4) * 256, b_voff[1], bso);
-        wbuf_dma16(rb, base + AF + (w + 8) * 256, b_voff[2], bso);
-        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
-        if (++d_c == nch) {
-            d_c = 0; d_seg = 0; d_kc = 0;
-            if (++d_tile < ntile) tile_rows(d_tile);
+        const unsigned bso = (ABL & 8) ? 0u : (unsigned)(d_c * nct_total) * 1024u;
+        wbuf_dma16(rb, base + AF + (w + 4 * (part - 1)) * 256, b_voff[part - 1], bso);
+        if (part == 3) {
+            d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+            if (++d_c == nch) {
+                d_c = 0; d_seg = 0; d_kc = 0;
+                if (++d_tile < ntile) tile_rows(d_tile);
+            }
         }
+    };
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(part);
     };
 
     // ---- compute side ---------------------------------------------------------------------------------------------
@@ -146,6 +201,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
     const int b_lds = AF + 3 * w * 256 + lane * 4;
     f32x4 acc[8][3], oa[8], ob[3], obn[3];
     int r_stage = 0, m_c = 0, m_tile = 0, epi_age = 100, epi_cnt = 0;
+    // the two workgroups of a CU (ids b and b + G/2) share each SIMD's matrix pipe; at equal priority the older one wins
+    // every arbitration and finishes far ahead of the other, which then runs alone: alternate who has priority
+    const int prio_mode = (flags >> 3) & 3, prio_phase = bid >= (int)gridDim.x / 2 ? 1 : 0;
+    if (prio_mode == 3 && prio_phase) EEG_SETPRIO(1);
 
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
@@ -169,6 +228,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
 
     for (int q = 0; q < Q; ++q) {
         const bool more = q + 1 < Q;
+        const long long t0 = PROBE ? cycle_now() : 0;
+        if (prio_mode == 1) { if ((q + prio_phase) & 1) EEG_SETPRIO(1); else EEG_SETPRIO(0); }
+        if (prio_mode == 2 && m_c == 0) { if ((m_tile + prio_phase) & 1) EEG_SETPRIO(1); else EEG_SETPRIO(0); }
         // chunk q+1 must have landed (the DMAs of chunks q+2 .. q+NS-2 and the C stores issued since it was requested may
         // stay in flight); after the barrier every wave has finished reading chunk q-1, whose stage is refilled next
         if (more) {
@@ -182,29 +244,56 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
             } else {
                 EEG_VM_WAIT_BARRIER(0);
             }
-            if ((ABL & 2) == 0 && q + NS - 1 < Q) issue_dma();
+            if (PROBE) {
+                const long long dt = cycle_now() - t0;
+                if (epi_age == 0) pc0 += dt; else if (epi_age == 1) pc1 += dt; else if (epi_age == 2) pc2 += dt; else { pc3 += dt; pc4 += 1; }
+            }
+            if ((ABL & (2 | 16)) == 0 && q + NS - 1 < Q) issue_dma();
         }
+        const bool spread = (ABL & 16) != 0 && (ABL & 2) == 0 && more && q + NS - 1 < Q;
         // (the last chunk of the range re-reads a stale stage into registers nobody uses: no branch around the reads)
         const float* st = sm + r_stage * ST;
 #pragma unroll
         for (int j = 0; j < 3; ++j) obn[j] = *reinterpret_cast<const f32x4*>(st + b_lds + j * 256);
-        const int nrt = m_tile == ntile - 1 ? nrt_last : 8;
+        const int nrt = tile_nrt(m_tile);
+        // A CU retires ~17 B/clk of stores: the 96 KB of a tile keep the 4 waves off the matrix pipe for ~5.5 k cycles
+        // (probe in tools/micro/gemm_lab.hip).  ABL 64 (lab) issues the 3 stores of a row tile right behind the MFMAs of
+        // the next one in the last chunk, so that they drain under MFMAs: the storing workgroup then loses nothing, but
+        // the OTHER workgroup of the CU (the younger one: every arbitration goes to the older wave) no longer gets the
+        // burst as its turn, falls ~25 % behind and runs alone at the end -- slower overall (0.705 vs 0.738), not shipped.
+        const int row0 = ((ABL & 32) ? rt0 : tile_rt(m_tile)) * 16;
+        const bool fast_tile = nrt == 8 && row0 + 128 <= R && cols_full;   // exactly NST unconditional stores: the counted waits rely on it
+        const bool store_now = (ABL & 64) != 0 && (ABL & 1) == 0 && fast_tile && m_c + 1 == nch;   // lab variant, see below
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (i < nrt) {                                 // (a partial last tile multiplies its own row tiles only)
+            if (i < nrt) {                                 // (a partial tile multiplies its own row tiles only)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(ob[j][s], oa[i][s], acc[i][j]);   // transposed issue
             }
             oa[i] = *reinterpret_cast<const f32x4*>(st + a_lds + i * 256);   // refilled in place from chunk q+1
+            if ((ABL & 16) != 0 && i < 4 && spread) issue_part(i);
+            if (store_now && i > 0) {                      // row tile i-1: its MFMAs have left the pipe by now
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * (i - 1)) * (unsigned)ldc, acc[i - 1][j]);
+                }
+            }
+        }
+        if (store_now) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * 7) * (unsigned)ldc, acc[7][j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) ob[j] = obn[j];
         r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
         ++epi_age;
+        const long long t2 = PROBE ? cycle_now() : 0;
+        if (PROBE) pc5 += t2 - t0;
         if (++m_c == nch) {                                // the tile of chunk q is complete
-            const int row0 = (rt0 + 8 * m_tile) * 16;
             if (ABL & 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -213,29 +302,372 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
 #if !defined(EEG_SIMT_EMU)
                         asm volatile("" ::"v"(acc[i][j]));
 #endif
+                        acc[i][j] = bv[j];
                     }
                 epi_cnt = 0;
-            } else if (nrt == 8 && row0 + 128 <= R && cols_full) {   // exactly NST unconditional stores: the counted waits rely on it
+            } else if (store_now) {                        // stored row tile by row tile above
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < 3; ++j) acc[i][j] = bv[j];
+                epi_cnt = NST;
+            } else if (fast_tile) {                        // the whole tile in one burst
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
                         wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+                        acc[i][j] = bv[j];
+                    }
                 epi_cnt = NST;
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
-                    for (int j = 0; j < 3; ++j)
+                    for (int j = 0; j < 3; ++j) {
                         if (i < nrt && row0 + 16 * i + lr < R && c_col + 16 * j < O)
                             wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+                        acc[i][j] = bv[j];
+                    }
                 epi_cnt = 0;                               // unknown number of stores: the next waits assume none (over-wait)
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = bv[j];
             m_c = 0; ++m_tile; epi_age = 0;
+            if (PROBE) { pc6 += cycle_now() - t2; pc7 += 1; }
+        }
+    }
+    if (PROBE && probe != nullptr && tid == 0) {
+        long long* o = probe + blockIdx.x * 10;
+        o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = pc5; o[6] = pc6; o[7] = pc7;
+        o[8] = tr0; o[9] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round-3 TN GEMM (weight gradients): partial[split][k][o] = sum over the rows of the split of A[r][k] * dY[r][ycol0 + o].
+//
+// Against gemm_tn_dma_kernel: (i) a workgroup owns a (2*KT*16) x (2*OT*16) output block (192 x 192 = the WHOLE gradient of a
+// 64-unit cell at K = 192: A and dY are read once, nothing is re-read per k-block) for a long row range (2 workgroups per
+// CU, persistent over their split); (ii) the transposed MFMA operands come from LDS as ds_read_b128 / b64: lane i of a
+// 16-lane group reads 4 (2) CONSECUTIVE columns of one row and the 4 (2) MFMAs that use them own the column sets {4i + e}
+// ({2i + e}) -- a permuted tile <-> column assignment that only the epilogue has to know; 4 LDS reads per 36 MFMAs instead
+// of 12 per 12; (iii) dY streams through a buffer descriptor (no vector address arithmetic), and so does A where the hop
+// planes are 64 wide (PLANAR: one plane per DMA instruction); otherwise A goes through per-lane running pointers (its
+// 16-byte pieces come from different hop planes); (iv) LDS ring of 3 stages, the chunk barrier sits in front of the LAST
+// k-step of a chunk so that the first fragments of the next chunk are read one k-step ahead of their MFMAs.
+// LDS image of an operand chunk (RC rows, both wave slices wv = 0, 1 of T tiles each): three sub-arrays so that each read
+// width is conflict-free with plain immediate offsets:  P128 [2][RC][64*n4]  (row stride = 0 mod 64 dwords: the four 16-lane
+// service groups of a ds_read_b128 each cover all 64 banks),  P64 [RC][2][32] and P32 [RC][2][16] with the two wave slots
+// of ODD rows swapped (lane groups kk and kk+1 of one half-wave read consecutive rows: the swap puts them on different banks).
+// The images are filled by LDS-DMA (lane-linear), i.e. the layout is realised on the SOURCE side: lane l of DMA d fetches
+// the global piece that belongs at image position 256 d + 4 l.
+template <int T> struct TnqSlice {
+    static constexpr int n4 = T / 4, rem = T % 4, has64 = rem >= 2 ? 1 : 0, has32 = rem & 1;
+    static constexpr int w128 = 64 * n4, base64 = w128, base32 = base64 + 32 * has64;
+    static constexpr int ngroups = n4 + has64 + has32;
+    // slice-local column of element e of lane i's read in group g (g < n4: b128, then b64, then b32)
+    __host__ __device__ static constexpr int col(int g, int i, int e) {
+        return g < n4 ? 64 * g + 4 * i + e : (has64 && g == n4 ? base64 + 2 * i + e : base32 + i);
+    }
+    __host__ __device__ static constexpr int width(int g) { return g < n4 ? 4 : (has64 && g == n4 ? 2 : 1); }
+    // column inside the (2 * T * 16)-wide block of slice-local column u of wave slice wv.  Natural order: wv * 16 T + u.
+    // PLANAR (64-wide planes, T in {2, 4, 6}): the b128 group of slice 0 is the first plane of the block, that of slice 1 the
+    // last one, and the two b64 groups are the halves of the middle plane -- every group lies inside ONE plane.
+    template <bool PLANAR> __host__ __device__ static constexpr int block_col(int wv, int u) {
+        if (!PLANAR) return wv * 16 * T + u;
+        return u < w128 ? (wv == 0 ? 0 : 64 * (T / 2 - 1)) + u : 64 * n4 + 32 * wv + (u - base64);
+    }
+};
+// (row, wave slice, slice-local column) of image position pos (floats, multiple of 4) of an operand with T tiles per slice
+template <int T, int RC>
+__device__ __forceinline__ void tnq_image_pos(int pos, int& row, int& wv, int& u) {
+    using S = TnqSlice<T>;
+    constexpr int n128 = RC * 2 * S::w128, n64 = RC * 64 * S::has64, w = S::w128 > 0 ? S::w128 : 1;
+    if (pos < n128) {
+        wv = pos / (RC * w);
+        const int c = pos - wv * RC * w;
+        row = c / w; u = c - row * w;
+    } else if (pos < n128 + n64) {
+        pos -= n128; row = pos >> 6;
+        const int c = pos & 63;
+        wv = (c >> 5) ^ (row & 1); u = S::base64 + (c & 31);
+    } else {
+        pos -= n128 + n64; row = pos >> 5;
+        const int c = pos & 31;
+        wv = (c >> 4) ^ (row & 1); u = S::base32 + (c & 15);
+    }
+}
+
+// BT: the A segments are batch-major (btB clips x btT steps x btN nodes, see gemm_nn_dma_kernel); dY is always time-major.
+// PLANAR: F == 64 and KT in {2, 4, 6} (a k-block = KT / 2 whole planes), not BT.  Requires Ov == 32 * OT (whole column block).
+// TAIL = false: R % RC == 0 and rows_per_split % RC == 0 (no partial chunk anywhere): the clamp / zero-fill paths are compiled out.
+template <int KT, int OT, int RC, bool BT, bool PLANAR, bool TAIL>
+__global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                         const float* __restrict__ dY, int ldy, int ycol0, int Ov,
+                                                         float* __restrict__ partial, int rows_per_split,
+                                                         int btT, int btB, int btN, int flags) {
+    using SA = TnqSlice<KT>;
+    using SY = TnqSlice<OT>;
+    constexpr int NS = 3, KS = RC / 4;
+    constexpr int A_FLOATS = RC * 32 * KT, Y_FLOATS = RC * 32 * OT, ST = A_FLOATS + Y_FLOATS;
+    constexpr int A_INS = A_FLOATS / 256, Y_INS = Y_FLOATS / 256, NIA = (A_INS + 3) / 4, NIY = (Y_INS + 3) / 4;
+    static_assert(KS % 2 == 0 && A_FLOATS % 256 == 0 && Y_FLOATS % 256 == 0, "chunk shape");
+    static_assert(SA::n4 <= 1 && SY::n4 <= 2, "slice widths");
+    static_assert(!PLANAR || (!BT && KT % 2 == 0 && SA::has32 == 0), "planar blocks are whole 64-wide planes");
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), wk = w >> 1, wo = w & 1, li = lane & 15, kk = lane >> 4;
+    const int K = nseg * F, k0 = blockIdx.x * (32 * KT), split = blockIdx.y;
+    const int rbeg = split * rows_per_split;
+    const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
+    const int Q = rend > rbeg ? ceil_div(rend - rbeg, RC) : 0;
+
+    // ---- DMA side ------------------------------------------------------------------------------------------------------
+    // A DMA instruction covers 256 consecutive floats of a sub-array = 4 rows x 64 positions (P128, P64) or 8 rows x 32 (P32),
+    // so the lane part of a source offset is the same for every DMA of a sub-array and the rest is wave-uniform:
+    //   dY (and A when PLANAR): buffer descriptor + ONE per-lane offset per sub-array + a scalar offset per DMA;
+    //   A otherwise: a running 64-bit pointer per DMA of this lane's piece (BT: pointer of storage row 0 + (clip, step, node)
+    //   counters of the lane's current time-major row).
+    constexpr int NA128 = RC * 2 * SA::w128 / 256, NA64 = RC * 64 * SA::has64 / 256;
+    constexpr int NY128 = RC * 2 * SY::w128 / 256, NY64 = RC * 64 * SY::has64 / 256;
+    // lane parts (floats): row-in-DMA * ld + column; P64 / P32 pick the wave slot by the row parity (see the image layout).
+    // They are a handful of integer operations on the lane id and are RE-computed at every use (opaque(): not hoisted) --
+    // as loop-invariant registers they were what the 192 x 192 instance spilled.
+    auto lane_part = [&](int kind, int ld, int slot_w, int b64, int b32) __attribute__((always_inline)) -> unsigned {
+        const int ln = opaque(lane);
+        const int l16 = ln >> 4, c16 = 4 * (ln & 15), l8 = ln >> 3, c8 = 4 * (ln & 7);
+        if (kind == 0) return (unsigned)(l16 * ld + c16);
+        if (kind == 1) return (unsigned)(l16 * ld + (((c16 >> 5) ^ (l16 & 1)) * slot_w + b64 + (c16 & 31)));
+        return (unsigned)(l8 * ld + (((c8 >> 4) ^ (l8 & 1)) * slot_w + b32 + (c8 & 15)));
+    };
+    const wbuf_t ry = make_wbuf(dY + ycol0);
+    const char* a_ptr[NIA];
+    int mb[NIA], mt[NIA], mn[NIA];
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+        mb[i] = mt[i] = mn[i] = 0;
+        a_ptr[i] = nullptr;
+        if (PLANAR) continue;
+        const int d = w + 4 * i < A_INS ? w + 4 * i : A_INS - 1;   // (a wave without a DMA of its own repeats the last one: same bytes)
+        int row, wv, u;
+        tnq_image_pos<KT, RC>(256 * d + 4 * lane, row, wv, u);
+        int k = k0 + SA::template block_col<false>(wv, u);
+        if (k >= K) k = K - 4;                             // columns past K: fetched, multiplied, never stored
+        const int seg = k / F, f = k - seg * F;
+        const float* base = segs.p[0];
+#pragma unroll
+        for (int m = 1; m < kMaxM; ++m)
+            if (m < nseg && seg == m) base = segs.p[m];
+        int r = rbeg + row;                                // (rows past R are clamped when they are requested)
+        if (BT) {
+            if (r >= R) r = R - 1;
+            const int sm_ = r / btN;
+            mn[i] = r - sm_ * btN; mt[i] = sm_ / btB; mb[i] = sm_ - mt[i] * btB;
+            r = 0;
+        }
+        a_ptr[i] = reinterpret_cast<const char*>(base + f) + (size_t)r * F * 4;
+    }
+    int d_q = 0, d_stage = 0;
+    // one DMA of a descriptor-addressed operand: sub-array / row block / wave slot from the DMA index (wave-uniform)
+    auto dma_desc = [&](wbuf_t rs, float* dst, int d, int n128, int n64, int ld, int slot_w, int b64, int b32,
+                        int r0, int slot_stride, bool tail) __attribute__((always_inline)) {
+        unsigned rows_first, slot = 0;
+        int kind;
+        if (d < n128) {
+            const int per = n128 / 2;
+            slot = d / per; rows_first = 4 * (d - slot * per); kind = 0;
+        } else if (d < n128 + n64) {
+            rows_first = 4 * (d - n128); kind = 1;
+        } else {
+            rows_first = 8 * (d - n128 - n64); kind = 2;
+        }
+        unsigned vo = lane_part(kind, ld, slot_w, b64, b32) * 4u;
+        const unsigned r1 = (unsigned)r0 + rows_first;
+        if (tail) {                                        // rows past R re-read row R-1 (they are zeroed in LDS / never stored)
+            const int rin = kind == 2 ? opaque(lane) >> 3 : opaque(lane) >> 4;
+            const int over = (int)r1 + rin - (R - 1);
+            if (over > 0) vo -= (unsigned)over * (unsigned)ld * 4u;
+        }
+        wbuf_dma16(rs, dst, vo, (r1 * (unsigned)ld + slot * (unsigned)slot_stride) * 4u);
+    };
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+        float* base = sm + d_stage * ST;
+        const int r0 = rbeg + d_q * RC;
+        const bool tail = TAIL && r0 + RC > R;             // only the last chunk of the last split
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int d = w + 4 * i < A_INS ? w + 4 * i : A_INS - 1;
+            if (PLANAR) {
+                // plane of DMA d: P128 slot 0 -> first plane of the block, slot 1 -> the last one, P64 -> the middle one
+                int pl = d < NA128 ? (d < NA128 / 2 ? 0 : KT / 2 - 1) : SA::n4;
+                pl += k0 / 64;
+                if (pl >= nseg) pl = nseg - 1;             // planes past K: fetched, multiplied, never stored
+                dma_desc(make_wbuf(segs.p[pl]), base + d * 256, d, NA128, NA64, F, 32, 0, 0, r0, 0, tail);
+                continue;
+            }
+            const char* src;
+            if (BT) {
+                int mapped = (mb[i] * btT + mt[i]) * btN + mn[i];
+                if (tail) {
+                    int row, wv, u;
+                    tnq_image_pos<KT, RC>(256 * d + 4 * opaque(lane), row, wv, u);
+                    if (r0 + row >= R) mapped = R - 1;     // (the last time-major row is the last storage row)
+                }
+                src = a_ptr[i] + (size_t)mapped * F * 4;
+                mn[i] += RC;
+                while (mn[i] >= btN) {
+                    mn[i] -= btN;
+                    if (++mb[i] == btB) { mb[i] = 0; ++mt[i]; }
+                }
+            } else {
+                src = a_ptr[i];
+                if (tail) {
+                    int row, wv, u;
+                    tnq_image_pos<KT, RC>(256 * d + 4 * opaque(lane), row, wv, u);
+                    if (r0 + row >= R) src -= (size_t)(r0 + row - (R - 1)) * F * 4;
+                }
+                a_ptr[i] += (size_t)RC * F * 4;
+            }
+            lds_dma16(base + d * 256, reinterpret_cast<const float*>(src));
+        }
+#pragma unroll
+        for (int i = 0; i < NIY; ++i) {
+            const int d = w + 4 * i < Y_INS ? w + 4 * i : Y_INS - 1;
+            dma_desc(ry, base + A_FLOATS + d * 256, d, NY128, NY64, ldy, 16 * OT, SY::base64, SY::base32, r0, 16 * OT, tail);
+        }
+        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+        ++d_q;
+    };
+
+    // ---- compute side -----------------------------------------------------------------------------------------------
+    f32x4 acc[KT][OT];
+    // fragment read offsets (floats) of k-step 0; k-step ks adds 4 * ks * (row stride of the sub-array)
+    constexpr int A128 = 0, A64 = A128 + RC * 2 * SA::w128, A32 = A64 + RC * 64 * SA::has64;
+    constexpr int Y128 = A_FLOATS, Y64 = Y128 + RC * 2 * SY::w128, Y32 = Y64 + RC * 64 * SY::has64;
+    const int a128 = A128 + (wk * RC + kk) * SA::w128 + 4 * li;
+    const int a64 = A64 + kk * 64 + ((wk ^ (kk & 1)) << 5) + 2 * li;
+    const int a32 = A32 + kk * 32 + ((wk ^ (kk & 1)) << 4) + li;
+    const int y128 = Y128 + (wo * RC + kk) * SY::w128 + 4 * li;
+    const int y64 = Y64 + kk * 64 + ((wo ^ (kk & 1)) << 5) + 2 * li;
+    const int y32 = Y32 + kk * 32 + ((wo ^ (kk & 1)) << 4) + li;
+    float fa[2][KT], fy[2][OT];
+    auto read_frags = [&](auto PAR, const float* st, int ks) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+#pragma unroll
+        for (int g = 0; g < SA::n4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + a128 + 64 * g + ks * 4 * SA::w128);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fa[p][4 * g + e] = v[e];
+        }
+        if (SA::has64) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(st + a64 + ks * 4 * 64);
+            fa[p][4 * SA::n4] = v[0]; fa[p][4 * SA::n4 + 1] = v[1];
+        }
+        if (SA::has32) fa[p][KT - 1] = st[a32 + ks * 4 * 32];
+#pragma unroll
+        for (int g = 0; g < SY::n4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(st + y128 + 64 * g + ks * 4 * SY::w128);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fy[p][4 * g + e] = v[e];
+        }
+        if (SY::has64) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(st + y64 + ks * 4 * 64);
+            fy[p][4 * SY::n4] = v[0]; fy[p][4 * SY::n4 + 1] = v[1];
+        }
+        if (SY::has32) fy[p][OT - 1] = st[y32 + ks * 4 * 32];
+    };
+    auto mfma_step = [&](auto PAR) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = 0; b < OT; ++b) acc[a][b] = mfma16(fa[p][a], fy[p][b], acc[a][b]);
+    };
+    auto zero_tail = [&](float* st, int valid) __attribute__((always_inline)) {   // dY rows >= valid of a chunk contribute nothing
+        for (int e = opaque(tid); e < 2 * (RC - valid) * SY::w128; e += 256) {
+            const int wv = e / ((RC - valid) * (SY::w128 > 0 ? SY::w128 : 1)), c = e - wv * (RC - valid) * SY::w128;
+            st[Y128 + (wv * RC + valid) * SY::w128 + c] = 0.f;
+        }
+        for (int e = opaque(tid); e < (RC - valid) * 64 * SY::has64; e += 256) st[Y64 + valid * 64 + e] = 0.f;
+        for (int e = opaque(tid); e < (RC - valid) * 32 * SY::has32; e += 256) st[Y32 + valid * 32 + e] = 0.f;
+    };
+
+    if (Q <= 0) {
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = 0; b < OT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+        issue_dma();
+        if (Q > 1) issue_dma();
+        __syncthreads();                                   // both chunks landed (once per workgroup)
+        if (TAIL && rbeg + RC > rend) { zero_tail(sm, rend - rbeg); __syncthreads(); }
+        EEG_SCHED_FENCE();                                 // (the accumulators are born here, after the set-up arithmetic)
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = 0; b < OT; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        read_frags(IntC<0>(), sm, 0);
+        int r_stage = 0;
+        for (int q = 0; q < Q; ++q) {
+            const float* st = sm + r_stage * ST;
+#pragma unroll
+            for (int ks = 0; ks + 1 < KS; ++ks) {
+                if (ks & 1) { read_frags(IntC<0>(), st, ks + 1); EEG_SCHED_FENCE(); mfma_step(IntC<1>()); }
+                else        { read_frags(IntC<1>(), st, ks + 1); EEG_SCHED_FENCE(); mfma_step(IntC<0>()); }
+                EEG_SCHED_FENCE();
+            }
+            r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+            float* nx = sm + r_stage * ST;
+            if (q + 1 < Q) {
+                // chunk q+1 (requested a chunk ago) must have landed; after the barrier every wave is past its reads of
+                // chunk q-1, whose stage takes chunk q+2
+                EEG_VM_WAIT_BARRIER(0);
+                if (q + 2 < Q) issue_dma();
+                const int r1 = rbeg + (q + 1) * RC;
+                if (TAIL && r1 + RC > rend) { zero_tail(nx, rend - r1); EEG_LDS_BARRIER(); }
+            }
+            read_frags(IntC<0>(), nx, 0);                  // (after the last chunk: a stale stage, unused)
+            EEG_SCHED_FENCE();
+            mfma_step(IntC<1>());                          // k-step KS-1 (KS is even)
+            EEG_SCHED_FENCE();
+        }
+    }
+    // ---- epilogue: partial[split][k][o], k / o through the tile <-> column maps of the two slices ----------------------------
+    // k = k0 + block_col(wk, col(ga, 4 kk + r, ea)): the lane part (kk) goes into the per-lane offset, the (r, ea) part is a
+    // wave-uniform row offset of the buffer store (requires K * Ov * 4 < 4 GB per split: it is a weight gradient)
+    if (flags & 1) {                                       // lab: no partial stores (the accumulators stay live)
+#if !defined(EEG_SIMT_EMU)
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = 0; b < OT; ++b) asm volatile("" ::"v"(acc[a][b]));
+#endif
+        return;
+    }
+    const wbuf_t ro = make_wbuf(partial + (size_t)((flags & 2) ? split & 7 : split) * K * Ov);   // flags 2 (lab): 8 cache-resident slots
+#pragma unroll
+    for (int ga = 0; ga < SA::ngroups; ++ga) {
+        const int kl = k0 + SA::template block_col<PLANAR>(wk, SA::col(ga, 4 * kk, 0));       // r = 0, ea = 0
+        const int kstep_r = SA::col(ga, 1, 0) - SA::col(ga, 0, 0);                               // columns per lane index step
+#pragma unroll
+        for (int ea = 0; ea < SA::width(ga); ++ea) {
+            const int a = ga < SA::n4 ? 4 * ga + ea : (SA::has64 && ga == SA::n4 ? 4 * SA::n4 + ea : KT - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int dk = r * kstep_r + ea;                                               // uniform part of k
+                const bool kok = kl + dk < K;
+#pragma unroll
+                for (int gb = 0; gb < SY::ngroups; ++gb) {
+                    const int o = wo * 16 * OT + SY::col(gb, li, 0);
+                    const unsigned vo = (unsigned)(kl * Ov + o), so = (unsigned)(dk * Ov);
+                    if (gb < SY::n4) {
+                        if (kok && o + 3 < Ov) wbuf_st4(ro, vo, so, (f32x4){acc[a][4 * gb][r], acc[a][4 * gb + 1][r], acc[a][4 * gb + 2][r], acc[a][4 * gb + 3][r]});
+                    } else if (SY::has64 && gb == SY::n4) {
+                        if (kok && o + 1 < Ov) wbuf_st2(ro, vo, so, acc[a][4 * SY::n4][r], acc[a][4 * SY::n4 + 1][r]);
+                    } else if (kok && o < Ov) {
+                        wbuf_st1(ro, vo, so, acc[a][OT - 1][r]);
+                    }
+                }
+            }
         }
     }
 }
