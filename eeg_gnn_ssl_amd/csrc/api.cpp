@@ -20,6 +20,7 @@
 #include "kernels_tail.h"
 #include "prof.h"
 #include "seq_launch.h"
+#include "gemmq_launch.h"
 
 #include <string>
 #include <vector>
@@ -113,6 +114,21 @@ int check_dims(int N, int H, int Fin, int M) {
     return 0;
 }
 
+// CUs of the current device (the persistent GEMMs size their grids by it); queried once per process
+int num_cus() {
+#if defined(EEG_SIMT_EMU)
+    return 4;                                         // (emulator: a small grid exercises the same paths)
+#else
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+#endif
+}
+
 // ---- GEMM dispatch ---------------------------------------------------------------------------
 template <int NCTW, int KC>
 int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
@@ -151,8 +167,15 @@ int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int 
     return run_nn<NCTW, 4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag);
 }
 // C[R x O] = [segments] @ packed B (nct_total col tiles) + bias
+// Bq: the same right-hand side in the quad order of gemm_nnq_kernel (kernels_pack.h: bxq / bxtq), or NULL.  The round-3
+// kernel takes the launch when it covers the shape and every one of its 2-per-CU workgroups gets at least two 128-row
+// tiles (dev knob 2 bit 0 = 1: never)
 int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
-            float* C, int ldc, int O, hipStream_t st, const char* tag = "gemm_nn", BtMap bt = BtMap()) {
+            float* C, int ldc, int O, hipStream_t st, const char* tag = "gemm_nn", BtMap bt = BtMap(), const float* Bq = nullptr) {
+    if (Bq != nullptr && (g_tune[2] & 1) == 0 && g_tune[0] == 0 && R >= 512 * num_cus() && nnq_supported(nseg, F, R, nct_total, ldc, O)) {
+        if (launch_nnq(segs, nseg, F, R, Bq, nct_total, bias, C, ldc, O, bt.T, bt.B, bt.N, num_cus(), st, tag)) return fail("gemm_nnq: launch failed");
+        return check_launch("gemm_nnq");
+    }
     // few row blocks (per-step decoder GEMMs): narrower column blocks fill more CUs
     if (nct_total <= 4 || ceil_div(R, 128) * ceil_div(nct_total, 12) < 160)
         return run_nn_kc<2>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
@@ -217,7 +240,12 @@ int tn_split(int nseg, int F, int R, int O, int* rows_per_split) {
 }
 // partial[nsplit][nseg*F][O] = per-split A^T dY[:, ycol0:ycol0+O]
 int gemm_tn(const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
-            float* partial, int nsplit, int rows_per_split, hipStream_t st, const char* tag = "gemm_tn", BtMap bt = BtMap()) {
+            float* partial, int nsplit, int rows_per_split, hipStream_t st, const char* tag = "gemm_tn", BtMap bt = BtMap(),
+            const TnqPlan* q = nullptr) {
+    if (q != nullptr && q->ok) {                         // round-3 kernel (nsplit / rows_per_split are the plan's)
+        if (launch_tnq(*q, segs, nseg, F, R, dY, ldy, ycol0, O, partial, bt.T, bt.B, bt.N, st, tag)) return fail("gemm_tnq: launch failed");
+        return check_launch("gemm_tnq");
+    }
     if (tn_dma_ok(F, O) && rows_per_split % 32 == 0 && R >= 1) {   // LDS-DMA staging (default)
 #define EEG_TN(NCTW, RC) run_tn_dma<2, NCTW, RC>(segs, nseg, F, R, dY, ldy, ycol0, O, partial, nsplit, rows_per_split, st, tag, bt)
         // row-chunk depth: the 192-column tile stages 16 rows at a time (32 KB of LDS per workgroup -> 4 workgroups
@@ -349,7 +377,13 @@ int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
 struct BwdWs {
     size_t dxw, dbias, hplanes, rhplanes, partial, part_g, part_c, z, total;   // partial = x-part region; part_g / part_c follow it
     int nsplit_x, rps_x, nsplit_hg, rps_hg, nsplit_hc, rps_hc;
+    TnqPlan qx, qg, qc;        // round-3 TN kernel where it covers the shape (ok = 1): its split plan replaces tn_split's
 };
+// dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
+TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
+    if ((g_tune[2] & 2) != 0 || g_tune[1] != 0 || R < 512 * num_cus()) return TnqPlan{};
+    return tnq_plan(nseg, F, R, O, bt, num_cus());
+}
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     BwdWs w;
     const size_t R = (size_t)d->T * d->B * d->N;
@@ -361,6 +395,12 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     w.nsplit_x = tn_split(d->M, d->Fin, (int)R, 3 * d->H, &w.rps_x);
     w.nsplit_hg = tn_split(d->M, d->H, (int)R, 2 * d->H, &w.rps_hg);
     w.nsplit_hc = tn_split(d->M, d->H, (int)R, d->H, &w.rps_hc);
+    w.qx = tn_plan_q(d->M, d->Fin, (int)R, 3 * d->H, d->x_batch_major != 0);
+    w.qg = tn_plan_q(d->M, d->H, (int)R, 2 * d->H, false);
+    w.qc = tn_plan_q(d->M, d->H, (int)R, d->H, false);
+    if (w.qx.ok) { w.nsplit_x = w.qx.nsplit; w.rps_x = w.qx.rps; }
+    if (w.qg.ok) { w.nsplit_hg = w.qg.nsplit; w.rps_hg = w.qg.rps; }
+    if (w.qc.ok) { w.nsplit_hc = w.qc.nsplit; w.rps_hc = w.qc.rps; }
     size_t px = (size_t)w.nsplit_x * d->M * d->Fin * 3 * d->H;
     size_t pg = (size_t)w.nsplit_hg * d->M * d->H * 2 * d->H;
     size_t pc = (size_t)w.nsplit_hc * d->M * d->H * d->H;
@@ -388,7 +428,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
     float* part_g = part + (w.part_g - w.partial);
     float* part_c = part + (w.part_c - w.partial);
-    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt)) return 1;
+    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt, &w.qx)) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
     size_t hs = h_stride;
@@ -399,7 +439,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * hs : nullptr);
-    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st, "gemm_tn_hg")) return 1;
+    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st, "gemm_tn_hg", BtMap(), &w.qg)) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     const float* rpl = rpl_in;
     size_t rs = h_stride;
@@ -410,7 +450,7 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * rs : nullptr);
-    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st, "gemm_tn_hc")) return 1;
+    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st, "gemm_tn_hc", BtMap(), &w.qc)) return 1;
     //   one fixed-order reduction of the three sets of split-K partials into the reference's gradient layout
     ReduceJobs jobs;
     const int Ks[3] = {M * Fin, M * H, M * H}, Os[3] = {3 * H, 2 * H, H}, ns[3] = {w.nsplit_x, w.nsplit_hg, w.nsplit_hc};
@@ -656,7 +696,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * xs : nullptr);
     float* XW = ws;
-    if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt)) return 1;
+    if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt, p.has_bxq ? pack + p.bxq : nullptr)) return 1;
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
@@ -703,7 +743,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         float* Z = ws + w.z;
         SegPtrs sd;
         for (int m = 0; m < kMaxM; ++m) sd.p[m] = m == 0 ? dXW : nullptr;
-        if (gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st, "gemm_nn_dx")) return 1;
+        if (gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st, "gemm_nn_dx", BtMap(), p.has_bxtq ? pack + p.bxtq : nullptr)) return 1;
         if (diffuse_adj(Z, P, d->p_batched, S, d->B, N, Fin, M, dX, st)) return 1;
     }
     return 0;

@@ -1,0 +1,103 @@
+// Instantiations + launch logic of the round-3 hoisted GEMMs (kernels_gemm_q.h), in their own translation unit.
+#include "kernels_gemm_q.h"
+#include "gemmq_launch.h"
+#include "prof.h"
+#include "seq_launch.h"
+
+namespace eeg {
+
+bool nnq_supported(int nseg, int F, int R, int nct_total, int ldc, int O) {
+    if (nseg < 1 || nseg > kMaxM || F < 4 || F % 4 != 0 || R < 1) return false;
+    if (nct_total < 12 || nct_total % 12 != 0 || O % 4 != 0 || ldc % 4 != 0 || O > 16 * nct_total) return false;
+    if (make_nnq_order(nseg, F).ntail > 2) return false;
+    return (double)R * F * 4.0 < 4.0e9 && (double)R * ldc * 4.0 < 4.0e9;
+}
+size_t nnq_pack_floats(int nseg, int F, int nct) { return (size_t)make_nnq_order(nseg, F).nch * nct * 256; }
+
+int launch_nnq(const SegPtrs& segs, int nseg, int F, int R, const float* Bq, int nct_total, const float* bias, float* C,
+               int ldc, int O, int btT, int btB, int btN, int num_cus, hipStream_t st, const char* tag) {
+    constexpr int NS = 4;                                  // 4 stages x 20 KB: two workgroups use the whole LDS of a CU
+    const size_t lds = (size_t)NS * kNnqStageFloats * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_nnq_kernel<NS, 0>), lds);
+    const int rt = ceil_div(R, 16);
+    int G = 2 * (num_cus > 0 ? num_cus : 256);
+    if (G > ceil_div(rt, 8)) G = ceil_div(rt, 8);          // at least one 128-row tile per workgroup
+    if (G < 1) G = 1;
+    EEG_LAUNCH_P(tag, (gemm_nnq_kernel<NS, 0>), dim3(G, nct_total / 12), dim3(256), lds, st, segs, nseg, F, R, Bq, nct_total, bias,
+                 C, ldc, O, btT, btB, btN, 0, (long long*)nullptr);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+TnqPlan tnq_plan(int nseg, int F, int R, int O, bool bt, int num_cus) {
+    TnqPlan p{};
+    if (nseg < 1 || nseg > kMaxM || F < 4 || F % 4 != 0 || R < 16 || R % 16 != 0) return p;
+    if (O != 64 && O != 128 && O != 192) return p;
+    if ((double)R * F * 4.0 >= 4.0e9) return p;
+    const int K = nseg * F;
+    p.OT = O / 32;
+    if (F == 64 && !bt) {                                  // whole 64-wide planes per k-block
+        p.planar = 1;
+        p.KT = nseg % 3 == 0 ? 6 : (nseg % 2 == 0 ? 4 : (nseg == 1 ? 2 : 6));
+        p.nkb = ceil_div(nseg, p.KT / 2);
+    } else {
+        if (O != 192) return p;
+        // k-block of 4 or 5 tiles per wave slice (6 x 6 tiles + per-lane source pointers spill): least padded K (= MFMA
+        // work), then the wider block
+        int best = 5, bcost = 1 << 30, bnkb = 1;
+        for (int kt = 5; kt >= 4; --kt) {
+            const int nkb = ceil_div(K, 32 * kt), cost = nkb * 32 * kt;
+            if (cost < bcost) { best = kt; bcost = cost; bnkb = nkb; }
+        }
+        p.KT = best; p.nkb = bnkb;
+    }
+    const int G = 2 * (num_cus > 0 ? num_cus : 256);
+    int nsplit = G / p.nkb;
+    if (nsplit < 1) nsplit = 1;
+    int rps = round_up(ceil_div(R, nsplit), 16);
+    if (rps < 64) rps = 64;
+    p.rps = rps;
+    p.nsplit = ceil_div(R, rps);
+    p.ok = 1;
+    return p;
+}
+
+namespace {
+template <int KT, int OT, bool BT, bool PLANAR>
+int launch_tnq_one(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+                   float* partial, int btT, int btB, int btN, hipStream_t st, const char* tag) {
+    constexpr int RC = 16;
+    const size_t lds = 3 * (size_t)(RC * 32 * (KT + OT)) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_tnq_kernel<KT, OT, RC, BT, PLANAR, false>), lds);
+    EEG_LAUNCH_P(tag, (gemm_tnq_kernel<KT, OT, RC, BT, PLANAR, false>), dim3(p.nkb, p.nsplit), dim3(256), lds, st, segs, nseg, F, R, dY, ldy,
+                 ycol0, O, partial, p.rps, btT, btB, btN, 0);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+template <int KT, bool BT, bool PLANAR>
+int launch_tnq_ot(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+                  float* partial, int btT, int btB, int btN, hipStream_t st, const char* tag) {
+#define EEG_TNQ(OT) launch_tnq_one<KT, OT, BT, PLANAR>(p, segs, nseg, F, R, dY, ldy, ycol0, O, partial, btT, btB, btN, st, tag)
+    if constexpr (PLANAR) {
+        if (p.OT == 2) return EEG_TNQ(2);
+        if (p.OT == 4) return EEG_TNQ(4);
+    }
+    return p.OT == 6 ? EEG_TNQ(6) : 1;
+#undef EEG_TNQ
+}
+}  // namespace
+
+int launch_tnq(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
+               float* partial, int btT, int btB, int btN, hipStream_t st, const char* tag) {
+#define EEG_TNQ(KT, BT, PL) launch_tnq_ot<KT, BT, PL>(p, segs, nseg, F, R, dY, ldy, ycol0, O, partial, btT, btB, btN, st, tag)
+    if (!p.ok) return 1;
+    if (p.planar) {
+        if (p.KT == 2) return EEG_TNQ(2, false, true);
+        if (p.KT == 4) return EEG_TNQ(4, false, true);
+        return EEG_TNQ(6, false, true);
+    }
+    const bool bt = btT > 0;
+    if (p.KT == 4) return bt ? EEG_TNQ(4, true, false) : EEG_TNQ(4, false, false);
+    return bt ? EEG_TNQ(5, true, false) : EEG_TNQ(5, false, false);
+#undef EEG_TNQ
+}
+
+}  // namespace eeg

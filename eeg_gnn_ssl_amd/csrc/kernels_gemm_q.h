@@ -22,23 +22,10 @@
 // Reference semantics: model/cell.py:98-117 (the dense contraction of the diffusion convolution, x-part).
 #pragma once
 #include "kernels_gemm.h"
+#include "nnq_order.h"
 
 namespace eeg {
 
-struct NnqOrder { int nseg, F, a, b, nmain, ntail, nch; };
-__host__ __device__ inline NnqOrder make_nnq_order(int nseg, int F) {
-    NnqOrder o;
-    o.nseg = nseg; o.F = F; o.a = F / 16; o.b = (F / 4) % 4;
-    o.nmain = nseg * o.a; o.ntail = (nseg * o.b + 3) / 4; o.nch = o.nmain + o.ntail;
-    return o;
-}
-// logical K index (seg*F + f) of element s of 16-byte piece p of chunk c; -1 = zero padding
-__host__ __device__ inline int nnq_k_of(const NnqOrder& o, int c, int p, int s) {
-    if (c < o.nmain) return (c / o.a) * o.F + (c % o.a) * 16 + 4 * p + s;
-    const int tp = (c - o.nmain) * 4 + p;
-    if (tp >= o.nseg * o.b) return -1;
-    return (tp / o.b) * o.F + o.a * 16 + (tp % o.b) * 4 + s;
-}
 constexpr int kNnqStageFloats = 128 * 16 + 12 * 256;   // A tile + 12 column tiles of the quad pack = 20 KB
 __host__ __device__ constexpr int nnq_gsw(int x) { return (4 - x) & 3; }
 
@@ -94,7 +81,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
                                                          int btT, int btB, int btN, int flags, long long* __restrict__ probe = nullptr) {
     constexpr int NB = 12, AF = 128 * 16, ST = kNnqStageFloats, NST = 24;
     constexpr bool PROBE = (ABL & 128) != 0;   // lab: cycle counters per workgroup (wave 0): probe[8]
-    const long long tk0 = PROBE ? cycle_now() : 0, tr0 = PROBE ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+#if defined(EEG_SIMT_EMU)
+    const long long tr0 = 0;
+#else
+    const long long tr0 = PROBE ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+#endif
     long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc6 = 0, pc7 = 0;   // waits after an epilogue (0, 1, 2 iterations), other waits, their count, iteration cycles, epilogue cycles, epilogues
     static_assert(NS >= 2 && NS <= 5, "ring depth");
     EEG_DYN_SMEM(sm);
@@ -338,7 +329,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
     if (PROBE && probe != nullptr && tid == 0) {
         long long* o = probe + blockIdx.x * 10;
         o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = pc5; o[6] = pc6; o[7] = pc7;
-        o[8] = tr0; o[9] = (long long)__builtin_amdgcn_s_memrealtime();
+        o[8] = tr0;
+#if !defined(EEG_SIMT_EMU)
+        o[9] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     }
 }
 

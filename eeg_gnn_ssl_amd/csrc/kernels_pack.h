@@ -11,6 +11,7 @@
 // (common.h) instead of 4*ks + (lane>>4), matching their ds_read_b128 A-fragment reads.
 #pragma once
 #include "common.h"
+#include "nnq_order.h"
 
 namespace eeg {
 
@@ -30,6 +31,11 @@ struct CellPack {
     //  layer of the decoder, so the streamed-weight addresses are base + immediate)
     size_t c1;     // K = M*H  (k = m*H + o),  O columns: [Wc^h | Wc^x | 0] transposed, quad-permuted K
     size_t c2;     // K = M*2H (k = m*2H + o), O columns: [Wg^h | Wg^x | 0] transposed, quad-permuted K
+    // round 3, gemm_nnq_kernel (kernels_gemm_q.h): the same two right-hand sides in quad order (one ds_read_b128 per lane feeds
+    // the four MFMAs of a 16-deep K chunk; chunk order of make_nnq_order); bxtq exists when M*Fin is a multiple of 192
+    size_t bxq;    // x-part:  nnq order over (M planes x Fin), 3H/16 column tiles
+    size_t bxtq;   // bwd dx:  nnq order over (1 segment x 3H), M*Fin/16 column tiles (0 floats when not applicable)
+    bool has_bxq, has_bxtq;
     size_t total;
 };
 
@@ -46,6 +52,10 @@ __host__ __device__ inline CellPack make_cell_pack(int Fin, int H, int M) {
     p.bxt = o;  o += (size_t)3 * H * round_up(M * Fin, 16);
     p.c1 = o;   o += (size_t)M * H * cell_pack_cx_cols(Fin, H);
     p.c2 = o;   o += (size_t)M * 2 * H * cell_pack_cx_cols(Fin, H);
+    p.has_bxq = (3 * H) % 192 == 0 && make_nnq_order(M, Fin).ntail <= 2;
+    p.has_bxtq = (M * Fin) % 192 == 0 && (3 * H) % 4 == 0 && make_nnq_order(1, 3 * H).ntail <= 2;
+    p.bxq = o;  o += p.has_bxq ? (size_t)make_nnq_order(M, Fin).nch * (3 * H / 16) * 256 : 0;
+    p.bxtq = o; o += p.has_bxtq ? (size_t)make_nnq_order(1, 3 * H).nch * (M * Fin / 16) * 256 : 0;
     p.total = o;
     return p;
 }
@@ -107,6 +117,21 @@ __global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __re
             if (j < M * Fin) {
                 const int m = j / Fin, f = j % Fin;
                 v = o < 2 * H ? ref_wg(Wg, M, H, f, m, o) : ref_wc(Wc, M, H, f, m, o - 2 * H);
+            }
+        } else if (idx >= p.bxq) {                // quad packs of gemm_nnq_kernel: [(c * nct + ct) * 64 + lane][s]
+            const bool tr = idx >= p.bxtq;
+            const size_t e = idx - (tr ? p.bxtq : p.bxq);
+            const int s4 = e & 3, lane = (e >> 2) & 63, nct = tr ? M * Fin / 16 : 3 * H / 16;
+            const int ct = (e >> 8) % nct, c = (e >> 8) / nct, j = 16 * ct + (lane & 15);
+            const int k = nnq_k_of(tr ? make_nnq_order(1, 3 * H) : make_nnq_order(M, Fin), c, lane >> 4, s4);
+            if (k >= 0) {
+                if (!tr) {                        // W^x[k = m*Fin + f][j]
+                    const int m = k / Fin, f = k % Fin;
+                    v = j < 2 * H ? ref_wg(Wg, M, H, f, m, j) : ref_wc(Wc, M, H, f, m, j - 2 * H);
+                } else {                          // (W^x)^T[k = o][j = m*Fin + f]
+                    const int m = j / Fin, f = j % Fin;
+                    v = k < 2 * H ? ref_wg(Wg, M, H, f, m, k) : ref_wc(Wc, M, H, f, m, k - 2 * H);
+                }
             }
         } else {                                  // c1 / c2 [k = m*W + o][j]: j < H hidden feature j, else input feature j - H
             const bool gate = idx >= p.c2;
