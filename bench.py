@@ -15,10 +15,17 @@ and `cpu_baseline` (the torch-eager oracle timed on the host cores on a bounded 
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
 import time
+
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # the CPU baseline leg (oracle on the host cores) is reported with pinned threads: its rate moved 131.9 <-> 162.7 clips/s
+    # between boxes of the pool with floating threads.  Must be set before the OpenMP runtime starts (= before torch).
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 import torch
@@ -29,7 +36,8 @@ sys.path.insert(0, ROOT)
 
 N_NODES, H_UNITS, D_IN, K_DIFF, LAYERS = 19, 64, 100, 2, 2
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6290 GB/s measured copy)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+ACHIEVABLE_HBM_GBS = 6290.0       # MI355X_MICROARCH.md: measured float4 copy (79 % of spec) = what any stream reaches
 
 WORKLOADS = {
     # name: (task, filter_type, T, per-GPU batch, classes)
@@ -57,7 +65,7 @@ def make_args(filter_type):
                                  use_curriculum_learning=False)
 
 
-def synthetic_batch(task, filter_type, t_len, batch, classes, seed):
+def synthetic_batch(task, filter_type, t_len, batch, classes, seed, host_supports=True):
     """x ~ N(0,1) (z-scored log-FFT amplitudes), seq_lengths = T (detection) or
     U[T/2, T] with zero padding (classification), distance-graph scaled Laplacian or per-clip
     top-3 dual random-walk supports, labels from a fixed statistic of the clip."""
@@ -82,6 +90,8 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed):
         adj = np.load(os.path.join(ROOT, "eeg_gnn_ssl_amd", "data", "electrode_adj_3d.npy"))
         s = utils.compute_supports(adj, "laplacian")[0]
         supports = [s.unsqueeze(0).repeat(batch, 1, 1)]     # the trainers always pass batched supports (Q5)
+    elif not host_supports:
+        supports = None          # per-clip graphs are built on the GPU (eeg_dcrnn_corr_graph): skip the per-clip numpy loop
     else:
         s1, s2 = [], []
         xn = x.numpy()
@@ -150,9 +160,9 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
 # kernel symbol behind every role at the cfg2 shapes (64 units, M = 3, 19 nodes)
 ROLE_SYMBOLS = {
     "seq_fwd": "seq_fwd2_kernel<64,3,5>", "seq_bwd": "seq_bwd2_kernel<64,3,5>",
-    "gemm_nn_xw": "gemm_nn_dma_kernel<6,20,2> (layer 0, K=300) + gemm_nn_dma_kernel<6,16,2> (layer 1, K=192)",
-    "gemm_nn_dx": "gemm_nn_dma_kernel<6,16,2>", "gemm_tn_x": "gemm_tn_dma_kernel<2,6,16>",
-    "gemm_tn_hg": "gemm_tn_dma_kernel<2,4,32>", "gemm_tn_hc": "gemm_tn_dma_kernel<2,2,32>",
+    "gemm_nn_xw": "gemm_nnq_kernel<4,0> (layer 0: K=300 in 19 chunks; layer 1: K=192)",
+    "gemm_nn_dx": "gemm_nnq_kernel<4,0>", "gemm_tn_x": "gemm_tnq_kernel<5,6,16,bt> (layer 0) + gemm_tnq_kernel<6,6,16,planar> (layer 1)",
+    "gemm_tn_hg": "gemm_tnq_kernel<6,4,16,planar>", "gemm_tn_hc": "gemm_tnq_kernel<6,2,16,planar>",
     "diffuse_fwd": "diffuse_fwd_stream_kernel<19>", "diffuse_adj": "diffuse_adj_stream_kernel<19>",
 }
 # per-clip algorithmic FLOPs (fwd+bwd) and compulsory HBM bytes -> the roofs the whole step is priced against
@@ -160,6 +170,17 @@ CLIP_GFLOP = {"cfg1": 1.302 * 12 / 60, "cfg2": 1.302, "cfg3": 2.221, "cfg4": 1.3
 CLIP_BYTES = {"cfg1": 8.208e6 * 12 / 60, "cfg2": 8.208e6, "cfg3": 8.213776e6, "cfg4": 8.208e6, "cfg5": 10.1e6}
 # the GENUINE reference on the survey container's 8 Xeon vCPUs at the same per-GPU batch (clips/s)
 REFERENCE_CPU_CLIPS_PER_S = {"cfg1": 136.0, "cfg2": 173.0, "cfg3": 108.0, "cfg4": 237.0, "cfg5": 110.0}
+
+
+def kernel_sources_sha256():
+    """Hash of everything the HIP library is built from (csrc + the C ABI headers): the build id of the PMC stamps."""
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".cpp", ".hip")) or f == "Makefile":
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def cpu_baseline(workload, budget_s=45.0):
@@ -198,17 +219,21 @@ def cpu_baseline(workload, budget_s=45.0):
     best_nt = min(probe, key=probe.get)
     torch.set_num_threads(best_nt)
     one(min(batch, 32))                          # warm-up of the allocator at a larger size
-    best = float("inf")
-    reps = 0
-    while reps < 3 and (reps == 0 or time.perf_counter() - t_start < budget_s):
-        best = min(best, one(batch))
-        reps += 1
+    times = []
+    while len(times) < 3 and (not times or time.perf_counter() - t_start < budget_s):
+        times.append(one(batch))
+    best, reps = min(times), len(times)
     value = batch / best
     ref = REFERENCE_CPU_CLIPS_PER_S.get(workload)
     return {"value": round(value, 2), "unit": "clips/s", "cores": best_nt, "host_logical_cpus": ncpu, "kind": "port",
             "sample": f"{batch} clips x T={t_len} of {workload} = the per-GPU batch (fwd+loss+bwd, {best:.2f} s/step, best of {reps} "
                       f"after a warm-up; torch-eager oracle = op-for-op restatement of the reference; thread count chosen by probe "
                       f"{ {k: round(4 / v, 1) for k, v in probe.items()} } clips/s on 4 clips)",
+            "runs_clips_per_s": [round(batch / t, 1) for t in times],
+            "spread": round((max(times) - min(times)) / min(times), 3),
+            "threads_pinned": os.environ.get("OMP_PROC_BIND", "") + "/" + os.environ.get("OMP_PLACES", ""),
+            "note": "host-dependent: the same code measured 131.9-162.7 clips/s on different boxes of the pool (+-20 %); a "
+                    "reported baseline, not the target",
             "reference_8vcpu_clips_per_s": ref,
             "ratio_to_reference_8vcpu": None if not ref else round(value / ref, 3)}
 
@@ -228,6 +253,8 @@ def main():
                     "captured HIP graph of forward+loss+backward (default: replay, at any number of GPUs)")
     ap.add_argument("--no-stream-inputs", action="store_true", help="skip the second timed pass that feeds a fresh pinned "
                     "host batch into the step's input tensors on a side stream every step")
+    ap.add_argument("--force-dist", action="store_true", help="single process: create a world-size-1 process group over "
+                    "the nccl (= RCCL) backend and issue the gradient all-reduce every step (exercises the RCCL path on one GPU)")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning); loads "
                     "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
     args = ap.parse_args()
@@ -240,9 +267,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (HIP) device: eeg_gnn_ssl_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")                     # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)     # "nccl" IS RCCL on ROCm
+    if world > 1:
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))            # host threads per rank (8 ranks share the host)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib, ops
@@ -263,12 +293,17 @@ def main():
     else:
         model = DCRNNModel_classification(make_args(filt), classes, device=dev).to(dev)
     model.train()
-    stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0)
-    hx, hy, hlen, hsup = synthetic_batch(task, filt, t_len, batch, classes, seed=123 + rank)
-    x, y, lengths = hx.to(dev), hy.to(dev), hlen.to(dev)
-    supports = [s.to(dev) for s in hsup]
+    stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0, always_reduce=args.force_dist)
     device_graph = filt == "dual_random_walk" and not args.host_supports
-    if device_graph:
+    # the host-side per-clip graph loop (numpy, 256-512 clips) is only needed to CHECK the device graphs: rank 0 of a
+    # single-GPU run does it; data-parallel ranks build their supports on the GPU only
+    check_graphs = device_graph and world == 1
+    hx, hy, hlen, hsup = synthetic_batch(task, filt, t_len, batch, classes, seed=123 + rank, host_supports=not device_graph or check_graphs)
+    x, y, lengths = hx.to(dev), hy.to(dev), hlen.to(dev)
+    supports = [s.to(dev) for s in hsup] if hsup is not None else None
+    if device_graph and not check_graphs:
+        supports = None
+    elif device_graph:
         # per-clip correlation graph + supports are rebuilt from the clips on the GPU inside every step
         # (eeg_dcrnn_corr_graph); they must match what the host pipeline prepared for the same clips
         chk = ops.correlation_supports(x, top_k=3)
@@ -314,34 +349,47 @@ def main():
     log(f"timed {args.steps} steps ({'graph replay' if graphed else 'eager'}): {elapsed / args.steps * 1e3:.3f} ms/step")
 
     # second timed pass: every step first receives a FRESH batch from pinned host memory (the trainer's situation: at
-    # 80 k clips/s the input stream is ~37 GB/s per GPU).  The copy of step k+1 runs on a side stream into a second
-    # device buffer while step k computes; the step's static input tensors are refreshed by a device-to-device copy.
+    # 85 k clips/s the input stream is ~40 GB/s per GPU).  The step is captured on TWO input sets; the host-to-device copy
+    # of batch k+1 runs on a side stream straight into the set the NEXT replay reads while batch k computes: no staging
+    # buffer and no device-to-device refresh (round 2 paid 0.39 ms/step for that).  Eager launches: one input set, the copy
+    # waits for the step that reads it.
     streamed = None
     if not args.no_stream_inputs:
         pin = [t.pin_memory() for t in (hx, hy)]
-        stage = [torch.empty_like(x), torch.empty_like(y)]
         side = torch.cuda.Stream()
-        ready = torch.cuda.Event()
-        consumed = torch.cuda.Event()
-        consumed.record()
+        sets = [(x, y)]
+        if graphed:
+            x2, y2 = torch.empty_like(x), torch.empty_like(y)
+            x2.copy_(x); y2.copy_(y)
+            stepper.capture(x2, y2, lengths, supports, slot=1)
+            sets.append((x2, y2))
+        landed = [torch.cuda.Event() for _ in sets]      # batch has arrived in set i
+        done = [torch.cuda.Event() for _ in sets]        # the step that read set i has finished
+        for e in done:
+            e.record()
+        state = {"k": 0}
 
-        def fetch():
+        def fetch(i):
             with torch.cuda.stream(side):
-                side.wait_event(consumed)                        # previous contents of the staging buffers were used
-                stage[0].copy_(pin[0], non_blocking=True)
-                stage[1].copy_(pin[1], non_blocking=True)
-                ready.record(side)
+                side.wait_event(done[i])                         # the previous contents of set i were consumed
+                sets[i][0].copy_(pin[0], non_blocking=True)
+                sets[i][1].copy_(pin[1], non_blocking=True)
+                landed[i].record(side)
 
-        fetch()
+        fetch(0)
 
         def streamed_step():
+            i = state["k"] % len(sets)
+            state["k"] += 1
             cur = torch.cuda.current_stream()
-            cur.wait_event(ready)
-            x.copy_(stage[0])
-            y.copy_(stage[1])
-            consumed.record(cur)
-            fetch()                                              # next batch travels while this step computes
-            return one_step()
+            if len(sets) > 1:
+                fetch((i + 1) % len(sets))                       # next batch travels while this step computes
+            cur.wait_event(landed[i])
+            out = stepper.replay_step(i) if graphed else stepper.step(sets[i][0], sets[i][1], lengths, supports)
+            done[i].record(cur)
+            if len(sets) == 1:
+                fetch(0)
+            return out
 
         el2, _ = timed(streamed_step)
         t2 = torch.tensor([el2], device=dev, dtype=torch.float64)
@@ -351,8 +399,10 @@ def main():
         streamed = {"value": round(batch * world / (el2 / args.steps), 1), "unit": "clips/s",
                     "ms_per_step": round(el2 / args.steps * 1e3, 3),
                     "host_bytes_per_step_per_gpu": int(hx.numel() * 4 + hy.numel() * hy.element_size()),
-                    "note": "a fresh batch per step from pinned host memory: H2D copy on a side stream into a staging buffer, "
-                            "overlapped with the previous step; D2D refresh of the step's input tensors inside the step"}
+                    "note": ("a fresh batch per step from pinned host memory: the step is captured on two input sets and the H2D "
+                             "copy of batch k+1 lands in the idle set on a side stream while batch k computes (no staging buffer, "
+                             "no device-side copy)") if graphed else
+                            "a fresh batch per step from pinned host memory, copied on a side stream between eager steps"}
         log(f"streamed inputs: {streamed['ms_per_step']} ms/step")
 
     prof = {}
@@ -370,6 +420,16 @@ def main():
         for line in buf.value.decode().strip().splitlines():
             name, cnt, ms = line.split()
             prof[name] = (int(cnt), float(ms))
+    # exchange + optimiser tail (all-reduce of the flat bucket when a process group exists, norm + fused clip/Adam):
+    # HIP events around reduce_and_update() on the launch stream, gradients left as they are
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(args.steps):
+        stepper.reduce_and_update()
+    e1.record()
+    torch.cuda.synchronize()
+    tail_ms = e0.elapsed_time(e1) / args.steps
     per_rank = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         allr = [torch.empty_like(per_rank) for _ in range(world)]
@@ -379,10 +439,12 @@ def main():
         backend = dist.get_backend()
         world_seen = dist.get_world_size()
     else:
-        per_rank_ms, backend, world_seen = [round(elapsed / args.steps * 1e3, 3)], None, 1
+        per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
+        backend = dist.get_backend() if dist.is_initialized() else None
+        world_seen = dist.get_world_size() if dist.is_initialized() else 1
     loss_val = float(loss.item())
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -399,7 +461,8 @@ def main():
         if name in work and work[name] > 0 and per_step_ms > 0:
             if "diffuse" in name or name == "corr_gram":
                 gbs = work[name] / (per_step_ms * 1e-3) / 1e9
-                ent.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+                ent.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                           frac_of_achievable=round(gbs / ACHIEVABLE_HBM_GBS, 4))
             else:
                 tf = work[name] / (per_step_ms * 1e-3) / 1e12
                 ent.update(bound="mfma", achieved=round(tf, 2), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
@@ -410,10 +473,18 @@ def main():
     if timed_k:
         dom = max(timed_k, key=lambda k: timed_k[k]["ms_per_step"])     # the kernel SYMBOL with the most time per step
         d = timed_k[dom]
-        traffic = None            # HBM bytes per launch from the committed PMC passes (same command)
+        # HBM bytes per launch from the committed PMC passes of the same command (tools/pmc_traffic.sh).  The file is stamped
+        # with the hash of the kernel sources it was collected on: a stale file yields `traffic: null` + a warning
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+            tj = json.load(open(tpath))
+            if tj.get("kernel_sources_sha256") == kernel_sources_sha256():
+                traffic = tj["traffic_bytes_per_launch"]
+            else:
+                traffic_note = (f"profiles/pmc_traffic_{args.workload}.json was collected on other kernel sources "
+                                f"(stamp {str(tj.get('kernel_sources_sha256'))[:12]} != {kernel_sources_sha256()[:12]}): not used")
+                print("[bench] WARNING: " + traffic_note, file=sys.stderr, flush=True)
         for name, tb in (traffic or {}).items():
             for k in kernels:
                 if k == name or (k.startswith(name + "_") and name in ("gemm_nn", "gemm_tn")):
@@ -430,7 +501,7 @@ def main():
         flops = sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram" and not k.endswith("_persist"))
         roofline = {"kernel": dom, "symbol": d.get("symbol"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"],
-                    "traffic": (traffic or {}).get(dom), "avg_launch_ms": d["avg_launch_ms"],
+                    "traffic": (traffic or {}).get(dom), "traffic_note": traffic_note, "avg_launch_ms": d["avg_launch_ms"],
                     "top_class": max(by_class, key=lambda k: by_class[k]["ms_per_step"]), "by_class": by_class,
                     "kernels": kernels,
                     "kernel_ms_per_step_total": round(sum(v["ms_per_step"] for v in kernels.values()), 3),
@@ -453,10 +524,19 @@ def main():
                    "library": "DEV build with tuning knobs " + ",".join(args.tune) if args.tune else "product",
                    "final_loss": round(loss_val, 5)},
         "distributed": {"world_size": world_seen, "backend": backend, "per_rank_ms_per_step": per_rank_ms,
+                        "all_reduce_issued": bool(stepper.reduce),
+                        "reduce_and_update_ms_per_step": round(tail_ms, 4),
                         "exchange": "one all-reduce of the flat fp32 gradient bucket per step "
-                                    f"({stepper.fp.flat_grad.numel() * 4} bytes), outside the HIP graph"},
+                                    f"({stepper.fp.flat_grad.numel() * 4} bytes), outside the HIP graph"
+                                    + ("" if stepper.reduce else " (no process group: not issued in this run)")},
         # the whole step against BOTH roofs: the binding fp32-MFMA roof and the HBM roof north_star names
-        "whole_step": {"mfma_roof_clips_per_s_per_gpu": round(mfma_roof, 0), "mfma_roof_frac": round(per_gpu / mfma_roof, 4),
+        # executed_mfma_frac = the FLOPs the kernels actually execute / time / peak (leads); *_survey_flops prices the step
+        # with SURVEY's per-clip figure, which includes the layer-0 dX that neither the reference's autograd nor this
+        # library computes (21 % more FLOPs at cfg2)
+        "whole_step": {"executed_mfma_frac": None if roofline is None else roofline["whole_step_mfma_frac"],
+                       "executed_gflop": None if roofline is None else roofline["whole_step_flops"],
+                       "mfma_roof_clips_per_s_per_gpu_survey_flops": round(mfma_roof, 0),
+                       "mfma_roof_frac_survey_flops": round(per_gpu / mfma_roof, 4),
                        "hbm_frac": round(per_gpu * CLIP_BYTES[args.workload] / (PEAK_HBM_GBS * 1e9), 4),
                        "hbm_roof_clips_per_s_per_gpu": round(PEAK_HBM_GBS * 1e9 / CLIP_BYTES[args.workload], 0)},
         # `value` is the training-loop rate (optimiser step included); the kernel figure takes the optimiser tail
@@ -472,7 +552,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload)
         out["speedup_vs_cpu_baseline"] = round(clips_per_s / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

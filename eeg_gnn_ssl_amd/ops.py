@@ -5,9 +5,8 @@ schema, device implementation (tensors in -> C-ABI launch on torch's current str
 a fake (meta) implementation for tracing, and — for the differentiable ones — the autograd formula,
 which calls the matching `*_bwd` operator.  PyTorch is plumbing here (device memory, streams, autograd
 bookkeeping); all arithmetic runs in the HIP kernels of libeeg_dcrnn_hip.so.  The implementations are
-registered for the CUDA (= HIP on ROCm) key; the same functions are also installed for the CPU key so
-that tests/ can drive the emulator build of the kernel sources — with the product library every
-operator raises on a non-GPU tensor: this package has no CPU path.
+registered for the CUDA (= HIP on ROCm) key only: this package has no CPU path (a CPU tensor gets the
+dispatcher's "no kernel for the CPU backend" error, and the C-ABI stub refuses non-GPU pointers).
 
 Operators (namespace `eeg_dcrnn`):
     hop_polys, pack_cell, diffusion_hops, dconv (+ dconv_bwd), dcgru_layer (+ dcgru_layer_bwd),
@@ -58,12 +57,15 @@ def _none_if_empty(t: Optional[torch.Tensor]):
     return None if (t is None or t.numel() == 0) else t
 
 
+_impls = {}       # operator name -> device implementation (read by tests/emu_support.py, which drives the same
+#                   implementations through the emulator build of the kernel sources)
+
+
 def _define(name: str, schema: str, impl, fake):
-    """schema + device implementation (CUDA key = HIP; CPU key only ever reaches the emulator in tests/)
-    + fake implementation."""
+    """schema + device implementation (CUDA key = HIP) + fake implementation."""
     _libdef.define(f"{name}{schema}")
     _libdef.impl(name, impl, "CUDA")
-    _libdef.impl(name, impl, "CPU")
+    _impls[name] = impl
     torch.library.register_fake(f"{NS}::{name}", fake, lib=_libdef)
 
 
@@ -297,7 +299,7 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
         _check(lib, x_planes, "x_planes")
         if tuple(x_planes.shape) != (m - 1, t_len + 1, b, n, fin):
             raise RuntimeError(f"x_planes has shape {tuple(x_planes.shape)}, expected {(m - 1, t_len + 1, b, n, fin)}")
-        planes, planes_ptr = empty, x_planes.data_ptr() + 4 * b * n * fin
+        planes, planes_ptr = _new((0,), p), x_planes.data_ptr() + 4 * b * n * fin      # (its own placeholder: outputs must not alias)
     else:
         planes = _new((m - 1, s, n, fin), x)
         planes_ptr = planes.data_ptr()
@@ -327,7 +329,12 @@ def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_pla
     hext, hsel = ne(t_len + 1, b, n * h), ne(b, n * h)
     if not save:
         return hext, hsel, []
-    xtm = ne(t_len, b, n, fin) if not x.is_contiguous() else ne(0)
+    # a non-contiguous x is copied time-major (kept for the backward) -- except the transposed view of a contiguous batch-major
+    # tensor at a layer without handed-over planes, which the kernels read through a row map (eeg_dcrnn_batch_major_ok = 2
+    # for every shape the streaming diffusion kernel covers: 19 nodes, Fin <= 512)
+    zero_copy = (not x.is_contiguous() and x_off == 0 and x_planes is None and x.transpose(0, 1).is_contiguous()
+                 and n == 19 and fin % 4 == 0 and fin <= 512)
+    xtm = ne(t_len, b, n, fin) if (not x.is_contiguous() and not zero_copy) else ne(0)
     planes = ne(0) if x_planes is not None else ne(m - 1, t_len * b, n, fin)
     return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + \
         [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)]
@@ -359,6 +366,11 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
     d_at_len = d_hsel if lengths is not None else None
     xk_ptr = ctypes.c_void_p(x.data_ptr() + 4 * x_off * b * n * fin)
     dx = _new((t_len + x_off, b, n, fin), hext) if need_dx else _new((0,), hext)
+    if need_dx and x_off:
+        # x is the `hext` of the layer below: its slot 0 is that layer's INITIAL state, which this layer never reads.  The
+        # kernels fill slots x_off.. only; the gradient of slot 0 is exactly zero (and must be a defined value: it flows
+        # through autograd accumulation, hooks and anomaly detection)
+        dx[:x_off].zero_()
     dx_ptr = ctypes.c_void_p(dx.data_ptr() + 4 * x_off * b * n * fin) if need_dx else None
     dh0 = _new((b, n * h), hext) if (need_dh0 and has_h0) else _new((0,), hext)
     ws = _new((lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),), hext)
@@ -671,6 +683,11 @@ def _masked_loss_impl(pred, y, use_scaler: bool, mean: float, std: float, mask_v
     lib = _lib.get_lib()
     pr = pred.contiguous()
     t = y.to(torch.float32).contiguous()
+    # the kernels read 16-byte vectors: a contiguous VIEW with an odd element offset (pred.view(-1)[1:]) is not aligned
+    if pr.data_ptr() % 16:
+        pr = pr.clone()
+    if t.data_ptr() % 16:
+        t = t.clone()
     _check(lib, pr, "y_predicted")
     _check(lib, t, "y_true")
     if pr.shape != t.shape:
@@ -724,7 +741,6 @@ _define("clip_adam_",
 # =============================================================================================
 # diagnostics: how often a layer took its input hop planes from the recurrent kernel of the layer below
 hop_plane_handovers = 0
-hop_plane_handover_enabled = True   # tests switch it off to compare against separately diffused planes
 
 
 def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: int) -> Tuple[torch.Tensor, int]:
@@ -800,11 +816,8 @@ def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activati
     act = ACT_CODES.get(activation, 1)
     save = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, h0, wg, bg, wc, bc))
     if x_planes is not None:
-        if not hop_plane_handover_enabled:
-            x_planes = None
-        else:
-            global hop_plane_handovers
-            hop_plane_handovers += 1
+        global hop_plane_handovers
+        hop_plane_handovers += 1
     hext, hsel, saved = torch.ops.eeg_dcrnn.dcgru_layer(x, int(x_off), h0, p, int(p_batched), wg, bg, wc, bc, lengths, x_planes,
                                                         n, h, m, act, save)
     return LayerOut(hext, hsel, saved[7].detach() if save else None)
@@ -863,8 +876,3 @@ def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, wei
     torch.ops.eeg_dcrnn.clip_adam_(params, grads, exp_avg, exp_avg_sq, int(step), float(lr), float(betas[0]), float(betas[1]),
                                    float(eps), float(weight_decay), float(max_norm), float(grad_scale), ws, norm_out)
 
-
-def new_forward_scope():
-    """Kept for callers of the round-1 API: the operators hold no caches any more (hop polynomials and weight
-    packs are built by explicit operators once per forward; hop planes are handed from layer to layer as
-    tensors), so there is nothing to drop."""

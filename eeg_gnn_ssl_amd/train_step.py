@@ -53,7 +53,10 @@ class TrainStep:
 
     def __init__(self, model: torch.nn.Module, task: str = "detection", lr: float = 3e-4,
                  weight_decay: float = 5e-4, max_grad_norm: float = 5.0,
-                 scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None):
+                 scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None,
+                 always_reduce: bool = False):
+        """always_reduce: issue the gradient all-reduce whenever a process group exists, also at world size 1 (exercises
+        the RCCL path on a single GPU; a sum over one rank is the identity)."""
         assert task in ("detection", "classification", "ssl")
         self.model, self.task, self.max_grad_norm = model, task, max_grad_norm
         self.fp = FlatParameters(model)
@@ -67,8 +70,11 @@ class TrainStep:
         # samples seen so far = the reference's `step += batch_size` (train_ssl.py:163,178): drives the scheduled-
         # sampling threshold of the SSL model under curriculum learning (global batch: every rank advances alike)
         self.samples_seen = 0
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        has_pg = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if has_pg else 1
+        self.reduce = has_pg and (self.world > 1 or always_reduce)
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
+        self._graphs = {}
 
     def set_epoch(self, epoch: int, num_epochs: int, eta_min: float = 0.0):
         """Cosine learning-rate schedule of the reference, stepped per epoch (train.py:224,329)."""
@@ -103,13 +109,15 @@ class TrainStep:
         return loss.detach()
 
     # -- HIP-graph replay of forward + loss + backward -------------------------------------------
-    def capture(self, x, y, seq_lengths, supports, warmup: int = 2):
+    def capture(self, x, y, seq_lengths, supports, warmup: int = 2, slot: int = 0):
         """Capture zero_grad -> forward -> loss -> backward on the given (static) input tensors into
         one HIP graph (torch.cuda.CUDAGraph: the library launches on torch's current stream, never
         synchronises and allocates only through torch, so the ~60 launches of a step replay as one
         graph launch).  The exchange + optimiser tail stay outside the graph: the RCCL all-reduce is
         issued eagerly between the replay and the fused clip+Adam kernel.  New data is fed by
-        copying into the captured tensors (`x.copy_(batch)`)."""
+        copying into the captured tensors (`x.copy_(batch)`) -- or, without any device-side copy, by capturing the step
+        on TWO input sets (`slot` 0 and 1) and alternating `replay_step(slot)`: the host-to-device copy of batch k+1
+        then lands directly in the tensors the next replay reads while batch k computes."""
         if self.task == "ssl" and getattr(self.model, "use_curriculum_learning", False):
             # the teacher-forcing coin flips (model.py:194-200) are host-side `random.random()` draws that select
             # which launches are issued: a captured graph would freeze one draw for ever
@@ -124,20 +132,20 @@ class TrainStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = self.forward_backward(x, y, seq_lengths, supports)
-        self._graph, self._graph_loss = graph, loss
-        self._graph_inputs = (x, y, seq_lengths, supports)
+        self._graphs[slot] = (graph, loss, (x, y, seq_lengths, supports))
         return graph
 
-    def replay_step(self):
-        """One optimisation step on the captured tensors: graph replay + all-reduce + clip/Adam."""
-        self._graph.replay()
-        self.samples_seen += self._graph_inputs[0].shape[0] * self.world
+    def replay_step(self, slot: int = 0):
+        """One optimisation step on the captured tensors of `slot`: graph replay + all-reduce + clip/Adam."""
+        graph, loss, inputs = self._graphs[slot]
+        graph.replay()
+        self.samples_seen += inputs[0].shape[0] * self.world
         self.reduce_and_update()
-        return self._graph_loss
+        return loss
 
     def reduce_and_update(self):
         g = self.fp.flat_grad
-        if self.world > 1:
+        if self.reduce:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)        # RCCL over xGMI: one flat bucket
         self.step_count += 1
         # mean over ranks (grad_scale), clip_grad_norm_(max_norm) and Adam in one pass over the buffers
@@ -162,6 +170,23 @@ class TrainStep:
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
 
 
+def _all_gather_uneven(t: torch.Tensor) -> torch.Tensor:
+    """Concatenation over the ranks of tensors whose FIRST dimension differs from rank to rank (evaluation shards of a
+    data set are uneven whenever its size is not a multiple of the world size): the lengths travel first, every rank
+    pads its shard to the longest one, one all_gather, and the padding is cut away again.  Same result on every rank."""
+    world = dist.get_world_size()
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    sizes = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    longest = max(sizes)
+    if t.shape[0] < longest:
+        t = torch.cat([t, t.new_zeros((longest - t.shape[0],) + tuple(t.shape[1:]))])
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous())
+    return torch.cat([p[:k] for p, k in zip(parts, sizes)])
+
+
 @torch.no_grad()
 def predict(model, batches, task: str = "detection"):
     """Evaluation forward passes (train.py:343-404 without the host round trip per batch): returns
@@ -178,11 +203,7 @@ def predict(model, batches, task: str = "detection"):
         labels.append(y.view(-1))
     prob, lab = torch.cat(probs), torch.cat(labels)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        gp = [torch.empty_like(prob) for _ in range(dist.get_world_size())]
-        gl = [torch.empty_like(lab) for _ in range(dist.get_world_size())]
-        dist.all_gather(gp, prob)
-        dist.all_gather(gl, lab)
-        prob, lab = torch.cat(gp), torch.cat(gl)
+        prob, lab = _all_gather_uneven(prob), _all_gather_uneven(lab)
     model.train(was_training)
     return prob.cpu().numpy(), lab.cpu().numpy()
 
@@ -222,12 +243,8 @@ def evaluate(model, batches, task: str = "detection", is_test: bool = False, eva
     prob, lab = torch.cat(probs), torch.cat(labels)
     tot = torch.stack([loss_sum.reshape(()).double(), torch.tensor(float(n_seen), device=prob.device, dtype=torch.float64)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        gp = [torch.empty_like(prob) for _ in range(dist.get_world_size())]
-        gl = [torch.empty_like(lab) for _ in range(dist.get_world_size())]
-        dist.all_gather(gp, prob)
-        dist.all_gather(gl, lab)
+        prob, lab = _all_gather_uneven(prob), _all_gather_uneven(lab)
         dist.all_reduce(tot)
-        prob, lab = torch.cat(gp), torch.cat(gl)
     model.train(was_training)
     y_prob, y_true = prob.cpu().numpy(), lab.cpu().numpy().astype(int)
     eval_loss = float((tot[0] / tot[1]).item())

@@ -174,7 +174,8 @@ def cosine_annealing_lr(base_lr, epoch, num_epochs, eta_min=0.0):
 # ---- checkpoints ----------------------------------------------------------------------------------
 def load_model_checkpoint(checkpoint_file, model, optimizer=None):
     """reference utils.py:156-163: restore `model_state` (and `optimizer_state` if asked)."""
-    ckpt = torch.load(checkpoint_file, map_location="cpu", weights_only=False)
+    # the reference's checkpoints (utils.py:84-150) hold plain tensors / numbers only: no unpickling of arbitrary objects
+    ckpt = torch.load(checkpoint_file, map_location="cpu", weights_only=True)
     model.load_state_dict(ckpt["model_state"])
     if optimizer is not None:
         optimizer.load_state_dict(ckpt["optimizer_state"])

@@ -15,7 +15,23 @@ def install_emulator():
     lib = _lib.EegDcrnnLib(path)
     assert not lib.is_device_build
     _lib._LIB = lib
+    _register_cpu_key()
     return lib
+
+
+_cpu_registered = False
+
+
+def _register_cpu_key():
+    """The product registers its operators for the CUDA (= HIP) key only.  The emulator runs on host memory, so the
+    tests install the SAME implementations for the CPU dispatch key here (once per process)."""
+    global _cpu_registered
+    if _cpu_registered:
+        return
+    from eeg_gnn_ssl_amd import ops
+    for name, impl in ops._impls.items():
+        ops._libdef.impl(name, impl, "CPU")
+    _cpu_registered = True
 
 
 def uninstall():

@@ -424,8 +424,18 @@ def check_plane_handover(device, adj3d):
         lengths = torch.tensor([5, 2, 4]).to(device)
         sup = [s.to(device) for s in cases.supports_for(filt, adj3d, 3)]
         res = []
+        real_layer = ops.dcgru_layer_ex
+
+        def no_handover(*a, **kw):                      # test-side switch: drop the planes handed over by the layer below
+            kw["x_planes"] = None
+            return real_layer(*a, **kw)
+
+        from eeg_gnn_ssl_amd.model import model as model_mod
         for on in (True, False):
-            ops.hop_plane_handover_enabled = on
+            patched = [(m, m.dcgru_layer_ex) for m in (ops, model_mod) if hasattr(m, "dcgru_layer_ex")]
+            if not on:
+                for m, _ in patched:
+                    m.dcgru_layer_ex = no_handover
             try:
                 before = ops.hop_plane_handovers
                 model.zero_grad()
@@ -434,7 +444,8 @@ def check_plane_handover(device, adj3d):
                 assert ops.hop_plane_handovers - before == (2 if on else 0)
                 res.append((out.detach().clone(), [q.grad.clone() for q in model.parameters()]))
             finally:
-                ops.hop_plane_handover_enabled = True
+                for m, f in patched:
+                    m.dcgru_layer_ex = f
         assert_close(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), f"{filt} logits", tol=1e-6)
         for a, b_, (nm, _) in zip(res[0][1], res[1][1], model.named_parameters()):
             assert_close_scaled(a.cpu().numpy(), b_.cpu().numpy(), f"{filt} grad {nm}", tol=1e-6)

@@ -72,7 +72,9 @@ def test_product_has_no_cpu_path():
     from eeg_gnn_ssl_amd import DCGRUCell, _lib
     _lib._LIB = None
     cell = DCGRUCell(100, 64, 2, 19)
-    with pytest.raises(RuntimeError, match="no CPU path"):
+    # the operators exist for the CUDA (= HIP) key only: the dispatcher refuses ("... from the 'CPU' backend"); when another
+    # test of this process has installed the emulator's CPU-key registrations, the C-ABI stub of the product library refuses
+    with pytest.raises(RuntimeError, match="no CPU path|'CPU' backend"):
         cell([torch.eye(19)], torch.zeros(2, 1900), torch.zeros(2, 19 * 64))
 
 

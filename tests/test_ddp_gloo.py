@@ -157,3 +157,32 @@ def test_four_ranks_uneven_shards(task, tmp_path):
     # global sample counter (drives scheduled sampling of the SSL model): per-rank batch x world, as on one process
     assert rs[0]["seen"] == 2 * 4
     emu_support.uninstall()
+
+
+def _gather_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from eeg_gnn_ssl_amd.train_step import _all_gather_uneven
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = [5, 0, 3][rank]                                     # uneven evaluation shards, one of them empty
+    prob = torch.arange(n, dtype=torch.float32) + 100 * rank
+    soft = (torch.arange(n * 4, dtype=torch.float32) + 1000 * rank).view(n, 4)      # class probabilities (n, C)
+    lab = torch.arange(n, dtype=torch.int64) + 10 * rank
+    torch.save({"prob": _all_gather_uneven(prob), "soft": _all_gather_uneven(soft), "lab": _all_gather_uneven(lab)},
+               os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_uneven_evaluation_shards_gather(tmp_path):
+    """predict / evaluate gather the per-rank probabilities and labels of shards of DIFFERENT sizes (a data set whose
+    size is not a multiple of the world size; here 5 / 0 / 3 samples): every rank must end with the concatenation in
+    rank order, for 1-D and 2-D tensors and for integer labels."""
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_gather_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    want_prob = torch.cat([torch.arange(5.0), torch.arange(3.0) + 200])
+    want_soft = torch.cat([torch.arange(20.0).view(5, 4), (torch.arange(12.0) + 2000).view(3, 4)])
+    want_lab = torch.cat([torch.arange(5), torch.arange(3) + 20])
+    for r in range(3):
+        got = torch.load(os.path.join(str(tmp_path), f"g{r}.pt"))
+        assert torch.equal(got["prob"], want_prob) and torch.equal(got["soft"], want_soft) and torch.equal(got["lab"], want_lab), r

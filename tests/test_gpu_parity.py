@@ -339,6 +339,84 @@ def test_hip_graph_replay_equals_eager_steps():
     assert torch.equal(finals[0], finals[1])
 
 
+def test_two_slot_replay_equals_eager_steps_on_alternating_batches():
+    """Streamed inputs without a device-side copy: the step captured on TWO input sets, replayed alternately while the
+    next batch is written into the idle set, must walk the same parameters (bit for bit) as eager steps on the same
+    sequence of batches."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, classes = "detection", "laplacian", 1
+    batches = [bench.synthetic_batch(task, filt, 9, 6, classes, seed=30 + i) for i in range(5)]
+    sup = [s.to(DEV) for s in batches[0][3]]
+    ld = batches[0][2].to(DEV)
+    finals = []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3)
+        if graphed:
+            bufs = [(torch.zeros_like(batches[0][0], device=DEV), torch.zeros_like(batches[0][1], device=DEV)) for _ in range(2)]
+            for slot in range(2):
+                st.capture(bufs[slot][0], bufs[slot][1], ld, sup, slot=slot)
+            st.step_count = 0; st.samples_seen = 0
+            st.exp_avg.zero_(); st.exp_avg_sq.zero_()
+            torch.manual_seed(1)                      # the capture warm-ups ran no optimiser step: parameters are untouched
+            side = torch.cuda.Stream()
+            for k, (x, y, _, _) in enumerate(batches):
+                slot = k & 1
+                with torch.cuda.stream(side):         # H2D of batch k into the idle input set
+                    side.wait_stream(torch.cuda.current_stream())
+                    bufs[slot][0].copy_(x.pin_memory(), non_blocking=True)
+                    bufs[slot][1].copy_(y.pin_memory(), non_blocking=True)
+                torch.cuda.current_stream().wait_stream(side)
+                st.replay_step(slot)
+        else:
+            for x, y, _, _ in batches:
+                st.step(x.to(DEV), y.to(DEV), ld, sup)
+        torch.cuda.synchronize()
+        finals.append(st.fp.flat.detach().clone())
+    assert torch.equal(finals[0], finals[1])
+
+
+def test_world1_rccl_step_equals_plain_step():
+    """The RCCL path on the hardware at hand: a process group of ONE rank over the `nccl` backend (= RCCL on ROCm);
+    graph replay -> dist.all_reduce of the flat gradient bucket -> fused clip/Adam must give bit for bit the parameters
+    of the step without a process group (a sum over one rank is the identity)."""
+    import torch.distributed as dist
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, classes = "detection", "laplacian", 1
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, 9, 6, classes, seed=5)
+    xd, yd, ld, supd = x.to(DEV), y.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup]
+
+    def run(always_reduce):
+        torch.manual_seed(1)
+        model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3, always_reduce=always_reduce)
+        assert st.reduce == always_reduce
+        st.capture(xd, yd, ld, supd)
+        for _ in range(3):
+            st.replay_step()
+        torch.cuda.synchronize()
+        return st.fp.flat.detach().clone()
+
+    plain = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 150))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        reduced = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(plain, reduced)
+
+
 @pytest.mark.parametrize("filt,dout,h,layers,t_out,b,ratio,act", [
     ("laplacian", 8, 16, 2, 5, 3, 0.5, "tanh"),            # teacher forcing on some steps
     ("dual_random_walk", 12, 32, 3, 4, 2, 0.6, "relu"),    # shared cell used by two layers + teacher forcing

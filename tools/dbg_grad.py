@@ -10,6 +10,7 @@ sets = sys.argv[2:]
 task, filt, t_len, batch, classes = bench.WORKLOADS[wl]
 x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123)
 x, y, lengths, sup = x.to(dev), y.to(dev), lengths.to(dev), [s.to(dev) for s in sup]
+_lib._LIB = _lib.EegDcrnnLib(_lib.DEV_LIB_PATH)      # the tuning knobs exist in the dev build only
 lib = _lib.get_lib()
 ref = None
 for st in sets:

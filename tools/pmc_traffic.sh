@@ -11,7 +11,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
       python "$OLDPWD/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph --no-stream-inputs "$@" > "$OLDPWD/gpurun_out/pmc_${W}_$c.log" 2>&1 )
 done
 python - "$W" <<'PY'
-import csv, glob, collections, json, sys
+import csv, glob, collections, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
 w = sys.argv[1]
 CLASSES = [("seq_fwd", "seq_fwd"), ("seq_bwd", "seq_bwd"), ("gemm_nn", "gemm_nn"), ("gemm_tn", "gemm_tn"),
            ("diffuse_fwd", "diffuse_fwd"), ("diffuse_adj", "diffuse_adj"), ("reduce_unpack", "reduce_unpack"),
@@ -38,7 +40,7 @@ for _, cls in CLASSES:
         rd = 2.0 * tot["FETCH_SIZE"][cls] / cnt["FETCH_SIZE"][cls] * 1024
         wr = tot["WRITE_SIZE"][cls] / cnt["WRITE_SIZE"][cls] * 1024
         out[cls] = int(rd + wr)
-doc = {"workload": w,
+doc = {"workload": w, "kernel_sources_sha256": bench.kernel_sources_sha256(),
        "note": "HBM bytes per launch (average over all launches of the class) = (2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc, "
                "separate passes (tools/pmc_traffic.sh); gfx950 correction per MI355X_MICROARCH.md",
        "traffic_bytes_per_launch": out,
