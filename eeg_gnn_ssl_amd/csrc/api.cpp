@@ -835,7 +835,8 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
         int dx = q4 % 25 == 0 ? 25 : (q4 % 16 == 0 ? 16 : (q4 % 5 == 0 ? 5 : (q4 % 4 == 0 ? 4 : 0)));
         if (g_tune[8] > 0 && q4 % g_tune[8] == 0) dx = g_tune[8];   // dev knob 8: weight-group size of the layer-0 x-part
         const size_t lds = dec_fwd_lds_floats(M, L, Dout) * sizeof(float);
-        if (g_tune[11] == 0 && H == 64 && N <= kDecRows && L <= 4 && d->T <= 64 && dx != 0 && lds <= kMaxLdsBytes) {
+        // (Dout <= 128 like the backward: the two persistent kernels always pair up over the shared `saved` layout)
+        if (g_tune[11] == 0 && H == 64 && N <= kDecRows && L <= 4 && d->T <= 64 && Dout <= 128 && dx != 0 && lds <= kMaxLdsBytes) {
             DecFwdArgs a;
             for (int l = 0; l < L; ++l) {
                 const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);

@@ -362,14 +362,15 @@ def test_two_slot_replay_equals_eager_steps_on_alternating_batches():
             st.step_count = 0; st.samples_seen = 0
             st.exp_avg.zero_(); st.exp_avg_sq.zero_()
             torch.manual_seed(1)                      # the capture warm-ups ran no optimiser step: parameters are untouched
-            side = torch.cuda.Stream()
-            for k, (x, y, _, _) in enumerate(batches):
+            side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+            pinned = [(x.pin_memory(), y.pin_memory()) for x, y, _, _ in batches]     # alive until the copies have run
+            for k, (x, y) in enumerate(pinned):
                 slot = k & 1
+                side.wait_stream(main)                # the replay that read this input set (step k-2) is done
                 with torch.cuda.stream(side):         # H2D of batch k into the idle input set
-                    side.wait_stream(torch.cuda.current_stream())
-                    bufs[slot][0].copy_(x.pin_memory(), non_blocking=True)
-                    bufs[slot][1].copy_(y.pin_memory(), non_blocking=True)
-                torch.cuda.current_stream().wait_stream(side)
+                    bufs[slot][0].copy_(x, non_blocking=True)
+                    bufs[slot][1].copy_(y, non_blocking=True)
+                main.wait_stream(side)
                 st.replay_step(slot)
         else:
             for x, y, _, _ in batches:
