@@ -16,15 +16,15 @@ size_t nnq_pack_floats(int nseg, int F, int nct) { return (size_t)make_nnq_order
 
 int launch_nnq(const SegPtrs& segs, int nseg, int F, int R, const float* Bq, int nct_total, const float* bias, float* C,
                int ldc, int O, int btT, int btB, int btN, int num_cus, hipStream_t st, const char* tag) {
-    constexpr int NS = 4;                                  // 4 stages x 20 KB: two workgroups use the whole LDS of a CU
-    const size_t lds = (size_t)NS * kNnqStageFloats * sizeof(float);
-    EEG_SET_MAX_LDS((gemm_nnq_kernel<NS, 0>), lds);
+    constexpr int NS = 4;                                  // gemm_nnr_kernel: 4 activation stages of 8 KB + 192 bias floats
+    const size_t lds = ((size_t)NS * 128 * 16 + 192) * sizeof(float);
+    EEG_SET_MAX_LDS((gemm_nnr_kernel<NS, 2>), lds);
     const int rt = ceil_div(R, 16);
     int G = 2 * (num_cus > 0 ? num_cus : 256);
     if (G > ceil_div(rt, 8)) G = ceil_div(rt, 8);          // at least one 128-row tile per workgroup
     if (G < 1) G = 1;
-    EEG_LAUNCH_P(tag, (gemm_nnq_kernel<NS, 0>), dim3(G, nct_total / 12), dim3(256), lds, st, segs, nseg, F, R, Bq, nct_total, bias,
-                 C, ldc, O, btT, btB, btN, 0, (long long*)nullptr);
+    EEG_LAUNCH_P(tag, (gemm_nnr_kernel<NS, 2>), dim3(G, nct_total / 12), dim3(256), lds, st, segs, nseg, F, R, Bq, nct_total, bias,
+                 C, ldc, O, btT, btB, btN);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -34,6 +34,7 @@ __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
 }
 #define EEG_VM_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+#define EEG_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 __device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {   // offsets in floats
     typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
     __builtin_amdgcn_raw_buffer_store_b64((u32x2_){__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, b, 4u * voff, 4u * soff, 0);
@@ -50,6 +51,7 @@ __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsig
     memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
 }
 #define EEG_VM_WAIT_BARRIER(n) __syncthreads()
+#define EEG_VM_WAIT(n) ((void)0)
 #endif
 
 #if defined(EEG_SIMT_EMU)
@@ -333,6 +335,349 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
 #if !defined(EEG_SIMT_EMU)
         o[9] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_nnr_kernel (the shipped NN kernel): gemm_nnq_kernel with the WEIGHTS going global -> registers.  In the 4 x 48-column
+// wave layout a wave is the only reader of its 3 weight column tiles, so staging them in LDS buys nothing: here every lane
+// fetches its three 16-byte fragments of the next chunk straight from the quad pack (L2-resident, one coalesced 1-KB load per
+// tile) while the current chunk is multiplied.  Per wave and chunk: 2 LDS-DMAs (activations) + 3 plain loads instead of 5
+// LDS-DMAs + 3 ds_reads, an 8-KB stage instead of 20 KB (ring of 4 = 32 KB + the bias).  Lab: 0.728 -> 0.751 (K = 192),
+// 0.743 -> 0.766 (K = 300) of the fp32-MFMA peak.
+// Queue discipline: per iteration a wave issues, in this order, the 3 weight loads of chunk q+1 and the 2 activation DMAs of
+// chunk q+3; the weight fragments are ordinary (compiler-visible) buffer loads, so the compiler itself waits for them where
+// they are first used -- the end of the iteration -- and, the vector-memory queue being in order (tools/micro/order_lab.hip),
+// everything older has arrived with them: the DMAs of chunk q+2 and the stores of the previous tile.  (Beside LDS-DMAs
+// hipcc makes that wait a vmcnt(0), i.e. the DMAs of chunk q+3 are drained too; they have had the whole iteration.)  The
+// explicit s_waitcnt in front of the copy restates what the next barrier relies on, whatever the compiler chooses.
+// A first version issued the weight loads as inline asm with hand-counted waits: sporadically wrong tiles (the register
+// allocator is free to place asm outputs where the asynchronous return collides with its own copies) -- do not do that.
+template <int NS, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_nnr_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                         const float* __restrict__ Bq, int nct_total,
+                                                         const float* __restrict__ bias, float* __restrict__ C, int ldc, int O,
+                                                         int btT, int btB, int btN) {
+    constexpr int NB = 12, ST = 128 * 16;                  // a stage = the 128 x 16 activation tile
+    static_assert(NS == 4, "the queue discipline above assumes a ring of 4");
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
+    const NnqOrder ko = make_nnq_order(nseg, F);
+    const int nch = ko.nch;
+    const int RT = ceil_div(R, 16);
+    const int rt0 = (int)((long long)blockIdx.x * RT / gridDim.x), rt1 = (int)((long long)(blockIdx.x + 1) * RT / gridDim.x);
+    const int nrows = rt1 - rt0;
+    if (nrows <= 0) return;
+    const int ntile = ceil_div(nrows, 8), nrt_last = nrows - 8 * (ntile - 1);
+    const int ct0 = blockIdx.y * NB;
+    const int Q = ntile * nch;
+    float* const bias_s = sm + NS * ST;                    // 192 floats behind the ring
+    if (tid < 192) bias_s[tid] = (bias != nullptr && 16 * ct0 + tid < O) ? bias[16 * ct0 + tid] : 0.f;
+
+    // ---- sources ----------------------------------------------------------------------------------------------------
+    const int ctw = ct0 + 3 * w + 2 < nct_total ? ct0 + 3 * w : (nct_total >= 3 ? nct_total - 3 : 0);   // (a partial block re-reads valid tiles)
+    const wbuf_t rb = make_wbuf(Bq + (size_t)ctw * 256);
+    const unsigned b_voff = (unsigned)lane * 16u;
+    const int a_piece = (lane & 3) ^ nnq_gsw(lg);
+    const float* tptr[2];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc) {
+        const int tp = tc * 4 + a_piece;
+        int seg = 0, f = 0;
+        if (tp < nseg * ko.b) { seg = tp / ko.b; f = ko.a * 16 + (tp - seg * ko.b) * 4; }
+        tptr[tc] = segs.p[seg] + f;
+    }
+    int d_tile = 0, d_c = 0, d_seg = 0, d_kc = 0, d_stage = 0;
+    unsigned a_voff[2];
+    auto tile_rows = [&](int tile) __attribute__((always_inline)) {
+        const int row0 = (rt0 + 8 * tile) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = row0 + 16 * (w + 4 * i) + (lane >> 2);
+            if (r >= R) r = R - 1;
+            if (btT > 0) {
+                const int sm_ = r / btN, n = r - sm_ * btN, t = sm_ / btB, b = sm_ - t * btB;
+                r = (b * btT + t) * btN + n;
+            }
+            a_voff[i] = ((unsigned)r * F + 4 * a_piece) * 4u;
+        }
+    };
+    tile_rows(0);
+    auto issue_a = [&]() __attribute__((always_inline)) {  // the 2 activation DMAs of this wave for the chunk at the DMA cursor
+        float* base = sm + d_stage * ST;
+        if (d_c < ko.nmain) {
+            const wbuf_t ra = make_wbuf(segs.p[d_seg]);
+            wbuf_dma16(ra, base + w * 256, a_voff[0], (unsigned)d_kc * 4u);
+            wbuf_dma16(ra, base + (w + 4) * 256, a_voff[1], (unsigned)d_kc * 4u);
+            d_kc += 16;
+            if (d_kc == ko.a * 16) { d_kc = 0; ++d_seg; }
+        } else {
+            const char* p = reinterpret_cast<const char*>(d_c == ko.nmain ? tptr[0] : tptr[1]) - 16 * a_piece;
+            lds_dma16(base + w * 256, reinterpret_cast<const float*>(p + a_voff[0]));
+            lds_dma16(base + (w + 4) * 256, reinterpret_cast<const float*>(p + a_voff[1]));
+        }
+        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+        if (++d_c == nch) {
+            d_c = 0; d_seg = 0; d_kc = 0;
+            if (++d_tile < ntile) tile_rows(d_tile);
+        }
+    };
+
+    // ---- compute side -----------------------------------------------------------------------------------------------
+    const int c_col = 16 * (ct0 + 3 * w) + 4 * lg;
+    const bool cols_full = 16 * (ct0 + 3 * w + 3) <= O;
+    const wbuf_t rc = make_wbuf(C);
+    const int a_lds = lr * 16 + 4 * (lg ^ nnq_gsw((lr >> 2) & 3));
+    f32x4 acc[8][3], oa[8], ob[3], obn[3];
+    // prologue: weights of chunk 0 and 1, activations of chunks 0 .. 2
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ob[j] = wbuf_ld4(rb, b_voff / 4 + 256 * j, 0u);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < Q) issue_a();
+    __syncthreads();                                       // bias_s + the prologue DMAs of all waves
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(bias_s + 16 * (3 * w + j) + 4 * lg);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oa[i] = *reinterpret_cast<const f32x4*>(sm + a_lds + i * 256);
+    int r_stage = 1, m_c = 0, m_tile = 0, b_c = 1;         // b_c: chunk index (within its tile) of the weights requested next
+    if (b_c == nch) b_c = 0;
+    for (int q = 0; q < Q; ++q) {
+        const bool more = q + 1 < Q, dma = q + NS - 1 < Q;
+        if (more) EEG_LDS_BARRIER();                       // chunk q+1 landed in every wave (each waited at the end of its iteration q-1)
+        if (more) {
+            const unsigned bso = (unsigned)(b_c * nct_total) * 1024u;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) obn[j] = wbuf_ld4(rb, b_voff / 4 + 256 * j, bso / 4);
+            b_c = b_c + 1 == nch ? 0 : b_c + 1;
+        }
+        if (dma) issue_a();                                // chunk q+3 into the stage of chunk q-1 (every wave is past its reads)
+        EEG_SCHED_FENCE();
+        const float* st = sm + r_stage * ST;               // (after the last chunk: a stale stage, unused)
+        const int nrt = m_tile == ntile - 1 ? nrt_last : 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < nrt) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(ob[j][s], oa[i][s], acc[i][j]);   // transposed issue
+            }
+            oa[i] = *reinterpret_cast<const f32x4*>(st + a_lds + i * 256);   // refilled in place from chunk q+1
+        }
+        EEG_SCHED_FENCE();
+        // the weight fragments of chunk q+1 (and with them everything requested before: the DMAs of chunk q+2, older stores)
+        if (more) {
+            // (the compiler waits for the weight loads where they are first used -- here -- with the count of what it saw
+            //  issued behind them, i.e. vmcnt(2): the explicit wait below only restates what the next barrier relies on)
+            if (dma) EEG_VM_WAIT(2); else EEG_VM_WAIT(0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ob[j] = obn[j];
+        }
+        r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+        if (++m_c == nch) {                                // the tile of chunk q is complete
+            const int row0 = (rt0 + 8 * m_tile) * 16;
+            if (nrt == 8 && row0 + 128 <= R && cols_full) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (i < nrt && row0 + 16 * i + lr < R && c_col + 16 * j < O)
+                            wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+            }
+            EEG_SCHED_FENCE();                             // (a store's data registers must not be rewritten right behind it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(bias_s + 16 * (3 * w + j) + 4 * lg);
+            m_c = 0; ++m_tile;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_nnl_kernel: gemm_nnq_kernel with a LOADER wave.  Workgroup = 5 waves: waves 0-3 are the four 48-column MFMA groups
+// of gemm_nnq_kernel, wave 4 issues all 20 LDS-DMAs of a chunk (8 activation + 12 weight pieces) and owns the vmcnt
+// bookkeeping.  An LDS-DMA costs its issuing wave ~60-180 cycles (MI355X_MICROARCH.md; ablation in tools/micro/gemm_lab.hip:
+// 5 DMAs per MFMA wave and chunk cost 7-14 % of the kernel even with cache-hot sources), which is time the wave cannot
+// issue MFMAs in; the loader wave has nothing else to do.  The MFMA waves then need no DMA state and fit 168 registers
+// (3 waves per SIMD: 2 x 4 MFMA waves + 2 loaders per CU).  Same operands, packs, K order, tiles and results as
+// gemm_nnq_kernel.  Barriers: one in front of the first chunk, one per chunk after it -- in both roles.
+template <int NS>
+__global__ __launch_bounds__(320, 3) void gemm_nnl_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                         const float* __restrict__ Bq, int nct_total,
+                                                         const float* __restrict__ bias, float* __restrict__ C, int ldc, int O,
+                                                         int btT, int btB, int btN) {
+    constexpr int NB = 12, AF = 128 * 16, ST = kNnqStageFloats;
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6);
+    const NnqOrder ko = make_nnq_order(nseg, F);
+    const int nch = ko.nch;
+    const int RT = ceil_div(R, 16);
+    const int rt0 = (int)((long long)blockIdx.x * RT / gridDim.x), rt1 = (int)((long long)(blockIdx.x + 1) * RT / gridDim.x);
+    const int nrows = rt1 - rt0;                           // row tiles of this workgroup
+    if (nrows <= 0) return;
+    const int ntile = ceil_div(nrows, 8), nrt_last = nrows - 8 * (ntile - 1);
+    const int ct0 = blockIdx.y * NB;
+    const int Q = ntile * nch;
+
+    if (w == 4) {
+        // ---- loader wave --------------------------------------------------------------------------------------------
+        const int lg = lane >> 4;
+        const wbuf_t rb = make_wbuf(Bq + (size_t)ct0 * 256);
+        const unsigned b_voff = (unsigned)lane * 16u;       // + 1 KB per column tile, + chunk offset: scalar
+        const int nb = nct_total - ct0 < NB ? nct_total - ct0 : NB;   // column tiles of this block (the rest re-fetch the last one)
+        const int a_piece = (lane & 3) ^ nnq_gsw(lg);      // logical 16-byte piece this lane fetches (rows 16j + lane/4)
+        const float* tptr[2];                              // tail chunks: this lane's plane + column (see gemm_nnq_kernel)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+            const int tp = tc * 4 + a_piece;
+            int seg = 0, f = 0;
+            if (tp < nseg * ko.b) { seg = tp / ko.b; f = ko.a * 16 + (tp - seg * ko.b) * 4; }
+            tptr[tc] = segs.p[seg] + f;
+        }
+        unsigned a_voff[8];
+        auto tile_rows = [&](int tile) __attribute__((always_inline)) {
+            const int row0 = (rt0 + 8 * tile) * 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int r = row0 + 16 * j + (lane >> 2);
+                if (r >= R) r = R - 1;
+                if (btT > 0) {                             // batch-major segments (see gemm_nn_dma_kernel)
+                    const int sm_ = r / btN, n = r - sm_ * btN, t = sm_ / btB, b = sm_ - t * btB;
+                    r = (b * btT + t) * btN + n;
+                }
+                a_voff[j] = ((unsigned)r * F + 4 * a_piece) * 4u;
+            }
+        };
+        int d_tile = 0, d_c = 0, d_seg = 0, d_kc = 0, d_stage = 0;
+        tile_rows(0);
+        auto issue_chunk = [&]() __attribute__((always_inline)) {
+            float* base = sm + d_stage * ST;
+            if (d_c < ko.nmain) {
+                const wbuf_t ra = make_wbuf(segs.p[d_seg]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wbuf_dma16(ra, base + j * 256, a_voff[j], (unsigned)d_kc * 4u);
+                d_kc += 16;
+                if (d_kc == ko.a * 16) { d_kc = 0; ++d_seg; }
+            } else {
+                const char* p = reinterpret_cast<const char*>(d_c == ko.nmain ? tptr[0] : tptr[1]) - 16 * a_piece;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lds_dma16(base + j * 256, reinterpret_cast<const float*>(p + a_voff[j]));
+            }
+            const unsigned bso = (unsigned)(d_c * nct_total) * 1024u;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) wbuf_dma16(rb, base + AF + j * 256, b_voff, bso + 1024u * (unsigned)(j < nb ? j : nb - 1));
+            d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+            if (++d_c == nch) {
+                d_c = 0; d_seg = 0; d_kc = 0;
+                if (++d_tile < ntile) tile_rows(d_tile);
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < Q) issue_chunk();
+        EEG_VM_WAIT_BARRIER(0);                            // chunk 0 (and the rest of the prologue) landed
+        for (int q = 0; q + 1 < Q; ++q) {
+            // chunk q+1 must have landed; chunks q+2 .. q+NS-2 (20 DMAs each) may stay in flight.  After the barrier every
+            // MFMA wave has finished reading chunk q-1, whose stage takes chunk q+NS-1
+            if (Q - 2 - q >= NS - 3) {
+                if (NS == 3) EEG_VM_WAIT_BARRIER(0);
+                if (NS == 4) EEG_VM_WAIT_BARRIER(20);
+                if (NS == 5) EEG_VM_WAIT_BARRIER(40);
+            } else {
+                EEG_VM_WAIT_BARRIER(0);
+            }
+            if (q + NS - 1 < Q) issue_chunk();
+        }
+        return;
+    }
+
+    // ---- MFMA waves ---------------------------------------------------------------------------------------------------
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c_col = 16 * (ct0 + 3 * w) + 4 * lg;         // first of this lane's 3 x 4 output columns (+ 16 j)
+    const bool cols_full = 16 * (ct0 + 3 * w + 3) <= O;
+    const wbuf_t rc = make_wbuf(C);
+    const int a_lds = lr * 16 + 4 * (lg ^ nnq_gsw((lr >> 2) & 3));
+    const int b_lds = AF + 3 * w * 256 + lane * 4;
+    f32x4 acc[8][3], oa[8], ob[3], obn[3];
+    // accumulators start from the bias: it is (re)loaded from global memory where a tile starts (3 cache-hot 16-byte loads
+    // per lane, issued in front of the previous tile's stores) instead of living in 12 registers -- these waves have no
+    // LDS-DMA in flight, so ordinary loads and their compiler-placed waits are harmless here
+    auto load_bias = [&](f32x4 (&bv)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (bias != nullptr && c_col + 16 * j + 3 < O) bv[j] = *reinterpret_cast<const f32x4*>(bias + c_col + 16 * j);
+        }
+    };
+    {
+        f32x4 bv[3];
+        load_bias(bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = bv[j];
+    }
+    EEG_LDS_BARRIER();                                     // chunk 0 landed (the loader waited for it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oa[i] = *reinterpret_cast<const f32x4*>(sm + a_lds + i * 256);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ob[j] = *reinterpret_cast<const f32x4*>(sm + b_lds + j * 256);
+    int r_stage = 1, m_c = 0, m_tile = 0;
+    for (int q = 0; q < Q; ++q) {
+        if (q + 1 < Q) EEG_LDS_BARRIER();                  // chunk q+1 landed
+        const float* st = sm + r_stage * ST;               // (after the last chunk: a stale stage, unused)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) obn[j] = *reinterpret_cast<const f32x4*>(st + b_lds + j * 256);
+        const int nrt = m_tile == ntile - 1 ? nrt_last : 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < nrt) {                                 // (a partial tile multiplies its own row tiles only)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(ob[j][s], oa[i][s], acc[i][j]);   // transposed issue
+            }
+            oa[i] = *reinterpret_cast<const f32x4*>(st + a_lds + i * 256);   // refilled in place from chunk q+1
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ob[j] = obn[j];
+        r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+        if (++m_c == nch) {                                // the tile of chunk q is complete
+            const int row0 = (rt0 + 8 * m_tile) * 16;
+            f32x4 bv[3];
+            load_bias(bv);
+            if (nrt == 8 && row0 + 128 <= R && cols_full) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (i < nrt && row0 + 16 * i + lr < R && c_col + 16 * j < O)
+                            wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+            }
+            EEG_SCHED_FENCE();                             // (a store's data registers must not be rewritten right behind it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = bv[j];
+            m_c = 0; ++m_tile;
+        }
     }
 }
 

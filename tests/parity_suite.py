@@ -427,7 +427,10 @@ def check_plane_handover(device, adj3d):
         real_layer = ops.dcgru_layer_ex
 
         def no_handover(*a, **kw):                      # test-side switch: drop the planes handed over by the layer below
-            kw["x_planes"] = None
+            if len(a) >= 15:                            # (x_planes is the 15th positional parameter of dcgru_layer_ex)
+                a = a[:14] + (None,) + a[15:]
+            else:
+                kw["x_planes"] = None
             return real_layer(*a, **kw)
 
         from eeg_gnn_ssl_amd.model import model as model_mod

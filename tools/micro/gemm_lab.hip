@@ -68,13 +68,14 @@ int main(int argc, char** argv) {
     const int only = argc > 2 ? atoi(argv[2]) : -1;
     const int R = 291840, O = 192;
     float *A, *Bold, *Bq, *C, *C2, *bias;
-    CK(hipMalloc(&A, (size_t)3 * R * 100 * 4)); CK(hipMalloc(&Bold, 320 * 192 * 4)); CK(hipMalloc(&Bq, 320 * 192 * 4));
+    CK(hipMalloc(&A, (size_t)5 * R * 100 * 4)); CK(hipMalloc(&Bold, 512 * 192 * 4)); CK(hipMalloc(&Bq, 512 * 192 * 4));
     CK(hipMalloc(&C, (size_t)R * O * 4)); CK(hipMalloc(&C2, (size_t)R * O * 4)); CK(hipMalloc(&bias, 192 * 4));
-    fill_rand(A, (size_t)3 * R * 100, 1); fill_rand(bias, 192, 3);
+    fill_rand(A, (size_t)5 * R * 100, 1); fill_rand(bias, 192, 3);
 
     struct Shape { const char* name; int nseg, F; int btT, btB, btN; };
-    const Shape shapes[] = {{"layer-1 x-part / dX (K=192)", 3, 64, 0, 0, 0}, {"layer-0 x-part (K=300, batch-major rows)", 3, 100, 60, 256, 19}};
-    for (int si = 0; si < 2; ++si) {
+    const Shape shapes[] = {{"layer-1 x-part / dX (K=192)", 3, 64, 0, 0, 0}, {"layer-0 x-part (K=300, batch-major rows)", 3, 100, 60, 256, 19},
+                            {"K=300 time-major", 3, 100, 0, 0, 0}, {"K=192 batch-major", 3, 64, 60, 256, 19}, {"K=320 (5 x 64)", 5, 64, 0, 0, 0}};
+    for (int si = 0; si < 5; ++si) {
         const Shape sh = shapes[si];
         if (only >= 0 && only != si) continue;
         const int K = sh.nseg * sh.F;
@@ -123,9 +124,50 @@ int main(int argc, char** argv) {
             size_t touched = 0; for (size_t i = (size_t)Rr * O; i < h2.size(); ++i) if (h2[i] == h2[i]) ++touched;   // 0xff.. = NaN pattern
             printf("  nnq<3,spread> G=37 half-first-tile R=%d: max |diff| %.3e, off: %zu, elements written past R: %zu\n", Rr, maxd, bad, touched);
         }
+        if (si >= 2 && only != si) continue;          // (extra shapes: correctness only unless selected)
         std::vector<Variant> vs;
         vs.push_back({"baseline gemm_nn_dma (round 2)", [&] { base(C); }, {}});
         vs.push_back({"nnq NS=4 G=512", [&] { cand(gemm_nnq_kernel<4, 0>, 4, 512, C2, R); }, {}});
+        auto candl = [&](auto kern, int ns, int G, float* out, int Rr) {
+            const size_t lds = (size_t)ns * kNnqStageFloats * 4;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(G, 1), dim3(320), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN);
+        };
+        {
+            CK(hipMemset(C2, 0xff, (size_t)R * O * 4));
+            candl(gemm_nnl_kernel<4>, 4, 512, C2, R); CK(hipDeviceSynchronize());
+            std::vector<float> h1((size_t)R * O), h2((size_t)R * O);
+            CK(hipMemcpy(h1.data(), C, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), C2, h2.size() * 4, hipMemcpyDeviceToHost));
+            double maxd = 0; size_t bad = 0;
+            for (size_t i = 0; i < h1.size(); ++i) { const double d = std::fabs((double)h1[i] - h2[i]); if (!(d <= 1e-3)) ++bad; if (d > maxd) maxd = d; }
+            printf("  nnl<4> (loader wave) vs baseline, full size: max |diff| %.3e, elements off by > 1e-3: %zu\n", maxd, bad);
+        }
+        auto candr = [&](int G, float* out, int Rr, int minw = 2) {
+            const size_t lds = ((size_t)4 * 128 * 16 + 192) * 4;
+            if (minw == 3) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nnr_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((gemm_nnr_kernel<4, 3>), dim3(G, 1), dim3(256), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN);
+            } else {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nnr_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((gemm_nnr_kernel<4, 2>), dim3(G, 1), dim3(256), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN);
+            }
+        };
+        for (int rep = 0; rep < 3; ++rep) {
+            const int dbg = 0;
+            CK(hipMemset(C2, 0xff, (size_t)R * O * 4));
+            candr(512, C2, R, 2); CK(hipDeviceSynchronize());
+            std::vector<float> h1((size_t)R * O), h2((size_t)R * O);
+            CK(hipMemcpy(h1.data(), C, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), C2, h2.size() * 4, hipMemcpyDeviceToHost));
+            double maxd = 0; size_t bad = 0, badrow_first = 0, nearbias = 0;
+            for (size_t i = 0; i < h1.size(); ++i) { const double d = std::fabs((double)h1[i] - h2[i]); if (!(d <= 1e-3)) { if (!bad) badrow_first = i / O; ++bad; } if (d > maxd) maxd = d; }
+            printf("  nnr dbg=%d (1: vmcnt(0) behind the tile stores, 2: vmcnt(0) at every chunk) vs baseline: max |diff| %.3e, off: %zu (first bad row %zu)\n", dbg, maxd, bad, badrow_first);
+        }
+        vs.push_back({"nnr G=512 (weights via registers, 2 WG/CU)", [&] { candr(512, C2, R); }, {}});
+        vs.push_back({"nnr G=768 (2 WG/CU resident)", [&] { candr(768, C2, R); }, {}});
+        vs.push_back({"nnr<168 regs, spills> G=768 (3 WG/CU)", [&] { candr(768, C2, R, 3); }, {}});
+        vs.push_back({"nnl NS=4 G=512 (loader wave)", [&] { candl(gemm_nnl_kernel<4>, 4, 512, C2, R); }, {}});
+        vs.push_back({"nnl NS=3 G=512 (loader wave)", [&] { candl(gemm_nnl_kernel<3>, 3, 512, C2, R); }, {}});
+        vs.push_back({"nnl NS=3 G=768 (loader wave, 3 workgroups per CU)", [&] { candl(gemm_nnl_kernel<3>, 3, 768, C2, R); }, {}});
         vs.push_back({"nnq NS=4 G=512 prio alternates per chunk", [&] { cand(gemm_nnq_kernel<4, 0>, 4, 512, C2, R, 8); }, {}});
         vs.push_back({"nnq NS=4 G=512 prio alternates per tile", [&] { cand(gemm_nnq_kernel<4, 0>, 4, 512, C2, R, 16); }, {}});
         vs.push_back({"nnq NS=4 G=512 prio static: younger half high", [&] { cand(gemm_nnq_kernel<4, 0>, 4, 512, C2, R, 24); }, {}});
