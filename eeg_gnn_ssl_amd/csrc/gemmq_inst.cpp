@@ -24,7 +24,7 @@ int launch_nnq(const SegPtrs& segs, int nseg, int F, int R, const float* Bq, int
     if (G > ceil_div(rt, 8)) G = ceil_div(rt, 8);          // at least one 128-row tile per workgroup
     if (G < 1) G = 1;
     EEG_LAUNCH_P(tag, (gemm_nnr_kernel<NS, 2>), dim3(G, nct_total / 12), dim3(256), lds, st, segs, nseg, F, R, Bq, nct_total, bias,
-                 C, ldc, O, btT, btB, btN);
+                 C, ldc, O, btT, btB, btN, 0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

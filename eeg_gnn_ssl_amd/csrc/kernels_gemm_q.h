@@ -357,7 +357,7 @@ template <int NS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm_nnr_kernel(SegPtrs segs, int nseg, int F, int R,
                                                          const float* __restrict__ Bq, int nct_total,
                                                          const float* __restrict__ bias, float* __restrict__ C, int ldc, int O,
-                                                         int btT, int btB, int btN) {
+                                                         int btT, int btB, int btN, int skew) {
     constexpr int NB = 12, ST = 128 * 16;                  // a stage = the 128 x 16 activation tile
     static_assert(NS == 4, "the queue discipline above assumes a ring of 4");
     EEG_DYN_SMEM(sm);
@@ -365,7 +365,18 @@ __global__ __launch_bounds__(256, MINW) void gemm_nnr_kernel(SegPtrs segs, int n
     const NnqOrder ko = make_nnq_order(nseg, F);
     const int nch = ko.nch;
     const int RT = ceil_div(R, 16);
-    const int rt0 = (int)((long long)blockIdx.x * RT / gridDim.x), rt1 = (int)((long long)(blockIdx.x + 1) * RT / gridDim.x);
+    // row tiles of this workgroup.  skew (per mille): the two workgroups of a CU are ids b and b + G/2; the older one (b) wins
+    // every arbitration for the matrix pipe and would finish ~5 % ahead of the other, which then runs alone: the lower half
+    // of the grid gets (1000 + skew) / 1000 of the average share, the upper half the rest
+    const int G = gridDim.x, half = G / 2, bid = blockIdx.x;
+    int rt0, rt1;
+    if (skew == 0 || (G & 1) != 0) {
+        rt0 = (int)((long long)bid * RT / G); rt1 = (int)((long long)(bid + 1) * RT / G);
+    } else {
+        const int lo = (int)((long long)RT * (1000 + skew) / 2000);      // row tiles of the lower half of the grid
+        if (bid < half) { rt0 = (int)((long long)bid * lo / half); rt1 = (int)((long long)(bid + 1) * lo / half); }
+        else { rt0 = lo + (int)((long long)(bid - half) * (RT - lo) / half); rt1 = lo + (int)((long long)(bid - half + 1) * (RT - lo) / half); }
+    }
     const int nrows = rt1 - rt0;
     if (nrows <= 0) return;
     const int ntile = ceil_div(nrows, 8), nrt_last = nrows - 8 * (ntile - 1);
@@ -960,7 +971,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg
                 // chunk q+1 (requested a chunk ago) must have landed; after the barrier every wave is past its reads of
                 // chunk q-1, whose stage takes chunk q+2
                 EEG_VM_WAIT_BARRIER(0);
-                if (q + 2 < Q) issue_dma();
+                if (q + 2 < Q && (flags & 4) == 0) issue_dma();          // (flags 4, lab: no DMA after the prologue)
                 const int r1 = rbeg + (q + 1) * RC;
                 if (TAIL && r1 + RC > rend) { zero_tail(nx, rend - r1); EEG_LDS_BARRIER(); }
             }

@@ -142,20 +142,20 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < h1.size(); ++i) { const double d = std::fabs((double)h1[i] - h2[i]); if (!(d <= 1e-3)) ++bad; if (d > maxd) maxd = d; }
             printf("  nnl<4> (loader wave) vs baseline, full size: max |diff| %.3e, elements off by > 1e-3: %zu\n", maxd, bad);
         }
-        auto candr = [&](int G, float* out, int Rr, int minw = 2) {
+        auto candr = [&](int G, float* out, int Rr, int minw = 2, int skew = 0) {
             const size_t lds = ((size_t)4 * 128 * 16 + 192) * 4;
             if (minw == 3) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nnr_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((gemm_nnr_kernel<4, 3>), dim3(G, 1), dim3(256), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN);
+                hipLaunchKernelGGL((gemm_nnr_kernel<4, 3>), dim3(G, 1), dim3(256), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN, skew);
             } else {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nnr_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL((gemm_nnr_kernel<4, 2>), dim3(G, 1), dim3(256), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN);
+                hipLaunchKernelGGL((gemm_nnr_kernel<4, 2>), dim3(G, 1), dim3(256), lds, 0, segs, sh.nseg, sh.F, Rr, Bq, 12, bias, out, O, O, sh.btT, sh.btB, sh.btN, skew);
             }
         };
         for (int rep = 0; rep < 3; ++rep) {
             const int dbg = 0;
             CK(hipMemset(C2, 0xff, (size_t)R * O * 4));
-            candr(512, C2, R, 2); CK(hipDeviceSynchronize());
+            candr(512, C2, R, 2, rep * 37); CK(hipDeviceSynchronize());
             std::vector<float> h1((size_t)R * O), h2((size_t)R * O);
             CK(hipMemcpy(h1.data(), C, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), C2, h2.size() * 4, hipMemcpyDeviceToHost));
             double maxd = 0; size_t bad = 0, badrow_first = 0, nearbias = 0;
@@ -163,7 +163,11 @@ int main(int argc, char** argv) {
             printf("  nnr dbg=%d (1: vmcnt(0) behind the tile stores, 2: vmcnt(0) at every chunk) vs baseline: max |diff| %.3e, off: %zu (first bad row %zu)\n", dbg, maxd, bad, badrow_first);
         }
         vs.push_back({"nnr G=512 (weights via registers, 2 WG/CU)", [&] { candr(512, C2, R); }, {}});
-        vs.push_back({"nnr G=768 (2 WG/CU resident)", [&] { candr(768, C2, R); }, {}});
+        vs.push_back({"nnr G=512 skew 20", [&] { candr(512, C2, R, 2, 20); }, {}});
+        vs.push_back({"nnr G=512 skew 40", [&] { candr(512, C2, R, 2, 40); }, {}});
+        vs.push_back({"nnr G=512 skew 60", [&] { candr(512, C2, R, 2, 60); }, {}});
+        vs.push_back({"nnr G=512 skew 80", [&] { candr(512, C2, R, 2, 80); }, {}});
+        vs.push_back({"nnr G=512 skew -40", [&] { candr(512, C2, R, 2, -40); }, {}});
         vs.push_back({"nnr<168 regs, spills> G=768 (3 WG/CU)", [&] { candr(768, C2, R, 3); }, {}});
         vs.push_back({"nnl NS=4 G=512 (loader wave)", [&] { candl(gemm_nnl_kernel<4>, 4, 512, C2, R); }, {}});
         vs.push_back({"nnl NS=3 G=512 (loader wave)", [&] { candl(gemm_nnl_kernel<3>, 3, 512, C2, R); }, {}});
@@ -316,6 +320,8 @@ int main(int argc, char** argv) {
             vs.push_back({"tnq G=512", [&] { launch_new(512, P2, R, 0); }, {}});
             vs.push_back({"tnq G=1024", [&] { launch_new(1024, P2, R, 0); }, {}});
             vs.push_back({"tnq G=512 no partial stores", [&] { launch_new(512, P2, R, 10); }, {}});
+            vs.push_back({"tnq G=512 no DMA after the prologue", [&] { launch_new(512, P2, R, 13); }, {}});
+            vs.push_back({"tnq G=512 no DMA, no partial stores", [&] { launch_new(512, P2, R, 14); }, {}});
             vs.push_back({"tnq G=512 partials into 8 cache-resident slots", [&] { launch_new(512, P2, R, 11); }, {}});
             vs.push_back({"tnq G=448", [&] { launch_new(448, P2, R, 0); }, {}});
             vs.push_back({"tnq G=256", [&] { launch_new(256, P2, R, 0); }, {}});
