@@ -129,6 +129,10 @@ int num_cus() {
 #endif
 }
 
+// fewest rows the persistent round-3 GEMMs are used for (below it the ramp of their 2-per-CU grid costs more than the
+// round-2 kernels' many small workgroups); dev knob 2, bits 2..: rows per CU instead of the default
+int q_min_rows() { return ((g_tune[2] >> 2) > 0 ? (g_tune[2] >> 2) : 256) * num_cus(); }
+
 // ---- GEMM dispatch ---------------------------------------------------------------------------
 template <int NCTW, int KC>
 int run_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
@@ -172,7 +176,7 @@ int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int 
 // tiles (dev knob 2 bit 0 = 1: never)
 int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,
             float* C, int ldc, int O, hipStream_t st, const char* tag = "gemm_nn", BtMap bt = BtMap(), const float* Bq = nullptr) {
-    if (Bq != nullptr && (g_tune[2] & 1) == 0 && g_tune[0] == 0 && R >= 512 * num_cus() && nnq_supported(nseg, F, R, nct_total, ldc, O)) {
+    if (Bq != nullptr && (g_tune[2] & 1) == 0 && g_tune[0] == 0 && R >= q_min_rows() && nnq_supported(nseg, F, R, nct_total, ldc, O)) {
         if (launch_nnq(segs, nseg, F, R, Bq, nct_total, bias, C, ldc, O, bt.T, bt.B, bt.N, num_cus(), st, tag)) return fail("gemm_nnq: launch failed");
         return check_launch("gemm_nnq");
     }
@@ -381,7 +385,7 @@ struct BwdWs {
 };
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
-    if ((g_tune[2] & 2) != 0 || g_tune[1] != 0 || R < 512 * num_cus()) return TnqPlan{};
+    if ((g_tune[2] & 2) != 0 || g_tune[1] != 0 || R < q_min_rows()) return TnqPlan{};
     return tnq_plan(nseg, F, R, O, bt, num_cus());
 }
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {

@@ -35,14 +35,16 @@ TnqPlan tnq_plan(int nseg, int F, int R, int O, bool bt, int num_cus) {
     if ((double)R * F * 4.0 >= 4.0e9) return p;
     const int K = nseg * F;
     p.OT = O / 32;
-    if (F == 64 && !bt) {                                  // whole 64-wide planes per k-block
+    const bool planar_exact = F == 64 && !bt && (nseg % 3 == 0 || nseg % 2 == 0 || nseg == 1);
+    if (planar_exact) {                                    // whole 64-wide planes per k-block, no padding plane
         p.planar = 1;
-        p.KT = nseg % 3 == 0 ? 6 : (nseg % 2 == 0 ? 4 : (nseg == 1 ? 2 : 6));
+        p.KT = nseg % 3 == 0 ? 6 : (nseg % 2 == 0 ? 4 : 2);
         p.nkb = ceil_div(nseg, p.KT / 2);
     } else {
-        if (O != 192) return p;
-        // k-block of 4 or 5 tiles per wave slice (6 x 6 tiles + per-lane source pointers spill): least padded K (= MFMA
-        // work), then the wider block
+        // per-lane source pointers (any F % 4 == 0, batch-major or not; also 5 or 7 planes of 64, where whole-plane
+        // blocks would multiply a padding plane: K = 320 is two exact blocks of 160 here).  k-block of 4 or 5 tiles per
+        // wave slice (6 x 6 tiles + per-lane pointers spill): least padded K (= MFMA work), then the wider block
+        if (bt && O != 192) return p;                      // (batch-major rows only occur on the x-part: 192 columns)
         int best = 5, bcost = 1 << 30, bnkb = 1;
         for (int kt = 5; kt >= 4; --kt) {
             const int nkb = ceil_div(K, 32 * kt), cost = nkb * 32 * kt;
@@ -76,7 +78,7 @@ template <int KT, bool BT, bool PLANAR>
 int launch_tnq_ot(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
                   float* partial, int btT, int btB, int btN, hipStream_t st, const char* tag) {
 #define EEG_TNQ(OT) launch_tnq_one<KT, OT, BT, PLANAR>(p, segs, nseg, F, R, dY, ldy, ycol0, O, partial, btT, btB, btN, st, tag)
-    if constexpr (PLANAR) {
+    if constexpr (!BT) {                                   // (batch-major segments: x-part only, 192 columns)
         if (p.OT == 2) return EEG_TNQ(2);
         if (p.OT == 4) return EEG_TNQ(4);
     }

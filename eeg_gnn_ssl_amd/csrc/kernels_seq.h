@@ -89,6 +89,13 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A lone accumulator makes every 16x16x4 MFMA wait for the one before it: 52 cycles per MFMA instead of the 32 of the issue
+    // rate, 64 beside a second MFMA wave on the SIMD (tools/micro/chain_lab.hip).  With one column tile and the second node tile
+    // on the 4x4x1 path the k-steps therefore alternate between two chains, added up at the end.
+    constexpr bool SPLIT = DO16 && REM4 && NT == 1;
+    f32x4 alt[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) alt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     if (DO16) a0 = frag(p0, s0, 0);
     if (!REM4 || DO4) a1 = frag(p1, s1, 0);
@@ -107,7 +114,8 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    acc[i][0] = mfma16(w[i][qw4 + j], x0[j], acc[i][0]);
+                    if (SPLIT && (j & 1)) alt[i] = mfma16(w[i][qw4 + j], x0[j], alt[i]);
+                    else acc[i][0] = mfma16(w[i][qw4 + j], x0[j], acc[i][0]);
                     if (!REM4) acc[i][1] = mfma16(w[i][qw4 + j], x1[j], acc[i][1]);
                 }
         }
@@ -120,6 +128,10 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
         EEG_SCHED_FENCE();
         a0 = n0;
         a1 = n1;
+    }
+    if (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i][0] += alt[i];
     }
     if (DO4) {
         // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr) (lane groups 80 floats apart);  reader (lr < 4, lg):

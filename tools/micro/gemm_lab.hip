@@ -233,8 +233,11 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&P1, pmax * 4)); CK(hipMalloc(&P2, pmax * 4));
         struct TShape { const char* name; int nseg, F, ycol0, Ov, btT, btB, btN; };
         const TShape ts[] = {{"x-part layer 1 (K=192, O=192)", 3, 64, 0, 192, 0, 0, 0}, {"h-gate (K=192, O=128)", 3, 64, 0, 128, 0, 0, 0},
-                             {"h-cand (K=192, O=64)", 3, 64, 128, 64, 0, 0, 0}, {"x-part layer 0 (K=300, O=192, batch-major rows)", 3, 100, 0, 192, 60, 256, 19}};
-        for (int ti = 0; ti < 4; ++ti) {
+                             {"h-cand (K=192, O=64)", 3, 64, 128, 64, 0, 0, 0}, {"x-part layer 0 (K=300, O=192, batch-major rows)", 3, 100, 0, 192, 60, 256, 19},
+                             {"5 planes x-part / dX (K=320, O=192)", 5, 64, 0, 192, 0, 0, 0}, {"5 planes h-gate (K=320, O=128)", 5, 64, 0, 128, 0, 0, 0},
+                             {"5 planes h-cand (K=320, O=64)", 5, 64, 128, 64, 0, 0, 0}};
+        for (int ti = 0; ti < 7; ++ti) {
+            if (ti >= 4 && only != 10 + ti) continue;
             if (only >= 10 && only != 10 + ti) continue;
             const TShape t = ts[ti];
             const int K = t.nseg * t.F;
@@ -271,6 +274,10 @@ int main(int argc, char** argv) {
                 if (ti == 0) return variant == 0 ? new_tn(gemm_tnq_kernel<6, 6, 16, false, true, TL>, 6, 6, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<4, 6, 16, false, true, TL>, 4, 6, 16, G, out, Rr, fl_);
                 if (ti == 1) return variant == 0 ? new_tn(gemm_tnq_kernel<6, 4, 16, false, true, TL>, 6, 4, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<6, 4, 32, false, true, TL>, 6, 4, 32, G, out, Rr, fl_);
                 if (ti == 2) return variant == 0 ? new_tn(gemm_tnq_kernel<6, 2, 16, false, true, TL>, 6, 2, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<6, 2, 32, false, true, TL>, 6, 2, 32, G, out, Rr, fl_);
+                // five planes of 64: generic blocks of 160 (exact) against whole-plane blocks of 192 (one padding plane)
+                if (ti == 4) return variant == 0 ? new_tn(gemm_tnq_kernel<5, 6, 16, false, false, TL>, 5, 6, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<6, 6, 16, false, true, TL>, 6, 6, 16, G, out, Rr, fl_);
+                if (ti == 5) return variant == 0 ? new_tn(gemm_tnq_kernel<5, 4, 16, false, false, TL>, 5, 4, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<6, 4, 16, false, true, TL>, 6, 4, 16, G, out, Rr, fl_);
+                if (ti == 6) return variant == 0 ? new_tn(gemm_tnq_kernel<5, 2, 16, false, false, TL>, 5, 2, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<6, 2, 16, false, true, TL>, 6, 2, 16, G, out, Rr, fl_);
                 return variant == 0 ? new_tn(gemm_tnq_kernel<5, 6, 16, true, false, TL>, 5, 6, 16, G, out, Rr, fl_) : new_tn(gemm_tnq_kernel<4, 6, 16, true, false, TL>, 4, 6, 16, G, out, Rr, fl_);
             };
             auto launch_new = [&](int G, float* out, int Rr, int variant) { return Rr % 32 == 0 ? launch_new_t(IntC<0>(), G, out, Rr, variant) : launch_new_t(IntC<1>(), G, out, Rr, variant); };
@@ -325,8 +332,8 @@ int main(int argc, char** argv) {
             vs.push_back({"tnq G=512 partials into 8 cache-resident slots", [&] { launch_new(512, P2, R, 11); }, {}});
             vs.push_back({"tnq G=448", [&] { launch_new(448, P2, R, 0); }, {}});
             vs.push_back({"tnq G=256", [&] { launch_new(256, P2, R, 0); }, {}});
-            vs.push_back({ti == 0 ? "tnq KT=4 (2 k-blocks, 2nd half empty) G=512" : ti == 3 ? "tnq KT=4 (3 k-blocks) G=512" : "tnq RC=32 G=512", [&] { launch_new(512, P2, R, 1); }, {}});
-            vs.push_back({ti == 0 ? "tnq KT=4 (2 k-blocks, 2nd half empty) G=1024" : ti == 3 ? "tnq KT=4 (3 k-blocks) G=1024" : "tnq RC=32 G=1024", [&] { launch_new(1024, P2, R, 1); }, {}});
+            vs.push_back({ti >= 4 ? "tnq whole planes KT=6 G=512" : ti == 0 ? "tnq KT=4 (2 k-blocks, 2nd half empty) G=512" : ti == 3 ? "tnq KT=4 (3 k-blocks) G=512" : "tnq RC=32 G=512", [&] { launch_new(512, P2, R, 1); }, {}});
+            vs.push_back({ti >= 4 ? "tnq whole planes KT=6 G=1024" : ti == 0 ? "tnq KT=4 (2 k-blocks, 2nd half empty) G=1024" : ti == 3 ? "tnq KT=4 (3 k-blocks) G=1024" : "tnq RC=32 G=1024", [&] { launch_new(1024, P2, R, 1); }, {}});
             run_variants(vs, rounds, fl);
         }
     }

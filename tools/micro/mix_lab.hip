@@ -41,12 +41,29 @@ __global__ __launch_bounds__(512) void mix_kernel(float* __restrict__ buf, long 
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int it = 0; it < nmem; ++it) s += *reinterpret_cast<const f32x4*>(mine + (size_t)(it % 4000) * 256 + lane * 4);
         if (s[0] == 12345.f) mine[lane] = s[1];
+    } else if (mode == 4 || mode == 5 || mode == 6) {
+        // VALU partner: nmem x 16 independent fp32 FMAs (mode 4), integer adds (mode 5), v_exp_f32 (mode 6)
+        float a[16]; int b[16];
+        for (int i = 0; i < 16; ++i) { a[i] = lane + i; b[i] = lane * i; }
+        const long long t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < nmem; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (mode == 4) a[i] = a[i] * 1.0001f + 0.5f;
+                else if (mode == 5) b[i] = b[i] + it;
+                else a[i] = __builtin_amdgcn_exp2f(a[i] * 0.001f);
+            }
+        }
+        const long long t1 = __builtin_readcyclecounter();
+        float s = 0; for (int i = 0; i < 16; ++i) s += a[i] + b[i];
+        if (s == 12345.f) mine[lane] = s;
+        if (lane == 0) out[1024 + blockIdx.x * 4 + (w - 4)] = t1 - t0;
     }
 }
 
 int main() {
     float* buf; long long* out;
-    CK(hipMalloc(&buf, (size_t)256 * (1 << 20) * 4)); CK(hipMalloc(&out, 256 * 4 * 8));
+    CK(hipMalloc(&buf, (size_t)256 * (1 << 20) * 4)); CK(hipMalloc(&out, 2 * 256 * 4 * 8)); CK(hipMemset(out, 0, 2 * 256 * 4 * 8));
     CK(hipMemset(buf, 0, (size_t)256 * (1 << 20) * 4));
     const int nm = 2000;                                            // 24 000 MFMAs per wave = 768 k cycles at the issue rate
     const char* names[4] = {"idle", "16-byte stores (GEMM epilogue pattern)", "LDS-DMA loads", "plain 16-byte loads"};
@@ -58,6 +75,18 @@ int main() {
             std::vector<long long> h(1024); CK(hipMemcpy(h.data(), out, 8192, hipMemcpyDeviceToHost));
             double avg = 0; for (auto v : h) avg += v / 1024.0;
             printf("partner waves: %-40s x %5d per wave -> MFMA waves %.0f cycles for %d MFMAs = %.1f cycles/MFMA (32.0 = issue rate)\n", names[mode], nmem, avg, nm * 12, avg / (nm * 12));
+        }
+    // VALU partners: how many cycles does a VALU instruction take beside an fp32 MFMA stream, and what does it cost the MFMAs?
+    const char* vn[3] = {"fp32 FMA", "int add", "v_exp_f32"};
+    for (int mode = 4; mode <= 6; ++mode)
+        for (int alone = 0; alone < 2; ++alone) {
+            const int nv = 20000;
+            hipLaunchKernelGGL(mix_kernel, dim3(256), dim3(512), 32768, 0, buf, out, alone ? 1 : nm, mode, nv);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> h(2048); CK(hipMemcpy(h.data(), out, 16384, hipMemcpyDeviceToHost));
+            double am = 0, av = 0; for (int i = 0; i < 1024; ++i) { am += h[i] / 1024.0; av += h[1024 + i] / 1024.0; }
+            printf("partner waves: %d x 16 %-9s %s: VALU waves %.1f cycles per instruction; MFMA waves %.1f cycles/MFMA\n", nv, vn[mode - 4],
+                   alone ? "ALONE (no MFMA stream) " : "beside the MFMA stream", av / (nv * 16.0), alone ? 0.0 : am / (nm * 12.0));
         }
     return 0;
 }
