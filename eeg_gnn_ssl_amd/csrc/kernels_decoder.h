@@ -88,14 +88,22 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
         f0 += D;
         if (f0 == kpp) { f0 = 0; ++slot; }
     };
-    auto mac = [&](const float (&w)[D][NT], const float (&x0)[D], const float (&x1)[D]) {
+    // One group = all its 16x16x4 MFMAs, then all its 4x4x1 MFMAs: a 4x4x1 behind a 16x16x4 costs ~19 cycles instead of 8, up
+    // to ~43 cycles per run however long (tools/micro/chain_lab.hip) -- alternating the shapes k-step by k-step paid that on
+    // every one.  A lone column tile alternates between two 16x16x4 chains (a dependent chain issues every 52 cycles, not 32).
+    f32x4 alt = {0.f, 0.f, 0.f, 0.f};
+    auto mac = [&](const float (&w)[D][NT], const float (&x0)[D], const float (&x1)[D]) __attribute__((always_inline)) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                acc[i][0] = mfma16(w[d][i], x0[d], acc[i][0]);
-                rem[i][d & 3] = mfma4(x1[d], w[d][i], rem[i][d & 3]);
+                if (NT == 1 && (d & 1)) alt = mfma16(w[d][i], x0[d], alt);
+                else acc[i][0] = mfma16(w[d][i], x0[d], acc[i][0]);
             }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) rem[i][d & 3] = mfma4(x1[d], w[d][i], rem[i][d & 3]);
     };
     float wb[D][NT], xa0[D], xa1[D];
     if (!PRE) plain_wload<NT, D>(wp, nct_total, wt, lane, 0, wa);
@@ -132,6 +140,7 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
             }
         }
     }
+    if (NT == 1) acc[0][0] += alt;
     // remainder hand-over (see mfma_nodes32)
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -192,6 +201,7 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!PRE) quad_prefetch<NT, NQ, PD, NTW>(wp, nct_total, wt, lane, w);
+    f32x4 alt = {0.f, 0.f, 0.f, 0.f};            // second 16x16x4 chain of a lone column tile
     float4 a0 = frag(p0, s0, 0), a1 = frag(p1, s1, 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -204,15 +214,20 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
         const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
         EEG_SCHED_FENCE();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)              // the quad's 16x16x4 MFMAs, then its 4x4x1 MFMAs (see gemm_stream_plain)
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                acc[i][0] = mfma16(w[q % (PD + 1)][j][i], x0[j], acc[i][0]);
-                rem[i][j] = mfma4(x1[j], w[q % (PD + 1)][j][i], rem[i][j]);
+                if (NT == 1 && (j & 1)) alt = mfma16(w[q % (PD + 1)][j][i], x0[j], alt);
+                else acc[i][0] = mfma16(w[q % (PD + 1)][j][i], x0[j], acc[i][0]);
             }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) rem[i][j] = mfma4(x1[j], w[q % (PD + 1)][j][i], rem[i][j]);
         a0 = n0;
         a1 = n1;
     }
+    if (NT == 1) acc[0][0] += alt;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll

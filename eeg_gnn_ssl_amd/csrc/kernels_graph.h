@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
     const int b = blockIdx.x, sp = blockIdx.y, NS = gridDim.y;
     f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = {0.f, 0.f, 0.f, 0.f}, c11 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c00b = c00, c01b = c00, c11b = c00;          // REM4: second chains (odd k of every pair), added at the end
     const int i1 = REM4 ? 16 + (i & 3) : 16 + i;          // second-tile row this lane feeds
     const bool has0 = i < N, has1 = i1 < N;
     float* buf = sm + wave * step_floats;
@@ -74,10 +75,12 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const float* __restrict_
         for (int q = 0; q < NQ; ++q) {
             const float4 x0 = a0[q], x1 = a1[q];
             if constexpr (REM4) {       // c01 / c11 registers hold [lane][r] = partial of G[16 + r][node of the lane] (see above)
-                c00 = mfma16(x0.x, x0.x, c00); c01 = mfma4(x1.x, x0.x, c01); c11 = mfma4(x1.x, x1.x, c11);
-                c00 = mfma16(x0.y, x0.y, c00); c01 = mfma4(x1.y, x0.y, c01); c11 = mfma4(x1.y, x1.y, c11);
-                c00 = mfma16(x0.z, x0.z, c00); c01 = mfma4(x1.z, x0.z, c01); c11 = mfma4(x1.z, x1.z, c11);
-                c00 = mfma16(x0.w, x0.w, c00); c01 = mfma4(x1.w, x0.w, c01); c11 = mfma4(x1.w, x1.w, c11);
+                // the quad's 16x16x4 MFMAs on two alternating chains (a lone chain issues every 52 cycles, not 32), then its
+                // 4x4x1 MFMAs as one run (a change of shape costs ~11 cycles per 4x4x1, up to ~43 per run; chain_lab.hip)
+                c00 = mfma16(x0.x, x0.x, c00); c00b = mfma16(x0.y, x0.y, c00b);
+                c00 = mfma16(x0.z, x0.z, c00); c00b = mfma16(x0.w, x0.w, c00b);
+                c01 = mfma4(x1.x, x0.x, c01); c11 = mfma4(x1.x, x1.x, c11); c01b = mfma4(x1.y, x0.y, c01b); c11b = mfma4(x1.y, x1.y, c11b);
+                c01 = mfma4(x1.z, x0.z, c01); c11 = mfma4(x1.z, x1.z, c11); c01b = mfma4(x1.w, x0.w, c01b); c11b = mfma4(x1.w, x1.w, c11b);
             } else {
                 c00 = mfma16(x0.x, x0.x, c00); c01 = mfma16(x0.x, x1.x, c01); c11 = mfma16(x1.x, x1.x, c11);
                 c00 = mfma16(x0.y, x0.y, c00); c01 = mfma16(x0.y, x1.y, c01); c11 = mfma16(x1.y, x1.y, c11);
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const float* __restrict_
             }
         }
     }
+    if constexpr (REM4) { c00 += c00b; c01 += c01b; c11 += c11b; }
     __syncthreads();                                        // staging buffers are free: reuse for the partial Grams
     float* mine = sm + wave * kGramFloats;
     if constexpr (REM4) {

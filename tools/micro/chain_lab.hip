@@ -86,6 +86,40 @@ template <int G16, int G4> void run_shape(float* buf, long long* out) {
     else printf("groups of %2d 16x16x4 + %2d 4x4x1: %.1f cycles per group (32 x %d + 8 x %d = %d)\n", G16, G4, t / n / 4, G16, G4, 32 * G16 + 8 * G4);
 }
 
+// Wave A streams 16x16x4 MFMAs (two chains), wave B on the same SIMD streams 4x4x1 MFMAs (four chains): is the cost of changing
+// shapes a property of the pipe (then the two streams disturb each other) or of one wave's instruction order?
+__global__ __launch_bounds__(512) void two_shape_kernel(float* __restrict__ buf, long long* __restrict__ out, int na, int nb) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float a = lane * 0.001f, b = 1.f + lane;
+    __syncthreads();
+    f32x4 p = {0.f, 0.f, 0.f, 0.f}, q = p, r2 = p, r3 = p;
+    const long long t0 = __builtin_readcyclecounter();
+    if (w < 4) {
+        for (int it = 0; it < na / 4; ++it) {
+            p = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, p, 0, 0, 0); q = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, q, 0, 0, 0);
+            p = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, p, 0, 0, 0); q = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, q, 0, 0, 0);
+        }
+    } else {
+        for (int it = 0; it < nb / 4; ++it) {
+            p = __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, p, 0, 0, 0); q = __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, q, 0, 0, 0);
+            r2 = __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, r2, 0, 0, 0); r3 = __builtin_amdgcn_mfma_f32_4x4x1f32(b, a, r3, 0, 0, 0);
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    const float s = p[0] + q[0] + r2[0] + r3[0];
+    if (s == 12345.f) buf[lane] = s;
+    if (lane == 0) out[blockIdx.x * 8 + w] = t1 - t0;
+}
+void run_two_shape(float* buf, long long* out, int na, int nb) {
+    hipLaunchKernelGGL(two_shape_kernel, dim3(256), dim3(512), 0, 0, buf, out, na, nb);
+    CK(hipDeviceSynchronize());
+    std::vector<long long> h(2048); CK(hipMemcpy(h.data(), out, 2048 * 8, hipMemcpyDeviceToHost));
+    double ta = 0, tb = 0;
+    for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) (w < 4 ? ta : tb) += h[b * 8 + w] / 1024.0;
+    printf("wave A: %d 16x16x4 (%d cycles at 32) in %.0f cycles | wave B: %d 4x4x1 (%d cycles at 8) in %.0f cycles | one after the other: %d\n",
+           na, na * 32, ta, nb, nb * 8, tb, na * 32 + nb * 8);
+}
+
 template <int CH, int PRIO, int BCH> void run(float* buf, long long* out, int na, int nb, const char* what) {
     hipLaunchKernelGGL((chain_kernel<CH, PRIO, BCH>), dim3(256), dim3(512), 0, 0, buf, out, na, nb);
     CK(hipDeviceSynchronize());
@@ -105,6 +139,7 @@ int main() {
     run<1, 1, 12>(buf, out, na, 9600, "12 chains, 2x the MFMAs");  run<2, 1, 12>(buf, out, na, 9600, "12 chains, 2x the MFMAs");  run<4, 1, 12>(buf, out, na, 9600, "12 chains, 2x the MFMAs");
     run<1, 0, 1>(buf, out, na, 4800, "1 chain, as many MFMAs");    run<1, 1, 1>(buf, out, na, 4800, "1 chain, as many MFMAs");
     run<2, 1, 1>(buf, out, na, 4800, "1 chain, as many MFMAs");    run<2, 1, 2>(buf, out, na, 4800, "2 chains, as many MFMAs");
+    run_two_shape(buf, out, 4800, 0); run_two_shape(buf, out, 0, 4800); run_two_shape(buf, out, 4800, 4800); run_two_shape(buf, out, 4800, 19200);
     run_shape<4, 0>(buf, out); run_shape<0, 4>(buf, out); run_shape<0, 16>(buf, out); run_shape<4, 4>(buf, out); run_shape<8, 8>(buf, out); run_shape<16, 16>(buf, out); run_shape<4, 1>(buf, out); run_shape<1, 1>(buf, out); run_shape<2, 2>(buf, out); run_shape<2, 1>(buf, out); run_shape<4, 2>(buf, out); run_shape<4, 3>(buf, out); run_shape<48, 48>(buf, out);
     return 0;
 }
