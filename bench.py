@@ -160,8 +160,8 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
 # kernel symbol behind every role at the cfg2 shapes (64 units, M = 3, 19 nodes)
 ROLE_SYMBOLS = {
     "seq_fwd": "seq_fwd2_kernel<64,3,5>", "seq_bwd": "seq_bwd2_kernel<64,3,5>",
-    "gemm_nn_xw": "gemm_nnq_kernel<4,0> (layer 0: K=300 in 19 chunks; layer 1: K=192)",
-    "gemm_nn_dx": "gemm_nnq_kernel<4,0>", "gemm_tn_x": "gemm_tnq_kernel<5,6,16,bt> (layer 0) + gemm_tnq_kernel<6,6,16,planar> (layer 1)",
+    "gemm_nn_xw": "gemm_nnr_kernel<4,2> (layer 0: K=300 in 19 chunks; layer 1: K=192)",
+    "gemm_nn_dx": "gemm_nnr_kernel<4,2>", "gemm_tn_x": "gemm_tnq_kernel<5,6,16,bt> (layer 0) + gemm_tnq_kernel<6,6,16,planar> (layer 1)",
     "gemm_tn_hg": "gemm_tnq_kernel<6,4,16,planar>", "gemm_tn_hc": "gemm_tnq_kernel<6,2,16,planar>",
     "diffuse_fwd": "diffuse_fwd_stream_kernel<19>", "diffuse_adj": "diffuse_adj_stream_kernel<19>",
 }

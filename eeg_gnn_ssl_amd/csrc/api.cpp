@@ -25,48 +25,6 @@
 #include <string>
 #include <vector>
 
-#if !defined(EEG_SIMT_EMU)
-namespace eeg {
-namespace {
-struct ProfRec { const char* name; hipEvent_t a, b; };
-bool g_prof_on = false;
-std::vector<ProfRec> g_recs;
-std::vector<hipEvent_t> g_pool;
-hipEvent_t g_open = nullptr;
-const char* g_open_name = nullptr;
-const char* g_prefix = nullptr;
-std::vector<std::string*> g_names;
-hipEvent_t prof_event() {
-    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e;
-    (void)hipEventCreate(&e);
-    return e;
-}
-}  // namespace
-void prof_set_prefix(const char* prefix) { g_prefix = prefix; }
-void prof_begin(const char* name, hipStream_t st) {
-    if (!g_prof_on) return;
-    g_open = prof_event();
-    if (g_prefix != nullptr) {                       // interned so that records can keep a plain pointer
-        std::string full = std::string(g_prefix) + name;
-        const std::string* hit = nullptr;
-        for (auto& n : g_names)
-            if (*n == full) { hit = n; break; }
-        if (hit == nullptr) { g_names.push_back(new std::string(full)); hit = g_names.back(); }
-        name = hit->c_str();
-    }
-    g_open_name = name;
-    (void)hipEventRecord(g_open, st);
-}
-void prof_end(hipStream_t st) {
-    if (!g_prof_on || g_open == nullptr) return;
-    hipEvent_t b = prof_event();
-    (void)hipEventRecord(b, st);
-    g_recs.push_back({g_open_name, g_open, b});
-    g_open = nullptr;
-}
-}  // namespace eeg
-#endif
 
 namespace {
 
@@ -115,19 +73,7 @@ int check_dims(int N, int H, int Fin, int M) {
 }
 
 // CUs of the current device (the persistent GEMMs size their grids by it); queried once per process
-int num_cus() {
-#if defined(EEG_SIMT_EMU)
-    return 4;                                         // (emulator: a small grid exercises the same paths)
-#else
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
-#endif
-}
+int num_cus() { return platform_num_cus(); }
 
 // fewest rows the persistent round-3 GEMMs are used for (below it the ramp of their 2-per-CU grid costs more than the
 // round-2 kernels' many small workgroups); dev knob 2, bits 2..: rows per CU instead of the default
@@ -551,12 +497,7 @@ int check_decoder_dims(const eeg_decoder_dims* d) {
     return check_dims(d->N, d->H, d->H, d->M);
 }
 int copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
-#if defined(EEG_SIMT_EMU)
-    memcpy(dst, src, n * sizeof(float));
-    return 0;
-#else
-    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess ? 0 : fail("device copy failed");
-#endif
+    return platform_copy_floats(dst, src, n, st) ? 0 : fail("device copy failed");
 }
 
 }  // namespace
@@ -565,13 +506,7 @@ extern "C" {
 
 const char* eeg_dcrnn_last_error(void) { return g_err; }
 int eeg_dcrnn_abi_version(void) { return 2; }
-int eeg_dcrnn_is_device_build(void) {
-#if defined(EEG_SIMT_EMU)
-    return 0;
-#else
-    return 1;
-#endif
-}
+int eeg_dcrnn_is_device_build(void) { return kPlatformIsDevice; }
 #if defined(EEG_DEV)
 int eeg_dcrnn_set_tuning(int key, int value) {
     if (key < 0 || key >= 16) return fail("set_tuning: key %d out of range", key);
@@ -584,38 +519,14 @@ int eeg_dcrnn_set_seq_probe(int64_t* probe) {
 }
 #endif
 int eeg_dcrnn_prof_enable(int on) {
-#if !defined(EEG_SIMT_EMU)
-    eeg::g_prof_on = on != 0;
-#endif
+    eeg::prof_enable(on != 0);
     return 0;
 }
 int eeg_dcrnn_prof_report(char* buf, size_t cap) {
     if (buf == nullptr || cap == 0) return fail("prof_report: empty buffer");
     buf[0] = 0;
-#if !defined(EEG_SIMT_EMU)
-    struct Agg { const char* name; int count; double ms; };
-    std::vector<Agg> agg;
-    for (auto& r : eeg::g_recs) {
-        (void)hipEventSynchronize(r.b);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, r.a, r.b);
-        bool found = false;
-        for (auto& a : agg)
-            if (strcmp(a.name, r.name) == 0) { a.count++; a.ms += ms; found = true; break; }
-        if (!found) agg.push_back({r.name, 1, (double)ms});
-        eeg::g_pool.push_back(r.a);
-        eeg::g_pool.push_back(r.b);
-    }
-    eeg::g_recs.clear();
-    std::string out;
-    char line[160];
-    for (auto& a : agg) {
-        snprintf(line, sizeof(line), "%s %d %.6f\n", a.name, a.count, a.ms);
-        out += line;
-    }
-    if (out.size() + 1 > cap) return fail("prof_report: buffer too small (%zu needed)", out.size() + 1);
-    memcpy(buf, out.c_str(), out.size() + 1);
-#endif
+    const size_t need = eeg::prof_report(buf, cap);
+    if (need != 0) return fail("prof_report: buffer too small (%zu needed)", need);
     return 0;
 }
 int eeg_dcrnn_supported(int N, int H, int Fin, int M) { return check_dims(N, H, Fin, M) == 0 ? 1 : 0; }

@@ -29,43 +29,12 @@ namespace eeg {
 constexpr int kNnqStageFloats = 128 * 16 + 12 * 256;   // A tile + 12 column tiles of the quad pack = 20 KB
 __host__ __device__ constexpr int nnq_gsw(int x) { return (4 - x) & 3; }
 
-#if !defined(EEG_SIMT_EMU)
-__device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
-}
-#define EEG_VM_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
-#define EEG_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-__device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {   // offsets in floats
-    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64((u32x2_){__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, b, 4u * voff, 4u * soff, 0);
-}
-__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), b, 4u * voff, 4u * soff, 0);
-}
-#else
-__device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {
-    float* q = const_cast<float*>(b.p) + (size_t)voff + soff; q[0] = x; q[1] = y;
-}
-__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) { const_cast<float*>(b.p)[(size_t)voff + soff] = x; }
-__device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
-    memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
-}
-#define EEG_VM_WAIT_BARRIER(n) __syncthreads()
-#define EEG_VM_WAIT(n) ((void)0)
-#endif
 
-#if defined(EEG_SIMT_EMU)
-struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
-#else
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#endif
 template <int V> struct IntC { static constexpr int value = V; };
 // a value the optimiser cannot see through: keeps rare-path computations from being hoisted out of a hot loop (and
 // parked in registers the loop needs)
 __device__ __forceinline__ int opaque(int v) {
-#if !defined(EEG_SIMT_EMU)
-    asm volatile("" : "+v"(v));
-#endif
+    EEG_PIN(v);
     return v;
 }
 
@@ -83,11 +52,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
                                                          int btT, int btB, int btN, int flags, long long* __restrict__ probe = nullptr) {
     constexpr int NB = 12, AF = 128 * 16, ST = kNnqStageFloats, NST = 24;
     constexpr bool PROBE = (ABL & 128) != 0;   // lab: cycle counters per workgroup (wave 0): probe[8]
-#if defined(EEG_SIMT_EMU)
-    const long long tr0 = 0;
-#else
-    const long long tr0 = PROBE ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
-#endif
+    const long long tr0 = PROBE ? realtime_now() : 0;
     long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc6 = 0, pc7 = 0;   // waits after an epilogue (0, 1, 2 iterations), other waits, their count, iteration cycles, epilogue cycles, epilogues
     static_assert(NS >= 2 && NS <= 5, "ring depth");
     EEG_DYN_SMEM(sm);
@@ -292,9 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-#if !defined(EEG_SIMT_EMU)
-                        asm volatile("" ::"v"(acc[i][j]));
-#endif
+                        EEG_USE(acc[i][j]);
                         acc[i][j] = bv[j];
                     }
                 epi_cnt = 0;
@@ -332,9 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nnq_kernel(SegPtrs segs, int nseg
         long long* o = probe + blockIdx.x * 10;
         o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = pc5; o[6] = pc6; o[7] = pc7;
         o[8] = tr0;
-#if !defined(EEG_SIMT_EMU)
-        o[9] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
+        o[9] = realtime_now();
     }
 }
 
@@ -985,12 +946,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg
     // k = k0 + block_col(wk, col(ga, 4 kk + r, ea)): the lane part (kk) goes into the per-lane offset, the (r, ea) part is a
     // wave-uniform row offset of the buffer store (requires K * Ov * 4 < 4 GB per split: it is a weight gradient)
     if (flags & 1) {                                       // lab: no partial stores (the accumulators stay live)
-#if !defined(EEG_SIMT_EMU)
 #pragma unroll
         for (int a = 0; a < KT; ++a)
 #pragma unroll
-            for (int b = 0; b < OT; ++b) asm volatile("" ::"v"(acc[a][b]));
-#endif
+            for (int b = 0; b < OT; ++b) EEG_USE(acc[a][b]);
         return;
     }
     const wbuf_t ro = make_wbuf(partial + (size_t)((flags & 2) ? split & 7 : split) * K * Ov);   // flags 2 (lab): 8 cache-resident slots

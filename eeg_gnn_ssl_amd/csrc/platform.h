@@ -1,0 +1,116 @@
+// gfx950 (MI355X, CDNA4) platform layer of the DCRNN kernels: the device intrinsics, launch macros and the few host-side HIP
+// calls the kernel sources and api.cpp use by name.  common.h includes EEG_PLATFORM_HEADER, which is THIS file in every product
+// build; a build may name another header with the same interface (the test tree does, to run the kernel sources on host memory
+// without a GPU).  Nothing in the product refers to such a substitute.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define EEG_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define EEG_SET_MAX_LDS(kern, bytes) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products; D[lane l][reg r] += A(lane 4*(l/4) + r) * B(lane l)
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+// pins the instruction order at this point (keeps hand-placed LDS prefetches ahead of the MFMAs)
+#define EEG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A wave executes in lockstep and its LDS operations complete in order, so data a wave wrote to LDS
+// is visible to its own later LDS reads; this only stops the compiler from reordering across it.
+#define EEG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#define EEG_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier, and the
+// fence makes the compiler drain the vector-memory counter (s_waitcnt vmcnt(0)) in front of every s_barrier: a wave
+// with global loads or stores in flight -- the recurrent kernels prefetch their operands a step ahead and stream
+// their results out -- then sits at the barrier for a full HBM round trip, every step (measured: ~2200 cycles per
+// barrier that follows a prefetch).  The waves of these kernels exchange data through LDS only (no wave reads global
+// memory another wave of its workgroup wrote in the same launch), so waiting for the LDS counter is sufficient; the
+// compiler still tracks the outstanding loads and waits where their registers are first used.
+#define EEG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// counted wait on the vector-memory queue (it retires in order), alone or in front of a raw workgroup barrier
+#define EEG_VM_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+#define EEG_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// EEG_PIN: the value is (re)defined here as far as the optimizer knows (blocks hoisting / sinking of what computes it);
+// EEG_USE: the value is needed here (keeps accumulators of ablated code paths alive).  No instructions.
+#define EEG_PIN(v) asm volatile("" : "+v"(v))
+#define EEG_USE(v) asm volatile("" ::"v"(v))
+__device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
+__device__ __forceinline__ long long realtime_now() { return (long long)__builtin_amdgcn_s_memrealtime(); }   // 100 MHz, chip-wide
+
+// LDS-DMA (gfx950 global_load_lds_dwordx4): every lane of the wave copies 16 bytes from its own global
+// address to LDS at `lds_wave_base + lane * 16 B` (the LDS side is lane-linear; lds_wave_base must be
+// wave-uniform).  Asynchronous: completes with the vector-memory counter (the compiler waits before
+// the next barrier).  wave_uniform(): tell the compiler a value derived from threadIdx is wave-uniform.
+__device__ __forceinline__ void lds_dma16(float* lds_wave_base, const float* g) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Streamed weight packs (kernels_decoder.h) are read through a buffer descriptor: the address of a load is
+// descriptor base (SGPRs) + a per-lane 32-bit offset (ONE VGPR for all loads of a tile) + a wave-uniform offset
+// (SGPR / literal).  With flat loads every k-step row further than 4 KB from the previous one needs its own 64-bit VGPR
+// address, which the compiler hoists out of the time loop -- hundreds of registers.  Offsets in floats.
+typedef __amdgpu_buffer_rsrc_t wbuf_t;
+__device__ __forceinline__ wbuf_t make_wbuf(const float* p) {              // p must be wave-uniform
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4u * voff, 4u * soff, 0));
+}
+// 16-byte accesses of activations through a descriptor (offsets in floats, < 2^29)
+__device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, 4u * voff, 4u * soff, 0));
+}
+__device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), b, 4u * voff, 4u * soff, 0);
+}
+__device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2_){__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y)}, b, 4u * voff, 4u * soff, 0);
+}
+__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), b, 4u * voff, 4u * soff, 0);
+}
+// LDS-DMA through a descriptor (buffer_load_dwordx4 ... lds): 16 bytes per lane to lds_wave_base + lane * 16; BYTE offsets
+__device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
+}
+
+namespace eeg {
+// Fast activations for the recurrent epilogues: v_exp_f32 / v_rcp_f32 (1 ulp each); absolute
+// error of sigmoid/tanh ~2e-7, far inside the 1e-4 parity budget (tests assert 2e-5).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// a*b + c with the product rounded first (what two separate framework kernels compute)
+__device__ __forceinline__ float unfused_mul_add(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------
+constexpr int kPlatformIsDevice = 1;
+// CUs of the current device (the persistent GEMMs size their grids by it); queried once per process
+inline int platform_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+inline bool platform_copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
+}
+}  // namespace eeg

@@ -5,15 +5,12 @@
 #include "common.h"
 
 namespace eeg {
-#if defined(EEG_SIMT_EMU)
-inline void prof_begin(const char*, hipStream_t) {}
-inline void prof_end(hipStream_t) {}
-inline void prof_set_prefix(const char*) {}
-#else
 void prof_begin(const char* name, hipStream_t st);
 void prof_end(hipStream_t st);
 void prof_set_prefix(const char* prefix);      // records made while set are named prefix+name
-#endif
+void prof_enable(bool on);
+// "name count total_ms\n" per kernel name since the last report, into buf; returns the bytes needed (incl. NUL) if cap is too small, else 0
+size_t prof_report(char* buf, size_t cap);
 struct ProfPrefix {                             // RAII: tag the launches of one API call (e.g. "dec_")
     explicit ProfPrefix(const char* p) { prof_set_prefix(p); }
     ~ProfPrefix() { prof_set_prefix(nullptr); }

@@ -44,11 +44,5 @@ struct DecBwdArgs;
 int launch_dec_fwd_persist(int M, int dx, const DecFwdArgs& a, size_t lds, hipStream_t st);
 int launch_dec_bwd_persist(int M, int dt, const DecBwdArgs& a, size_t lds, hipStream_t st);
 
-#if defined(EEG_SIMT_EMU)
-#define EEG_SET_MAX_LDS(kern, bytes) ((void)0)
-#else
-#define EEG_SET_MAX_LDS(kern, bytes) \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))
-#endif
 
 }  // namespace eeg

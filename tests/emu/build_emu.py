@@ -20,7 +20,7 @@ def _newest(paths):
 
 def sources():
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".cpp"))]
-    deps += [os.path.join(HERE, "simt_emu.h"), os.path.join(HERE, "emu_impl.cpp"),
+    deps += [os.path.join(HERE, "simt_emu.h"), os.path.join(HERE, "platform_emu.h"), os.path.join(HERE, "emu_impl.cpp"),
              os.path.join(ROOT, "include", "eeg_dcrnn.h"), os.path.join(ROOT, "include", "eeg_dcrnn_dev.h"),
              os.path.join(ROOT, "include", "eeg_dcrnn_prof.h"), os.path.abspath(__file__)]
     return deps
@@ -31,7 +31,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest(sources()):
         return OUT
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    common = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-DEEG_SIMT_EMU", "-DEEG_DEV", "-I", HERE, "-I", CSRC,
+    common = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-DEEG_PLATFORM_HEADER=\"platform_emu.h\"", "-DEEG_DEV", "-I", HERE, "-I", CSRC,
               "-Wno-unused-function", "-Wno-unknown-attributes"]
     objs = []
     jobs = []

@@ -1,0 +1,60 @@
+// TEST INFRASTRUCTURE ONLY: the platform layer of eeg_gnn_ssl_amd/csrc (same names as csrc/platform.h) on the fiber-based SIMT
+// emulator of simt_emu.h, so that the kernel SOURCES, the C-ABI orchestration and the Python host layer can be exercised on a
+// machine without a GPU.  Selected by tests/emu/build_emu.py through -DEEG_PLATFORM_HEADER; the product build never sees it.
+#pragma once
+#include "simt_emu.h"
+
+struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+#define EEG_DYN_SMEM(name) float* name = reinterpret_cast<float*>(emu::g.smem)
+#define EEG_LAUNCH(kern, grid, block, smem, stream, ...) \
+    emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define EEG_SET_MAX_LDS(kern, bytes) ((void)0)
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::mfma4(a, b, c); }
+#define EEG_SCHED_FENCE() ((void)0)
+#define EEG_WAVE_SYNC() emu::wave_sync()
+#define EEG_SETPRIO(p) ((void)0)
+#define EEG_LDS_BARRIER() __syncthreads()
+#define EEG_VM_WAIT_BARRIER(n) __syncthreads()
+#define EEG_VM_WAIT(n) ((void)0)
+#define EEG_PIN(v) ((void)0)
+#define EEG_USE(v) ((void)0)
+__device__ __forceinline__ long long cycle_now() { return 0; }
+__device__ __forceinline__ long long realtime_now() { return 0; }
+
+__device__ __forceinline__ void lds_dma16(float* lds_wave_base, const float* g) {
+    memcpy(lds_wave_base + 4 * (threadIdx.x & 63), g, 16);
+}
+__device__ __forceinline__ int wave_uniform(int v) { return v; }
+
+struct wbuf_t { const float* p; };
+__device__ __forceinline__ wbuf_t make_wbuf(const float* p) { return wbuf_t{p}; }
+__device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) { return b.p[(size_t)voff + soff]; }
+__device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff) {
+    const float* q = b.p + (size_t)voff + soff;
+    return f32x4{q[0], q[1], q[2], q[3]};
+}
+__device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
+    float* q = const_cast<float*>(b.p) + (size_t)voff + soff;
+    q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+}
+__device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {
+    float* q = const_cast<float*>(b.p) + (size_t)voff + soff; q[0] = x; q[1] = y;
+}
+__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) { const_cast<float*>(b.p)[(size_t)voff + soff] = x; }
+__device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
+    memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
+}
+
+namespace eeg {
+__device__ __forceinline__ float fast_exp(float x) { return expf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float unfused_mul_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
+
+constexpr int kPlatformIsDevice = 0;
+inline int platform_num_cus() { return 4; }          // a small grid exercises the same persistent-kernel paths
+inline bool platform_copy_floats(float* dst, const float* src, size_t n, hipStream_t) {
+    memcpy(dst, src, n * sizeof(float));
+    return true;
+}
+}  // namespace eeg

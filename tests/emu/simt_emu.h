@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY — a tiny single-OS-thread SIMT emulator used by tests/ to execute the
 // HIP kernel SOURCES of eeg_gnn_ssl_amd/csrc on the CPU (no GPU in the build container; GPU
 // minutes are scarce).  It is NOT a CPU fallback: the product library never includes this file
-// (it is only reachable with -DEEG_SIMT_EMU, which only tests/emu/build_emu.py passes).
+// (it is only reachable through tests/emu/platform_emu.h, which only tests/emu/build_emu.py selects as the platform header).
 //
 // Model: one fiber (ucontext) per HIP thread, run-to-barrier scheduling inside one workgroup at a
 // time; __syncthreads() and the wave-collective v_mfma_f32_16x16x4_f32 are rendezvous points.

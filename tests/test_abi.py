@@ -78,6 +78,26 @@ def test_product_has_no_cpu_path():
         cell([torch.eye(19)], torch.zeros(2, 1900), torch.zeros(2, 19 * 64))
 
 
+def test_product_sources_do_not_know_the_emulator():
+    """The SIMT emulator is test scaffolding: the product tree reaches its platform layer through one #include of
+    EEG_PLATFORM_HEADER (csrc/platform.h by default) and carries no emulator switch, oracle import or CPU stand-in."""
+    import os
+    import re
+    pkg = os.path.join(ROOT, "eeg_gnn_ssl_amd")
+    hits = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".h", ".cpp", ".hip", ".py")) and f != "Makefile":
+                continue
+            text = open(os.path.join(base, f), errors="replace").read()
+            for pat in (r"EEG_SIMT_EMU", r"simt_emu", r"platform_emu", r"^\s*(from|import)\s+oracle"):
+                if re.search(pat, text, flags=re.M):
+                    hits.append((os.path.relpath(os.path.join(base, f), ROOT), pat))
+    assert not hits, hits
+    common = open(os.path.join(pkg, "csrc", "common.h")).read()
+    assert '#define EEG_PLATFORM_HEADER "platform.h"' in common and "#include EEG_PLATFORM_HEADER" in common
+
+
 def test_cosine_schedule_matches_torch():
     """utils.cosine_annealing_lr == CosineAnnealingLR(T_max=num_epochs) stepped per epoch (train.py:224,329)."""
     import torch

@@ -120,6 +120,57 @@ void run_two_shape(float* buf, long long* out, int na, int nb) {
            na, na * 32, ta, nb, nb * 8, tb, na * 32 + nb * 8);
 }
 
+// VALU beside the matrix pipe.  SAME: one wave per SIMD issues NV v_pk_fma_f32 behind every 16x16x4 MFMA (two chains).  CROSS: wave
+// A streams MFMAs, wave B on the same SIMD streams v_pk_fma_f32.  (Would the 4-node remainder of the recurrent GEMMs be cheaper on the
+// VALU than as 4x4x1 MFMAs?)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NV, bool CROSS>
+__global__ __launch_bounds__(512) void valu_kernel(float* __restrict__ buf, long long* __restrict__ out, int n) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float a = lane * 0.001f, b = 1.f + lane;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f}, q = p;
+    f32x2 v[8], x = {a, b}, y = {b, a};
+    for (int i = 0; i < 8; ++i) v[i] = (f32x2){(float)i, a};
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    if (!CROSS || w < 4) {
+        if (CROSS || w < 4)
+        for (int it = 0; it < n; ++it) {
+            p = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, p, 0, 0, 0);
+            if (!CROSS) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(v[i & 7]) : "v"(x), "v"(y));
+            }
+            q = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, q, 0, 0, 0);
+            if (!CROSS) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(v[i & 7]) : "v"(x), "v"(y));
+            }
+        }
+    } else {
+        for (int it = 0; it < n; ++it) {
+#pragma unroll
+            for (int i = 0; i < 2 * NV; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(v[i & 7]) : "v"(x), "v"(y));
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = p[0] + q[0];
+    for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
+    if (s == 12345.f) buf[lane] = s;
+    if (lane == 0) out[blockIdx.x * 8 + w] = t1 - t0;
+}
+template <int NV, bool CROSS> void run_valu(float* buf, long long* out) {
+    const int n = 2000;
+    CK(hipMemset(out, 0, 2048 * 8));
+    hipLaunchKernelGGL((valu_kernel<NV, CROSS>), dim3(256), dim3(512), 0, 0, buf, out, n);
+    CK(hipDeviceSynchronize());
+    std::vector<long long> h(2048); CK(hipMemcpy(h.data(), out, 2048 * 8, hipMemcpyDeviceToHost));
+    double ta = 0, tb = 0;
+    for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) (w < 4 ? ta : tb) += h[b * 8 + w] / 1024.0;
+    if (!CROSS) printf("same wave: %d v_pk_fma_f32 behind every 16x16x4 MFMA: %.1f cycles per MFMA (+ its VALU)\n", NV, ta / (2.0 * n));
+    else printf("cross wave: A %.1f cycles per MFMA | B %.2f cycles per v_pk_fma_f32 (%d per A-MFMA slot)\n", ta / (2.0 * n), tb / (2.0 * n * NV), NV);
+}
+
 template <int CH, int PRIO, int BCH> void run(float* buf, long long* out, int na, int nb, const char* what) {
     hipLaunchKernelGGL((chain_kernel<CH, PRIO, BCH>), dim3(256), dim3(512), 0, 0, buf, out, na, nb);
     CK(hipDeviceSynchronize());
@@ -139,6 +190,8 @@ int main() {
     run<1, 1, 12>(buf, out, na, 9600, "12 chains, 2x the MFMAs");  run<2, 1, 12>(buf, out, na, 9600, "12 chains, 2x the MFMAs");  run<4, 1, 12>(buf, out, na, 9600, "12 chains, 2x the MFMAs");
     run<1, 0, 1>(buf, out, na, 4800, "1 chain, as many MFMAs");    run<1, 1, 1>(buf, out, na, 4800, "1 chain, as many MFMAs");
     run<2, 1, 1>(buf, out, na, 4800, "1 chain, as many MFMAs");    run<2, 1, 2>(buf, out, na, 4800, "2 chains, as many MFMAs");
+    run_valu<0, false>(buf, out); run_valu<2, false>(buf, out); run_valu<4, false>(buf, out); run_valu<6, false>(buf, out); run_valu<8, false>(buf, out); run_valu<12, false>(buf, out);
+    run_valu<4, true>(buf, out); run_valu<8, true>(buf, out); run_valu<16, true>(buf, out);
     run_two_shape(buf, out, 4800, 0); run_two_shape(buf, out, 0, 4800); run_two_shape(buf, out, 4800, 4800); run_two_shape(buf, out, 4800, 19200);
     run_shape<4, 0>(buf, out); run_shape<0, 4>(buf, out); run_shape<0, 16>(buf, out); run_shape<4, 4>(buf, out); run_shape<8, 8>(buf, out); run_shape<16, 16>(buf, out); run_shape<4, 1>(buf, out); run_shape<1, 1>(buf, out); run_shape<2, 2>(buf, out); run_shape<2, 1>(buf, out); run_shape<4, 2>(buf, out); run_shape<4, 3>(buf, out); run_shape<48, 48>(buf, out);
     return 0;
