@@ -71,5 +71,23 @@ __host__ __device__ constexpr int kperm(int ks, int g) { return 16 * (ks / 4) + 
 // sigmoid / tanh on the platform's fast exp and reciprocal (platform.h: v_exp_f32 / v_rcp_f32)
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x)); }
+// Four at a time: the scale, the +1 and the final multiply-add as packed fp32 instructions (two per float4), only v_exp_f32 /
+// v_rcp_f32 per element -- VALU instructions cost matrix-pipe time in the fp32 recurrent kernels.
+__device__ __forceinline__ f32x4 sigmoid4_(f32x4 x) {
+    const f32x4 z = x * -1.44269504088896340736f;
+    f32x4 d = {fast_exp2(z[0]), fast_exp2(z[1]), fast_exp2(z[2]), fast_exp2(z[3])};
+    d = d + 1.0f;
+    return (f32x4){fast_rcp(d[0]), fast_rcp(d[1]), fast_rcp(d[2]), fast_rcp(d[3])};
+}
+__device__ __forceinline__ f32x4 tanh4_(f32x4 x) {
+    const f32x4 z = x * (2.0f * 1.44269504088896340736f);
+    f32x4 d = {fast_exp2(z[0]), fast_exp2(z[1]), fast_exp2(z[2]), fast_exp2(z[3])};
+    d = d + 1.0f;
+    const f32x4 r = {fast_rcp(d[0]), fast_rcp(d[1]), fast_rcp(d[2]), fast_rcp(d[3])};
+    return 1.0f - 2.0f * r;
+}
+__device__ __forceinline__ f32x4 relu4_(f32x4 x) {
+    return (f32x4){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f), fmaxf(x[2], 0.f), fmaxf(x[3], 0.f)};
+}
 
 }  // namespace eeg

@@ -137,10 +137,12 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
         // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr) (lane groups 80 floats apart);  reader (lr < 4, lg):
         // sum over the 4 groups of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i) {
+            f32x4 t = (rem[i][0] + rem[i][1]) + (rem[i][2] + rem[i][3]);
+            EEG_PIN(t);                                  // (keeps the three adds packed: 6 v_pk_add_f32, not 12 v_add_f32)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                scratch[i * kRemTile + lg * 80 + r * 16 + lr] = (rem[i][0][r] + rem[i][1][r]) + (rem[i][2][r] + rem[i][3][r]);
+            for (int r = 0; r < 4; ++r) scratch[i * kRemTile + lg * 80 + r * 16 + lr] = t[r];
+        }
         EEG_WAVE_SYNC();
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -441,15 +443,15 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         auto diffuse_own = [&](float* buf, float* planes, int t) {
             EEG_WAVE_SYNC();
             float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
-            lds_diffuse_tile<M, NKS>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N);
+            lds_diffuse_tile<M, NKS, 32, true>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N);
         };
         diffuse_own(A, Hpl, 0);
         f32x4 nxr[2], nxc;
-        auto fetch_xw = [&](int t) {
-            const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
-            nxr[0] = ld4(xw + oxw[0]);
-            nxr[1] = ld4(xw + oxw[1]);
-            nxc = ld4(xw + oxw[0] + 2 * H);
+        auto fetch_xw = [&](int t) {                                  // (descriptor on the step's rows: no 64-bit lane addresses)
+            const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
+            nxr[0] = wbuf_ld4(bx, oxw[0], 0u);
+            nxr[1] = wbuf_ld4(bx, oxw[1], 0u);
+            nxc = wbuf_ld4(bx, oxw[0] + 2 * H, 0u);
         };
         fetch_xw(0);
         for (int t = 0; t < T; ++t) {
@@ -464,9 +466,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             pp.mark(1);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f32x4 rg;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rg[r] = sigmoidf_(ar[0][nt][r]);
+                const f32x4 rg = sigmoid4_(ar[0][nt]);
                 f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
                 rh = valid[nt] ? rh : zero4;
                 st4(A2 + lds_sw(node[nt], col, KAP), rh);
@@ -485,13 +485,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             pp.mark(4);
             {
                 const f32x4 u = ld4(U + lds_sw(lr, col, UST)), h = ld4(A + lds_sw(lr, col, KAP));
-                f32x4 c, hn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pre = ac[0][0][r];
-                    c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
-                    hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
-                }
+                const f32x4 c = act == 0 ? tanh4_(ac[0][0]) : relu4_(ac[0][0]);
+                f32x4 hn = u * h + (1.f - u) * c;
                 hn = valid[0] ? hn : zero4;
                 st4(A + lds_sw(lr, col, KAP), hn);
                 if (valid[0]) {
@@ -507,10 +502,10 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     } else {
         f32x4 nxu[2], nxc;
         auto fetch_x = [&](int t) {
-            const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
-            nxu[0] = ld4(xw + oxw[0] + H);
-            nxu[1] = ld4(xw + oxw[1] + H);
-            nxc = ld4(xw + oxw[1] + 2 * H);
+            const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
+            nxu[0] = wbuf_ld4(bx, oxw[0] + H, 0u);
+            nxu[1] = wbuf_ld4(bx, oxw[1] + H, 0u);
+            nxc = wbuf_ld4(bx, oxw[1] + 2 * H, 0u);
         };
         fetch_x(0);
         for (int t = 0; t < T; ++t) {
@@ -522,12 +517,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, au, RS);
             f32x4 u;                                                // nodes 16..19: stays in registers for the blend
             {
-                f32x4 u0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    u0[r] = sigmoidf_(au[0][0][r]);
-                    u[r] = sigmoidf_(au[0][1][r]);
-                }
+                const f32x4 u0 = sigmoid4_(au[0][0]);
+                u = sigmoid4_(au[0][1]);
                 st4(U + lds_sw(lr, col, UST), u0);                        // nodes >= N: finite, never used
                 if (save && valid[0]) wbuf_st4(bU, oh[0], so, u0);
             }
@@ -536,13 +527,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             mfma_nodes32<1, KS, true, 2>(A2, KAP, lane, lr, lg, w1, ac, RS);
             {
                 const f32x4 h = ld4(A + lds_sw(node[1], col, KAP));
-                f32x4 c, hn;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pre = ac[0][1][r];
-                    c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
-                    hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
-                }
+                const f32x4 c = act == 0 ? tanh4_(ac[0][1]) : relu4_(ac[0][1]);
+                f32x4 hn = u * h + (1.f - u) * c;
                 hn = valid[1] ? hn : zero4;
                 if (lr < 4) st4(A + lds_sw(node[1], col, KAP), hn);       // rows 16..19 (the others belong to nobody here)
                 if (valid[1]) {

@@ -91,6 +91,7 @@ namespace eeg {
 // error of sigmoid/tanh ~2e-7, far inside the 1e-4 parity budget (tests assert 2e-5).
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // a*b + c with the product rounded first (what two separate framework kernels compute)
 __device__ __forceinline__ float unfused_mul_add(float a, float b, float c) {
 #pragma clang fp contract(off)
