@@ -257,38 +257,43 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 
     // hop-diffuse this wave's own column tiles of buf; planes != nullptr: the hop rows of step t also go to
     // global memory (Hpl / RHpl, the A operands of the hoisted weight-gradient GEMMs)
+    const bool plane_buf = (double)(M - 1) * plane_stride * sizeof(float) < 4294967296.0;   // 32-bit offsets reach every hop plane
     auto diffuse_own = [&](float* buf, float* planes, int t) {
         EEG_WAVE_SYNC();
         float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
 #pragma unroll
         for (int i = 0; i < CT; ++i)
-            if (wave + 4 * i < NCT) lds_diffuse_tile<M, NKS>(buf, KAP, (wave + 4 * i) * 16, H, pf, lr, lg, g, plane_stride, N);
+            if (wave + 4 * i < NCT) lds_diffuse_tile<M, NKS>(buf, KAP, (wave + 4 * i) * 16, H, pf, lr, lg, g, plane_stride, N, plane_buf);
     };
     diffuse_own(A, Hpl, 0);                                         // hops(h_0)
     // The hoisted pre-activations of step t+1 are fetched in the middle of step t, AHEAD of that step's
     // h / c stores in the memory queue, so that waiting for them does not have to drain those stores.
     f32x4 nxr[CT][2], nxu[CT][2], nxc[CT][2];
+    // operands and results of a step go through buffer descriptors on the step's rows (scalar base, one 32-bit lane offset per
+    // tile): 64-bit per-lane addresses cost two VALU instructions per access, and VALU time is matrix-pipe time here
     auto fetch_xw = [&](int t) {
-        const float* xw = XW + ((size_t)t * B + b) * N * (3 * H);
+        const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                nxr[i][nt] = ld4(xw + oxw[i][nt]);
-                nxu[i][nt] = ld4(xw + oxw[i][nt] + H);
-                nxc[i][nt] = ld4(xw + oxw[i][nt] + 2 * H);
+                nxr[i][nt] = wbuf_ld4(bx, oxw[i][nt], 0u);
+                nxu[i][nt] = wbuf_ld4(bx, oxw[i][nt] + H, 0u);
+                nxc[i][nt] = wbuf_ld4(bx, oxw[i][nt] + 2 * H, 0u);
             }
     };
     fetch_xw(0);
     for (int t = 0; t < T; ++t) {
         const size_t s = (size_t)t * B + b;
-        f32x4 xr[CT][2], xu[CT][2], xc[CT][2], ag[2 * CT][2], ac[CT][2], ug[CT][2];
+        f32x4 ag[2 * CT][2], ac[CT][2], ug[CT][2];
+        // the accumulators start from the hoisted pre-activations (no zero fill, no add behind the GEMM); with the 4x4x1
+        // remainder the second tile's accumulator is read on lanes lr < 4 only
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                ag[i][nt] = zero4; ag[CT + i][nt] = zero4; ac[i][nt] = zero4;
-                xr[i][nt] = nxr[i][nt]; xu[i][nt] = nxu[i][nt]; xc[i][nt] = nxc[i][nt];
+                const bool keep = !(REM4 && nt == 1) || lr < 4;
+                ag[i][nt] = keep ? nxr[i][nt] : zero4; ag[CT + i][nt] = keep ? nxu[i][nt] : zero4; ac[i][nt] = keep ? nxc[i][nt] : zero4;
             }
         EEG_LDS_BARRIER();                                            // (1) hops(h) complete
         pp.mark(0);
@@ -296,9 +301,8 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         // gate GEMM: (2H cols) x (32 nodes), K = M*H
         mfma_nodes32<2 * CT, KS, REM4>(A, KAP, lane, lr, lg, wg, ag, RS);
         pp.mark(1);
-        float* r_t = Rs + s * N * H;
-        float* rh_t = RHs + s * N * H;
-        float* u_t = Us + s * N * H;
+        const wbuf_t bR = make_wbuf((save ? Rs : Hseq) + s * N * H), bRH = make_wbuf((save ? RHs : Hseq) + s * N * H),
+                     bU = make_wbuf((save ? Us : Hseq) + s * N * H);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave + 4 * i;
@@ -306,20 +310,15 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                 const int col = ct * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 rg, u;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        rg[r] = sigmoidf_(ag[i][nt][r] + xr[i][nt][r]);
-                        u[r] = sigmoidf_(ag[CT + i][nt][r] + xu[i][nt][r]);
-                    }
+                    const f32x4 rg = sigmoid4_(ag[i][nt]), u = sigmoid4_(ag[CT + i][nt]);
                     ug[i][nt] = u;
                     f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
                     rh = valid[nt] ? rh : zero4;
                     st4(A2 + lds_sw(node[nt], col, KAP), rh);
                     if (save && valid[nt]) {
-                        st4(r_t + oh[i][nt], rg);
-                        st4(rh_t + oh[i][nt], rh);
-                        st4(u_t + oh[i][nt], u);
+                        wbuf_st4(bR, oh[i][nt], 0u, rg);
+                        wbuf_st4(bRH, oh[i][nt], 0u, rh);
+                        wbuf_st4(bU, oh[i][nt], 0u, u);
                     }
                 }
             }
@@ -334,8 +333,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         // candidate GEMM: (H cols) x (32 nodes), K = M*H
         mfma_nodes32<CT, KS, REM4>(A2, KAP, lane, lr, lg, wc, ac, RS);
         pp.mark(4);
-        float* h_t = Hseq + s * N * H;
-        float* c_t = Cs + s * N * H;
+        const wbuf_t bH = make_wbuf(Hseq + s * N * H), bC = make_wbuf((save ? Cs : Hseq) + s * N * H);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
             const int ct = wave + 4 * i;
@@ -344,18 +342,13 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const f32x4 u = ug[i][nt], h = ld4(A + lds_sw(node[nt], col, KAP));
-                    f32x4 c, hn;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pre = ac[i][nt][r] + xc[i][nt][r];
-                        c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
-                        hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
-                    }
+                    const f32x4 c = act == 0 ? tanh4_(ac[i][nt]) : relu4_(ac[i][nt]);
+                    f32x4 hn = u * h + (1.f - u) * c;
                     hn = valid[nt] ? hn : zero4;
                     st4(A + lds_sw(node[nt], col, KAP), hn);
                     if (valid[nt]) {
-                        st4(h_t + oh[i][nt], hn);
-                        if (save) st4(c_t + oh[i][nt], c);
+                        wbuf_st4(bH, oh[i][nt], 0u, hn);
+                        if (save) wbuf_st4(bC, oh[i][nt], 0u, c);
                     }
                 }
             }
@@ -443,7 +436,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         auto diffuse_own = [&](float* buf, float* planes, int t) {
             EEG_WAVE_SYNC();
             float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
-            lds_diffuse_tile<M, NKS, 32, true>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N);
+            lds_diffuse_tile<M, NKS>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N, true);
         };
         diffuse_own(A, Hpl, 0);
         f32x4 nxr[2], nxc;

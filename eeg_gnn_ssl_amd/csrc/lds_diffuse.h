@@ -126,13 +126,14 @@ __device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[pol
 // weight-gradient GEMMs): plane m at gout + (m-1)*gplane, element (node, col) at node*slot_w + col.
 // ROWS < 32: the LDS tile holds only ROWS node rows (ROWS >= 4*NKS); result rows beyond are dropped.
 // (NKS == 5: rows 20..31 of the hop slots are never written -- nothing reads them in that regime.)
-// GBUF: the global copies leave through a buffer descriptor on `gout` (per-lane 32-bit offsets that do not change over a
+// gbuf (wave-uniform): the global copies leave through a buffer descriptor on `gout` (per-lane 32-bit offsets that do not change over a
 // sequence; the step offset is in the scalar base) instead of 64-bit per-lane addresses, which cost two VALU instructions per
 // store and step -- VALU time is matrix-pipe time for fp32.  The caller guarantees (M-1) * gplane * 4 < 2^32.
-template <int M, int NKS, int ROWS = 32, bool GBUF = false>
+template <int M, int NKS, int ROWS = 32>
 __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src_col, int slot_w,
                                                  const float (&pf)[poly_slots<M, NKS>()][NKS], int lr, int lg,
-                                                 float* __restrict__ gout = nullptr, size_t gplane = 0, int n_nodes = 0) {
+                                                 float* __restrict__ gout = nullptr, size_t gplane = 0, int n_nodes = 0,
+                                                 bool gbuf = false) {
     constexpr int NC = poly_chains<M, NKS>();
     if constexpr (NC == 0) return;                       // max_diffusion_step = 0: nothing to mix
     constexpr int NA = NC > 0 ? NC : 1;
@@ -160,7 +161,7 @@ __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src
         if (live && (ROWS == 32 || node < ROWS))
             *reinterpret_cast<float4*>(buf + lds_sw(node, (hop + 1) * slot_w + src_col + 4 * lg, stride)) = v;
         if (gout != nullptr && live && node < n_nodes) {
-            if constexpr (GBUF)
+            if (gbuf)
                 wbuf_st4(make_wbuf(gout), (unsigned)hop * (unsigned)gplane + (unsigned)(node * slot_w + src_col + 4 * lg), 0u, acc[c]);
             else
                 *reinterpret_cast<float4*>(gout + (size_t)hop * gplane + node * slot_w + src_col + 4 * lg) = v;
