@@ -10,7 +10,8 @@ bool nnq_supported(int nseg, int F, int R, int nct_total, int ldc, int O) {
     if (nseg < 1 || nseg > kMaxM || F < 4 || F % 4 != 0 || R < 1) return false;
     if (nct_total < 12 || nct_total % 12 != 0 || O % 4 != 0 || ldc % 4 != 0 || O > 16 * nct_total) return false;
     if (make_nnq_order(nseg, F).ntail > 2) return false;
-    return (double)R * F * 4.0 < 4.0e9 && (double)R * ldc * 4.0 < 4.0e9;
+    // operands and results go through 2 GB buffer descriptors (platform.h make_wbuf): accesses beyond are dropped by the hardware
+    return (double)R * F * 4.0 < 2147483648.0 && (double)R * ldc * 4.0 < 2147483648.0;
 }
 size_t nnq_pack_floats(int nseg, int F, int nct) { return (size_t)make_nnq_order(nseg, F).nch * nct * 256; }
 
@@ -32,7 +33,7 @@ TnqPlan tnq_plan(int nseg, int F, int R, int O, bool bt, int num_cus) {
     TnqPlan p{};
     if (nseg < 1 || nseg > kMaxM || F < 4 || F % 4 != 0 || R < 16 || R % 16 != 0) return p;
     if (O != 64 && O != 128 && O != 192) return p;
-    if ((double)R * F * 4.0 >= 4.0e9) return p;
+    if ((double)R * (F > 192 ? F : 192) * 4.0 >= 2147483648.0) return p;    // 2 GB descriptors on the segments and on dY (ldy <= 192)
     const int K = nseg * F;
     p.OT = O / 32;
     const bool planar_exact = F == 64 && !bt && (nseg % 3 == 0 || nseg % 2 == 0 || nseg == 1);

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 
     // hop-diffuse this wave's own column tiles of buf; planes != nullptr: the hop rows of step t also go to
     // global memory (Hpl / RHpl, the A operands of the hoisted weight-gradient GEMMs)
-    const bool plane_buf = (double)(M - 1) * plane_stride * sizeof(float) < 4294967296.0;   // 32-bit offsets reach every hop plane
+    const bool plane_buf = (double)(M - 1) * plane_stride * sizeof(float) < 2147483648.0;   // a 2 GB descriptor reaches every hop plane
     auto diffuse_own = [&](float* buf, float* planes, int t) {
         EEG_WAVE_SYNC();
         float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;

@@ -128,7 +128,7 @@ __device__ __forceinline__ void load_poly_frags(const float* Pl, float (&pf)[pol
 // (NKS == 5: rows 20..31 of the hop slots are never written -- nothing reads them in that regime.)
 // gbuf (wave-uniform): the global copies leave through a buffer descriptor on `gout` (per-lane 32-bit offsets that do not change over a
 // sequence; the step offset is in the scalar base) instead of 64-bit per-lane addresses, which cost two VALU instructions per
-// store and step -- VALU time is matrix-pipe time for fp32.  The caller guarantees (M-1) * gplane * 4 < 2^32.
+// store and step -- VALU time is matrix-pipe time for fp32.  The caller guarantees (M-1) * gplane * 4 < 2^31 (the descriptors span 2 GB; accesses beyond are dropped by the hardware).
 template <int M, int NKS, int ROWS = 32>
 __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src_col, int slot_w,
                                                  const float (&pf)[poly_slots<M, NKS>()][NKS], int lr, int lg,

@@ -31,7 +31,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
 #endif
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // M >= 4: the r + c weights of a wave no longer fit in 256 registers
         if (a.variant == 1 && (double)a.T * a.B * a.N * H * sizeof(float) < 2147483648.0      // (32-bit buffer offsets of its stores
-            && (double)(M - 1) * a.plane_stride * sizeof(float) < 4294967296.0) {                //  and of the hop planes it leaves behind)
+            && (double)(M - 1) * a.plane_stride * sizeof(float) < 2147483648.0) {                //  and of the hop planes it leaves behind: 2 GB descriptors)
             const size_t lds2 = lds + 16 * 64 * sizeof(float);      // + the update-gate tile U [16][64]
 #if defined(EEG_DEV)
             if constexpr (M == 3) {

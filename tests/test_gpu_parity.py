@@ -146,11 +146,13 @@ def test_full_size_slice_vs_oracle_and_determinism(workload, adj3d):
     assert err < 1e-4, f"{workload}: logits of the first clips differ from the oracle by {err:.2e}"
 
 
-@pytest.mark.parametrize("filt,batch,t_len", [("laplacian", 1531, 60), ("dual_random_walk", 517, 150)])
+@pytest.mark.parametrize("filt,batch,t_len", [("laplacian", 1531, 60), ("dual_random_walk", 517, 150), ("laplacian", 2611, 60)])
 def test_beyond_benchmark_sizes(filt, batch, t_len, adj3d):
     """Batches / clip lengths several times the benchmark's, with odd counts (grid tails, 32-bit offset
     headroom: up to 1.7e8 rows x 3H columns): clips far into the batch equal the oracle on just those clips;
-    the full-batch gradient equals the sum over two uneven parts; everything finite."""
+    the full-batch gradient equals the sum over two uneven parts; everything finite.  The 2611-clip case has
+    2.98 M rows: the (rows x 3H) pre-activations are 2.3 GB, beyond the 2 GB a buffer descriptor spans, so the
+    descriptor-based GEMMs must hand over to the pointer-based ones (a dropped store would show up in the last clips)."""
     import bench
     from oracle import dcrnn_oracle as orc
     x, y, lengths, sup = bench.synthetic_batch("detection", filt, t_len, batch, 1, seed=9)
