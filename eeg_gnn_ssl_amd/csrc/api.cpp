@@ -117,7 +117,7 @@ int run_nn_kc(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int 
     return run_nn<NCTW, 4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag);
 }
 // C[R x O] = [segments] @ packed B (nct_total col tiles) + bias
-// Bq: the same right-hand side in the quad order of gemm_nnq_kernel (kernels_pack.h: bxq / bxtq), or NULL.  The round-3
+// Bq: the same right-hand side in the quad order of gemm_nnr_kernel (kernels_pack.h: bxq / bxtq), or NULL.  The round-3
 // kernel takes the launch when it covers the shape and every one of its 2-per-CU workgroups gets at least two 128-row
 // tiles (dev knob 2 bit 0 = 1: never)
 int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nct_total, const float* bias,

@@ -4,7 +4,7 @@
 
 namespace eeg {
 
-// ---- NN: C[R x O] = [segments] @ quad pack + bias (gemm_nnq_kernel) ---------------------------------------------------
+// ---- NN: C[R x O] = [segments] @ quad pack + bias (gemm_nnr_kernel) ---------------------------------------------------
 // Applies to whole 192-column blocks (nct_total % 12 == 0), F % 4 == 0 with at most two tail chunks, 32-bit offsets.
 bool nnq_supported(int nseg, int F, int R, int nct_total, int ldc, int O);
 // floats of the quad pack of a (nseg * F) x (16 * nct) right-hand side

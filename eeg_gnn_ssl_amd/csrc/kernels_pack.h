@@ -31,7 +31,7 @@ struct CellPack {
     //  layer of the decoder, so the streamed-weight addresses are base + immediate)
     size_t c1;     // K = M*H  (k = m*H + o),  O columns: [Wc^h | Wc^x | 0] transposed, quad-permuted K
     size_t c2;     // K = M*2H (k = m*2H + o), O columns: [Wg^h | Wg^x | 0] transposed, quad-permuted K
-    // round 3, gemm_nnq_kernel (kernels_gemm_q.h): the same two right-hand sides in quad order (one ds_read_b128 per lane feeds
+    // round 3, gemm_nnr_kernel (kernels_gemm_q.h): the same two right-hand sides in quad order (one ds_read_b128 per lane feeds
     // the four MFMAs of a 16-deep K chunk; chunk order of make_nnq_order); bxtq exists when M*Fin is a multiple of 192
     size_t bxq;    // x-part:  nnq order over (M planes x Fin), 3H/16 column tiles
     size_t bxtq;   // bwd dx:  nnq order over (1 segment x 3H), M*Fin/16 column tiles (0 floats when not applicable)
@@ -118,7 +118,7 @@ __global__ void pack_cell_kernel(const float* __restrict__ Wg, const float* __re
                 const int m = j / Fin, f = j % Fin;
                 v = o < 2 * H ? ref_wg(Wg, M, H, f, m, o) : ref_wc(Wc, M, H, f, m, o - 2 * H);
             }
-        } else if (idx >= p.bxq) {                // quad packs of gemm_nnq_kernel: [(c * nct + ct) * 64 + lane][s]
+        } else if (idx >= p.bxq) {                // quad packs of gemm_nnr_kernel: [(c * nct + ct) * 64 + lane][s]
             const bool tr = idx >= p.bxtq;
             const size_t e = idx - (tr ? p.bxtq : p.bxq);
             const int s4 = e & 3, lane = (e >> 2) & 63, nct = tr ? M * Fin / 16 : 3 * H / 16;

@@ -1,4 +1,4 @@
-// K order of the quad-packed right-hand sides of gemm_nnq_kernel (kernels_gemm_q.h), shared by the pack kernel.
+// K order of the quad-packed right-hand sides of gemm_nnr_kernel (kernels_gemm_q.h), shared by the pack kernel.
 // The 16-deep chunks never straddle a hop plane: first the a = F/16 whole chunks of every plane, then the leftover 16-byte
 // pieces of all planes gathered into tail chunks (F = 100, 3 planes: 18 chunks + 1 tail chunk with one zero piece).
 #pragma once

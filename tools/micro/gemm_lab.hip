@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 #include "../../eeg_gnn_ssl_amd/csrc/kernels_gemm.h"
-#include "../../eeg_gnn_ssl_amd/csrc/kernels_gemm_q.h"
+#include "gemm_lab_kernels.h"
 using namespace eeg;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
