@@ -185,6 +185,31 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
+def split_bf16_experiment():
+    """Gated experiment (never the headline): run the lab binary tools/micro/bf16x3_lab and parse its report -- the layer-1 NN
+    GEMM (R x 192 x 192 at the cfg2 row count) with fp32 operands / results computed (a) by the product's true-fp32 MFMA kernel
+    and (b) as a three-term bf16 split (6 or 3 of the 9 partial products) on v_mfma_f32_16x16x32_bf16, each against an fp64
+    host sum over 2000 sampled rows."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "micro", "bf16x3_lab")
+    if not os.path.exists(exe):
+        return {"error": "tools/micro/bf16x3_lab not built (make -C tools/micro bf16x3_lab)"}
+    txt = subprocess.run([exe, "11"], capture_output=True, text=True, timeout=300).stdout
+    res = {"scope": "lab kernel tools/micro/bf16x3_lab.hip, hoisted NN GEMM of layer 1 only (R=291840, K=192, O=192); NOT in the "
+                    "product path, `value` and `dtype` above are true fp32 MFMA", "raw": txt.strip().splitlines()}
+    err = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^\s+(.*?)\s+max \|err\| vs fp64 ([0-9.e+-]+)", txt, flags=re.M)}
+    tms = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^\s+(fp32 MFMA|bf16 split, \d products)\s+([0-9.]+) ms", txt, flags=re.M)}
+    if "fp32 MFMA" in tms:
+        res["fp32_mfma_ms"] = tms["fp32 MFMA"]
+        for k in ("bf16 split, 6 products", "bf16 split, 3 products"):
+            if k in tms:
+                key = "six_products" if ", 6 products" in k else "three_products"
+                res[key] = {"ms": tms[k], "speedup_vs_fp32_mfma": round(tms["fp32 MFMA"] / tms[k], 3), "max_abs_err_vs_fp64": err.get(k)}
+        res["fp32_mfma_max_abs_err_vs_fp64"] = err.get("fp32 MFMA (gemm_nnr_kernel)")
+    return res
+
+
 def cpu_baseline(workload, budget_s=45.0):
     """The oracle (torch-eager restatement of the reference's op sequence, autograd backward) timed on this host's
     cores at the workload's PER-GPU batch (SURVEY.md §8(d) / BASELINE.md §4: B=256 for cfg2; ~2 s per step), fwd + loss +
@@ -257,6 +282,9 @@ def main():
                     "host batch into the step's input tensors on a side stream every step")
     ap.add_argument("--force-dist", action="store_true", help="single process: create a world-size-1 process group over "
                     "the nccl (= RCCL) backend and issue the gradient all-reduce every step (exercises the RCCL path on one GPU)")
+    ap.add_argument("--split-bf16-experiment", action="store_true", help="also run tools/micro/bf16x3_lab (a LAB kernel, not "
+                    "the product path: the hoisted NN GEMM as a three-term bf16 split on the bf16 matrix pipe) and report its "
+                    "time and error beside the true-fp32 kernel under `experimental_split_bf16`; `value` / `dtype` are untouched")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning); loads "
                     "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
     args = ap.parse_args()
@@ -560,6 +588,8 @@ def main():
         log("cpu baseline (oracle on host cores, per-GPU batch)")
         out["cpu_baseline"] = cpu_baseline(args.workload)
         out["speedup_vs_cpu_baseline"] = round(clips_per_s / out["cpu_baseline"]["value"], 1)
+    if world == 1 and args.split_bf16_experiment:
+        out["experimental_split_bf16"] = split_bf16_experiment()
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
