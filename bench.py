@@ -196,6 +196,12 @@ def split_bf16_experiment():
     if not os.path.exists(exe):
         return {"error": "tools/micro/bf16x3_lab not built (make -C tools/micro bf16x3_lab)"}
     txt = subprocess.run([exe, "11"], capture_output=True, text=True, timeout=300).stdout
+    return parse_split_bf16_report(txt)
+
+
+def parse_split_bf16_report(txt):
+    """The report of tools/micro/bf16x3_lab -> the `experimental_split_bf16` object of the bench line."""
+    import re
     res = {"scope": "lab kernel tools/micro/bf16x3_lab.hip, hoisted NN GEMM of layer 1 only (R=291840, K=192, O=192); NOT in the "
                     "product path, `value` and `dtype` above are true fp32 MFMA", "raw": txt.strip().splitlines()}
     err = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"^\s+(.*?)\s+max \|err\| vs fp64 ([0-9.e+-]+)", txt, flags=re.M)}

@@ -95,6 +95,18 @@ def test_cpp_operator_library_loads_and_refuses_cpu_tensors():
         lib.dconv(torch.zeros(2, 19, 8), torch.zeros(1, 2, 19, 19), 0, torch.zeros(24, 16), torch.zeros(16))
 
 
+def test_split_bf16_report_parser():
+    """bench.py --split-bf16-experiment: the lab binary's report (a committed run: profiles/r03_bf16x3_lab.txt) becomes the
+    `experimental_split_bf16` object; the 6-product split is no less accurate than the fp32 matrix pipe."""
+    import bench
+    e = bench.parse_split_bf16_report(open(os.path.join(ROOT, "profiles", "r03_bf16x3_lab.txt")).read())
+    assert e["six_products"]["ms"] > 0 and e["three_products"]["ms"] > 0 and e["fp32_mfma_ms"] > 0
+    assert e["six_products"]["ms"] > e["three_products"]["ms"]
+    assert e["six_products"]["max_abs_err_vs_fp64"] <= 1.5 * e["fp32_mfma_max_abs_err_vs_fp64"] < 2e-5
+    assert e["three_products"]["max_abs_err_vs_fp64"] < 2e-5
+    assert "NOT in the product path" in e["scope"]
+
+
 def test_product_sources_do_not_know_the_emulator():
     """The SIMT emulator is test scaffolding: the product tree reaches its platform layer through one #include of
     EEG_PLATFORM_HEADER (csrc/platform.h by default) and carries no emulator switch, oracle import or CPU stand-in."""
