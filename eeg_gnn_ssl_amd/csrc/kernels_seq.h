@@ -68,7 +68,25 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float
 // QM (the two-role BPTT kernel splits its K = M*2H gate GEMM by column half): 0: weight quad q' reads tile quad q';
 // 1 / 2: the quads of the dR / dU halves of every 2H-wide hop slot (tile quad 8*(q'/4) + q'%4 [+ 4]).
 // WQ: `w` holds ALL k-steps and is indexed by the mapped quad too (only half of the quads are visited).
-template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false>
+// compile-time loop: f(SeqIdx<I>()) for I in [B, E) -- every index is a constant inside the body (register arrays stay registers)
+template <int V> struct SeqIdx { static constexpr int value = V; };
+template <int B, int E, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (B < E) { f(SeqIdx<B>()); static_for<B + 1, E>(f); }
+}
+#ifndef EEG_REM_COVER
+#define EEG_REM_COVER 128
+#endif
+// TWOPASS item stream (N16 quads of 16x16x4 MFMAs, then N4 quads of 4x4x1 MFMAs): index of the last item whose LDS fragment is
+// requested before item i starts -- the MFMAs of the items in between (128 / 32 cycles per quad) cover the ds_read_b128 latency.
+template <int N16, int N4>
+constexpr int rem_ahead(int i) {
+    int cyc = 0, l = i;
+    while (l + 1 < N16 + N4 && cyc < EEG_REM_COVER) { cyc += l < N16 ? 128 : 32; ++l; }
+    return l;
+}
+
+template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false, bool TWOPASS = false>
 __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
                                              const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
@@ -79,7 +97,7 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     const float* p0 = X + lr * stride;
     const float* p1 = X + (REM4 ? 16 + (lane & 3) : 16 + lr) * stride;
     constexpr int NQ = WQ ? NKS / 8 : NKS / 4;                       // quads visited
-    auto qmap = [](int qw) { return QM == 0 ? qw : 8 * (qw >> 2) + (qw & 3) + (QM == 2 ? 4 : 0); };
+    constexpr auto qmap = [](int qw) constexpr { return QM == 0 ? qw : 8 * (qw >> 2) + (qw & 3) + (QM == 2 ? 4 : 0); };
     auto frag = [&](const float* rowp, int sx, int qw) {
         const int q = qmap(qw);
         return *reinterpret_cast<const float4*>(rowp + 64 * (q >> 2) + 4 * ((4 * (q & 3)) ^ sx));
@@ -96,11 +114,45 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     f32x4 alt[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) alt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    if (DO16) a0 = frag(p0, s0, 0);
-    if (!REM4 || DO4) a1 = frag(p1, s1, 0);
+    if constexpr (TWOPASS) {
+        // A wave that has the matrix pipe to itself (role B's dR half in window 2 of the BPTT kernel): all 16x16x4 MFMAs of
+        // the GEMM, then all its 4x4x1 MFMAs -- one change of shape (~43 cycles) instead of one per quad.
+        static_assert(REM4 && NT == 1, "two-pass stream: one column tile, 4x4x1 remainder");
+        constexpr int N16 = DO16 ? NQ : 0, N4 = DO4 ? NQ : 0, NI = N16 + N4;
+        float4 xb[NI];
+        static_for<0, rem_ahead<N16, N4>(0) + 1>([&](auto L) __attribute__((always_inline)) {
+            constexpr int l = decltype(L)::value;
+            xb[l] = l < N16 ? frag(p0, s0, l) : frag(p1, s1, l - N16);
+        });
+        static_for<0, NI>([&](auto IT) __attribute__((always_inline)) {
+            constexpr int it = decltype(IT)::value;
+            constexpr int lo = it > 0 ? rem_ahead<N16, N4>(it > 0 ? it - 1 : 0) + 1 : 0, hi = it > 0 ? rem_ahead<N16, N4>(it) + 1 : 0;
+            static_for<lo, hi>([&](auto L) __attribute__((always_inline)) {
+                constexpr int l = decltype(L)::value;
+                xb[l] = l < N16 ? frag(p0, s0, l) : frag(p1, s1, l - N16);
+            });
+            EEG_SCHED_FENCE();
+            constexpr int q = it < N16 ? it : it - N16;
+            constexpr int qw4 = 4 * (WQ ? qmap(q) : q);
+            const float x[4] = {xb[it].x, xb[it].y, xb[it].z, xb[it].w};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
+            for (int j = 0; j < 4; ++j) {
+                if (it < N16) {
+                    if (j & 1) alt[0] = mfma16(w[0][qw4 + j], x[j], alt[0]);
+                    else acc[0][0] = mfma16(w[0][qw4 + j], x[j], acc[0][0]);
+                } else {
+                    rem[0][j] = mfma4(x[j], w[0][qw4 + j], rem[0][j]);
+                }
+            }
+            if (it < N16) EEG_PIN(alt[0]);       // (else LLVM sinks the whole second chain behind the 4x4x1 pass, as ONE dependent chain)
+            EEG_SCHED_FENCE();
+        });
+    }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (!TWOPASS && DO16) a0 = frag(p0, s0, 0);
+    if (!TWOPASS && (!REM4 || DO4)) a1 = frag(p1, s1, 0);
+#pragma unroll
+    for (int q = 0; q < (TWOPASS ? 0 : NQ); ++q) {
         const int qw4 = 4 * (WQ ? qmap(q) : q);                      // first weight k-step of this quad
         float4 n0 = a0, n1 = a1;
         if (q + 1 < NQ) {
@@ -893,7 +945,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                     if (t > 1) fetch(t - 2);                            // ... and the same registers request step t-2
                 }
                 f32x4 acc[1][2] = {{zero4, zero4}};
-                mfma_nodes32<1, KSG, true, 0, 2, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
+                mfma_nodes32<1, KSG, true, 0, 2, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
                 sb_c += ld4(EC + lds_sw(orow[0], col, KAP));
                 sb_u += ld4(EG + lds_sw(orow[0], H + col, KGP));
                 if (valid[1]) {
@@ -902,7 +954,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                 }
                 EEG_LDS_BARRIER();                                      // (2) P_m^T dR complete
                 EEG_SETPRIO(3);                                         // the dR half is on the chain
-                mfma_nodes32<1, KSG, true, 0, 1, true>(EG, KGP, lane, lr, lg, w2, acc, RS);
+                mfma_nodes32<1, KSG, true, 0, 1, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);
                 EEG_SETPRIO(0);
                 if (t > 0) { acc[0][0] += gx[0]; acc[0][1] += gx[1]; }
                 st4(DP + odp[0], acc[0][0]);
