@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 N_NODES, H_UNITS, D_IN, K_DIFF, LAYERS = 19, 64, 100, 2, 2
 PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_CLOCK_MHZ = 2400.0           # the clock that peak is quoted at
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 ACHIEVABLE_HBM_GBS = 6290.0       # MI355X_MICROARCH.md: measured float4 copy (79 % of spec) = what any stream reaches
 
@@ -57,11 +58,11 @@ DESCR = {
 }
 
 
-def make_args(filter_type):
+def make_args(filter_type, dropout=0.0, layers=LAYERS):
     import types
-    return types.SimpleNamespace(num_nodes=N_NODES, num_rnn_layers=LAYERS, rnn_units=H_UNITS, input_dim=D_IN,
+    return types.SimpleNamespace(num_nodes=N_NODES, num_rnn_layers=layers, rnn_units=H_UNITS, input_dim=D_IN,
                                  output_dim=D_IN, max_diffusion_step=K_DIFF, dcgru_activation="tanh",
-                                 filter_type=filter_type, dropout=0.0, cl_decay_steps=3000,
+                                 filter_type=filter_type, dropout=dropout, cl_decay_steps=3000,
                                  use_curriculum_learning=False)
 
 
@@ -104,7 +105,7 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed, host_support
     return x, y, lengths, supports
 
 
-def algorithmic_work(filter_type, t_len, batch, task="detection"):
+def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS):
     """Per-step algorithmic FLOPs / bytes of every profiled kernel role.  Roles = the names the
     library's event recorder uses; at the benchmark shapes each role is ONE kernel symbol per layer
     (`ROLE_SYMBOLS`), so `roofline.kernels` is a by-symbol table."""
@@ -112,7 +113,7 @@ def algorithmic_work(filter_type, t_len, batch, task="detection"):
     n, h = N_NODES, H_UNITS
     s = t_len * batch
     r = s * n
-    fins = [D_IN] + [h] * (LAYERS - 1)
+    fins = [D_IN] + [h] * (layers - 1)
     w = {k: 0.0 for k in ("seq_fwd", "seq_bwd", "gemm_nn_xw", "gemm_nn_dx", "gemm_tn_x", "gemm_tn_hg", "gemm_tn_hc",
                           "diffuse_fwd", "diffuse_adj")}
     if filter_type == "dual_random_walk":
@@ -278,6 +279,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (default: workload's)")
+    ap.add_argument("--layers", type=int, default=LAYERS, help="num_rnn_layers (BASELINE's configs: 2; the reference's SSL recipe "
+                    "README.md:91 and its shipped checkpoints use 3 -- decoder layers >= 1 then share one cell)")
+    ap.add_argument("--dropout", type=float, default=0.0, help="nn.Dropout probability of the model in train() mode (the "
+                    "reference trains the 4-class model of cfg4 with --dropout 0.5, README.md:83; the masks are generated inside "
+                    "the head / decoder kernels from a device-resident Philox state, so the captured graph draws fresh ones "
+                    "on every replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="disable the live per-kernel HIP-event timing")
     ap.add_argument("--host-supports", action="store_true", help="correlation-graph workloads: use supports prepared "
@@ -293,6 +300,8 @@ def main():
                     "time and error beside the true-fp32 kernel under `experimental_split_bf16`; `value` / `dtype` are untouched")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning); loads "
                     "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
+    ap.add_argument("--lib", default=None, help="development A/B runs only: load this build of the C ABI (e.g. a library built "
+                    "from an older commit, kept under build/ab/) instead of the product library; named in config.library")
     args = ap.parse_args()
 
     t_boot = time.perf_counter()
@@ -321,8 +330,11 @@ def main():
     from eeg_gnn_ssl_amd import DCRNNModel_classification, _lib, ops
     from eeg_gnn_ssl_amd.train_step import TrainStep
 
+    if args.lib:                                                     # development A/B runs only
+        _lib._LIB = _lib.EegDcrnnLib(os.path.abspath(args.lib), strict=False)
     if args.tune:                                                    # development A/B runs only
-        _lib._LIB = _lib.EegDcrnnLib(_lib.DEV_LIB_PATH)
+        if not args.lib:
+            _lib._LIB = _lib.EegDcrnnLib(_lib.DEV_LIB_PATH)
         for kv in args.tune:
             k, v = kv.split("=")
             _lib._LIB.call("eeg_dcrnn_set_tuning", int(k), int(v))
@@ -332,9 +344,9 @@ def main():
     torch.manual_seed(123)                                   # identical replicas on every rank
     if task == "ssl":
         from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
-        model = DCRNNModel_nextTimePred(make_args(filt), device=dev).to(dev)
+        model = DCRNNModel_nextTimePred(make_args(filt, args.dropout, args.layers), device=dev).to(dev)
     else:
-        model = DCRNNModel_classification(make_args(filt), classes, device=dev).to(dev)
+        model = DCRNNModel_classification(make_args(filt, args.dropout, args.layers), classes, device=dev).to(dev)
     model.train()
     stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0, always_reduce=args.force_dist)
     device_graph = filt == "dual_random_walk" and not args.host_supports
@@ -378,18 +390,36 @@ def main():
             torch.cuda.synchronize()
     one_step = stepper.replay_step if graphed else (lambda: stepper.step(x, y, lengths, supports))
 
-    def timed(step_fn):
+    clock_buf = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def timed(step_fn, marks=None):
+        """the contract's timed region: W untimed steps, barrier + synchronize, K steps on the wall clock, barrier + synchronize.
+        marks: a HIP event is recorded on the launch stream in front of every timed step and behind the last one (K + 1 records of
+        ~1 us each) so that the line can show the per-step durations the wall-clock mean is made of."""
         for _ in range(args.warmup):
             step_fn()
         sync_all()
+        cur = torch.cuda.current_stream()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for k in range(args.steps):
+            if marks is not None:
+                marks[k].record(cur)
             loss = step_fn()
+        if marks is not None:
+            marks[args.steps].record(cur)
+            # shader clock right behind the last timed step (a 20 us one-wave kernel): what the chip held under this load
+            if hasattr(lib._dll, "eeg_dcrnn_prof_clock_probe"):
+                lib.call("eeg_dcrnn_prof_clock_probe", ctypes.c_void_p(clock_buf.data_ptr()), ctypes.c_void_p(cur.cuda_stream))
         sync_all()
         return time.perf_counter() - t0, loss
 
-    elapsed, loss = timed(one_step)
-    log(f"timed {args.steps} steps ({'graph replay' if graphed else 'eager'}): {elapsed / args.steps * 1e3:.3f} ms/step")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    elapsed, loss = timed(one_step, marks)
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    cyc, ticks = (int(v) for v in clock_buf.tolist())
+    sclk_mhz = round(cyc / ticks * 100.0, 1) if ticks > 0 else None
+    log(f"timed {args.steps} steps ({'graph replay' if graphed else 'eager'}): {elapsed / args.steps * 1e3:.3f} ms/step "
+        f"(first {step_ms[0]:.3f}, median {sorted(step_ms)[len(step_ms) // 2]:.3f}, last {step_ms[-1]:.3f}; shader clock behind the last step {sclk_mhz} MHz)")
 
     # second timed pass: every step first receives a FRESH batch from pinned host memory (the trainer's situation: at
     # 85 k clips/s the input stream is ~40 GB/s per GPU).  The step is captured on TWO input sets; the host-to-device copy
@@ -465,14 +495,23 @@ def main():
             prof[name] = (int(cnt), float(ms))
     # exchange + optimiser tail (all-reduce of the flat bucket when a process group exists, norm + fused clip/Adam):
     # HIP events around reduce_and_update() on the launch stream, gradients left as they are
+    # (measured on a scratch copy of the optimiser state: with a process group every call all-reduces -- SUMS -- the bucket in
+    # place, so repeating it on the live buffers would grow the gradient by world^steps and apply `steps` extra updates)
+    keep = [t.clone() for t in (stepper.fp.flat, stepper.fp.flat_grad, stepper.exp_avg, stepper.exp_avg_sq)]
+    keep_count = stepper.step_count
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
+    tail_ms = 0.0
     for _ in range(args.steps):
+        stepper.fp.flat_grad.copy_(keep[1])                      # the same (finite) gradient every time
+        e0.record()
         stepper.reduce_and_update()
-    e1.record()
-    torch.cuda.synchronize()
-    tail_ms = e0.elapsed_time(e1) / args.steps
+        e1.record()
+        torch.cuda.synchronize()
+        tail_ms += e0.elapsed_time(e1) / args.steps
+    with torch.no_grad():
+        for dst, src in zip((stepper.fp.flat, stepper.fp.flat_grad, stepper.exp_avg, stepper.exp_avg_sq), keep):
+            dst.copy_(src)
+    stepper.step_count = keep_count
     per_rank = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         allr = [torch.empty_like(per_rank) for _ in range(world)]
@@ -493,7 +532,7 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     clips_per_s = batch * world / (elapsed / args.steps)
-    work = algorithmic_work(filt, t_len, batch, task)
+    work = algorithmic_work(filt, t_len, batch, task, args.layers)
     kernels = {}
     for name, (cnt, ms) in prof.items():
         per_step_ms = ms / args.steps
@@ -542,8 +581,18 @@ def main():
                         "frac": round(v["work"] / (v["ms_per_step"] * 1e-3) / (PEAK_HBM_GBS * 1e9 if v["bound"] == "hbm" else PEAK_MFMA_F32_TFLOPS * 1e12), 4)}
                     for k, v in classes_ms.items()}
         flops = sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram" and not k.endswith("_persist"))
+        held = (sclk_mhz / PEAK_CLOCK_MHZ) if sclk_mhz else None
+        if held:
+            for v in kernels.values():
+                if v.get("bound") == "mfma":
+                    v["frac_at_held_clock"] = round(v["frac"] / held, 4)
         roofline = {"kernel": dom, "symbol": d.get("symbol"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"],
+                    # the MFMA peak is a 2.4 GHz figure; the part holds less under sustained fp32 matrix load.  frac_at_held_clock =
+                    # frac x 2400 / (shader clock measured right behind the last timed step): the share of the cycles the chip
+                    # actually ran.  `frac` (against the spec-sheet peak) stays the reported figure.
+                    "shader_clock_mhz_under_load": sclk_mhz,
+                    "frac_at_held_clock": d.get("frac_at_held_clock"),
                     "traffic": (traffic or {}).get(dom), "traffic_note": traffic_note, "avg_launch_ms": d["avg_launch_ms"],
                     "top_class": max(by_class, key=lambda k: by_class[k]["ms_per_step"]), "by_class": by_class,
                     "kernels": kernels,
@@ -555,16 +604,23 @@ def main():
     out = {
         "metric": "EEG clips/sec (60s, 19ch, K=2, 2-layer x64) fwd+bwd",
         "value": round(clips_per_s, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        # what the wall-clock mean is made of (HIP events in front of every timed step, rank 0): a fresh process shows whether
+        # its first replays are slower than the rest (clock ramp / first-use costs) instead of hiding it in the mean
+        "ms_per_step_p50": round(sorted(step_ms)[len(step_ms) // 2], 3),
+        "first5_ms": [round(v, 3) for v in step_ms[:5]], "last5_ms": [round(v, 3) for v in step_ms[-5:]],
+        "ms_per_step_events_mean": round(sum(step_ms) / len(step_ms), 3),
+        "shader_clock_mhz_under_load": sclk_mhz,
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": DESCR[args.workload], "per_gpu_batch": batch, "global_batch": batch * world,
-                   "clip_len": t_len, "parallelism": f"dp{world}", "optimizer_step_included": True,
+                   "clip_len": t_len, "parallelism": f"dp{world}", "optimizer_step_included": True, "dropout": args.dropout, "num_rnn_layers": args.layers,
                    "supports": ("per-clip correlation graph + dual random-walk supports built on the GPU inside the step"
                                 if device_graph else "prepared on the host (distance graph is fixed)"
                                 if filt == "laplacian" else "prepared on the host"),
                    "launch": "hip-graph replay (fwd+loss+bwd) + eager all-reduce/clip+Adam" if graphed else "eager",
                    "timed_region": f"{args.steps} steps on one batch resident in HBM = {elapsed * 1e3:.1f} ms wall",
-                   "library": "DEV build with tuning knobs " + ",".join(args.tune) if args.tune else "product",
+                   "library": (("A/B build " + args.lib + " ") if args.lib else "") + ("DEV build with tuning knobs " + ",".join(args.tune) if args.tune else ("" if args.lib else "product")),
                    "final_loss": round(loss_val, 5)},
         "distributed": {"world_size": world_seen, "backend": backend, "per_rank_ms_per_step": per_rank_ms,
                         "all_reduce_issued": bool(stepper.reduce),
@@ -577,6 +633,8 @@ def main():
         # with SURVEY's per-clip figure, which includes the layer-0 dX that neither the reference's autograd nor this
         # library computes (21 % more FLOPs at cfg2)
         "whole_step": {"executed_mfma_frac": None if roofline is None else roofline["whole_step_mfma_frac"],
+                       "executed_mfma_frac_at_held_clock": None if (roofline is None or not sclk_mhz) else
+                       round(roofline["whole_step_mfma_frac"] * PEAK_CLOCK_MHZ / sclk_mhz, 4),
                        "executed_gflop": None if roofline is None else roofline["whole_step_flops"],
                        "mfma_roof_clips_per_s_per_gpu_survey_flops": round(mfma_roof, 0),
                        "mfma_roof_frac_survey_flops": round(per_gpu / mfma_roof, 4),

@@ -15,7 +15,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip.so")
 DEV_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip_dev.so")     # `make dev`: tools/ and `bench.py --tune` only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class LayerDims(ctypes.Structure):
@@ -28,7 +28,7 @@ class LayerDims(ctypes.Structure):
 class DecoderDims(ctypes.Structure):
     """mirror of `eeg_decoder_dims` (include/eeg_dcrnn.h)."""
     _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Dout", c_int32),
-                ("M", c_int32), ("L", c_int32), ("act", c_int32), ("p_batched", c_int32)]
+                ("M", c_int32), ("L", c_int32), ("act", c_int32), ("p_batched", c_int32), ("dropout_p", c_float)]
 
 
 _FP = c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -40,6 +40,7 @@ _SIGNATURES = {
     "eeg_dcrnn_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "eeg_dcrnn_prof_enable": (c_int, [c_int]),
     "eeg_dcrnn_prof_report": (c_int, [ctypes.c_char_p, c_size_t]),
+    "eeg_dcrnn_prof_clock_probe": (c_int, [_FP, c_void_p]),
     "eeg_dcrnn_hop_polys": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_fft_features": (c_int, [_FP, c_int, c_int, c_int, c_int, _FP, _FP, c_float, c_float, _FP, _FP, c_void_p]),
     "eeg_dcrnn_corr_graph_ws_floats": (c_size_t, [c_int, c_int]),
@@ -61,13 +62,15 @@ _SIGNATURES = {
     "eeg_dcrnn_decoder_fwd_ws_floats": (c_size_t, [POINTER(DecoderDims)]),
     "eeg_dcrnn_decoder_bwd_ws_floats": (c_size_t, [POINTER(DecoderDims)]),
     "eeg_dcrnn_decoder_fwd": (c_int, [POINTER(DecoderDims), _FP, POINTER(c_int32), _FP, _FP, POINTER(c_void_p), _FP, _FP,
-                                      _FP, _FP, _FP, c_void_p]),
-    "eeg_dcrnn_decoder_bwd": (c_int, [POINTER(DecoderDims), POINTER(c_int32), _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP,
+                                      _FP, _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_decoder_bwd": (c_int, [POINTER(DecoderDims), POINTER(c_int32), _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP,
                                       POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                       _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
-    "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
-    "eeg_dcrnn_cls_head_bwd": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_rng_take": (c_int, [_FP, ctypes.c_uint64, _FP, c_void_p]),
+    "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_cls_head_bwd": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, _FP, _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_dropout_mask": (c_int, [_FP, c_size_t, c_float, _FP, c_void_p]),
     "eeg_dcrnn_bce_logits": (c_int, [_FP, _FP, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_ce_logits": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_masked_loss_ws_floats": (c_size_t, []),
@@ -90,7 +93,9 @@ class EegDcrnnError(RuntimeError):
 
 
 class EegDcrnnLib:
-    def __init__(self, path: str = HIP_LIB_PATH):
+    def __init__(self, path: str = HIP_LIB_PATH, strict: bool = True):
+        """strict=False (development A/B runs against a library built from an older commit, `bench.py --lib`): entry points
+        the file does not export are skipped instead of refused."""
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} not found: the MI355X HIP library is not built. Run `python -c 'import "
@@ -101,6 +106,8 @@ class EegDcrnnLib:
             try:
                 fn = getattr(self._dll, name)
             except AttributeError as e:
+                if not strict:
+                    continue
                 raise ImportError(f"{path} does not export {name} (declared in include/eeg_dcrnn.h)") from e
             fn.restype = res
             fn.argtypes = args
@@ -109,7 +116,7 @@ class EegDcrnnLib:
             for name, (res, args) in _SIGNATURES_DEV.items():
                 fn = getattr(self._dll, name)
                 fn.restype, fn.argtypes = res, args
-        if self._dll.eeg_dcrnn_abi_version() != ABI_VERSION:
+        if strict and self._dll.eeg_dcrnn_abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self._dll.eeg_dcrnn_abi_version()} != {ABI_VERSION}; rebuild")
         self.is_device_build = bool(self._dll.eeg_dcrnn_is_device_build())
 

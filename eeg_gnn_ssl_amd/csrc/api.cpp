@@ -434,7 +434,7 @@ int colsum(const float* A, int R, int C, int split, float* ws, float* out0, floa
 // ---- decoder (model.py:112-204): buffer carving shared by forward and backward -------------------
 struct DecLayout {
     // saved (forward -> backward)
-    size_t xin, proj_pack, proj_bias, saved_total;
+    size_t xin, proj_pack, proj_bias, hd, saved_total;
     size_t planes[8], hext[8], rs[8], us[8], cs[8], rhs[8], hpl[8], rpl[8];
     // backward workspace
     size_t dxw[8], dbias[8], dotot, da, dhn, z, partial, projt_pack, colsum, bwd_total;
@@ -465,6 +465,10 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
         y.hpl[l] = o;    o += align64((size_t)(d->M - 1) * (d->T + 1) * state);
         y.rpl[l] = o;    o += align64((size_t)(d->M - 1) * (d->T + 1) * state);
     }
+    // dropout in front of the projection: the dropped top-layer outputs (T,B,N,H) (A operand of dW_p); without dropout they
+    // ARE hext[L-1] slots 1..T
+    y.hd = d->dropout_p > 0.f ? o : y.hext[d->L - 1] + state;
+    if (d->dropout_p > 0.f) o += align64((size_t)d->T * state);
     y.saved_total = o;
     o = 0;
     size_t part = 0;
@@ -490,9 +494,15 @@ DecLayout dec_layout(const eeg_decoder_dims* d) {
     y.bwd_total = o;
     return y;
 }
+// nn.Dropout's own argument check (torch: "dropout probability has to be between 0 and 1, but got ...")
+int check_dropout_p(const char* who, float p) {
+    if (!(p >= 0.f && p <= 1.f)) return fail("%s: dropout probability has to be between 0 and 1, but got %g", who, p);
+    return 0;
+}
 int check_decoder_dims(const eeg_decoder_dims* d) {
     if (d->L < 1 || d->L > 8) return fail("decoder: num_rnn_layers=%d unsupported (1..8)", d->L);
     if (d->T < 1 || d->B < 1) return fail("decoder: empty sequence/batch (T=%d, B=%d)", d->T, d->B);
+    if (check_dropout_p("decoder", d->dropout_p)) return 1;
     if (check_dims(d->N, d->H, d->Dout, d->M)) return 1;
     return check_dims(d->N, d->H, d->H, d->M);
 }
@@ -505,7 +515,7 @@ int copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
 extern "C" {
 
 const char* eeg_dcrnn_last_error(void) { return g_err; }
-int eeg_dcrnn_abi_version(void) { return 2; }
+int eeg_dcrnn_abi_version(void) { return 3; }
 int eeg_dcrnn_is_device_build(void) { return kPlatformIsDevice; }
 #if defined(EEG_DEV)
 int eeg_dcrnn_set_tuning(int key, int value) {
@@ -528,6 +538,21 @@ int eeg_dcrnn_prof_report(char* buf, size_t cap) {
     const size_t need = eeg::prof_report(buf, cap);
     if (need != 0) return fail("prof_report: buffer too small (%zu needed)", need);
     return 0;
+}
+namespace {
+// one wave spins for `ticks` of the chip-wide 100 MHz counter and reports how many shader-clock cycles passed meanwhile
+__global__ void clock_probe_kernel(long long ticks, long long* __restrict__ out) {
+    const long long r0 = realtime_now(), c0 = cycle_now();
+    long long r1 = r0;
+    for (int i = 0; i < (1 << 22) && r1 - r0 < ticks; ++i) r1 = realtime_now();
+    const long long c1 = cycle_now();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+}  // namespace
+int eeg_dcrnn_prof_clock_probe(int64_t* out2, void* stream) {
+    if (out2 == nullptr) return fail("prof_clock_probe: null output");
+    EEG_LAUNCH(clock_probe_kernel, dim3(1), dim3(64), 0, S_(stream), (long long)2000, reinterpret_cast<long long*>(out2));   // 20 us
+    return check_launch("clock_probe");
 }
 int eeg_dcrnn_supported(int N, int H, int Fin, int M) { return check_dims(N, H, Fin, M) == 0 ? 1 : 0; }
 
@@ -724,12 +749,15 @@ size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d) { return (size
 size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d) { return dec_layout(d).bwd_total; }
 
 int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const int32_t* teacher, const float* h0,
-                          const float* P, const float* const* packs, const float* Wp, const float* bp, float* out,
-                          float* saved, float* ws, void* stream) {
+                          const float* P, const float* const* packs, const float* Wp, const float* bp,
+                          const uint64_t* rng_used, float* out, float* saved, float* ws, void* stream) {
     if (check_decoder_dims(d)) return 1;
     ProfPrefix tag("dec_");
     hipStream_t st = S_(stream);
     const DecLayout y = dec_layout(d);
+    const DropCfg drop = make_drop_cfg(d->dropout_p);
+    const unsigned long long* used = reinterpret_cast<const unsigned long long*>(rng_used);
+    if (drop.on && rng_used == nullptr) return fail("decoder_fwd: dropout_p > 0 needs the {seed, offset} pair of eeg_dcrnn_rng_take");
     const int B = d->B, N = d->N, H = d->H, M = d->M, Dout = d->Dout, L = d->L, RB = B * N;
     const size_t state = (size_t)RB * H, xstep = (size_t)RB * Dout;
     const int nct_o = ceil_div(Dout, 16);
@@ -768,6 +796,7 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
             for (int t = 0; t < d->T; ++t)
                 if (teacher != nullptr && teacher[t] != 0) a.teacher_mask |= 1ull << t;
             a.p_batched = d->p_batched; a.T = d->T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
+            a.drop = drop; a.rng_used = used; a.hd = saved + y.hd;
             const int rc = launch_dec_fwd_persist(M, dx, a, lds, st);
             if (rc == 0) return 0;
             if (rc == 2) return fail("decoder_fwd: persistent kernel launch failed");
@@ -797,9 +826,14 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
             a.variant = g_tune[12] == 0 ? 1 : 0;
             if (seq_fwd(H, M, a, st)) return 1;
         }
-        // projection (model.py:188-190): out_t = h_top W_p^T + b_p
+        // projection (model.py:188-191): out_t = drop(h_top) W_p^T + b_p
+        if (drop.on) {
+            EEG_LAUNCH_P("dropout_apply", dropout_apply_kernel, dim3(ceil_div((int)(state / 4), 256)), dim3(256), 0, st,
+                         saved + y.hext[L - 1] + (size_t)(t + 1) * state, saved + y.hd + (size_t)t * state, state, (size_t)t * state, used, drop);
+            if (check_launch("dropout_apply")) return 1;
+        }
         SegPtrs sp;
-        for (int m = 0; m < kMaxM; ++m) sp.p[m] = m == 0 ? saved + y.hext[L - 1] + (size_t)(t + 1) * state : nullptr;
+        for (int m = 0; m < kMaxM; ++m) sp.p[m] = m == 0 ? saved + y.hd + (size_t)t * state : nullptr;
         if (gemm_nn(sp, 1, H, RB, ppack, nct_o, pbias, out + (size_t)t * xstep, Dout, Dout, st)) return 1;
         if (t + 1 < d->T) {   // next decoder input: the projection, or the target under teacher forcing (model.py:194-200)
             const bool tf = teacher != nullptr && teacher[t] != 0;
@@ -810,13 +844,16 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
 }
 
 int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, const float* P, const float* const* packs,
-                          const float* Wp, const float* saved, const float* dOut, float* dh0, float* const* dWg,
-                          float* const* dbg, float* const* dWc, float* const* dbc, float* dWp, float* dbp, float* ws,
-                          void* stream) {
+                          const float* Wp, const float* saved, const float* dOut, const uint64_t* rng_used, float* dh0,
+                          float* const* dWg, float* const* dbg, float* const* dWc, float* const* dbc, float* dWp, float* dbp,
+                          float* ws, void* stream) {
     if (check_decoder_dims(d)) return 1;
     ProfPrefix tag("dec_");
     hipStream_t st = S_(stream);
     const DecLayout y = dec_layout(d);
+    const DropCfg drop = make_drop_cfg(d->dropout_p);
+    const unsigned long long* used = reinterpret_cast<const unsigned long long*>(rng_used);
+    if (drop.on && rng_used == nullptr) return fail("decoder_bwd: dropout_p > 0 needs the rng_used pair of the forward call");
     const int B = d->B, N = d->N, H = d->H, M = d->M, Dout = d->Dout, L = d->L, RB = B * N, T = d->T;
     const size_t state = (size_t)RB * H, xstep = (size_t)RB * Dout, Rall = (size_t)T * RB;
     const int nct_h = ceil_div(H, 16);
@@ -848,6 +885,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
             for (int t = 0; t < T; ++t)
                 if (feeds_back(t)) a.feeds_mask |= 1ull << t;
             a.p_batched = d->p_batched; a.T = T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
+            a.drop = drop; a.rng_used = used;
             const int rc = launch_dec_bwd_persist(M, dt, a, lds, st);
             if (rc == 2) return fail("decoder_bwd: persistent kernel launch failed");
             persistent = rc == 0;
@@ -860,7 +898,11 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
         if (!feeds_back(t) && copy_floats(dOtot + (size_t)t * xstep, dO, xstep, st)) return 1;   // dense copy for the hoisted GEMM
         SegPtrs sp;
         for (int m = 0; m < kMaxM; ++m) sp.p[m] = m == 0 ? dOtot + (size_t)t * xstep : nullptr;
-        if (gemm_nn(sp, 1, Dout, RB, tpack, nct_h, nullptr, dA, H, H, st)) return 1;               // d h_top = dO W_p
+        if (gemm_nn(sp, 1, Dout, RB, tpack, nct_h, nullptr, dA, H, H, st)) return 1;               // d drop(h_top) = dO W_p
+        if (drop.on) {                                                                              // d h_top = mask * that
+            EEG_LAUNCH_P("dropout_apply", dropout_apply_kernel, dim3(ceil_div((int)(state / 4), 256)), dim3(256), 0, st, dA, dA, state, (size_t)t * state, used, drop);
+            if (check_launch("dropout_apply")) return 1;
+        }
         for (int l = L - 1; l >= 0; --l) {
             const int Fin = l == 0 ? Dout : H;
             const CellPack p = make_cell_pack(Fin, H, M);
@@ -910,7 +952,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
     // projection: dW_p (Dout x H) = sum_rows dOtot^T h_top ;  db_p = column sums of dOtot
     SegPtrs so;
     for (int m = 0; m < kMaxM; ++m) so.p[m] = m == 0 ? dOtot : nullptr;
-    if (gemm_tn(so, 1, Dout, (int)Rall, saved + y.hext[L - 1] + state, H, 0, H, ws + y.partial, y.nsplit_p, y.rps_p, st)) return 1;
+    if (gemm_tn(so, 1, Dout, (int)Rall, saved + y.hd, H, 0, H, ws + y.partial, y.nsplit_p, y.rps_p, st)) return 1;   // (hd = h_top without dropout)
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack_kernel, dim3(ceil_div(Dout * H, 64)), dim3(256), 256 * sizeof(float4), st, ws + y.partial, y.nsplit_p, Dout, H, 3, Dout, H, 1, dWp, dWp);
     if (check_launch("reduce_unpack(proj)")) return 1;
     return colsum(dOtot, (int)Rall, Dout, Dout, ws + y.colsum, dbp, nullptr, st);
@@ -921,17 +963,40 @@ int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int 
                reinterpret_cast<const long long*>(lengths), T, B, NH, last);
     return check_launch("gather_last");
 }
-int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H, int C,
-                           float* logits, int32_t* arg, void* stream) {
+int eeg_dcrnn_dropout_mask(const uint64_t* rng_used, size_t n, float dropout_p, float* mask, void* stream) {
+    if (check_dropout_p("dropout_mask", dropout_p)) return 1;
+    const DropCfg drop = make_drop_cfg(dropout_p);
+    if (drop.on && rng_used == nullptr) return fail("dropout_mask: dropout_p > 0 needs the rng_used pair of a forward call");
+    if (n == 0) return 0;
+    EEG_LAUNCH_P("dropout_mask", dropout_mask_kernel, dim3(256), dim3(256), 0, S_(stream), reinterpret_cast<const unsigned long long*>(rng_used), n, drop, mask);
+    return check_launch("dropout_mask");
+}
+int eeg_dcrnn_rng_take(uint64_t* rng_state, uint64_t groups, uint64_t* rng_used, void* stream) {
+    if (rng_state == nullptr || rng_used == nullptr) return fail("rng_take: null state / output");
+    EEG_LAUNCH_P("rng_take", rng_take_kernel, dim3(1), dim3(64), 0, S_(stream), reinterpret_cast<unsigned long long*>(rng_state),
+                 reinterpret_cast<unsigned long long*>(rng_used), (unsigned long long)groups);
+    return check_launch("rng_take");
+}
+int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H, int C, float dropout_p,
+                           const uint64_t* rng_used, float* logits, int32_t* arg, void* stream) {
     if (N > 64) return fail("cls_head: num_nodes=%d unsupported (<= 64)", N);
-    EEG_LAUNCH_P("cls_head_fwd", cls_head_fwd_kernel, dim3(B), dim3(64), (size_t)N * C * sizeof(float), S_(stream), z, W, bias, B, N, H, C, logits, arg);
+    if (H % 4 != 0) return fail("cls_head: rnn_units=%d must be a multiple of 4", H);
+    if (check_dropout_p("cls_head", dropout_p)) return 1;
+    const DropCfg drop = make_drop_cfg(dropout_p);
+    if (drop.on && rng_used == nullptr) return fail("cls_head: dropout_p > 0 needs the {seed, offset} pair of eeg_dcrnn_rng_take");
+    EEG_LAUNCH_P("cls_head_fwd", cls_head_fwd_kernel, dim3(B), dim3(64), (size_t)N * (C + H) * sizeof(float), S_(stream), z, W, bias, B, N, H, C, drop,
+                 reinterpret_cast<const unsigned long long*>(rng_used), logits, arg);
     return check_launch("cls_head_fwd");
 }
 int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg, int B, int N,
-                           int H, int C, float* dz, float* dW, float* dbias, void* stream) {
-    EEG_LAUNCH_P("cls_head_bwd_dz", cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, dz);
+                           int H, int C, float dropout_p, const uint64_t* rng_used, float* dz, float* dW, float* dbias, void* stream) {
+    if (check_dropout_p("cls_head_bwd", dropout_p)) return 1;
+    const DropCfg drop = make_drop_cfg(dropout_p);
+    if (drop.on && rng_used == nullptr) return fail("cls_head_bwd: dropout_p > 0 needs the rng_used pair of the forward call");
+    const unsigned long long* used = reinterpret_cast<const unsigned long long*>(rng_used);
+    EEG_LAUNCH_P("cls_head_bwd_dz", cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, drop, used, dz);
     if (check_launch("cls_head_bwd_dz")) return 1;
-    EEG_LAUNCH_P("cls_head_bwd_w", cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 16)), dim3(256), 256 * sizeof(float), S_(stream), z, dlogits, arg, B, N, H, C, dW, dbias);
+    EEG_LAUNCH_P("cls_head_bwd_w", cls_head_bwd_w_kernel, dim3(ceil_div(C * H + C, 16)), dim3(256), 256 * sizeof(float), S_(stream), z, dlogits, arg, B, N, H, C, drop, used, dW, dbias);
     return check_launch("cls_head_bwd_w");
 }
 

@@ -59,6 +59,19 @@ __host__ __device__ constexpr int lds_sw(int row, int col, int stride) {
 // 80 floats apart (80 = 16 mod 32: the two lane groups of a half-wave write different bank halves)
 constexpr int kRemTile = 4 * 80;
 
+// Reduce-scatter of a 4x4x1 remainder chain inside the wave, no LDS: register r of lane (lr, lg) holds lane group lg's partial of
+// out[node 16 + r][col lr]; the return value of lane (lr, lg) is the complete out[node 16 + lg][col lr] -- every lane ends up with
+// ONE element of the 4-node remainder tile (the "one value per lane" layout of the remainder epilogues).  Three register swaps
+// (gfx950 v_permlane32_swap / v_permlane16_swap) and three adds; sum order per element: (g0 + g2) + (g1 + g3).
+__device__ __forceinline__ float rem4_reduce(f32x4 t) {
+    float a = t[0], b = t[1], c = t[2], d = t[3];
+    permlane32_swap(a, c);            // a = rows [t0.g0, t0.g1, t2.g0, t2.g1], c = [t0.g2, t0.g3, t2.g2, t2.g3]
+    permlane32_swap(b, d);            // b = rows [t1.g0, t1.g1, t3.g0, t3.g1], d = [t1.g2, t1.g3, t3.g2, t3.g3]
+    float s02 = a + c, s13 = b + d;   // rows [t0(g0+g2), t0(g1+g3), t2(g0+g2), t2(g1+g3)] / the same of t1, t3
+    permlane16_swap(s02, s13);        // s02 = rows [t0, t1, t2, t3](g0+g2), s13 = [t0, t1, t2, t3](g1+g3)
+    return s02 + s13;
+}
+
 // columns of the packs c1 / c2 (kernels_pack.h): hidden units, then input features padded so that the decoder's
 // layers (Fin <= 128, 64 units) all have the SAME column-tile count, a literal in kernels_decoder.h
 __host__ __device__ constexpr int cell_pack_cx_cols(int Fin, int H) { return H + (Fin <= 128 ? 128 : round_up(Fin, 64)); }
@@ -90,4 +103,51 @@ __device__ __forceinline__ f32x4 relu4_(f32x4 x) {
     return (f32x4){fmaxf(x[0], 0.f), fmaxf(x[1], 0.f), fmaxf(x[2], 0.f), fmaxf(x[3], 0.f)};
 }
 
+// ---- dropout (nn.Dropout in front of the classification head, model.py:267, and of the decoder's projection, model.py:191) ------
+// Keep decisions come from Philox4x32-10 (Salmon et al., SC'11 -- the counter-based generator torch's own GPU dropout uses): group
+// g of four consecutive elements of the dropped tensor takes the four 32-bit words of counter (offset + g) under key `seed`;
+// element 4g + j is kept when word j >= thr = p * 2^32 and then scaled by 1 / (1 - p).  Nothing is stored: the backward kernels
+// recompute the words from the (seed, offset) pair the forward call used.  The generator state lives in DEVICE memory
+// (uint64 {seed, offset}): a forward entry point first launches rng_take_kernel, which copies the pair to `used` and advances
+// the offset by the counters the call draws -- so a captured HIP graph draws fresh masks on every replay.
+struct DropCfg {
+    float p, scale;             // scale = 1 / (1 - p) (0 when p >= 1: everything dropped, like torch)
+    unsigned thr;               // keep iff word >= thr
+    bool on;                    // p > 0
+};
+inline DropCfg make_drop_cfg(float p) {
+    DropCfg c;
+    c.p = p;
+    c.on = p > 0.f;
+    c.scale = p >= 1.f ? 0.f : 1.f / (1.f - p);
+    const double t = (double)p * 4294967296.0;
+    c.thr = p >= 1.f ? 0xffffffffu : (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
+    return c;
+}
+__host__ __device__ inline void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1;
+        c3 = (unsigned)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// keep-mask x scale of elements 4g .. 4g+3 (p >= 1: keep nothing -- word >= 0xffffffff would still keep one in 2^32)
+__host__ __device__ inline f32x4 dropout_mask4(unsigned long long seed, unsigned long long offset, unsigned long long g,
+                                               unsigned thr, float scale) {
+    const unsigned long long c = offset + g;
+    unsigned w[4];
+    philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+    f32x4 m;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = (scale != 0.f && w[j] >= thr) ? scale : 0.f;
+    return m;
+}
 }  // namespace eeg

@@ -40,6 +40,12 @@ struct DecFwdArgs {
     size_t hplane_stride;         // floats between two planes of hpl / rpl = (T+1)*B*N*H
     unsigned long long teacher_mask;   // bit t: step t+1 is fed targets[t] instead of out[t] (model.py:194-200)
     int p_batched, T, B, N, Dout, L, act;
+    // nn.Dropout in front of the projection (model.py:191, training): the projection reads drop(h_top_t) = mask * h_top_t; the
+    // recurrence keeps h_top_t.  Element ((t*B + b)*N + n)*H + h of the (T,B,N,H) top outputs takes word e % 4 of Philox counter
+    // rng_used[1] + e / 4 under key rng_used[0] (common.h).  hd (T,B,N,H): the dropped rows, the A operand of dW_p in the backward.
+    DropCfg drop;
+    const unsigned long long* rng_used;
+    float* hd;
 };
 
 // ---- GEMMs with streamed weights -------------------------------------------------------------------------------
@@ -255,7 +261,8 @@ constexpr int kDecRows = 20;     // node rows of the LDS tiles (montages of at m
 // LDS floats of dec_fwd_persist_kernel<64, M>
 __host__ __device__ constexpr size_t dec_fwd_lds_floats(int M, int L, int Dout) {
     const int H = 64, KAP = M * H, XS = lds_stride_q(M * round_up(Dout, 16));
-    return (size_t)(M - 1) * kPFloats + (size_t)L * kDecRows * KAP + (size_t)kDecRows * (XS > KAP ? XS : KAP) + 4 * 3 * kRemTile;
+    return (size_t)(M - 1) * kPFloats + (size_t)L * kDecRows * KAP + (size_t)kDecRows * (XS > KAP ? XS : KAP) + 4 * 3 * kRemTile
+           + (size_t)kDecRows * 64;      // + the dropped copy of the top state the projection reads (swizzled [rows][64])
 }
 
 // DX = k-steps per weight group of the layer-0 x-part ((Dout/4) % DX == 0; the larger, the further ahead the weights are requested).
@@ -274,10 +281,13 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
     float* RS0 = XA + ROWS * XK;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
     float* RS = RS0 + wave * (3 * kRemTile);
+    float* HD = RS0 + 4 * 3 * kRemTile;             // [ROWS][64] swizzled: drop(h^{L-1}_t), written and read only when a.drop.on
     const int ct = wave, col = ct * 16 + 4 * lg;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int nct_o = ceil_div(Dout, 16);
     const size_t xstep = (size_t)B * N * Dout;
+    const DropCfg drop = a.drop;
+    const unsigned long long dseed = drop.on ? a.rng_used[0] : 0ull, doff = drop.on ? a.rng_used[1] : 0ull;
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
@@ -387,6 +397,11 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                         st4(lp.hext + (s + B) * N * H + oh[nt], hn);             // hext slot t+1
                         st4(lp.cs + s * N * H + oh[nt], c);
                     }
+                    if (drop.on && l == L - 1) {                                 // what the projection reads (model.py:191)
+                        const f32x4 hd = hn * dropout_mask4(dseed, doff, (s * N * H + oh[nt]) >> 2, drop.thr, drop.scale);
+                        if (nt == 0 || lr < 4) st4(HD + lds_sw(nt == 0 ? lr : 16 + lr, col, 64), hd);
+                        if (valid[nt]) st4(a.hd + s * N * H + oh[nt], hd);
+                    }
                 }
                 EEG_WAVE_SYNC();
                 lds_diffuse_tile<M, NKS, ROWS>(Al, KAP, ct * 16, H, pf, lr, lg, lp.hpl + (s + B) * N * H, a.hplane_stride, N);
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                         po[i][0] = bv;
                         po[i][1] = lr < 4 ? bv : zero4;
                     }
-                    gemm_stream_plain<2, 16, true>(Atop, KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po, RS);
+                    gemm_stream_plain<2, 16, true>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po, RS);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (i == 1 && !two) continue;
@@ -463,6 +478,8 @@ struct DecBwdArgs {
     float *dbias0, *dbias1;       // (B,3H) per-clip bias-gradient sums [r|u|c] over steps and nodes: layer 0, layers >= 1 (one shared cell)
     unsigned long long feeds_mask;     // bit t: out_t is the input of step t+1 (no teacher forcing there, t+1 < T)
     int p_batched, T, B, N, Dout, L, act;
+    DropCfg drop;                      // dropout in front of the projection (DecFwdArgs): d h_top = mask * (dO W_p), mask recomputed
+    const unsigned long long* rng_used;
 };
 
 __host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) {
@@ -578,6 +595,11 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 gemm_stream_plain<1, DT, false, true>(DO, FS, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS, wpt);
                 gext[0] = pa[0][0];
                 gext[1] = pa[0][1];
+                if (a.drop.on) {      // through the dropout in front of the projection: the forward's mask, recomputed
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        gext[nt] *= dropout_mask4(a.rng_used[0], a.rng_used[1], (s * N * H + oh[nt]) >> 2, a.drop.thr, a.drop.scale);
+                }
             }
             prefetch1(L - 1, pair_nt(L - 1, t));
             for (int l = L - 1; l >= 0; --l) {

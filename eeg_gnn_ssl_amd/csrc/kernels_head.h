@@ -5,6 +5,11 @@
 
 namespace eeg {
 
+__device__ __forceinline__ f32x4 ld4g(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return (f32x4){v.x, v.y, v.z, v.w};
+}
+
 // last[b][:] = Htop[lengths[b]-1][b][:]            (utils.py:346-357, batch-first gather)
 __global__ void gather_last_kernel(const float* __restrict__ Htop, const long long* __restrict__ lengths,
                                    int T, int B, int NH, float* __restrict__ last) {
@@ -17,17 +22,33 @@ __global__ void gather_last_kernel(const float* __restrict__ Htop, const long lo
     }
 }
 
-// logits[b][c] = max_n ( sum_h relu(z[b][n][h]) W[c][h] + bias[c] ); arg = first maximising node.
-// one 64-thread workgroup per clip; thread n (< N) scores node n for every class.
+// logits[b][c] = max_n ( sum_h relu(drop(z)[b][n][h]) W[c][h] + bias[c] ); arg = first maximising node.
+// drop = nn.Dropout(p) of model.py:267 (training): element kept with probability 1-p and scaled by 1/(1-p); since the scale is
+// positive, relu(drop(z)) = mask * relu(z).  One 64-thread workgroup per clip: the masked relu(z) rows are staged in LDS (one
+// Philox call per 16-byte group), then thread n (< N) scores node n for every class.
+// used (drop.on only): device {seed, offset} of this call (common.h rng_take_kernel); element e of z takes word e % 4 of counter
+// offset + e / 4.
 __global__ void cls_head_fwd_kernel(const float* __restrict__ z, const float* __restrict__ W,
-                                    const float* __restrict__ bias, int B, int N, int H, int C,
-                                    float* __restrict__ logits, int* __restrict__ arg) {
-    EEG_DYN_SMEM(sm);                   // [N][C] node logits
+                                    const float* __restrict__ bias, int B, int N, int H, int C, DropCfg drop,
+                                    const unsigned long long* __restrict__ used, float* __restrict__ logits, int* __restrict__ arg) {
+    EEG_DYN_SMEM(sm);                   // [N][C] node logits, then [N][H] masked relu(z)
+    float* zs = sm + N * C;
     const int b = blockIdx.x, n = threadIdx.x;
+    const unsigned long long seed = drop.on ? used[0] : 0ull, off = drop.on ? used[1] : 0ull;
+    const int groups = N * H / 4;       // H % 4 == 0
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        const size_t gg = (size_t)b * groups + g;
+        f32x4 v = ld4g(z + 4 * gg);
+        f32x4 m = {1.f, 1.f, 1.f, 1.f};
+        if (drop.on) m = dropout_mask4(seed, off, gg, drop.thr, drop.scale);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zs[4 * g + j] = fmaxf(v[j], 0.f) * m[j];
+    }
+    __syncthreads();
     if (n < N) {
         for (int c = 0; c < C; ++c) {
             float s = bias[c];
-            for (int h = 0; h < H; ++h) s = fmaf(fmaxf(z[((size_t)b * N + n) * H + h], 0.f), W[c * H + h], s);
+            for (int h = 0; h < H; ++h) s = fmaf(zs[n * H + h], W[c * H + h], s);
             sm[n * C + c] = s;
         }
     }
@@ -42,10 +63,17 @@ __global__ void cls_head_fwd_kernel(const float* __restrict__ z, const float* __
     }
 }
 
-// dz[b][n][h] = sum_c [arg[b][c]==n] dlogits[b][c] W[c][h] * (z>0)
+// the mask x scale value of element i of the (B,N,H) head input (1 without dropout)
+__device__ __forceinline__ float head_mask(const DropCfg& drop, const unsigned long long* __restrict__ used, size_t i) {
+    if (!drop.on) return 1.f;
+    return dropout_mask4(used[0], used[1], i >> 2, drop.thr, drop.scale)[i & 3];
+}
+
+// dz[b][n][h] = sum_c [arg[b][c]==n] dlogits[b][c] W[c][h] * (z>0) * mask
 __global__ void cls_head_bwd_dz_kernel(const float* __restrict__ z, const float* __restrict__ W,
                                        const float* __restrict__ dlogits, const int* __restrict__ arg,
-                                       int B, int N, int H, int C, float* __restrict__ dz) {
+                                       int B, int N, int H, int C, DropCfg drop, const unsigned long long* __restrict__ used,
+                                       float* __restrict__ dz) {
     const size_t total = (size_t)B * N * H;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int h = i % H, n = (i / H) % N, b = i / ((size_t)H * N);
@@ -53,15 +81,16 @@ __global__ void cls_head_bwd_dz_kernel(const float* __restrict__ z, const float*
         if (z[i] > 0.f)
             for (int c = 0; c < C; ++c)
                 if (arg[(size_t)b * C + c] == n) s = fmaf(dlogits[(size_t)b * C + c], W[c * H + h], s);
-        dz[i] = s;
+        dz[i] = s * head_mask(drop, used, i);
     }
 }
 
-// dW[c][h] = sum_b dlogits[b][c] relu(z[b][arg[b][c]][h]);  dbias[c] = sum_b dlogits[b][c]
+// dW[c][h] = sum_b dlogits[b][c] mask relu(z[b][arg[b][c]][h]);  dbias[c] = sum_b dlogits[b][c]
 // block = 16 outputs x 16 batch slices, LDS combine in a fixed order (deterministic).
 __global__ void cls_head_bwd_w_kernel(const float* __restrict__ z, const float* __restrict__ dlogits,
-                                      const int* __restrict__ arg, int B, int N, int H, int C,
-                                      float* __restrict__ dW, float* __restrict__ dbias) {
+                                      const int* __restrict__ arg, int B, int N, int H, int C, DropCfg drop,
+                                      const unsigned long long* __restrict__ used, float* __restrict__ dW,
+                                      float* __restrict__ dbias) {
     EEG_DYN_SMEM(sm);                                 // [16][16]
     const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + o;
@@ -70,7 +99,8 @@ __global__ void cls_head_bwd_w_kernel(const float* __restrict__ z, const float* 
         const int c = i / H, h = i % H;
         for (int b = q; b < B; b += 16) {
             const int n = arg[(size_t)b * C + c];
-            s = fmaf(dlogits[(size_t)b * C + c], fmaxf(z[((size_t)b * N + n) * H + h], 0.f), s);
+            const size_t e = ((size_t)b * N + n) * H + h;
+            s = fmaf(dlogits[(size_t)b * C + c], fmaxf(z[e], 0.f) * head_mask(drop, used, e), s);
         }
     } else if (i < C * H + C) {
         const int c = i - C * H;
@@ -82,6 +112,38 @@ __global__ void cls_head_bwd_w_kernel(const float* __restrict__ z, const float* 
         float t = 0.f;
         for (int k = 0; k < 16; ++k) t += sm[k * 16 + o];
         if (i < C * H) dW[i] = t; else dbias[i - C * H] = t;
+    }
+}
+
+// ---- dropout generator plumbing (common.h: Philox4x32-10 keep masks) --------------------------------------------------------
+// first launch of a forward entry point that drops: hands the {seed, offset} pair of this call to `used` and advances the
+// generator state by the counters the call will draw.  The compute kernels behind it on the stream only read `used`.
+__global__ void rng_take_kernel(unsigned long long* __restrict__ state, unsigned long long* __restrict__ used, unsigned long long groups) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long seed = state[0], off = state[1];
+        used[0] = seed;
+        used[1] = off;
+        state[1] = off + groups;
+    }
+}
+// mask[e] = keep(e) * scale for e < n: the values the fused kernels multiply with, materialised (tests hand them to the oracle)
+__global__ void dropout_mask_kernel(const unsigned long long* __restrict__ used, size_t n, DropCfg drop, float* __restrict__ mask) {
+    const size_t groups = (n + 3) / 4;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 m = drop.on ? dropout_mask4(used[0], used[1], g, drop.thr, drop.scale) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * g + j < n) mask[4 * g + j] = m[j];
+    }
+}
+// y = x * mask (per-step decoder path: the projection input) / x *= mask (its gradient); e0 = index of x[0] in the dropped tensor
+__global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, size_t e0,
+                                     const unsigned long long* __restrict__ used, DropCfg drop) {
+    const size_t groups = n / 4;        // n % 4 == 0, e0 % 4 == 0
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 m = dropout_mask4(used[0], used[1], e0 / 4 + g, drop.thr, drop.scale);
+        const float4 v = *reinterpret_cast<const float4*>(x + 4 * g);
+        *reinterpret_cast<float4*>(y + 4 * g) = make_float4(v.x * m[0], v.y * m[1], v.z * m[2], v.w * m[3]);
     }
 }
 

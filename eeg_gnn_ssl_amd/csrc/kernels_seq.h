@@ -68,6 +68,10 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float
 // QM (the two-role BPTT kernel splits its K = M*2H gate GEMM by column half): 0: weight quad q' reads tile quad q';
 // 1 / 2: the quads of the dR / dU halves of every 2H-wide hop slot (tile quad 8*(q'/4) + q'%4 [+ 4]).
 // WQ: `w` holds ALL k-steps and is indexed by the mapped quad too (only half of the quads are visited).
+// L1 (REM4 only): the remainder leaves in the ONE-VALUE-PER-LANE layout -- lane (lr, lg) <-> node 16 + lg, column lr of the tile --
+// as acc[i][1][0] += out[16 + lg][lr] (components 1..3 of acc[i][1] are not touched): the four lane-group partials are reduced
+// and scattered with three register swaps (common.h rem4_reduce), no LDS hand-over, and the remainder epilogue of the caller
+// is scalar work on 64 distinct elements instead of float4 work on lanes of which a quarter hold real nodes.
 // compile-time loop: f(SeqIdx<I>()) for I in [B, E) -- every index is a constant inside the body (register arrays stay registers)
 template <int V> struct SeqIdx { static constexpr int value = V; };
 template <int B, int E, typename Fn>
@@ -86,11 +90,12 @@ constexpr int rem_ahead(int i) {
     return l;
 }
 
-template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false, bool TWOPASS = false>
+template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false, bool TWOPASS = false, bool L1 = false>
 __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
                                              const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
     static_assert(MODE == 0 || REM4, "split modes exist for the 4x4x1 remainder only");
+    static_assert(!L1 || REM4, "the one-value-per-lane remainder layout exists for the 4x4x1 remainder only");
     constexpr bool DO16 = MODE != 2, DO4 = REM4 && MODE != 1;
     // swizzled tile (common.h): quad q of row r is the 16-byte piece 16*(q>>2) + ((4*(q&3) + lg) ^ sigma4(r))
     const int s0 = lg ^ sigma4(lr), s1 = REM4 ? (lg ^ sigma4(lane & 3)) : s0;
@@ -185,7 +190,14 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[i][0] += alt[i];
     }
-    if (DO4) {
+    if constexpr (DO4 && L1) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            f32x4 t = (rem[i][0] + rem[i][1]) + (rem[i][2] + rem[i][3]);
+            EEG_PIN(t);                                  // (keeps the three adds packed)
+            acc[i][1][0] += rem4_reduce(t);
+        }
+    } else if (DO4) {
         // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr) (lane groups 80 floats apart);  reader (lr < 4, lg):
         // sum over the 4 groups of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
 #pragma unroll
@@ -470,17 +482,16 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     }
     __syncthreads();
 
-    const int node[2] = {lr, 16 + lr};
     const bool valid[2] = {lr < N, 16 + lr < N};
     const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int col = ct * 16 + 4 * lg;
-    int oxw[2], oh[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        oxw[nt] = nodec[nt] * (3 * H) + col;
-        oh[nt] = nodec[nt] * H + col;
-    }
+    const int oxw0 = nodec[0] * (3 * H) + col, oh0 = nodec[0] * H + col;
+    // remainder nodes 16..19, one value per lane (mfma_nodes32 L1): lane (lr, lg) <-> node 16 + lg, column ct*16 + lr
+    const int node1 = 16 + lg, col1 = ct * 16 + lr;
+    const bool valid1 = node1 < N;
+    const int oxw1 = (valid1 ? node1 : N - 1) * (3 * H) + col1, oh1 = (valid1 ? node1 : N - 1) * H + col1;
+    const int l1 = lds_sw(node1, col1, KAP);           // this lane's element of the h / r*h slot (rows 16..19)
     if (role == 0) {
         EEG_SETPRIO(3);         // the r -> r*h -> c chain is the critical path: its instructions issue first
         float pf[poly_slots<M, NKS>()][NKS];
@@ -491,33 +502,40 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             lds_diffuse_tile<M, NKS>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N, true);
         };
         diffuse_own(A, Hpl, 0);
-        f32x4 nxr[2], nxc;
+        f32x4 nxr0, nxc;
+        float nxr1;
         auto fetch_xw = [&](int t) {                                  // (descriptor on the step's rows: no 64-bit lane addresses)
             const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
-            nxr[0] = wbuf_ld4(bx, oxw[0], 0u);
-            nxr[1] = wbuf_ld4(bx, oxw[1], 0u);
-            nxc = wbuf_ld4(bx, oxw[0] + 2 * H, 0u);
+            nxr0 = wbuf_ld4(bx, oxw0, 0u);
+            nxr1 = wbuf_ld(bx, oxw1, 0u);
+            nxc = wbuf_ld4(bx, oxw0 + 2 * H, 0u);
         };
         fetch_xw(0);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
             // the accumulators start from the hoisted pre-activations (no zero fill, no add behind the GEMM); the
-            // remainder tile's accumulator is read on lanes lr < 4 only
-            f32x4 ar[1][2] = {{nxr[0], lr < 4 ? nxr[1] : zero4}}, ac[1][2] = {{nxc, zero4}};
+            // remainder's is one value per lane (component 0)
+            f32x4 ar[1][2] = {{nxr0, (f32x4){nxr1, 0.f, 0.f, 0.f}}}, ac[1][2] = {{nxc, zero4}};
             const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1) hops(h) complete
             pp.mark(0);
-            mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, ar, RS);
+            mfma_nodes32<1, KS, true, 0, 0, false, false, true>(A, KAP, lane, lr, lg, w0, ar, RS);
             pp.mark(1);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 rg = sigmoid4_(ar[0][nt]);
-                f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
-                rh = valid[nt] ? rh : zero4;
-                st4(A2 + lds_sw(node[nt], col, KAP), rh);
-                if (save && valid[nt]) {
-                    wbuf_st4(bR, oh[nt], so, rg);
-                    wbuf_st4(bRH, oh[nt], so, rh);
+            {
+                const f32x4 rg = sigmoid4_(ar[0][0]);
+                f32x4 rh = rg * ld4(A + lds_sw(lr, col, KAP));
+                rh = valid[0] ? rh : zero4;
+                st4(A2 + lds_sw(lr, col, KAP), rh);
+                const float rg1 = sigmoidf_(ar[0][1][0]);
+                const float rh1 = valid1 ? rg1 * A[l1] : 0.f;
+                A2[l1] = rh1;
+                if (save && valid[0]) {
+                    wbuf_st4(bR, oh0, so, rg);
+                    wbuf_st4(bRH, oh0, so, rh);
+                }
+                if (save && valid1) {
+                    wbuf_st1(bR, oh1, so, rg1);
+                    wbuf_st1(bRH, oh1, so, rh1);
                 }
             }
             pp.mark(2);
@@ -535,8 +553,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 hn = valid[0] ? hn : zero4;
                 st4(A + lds_sw(lr, col, KAP), hn);
                 if (valid[0]) {
-                    wbuf_st4(bH, oh[0], so, hn);
-                    if (save) wbuf_st4(bC, oh[0], so, c);
+                    wbuf_st4(bH, oh0, so, hn);
+                    if (save) wbuf_st4(bC, oh0, so, c);
                 }
             }
             pp.mark(5);
@@ -545,42 +563,42 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             pp.mark(6);
         }
     } else {
-        f32x4 nxu[2], nxc;
+        f32x4 nxu0;
+        float nxu1, nxc1;
         auto fetch_x = [&](int t) {
             const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
-            nxu[0] = wbuf_ld4(bx, oxw[0] + H, 0u);
-            nxu[1] = wbuf_ld4(bx, oxw[1] + H, 0u);
-            nxc = wbuf_ld4(bx, oxw[1] + 2 * H, 0u);
+            nxu0 = wbuf_ld4(bx, oxw0 + H, 0u);
+            nxu1 = wbuf_ld(bx, oxw1 + H, 0u);
+            nxc1 = wbuf_ld(bx, oxw1 + 2 * H, 0u);
         };
         fetch_x(0);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
-            f32x4 au[1][2] = {{nxu[0], lr < 4 ? nxu[1] : zero4}}, ac[1][2] = {{zero4, lr < 4 ? nxc : zero4}};
+            f32x4 au[1][2] = {{nxu0, (f32x4){nxu1, 0.f, 0.f, 0.f}}}, ac[1][2] = {{zero4, (f32x4){nxc1, 0.f, 0.f, 0.f}}};
             const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1)
             if (t + 1 < T) fetch_x(t + 1);
-            mfma_nodes32<1, KS, true>(A, KAP, lane, lr, lg, w0, au, RS);
-            f32x4 u;                                                // nodes 16..19: stays in registers for the blend
+            mfma_nodes32<1, KS, true, 0, 0, false, false, true>(A, KAP, lane, lr, lg, w0, au, RS);
+            float u1;                                                // node 16 + lg: stays in a register for the blend
             {
                 const f32x4 u0 = sigmoid4_(au[0][0]);
-                u = sigmoid4_(au[0][1]);
+                u1 = sigmoidf_(au[0][1][0]);
                 st4(U + lds_sw(lr, col, UST), u0);                        // nodes >= N: finite, never used
-                if (save && valid[0]) wbuf_st4(bU, oh[0], so, u0);
+                if (save && valid[0]) wbuf_st4(bU, oh0, so, u0);
             }
             EEG_LDS_BARRIER();                                        // (2)
-            // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend
-            mfma_nodes32<1, KS, true, 2>(A2, KAP, lane, lr, lg, w1, ac, RS);
+            // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend, one element per lane
+            mfma_nodes32<1, KS, true, 2, 0, false, false, true>(A2, KAP, lane, lr, lg, w1, ac, RS);
             {
-                const f32x4 h = ld4(A + lds_sw(node[1], col, KAP));
-                const f32x4 c = act == 0 ? tanh4_(ac[0][1]) : relu4_(ac[0][1]);
-                f32x4 hn = u * h + (1.f - u) * c;
-                hn = valid[1] ? hn : zero4;
-                if (lr < 4) st4(A + lds_sw(node[1], col, KAP), hn);       // rows 16..19 (the others belong to nobody here)
-                if (valid[1]) {
-                    wbuf_st4(bH, oh[1], so, hn);
+                const float h1 = A[l1];
+                const float c1 = act == 0 ? tanhf_(ac[0][1][0]) : fmaxf(ac[0][1][0], 0.f);
+                const float hn1 = valid1 ? u1 * h1 + (1.f - u1) * c1 : 0.f;
+                A[l1] = hn1;                                             // rows 16..19 of this column tile (64 distinct elements)
+                if (valid1) {
+                    wbuf_st1(bH, oh1, so, hn1);
                     if (save) {
-                        wbuf_st4(bC, oh[1], so, c);
-                        wbuf_st4(bU, oh[1], so, u);
+                        wbuf_st1(bC, oh1, so, c1);
+                        wbuf_st1(bU, oh1, so, u1);
                     }
                 }
             }
@@ -864,14 +882,21 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int col = ct * 16 + 4 * lg;
-    const int odp[2] = {lr * DPS + 4 * lg, (16 + (lr & 3)) * DPS + 4 * lg};   // lane <-> lane hand-over
+    // remainder nodes 16..19, one value per lane (mfma_nodes32 L1): lane (lr, lg) <-> node 16 + lg, column ct*16 + lr
+    const int node1 = 16 + lg, col1 = ct * 16 + lr;
+    const bool valid1 = node1 < N;
+    const int odp0 = lr * DPS + 4 * lg, odp1 = node1 * DPS + lr;               // lane <-> lane hand-over ([20][DPS] = [node][col])
+    // coefficient slots of the remainder element: one float4 {kC, kU, u, hr1} per lane in the nt = 1 slot of coefficient 0, r in
+    // the nt = 1 slot of coefficient 1 (lane-linear dwords); the nt = 1 slots of coefficients 2..4 are unused
+    float* CF1 = CF + (0 * 2 + 1) * 256;
+    float* CFr1 = CF - 4 * lane + (1 * 2 + 1) * 256 + lane;
 
     if (role == 1) {
         // ================= role B =================
         float w2[1][KSG];
 #pragma unroll
         for (int ks = 0; ks < KSG; ++ks) w2[0][ks] = b2p[((size_t)ks * NCT + ct) * 64 + lane];
-        const int oh[2] = {nodec[0] * H + col, nodec[1] * H + col};
+        const int oh0 = nodec[0] * H + col, oh1 = (valid1 ? node1 : N - 1) * H + col1;
         const int orow[2] = {lr, valid[1] ? 16 + lr : 16};             // bias sums, nt = 1: only lanes with a real node add
         for (int b = blockIdx.x; b < B; b += gridDim.x) {
             __syncthreads();
@@ -883,33 +908,36 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                 t_len = t_len < 0 ? 0 : (t_len >= T ? T - 1 : t_len);
             }
             const size_t tstride = (size_t)B * N * H, boff = (size_t)b * N * H;
-            f32x4 nh[2], nr[2], nu[2], nc[2], ng[2];
+            f32x4 nh, nr, nu, nc, ng;                                   // nodes 0..15: four columns per lane
+            float nh1, nr1, nu1, nc1, ng1;                              // node 16 + lg: one column per lane
             // operands through buffer descriptors (one VGPR offset per node tile, the step offset in an SGPR): no 64-bit
             // per-lane address arithmetic on the VALU, which shares its ALUs with the fp32 MFMAs of the other role
             const wbuf_t bH = make_wbuf(Hseq), bH0 = make_wbuf(h0 != nullptr ? h0 : Hseq), bR = make_wbuf(Rs), bU = make_wbuf(Us),
                          bC = make_wbuf(Cs), bG = make_wbuf(dHseq != nullptr ? dHseq : Hseq);
             auto fetch = [&](int t) {
                 const unsigned so = (unsigned)((size_t)t * tstride + boff);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const unsigned o = oh[nt];
-                    nh[nt] = t > 0 ? wbuf_ld4(bH, o, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld4(bH0, o, (unsigned)boff) : zero4);
-                    nr[nt] = wbuf_ld4(bR, o, so);
-                    nu[nt] = wbuf_ld4(bU, o, so);
-                    nc[nt] = wbuf_ld4(bC, o, so);
-                    f32x4 g = dHseq != nullptr ? wbuf_ld4(bG, o, so) : zero4;
-                    if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + boff + o);
-                    if (t == t_len) g += ld4(d_at_len + boff + o);
-                    ng[nt] = g;
-                }
+                nh = t > 0 ? wbuf_ld4(bH, oh0, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld4(bH0, oh0, (unsigned)boff) : zero4);
+                nr = wbuf_ld4(bR, oh0, so);
+                nu = wbuf_ld4(bU, oh0, so);
+                nc = wbuf_ld4(bC, oh0, so);
+                nh1 = t > 0 ? wbuf_ld(bH, oh1, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld(bH0, oh1, (unsigned)boff) : 0.f);
+                nr1 = wbuf_ld(bR, oh1, so);
+                nu1 = wbuf_ld(bU, oh1, so);
+                nc1 = wbuf_ld(bC, oh1, so);
+                f32x4 g = dHseq != nullptr ? wbuf_ld4(bG, oh0, so) : zero4;
+                float g1 = dHseq != nullptr ? wbuf_ld(bG, oh1, so) : 0.f;
+                if (d_at_end != nullptr && t == T - 1) { g += ld4(d_at_end + boff + oh0); g1 += d_at_end[boff + oh1]; }
+                if (t == t_len) { g += ld4(d_at_len + boff + oh0); g1 += d_at_len[boff + oh1]; }
+                ng = g;
+                ng1 = g1;
             };
             // the five coefficient vectors of one step from its operands -> this lane's LDS slots; the external gradient
             // of that step is kept (gx) and added to the GEMM2 result that becomes its incoming gradient
-            f32x4 gx[2];
+            f32x4 gx;
+            float gx1;
             auto coef = [&]() {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 h = nh[nt], u = nu[nt], c = nc[nt], r = nr[nt];
+                {
+                    const f32x4 h = nh, u = nu, c = nc, r = nr;
                     f32x4 kC, kU, hr1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -918,20 +946,27 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                         kU[e] = (h[e] - c[e]) * u[e] * one_u;
                         hr1[e] = h[e] * r[e] * (1.f - r[e]);
                     }
-                    st4(CF + (0 * 2 + nt) * 256, kC);
-                    st4(CF + (1 * 2 + nt) * 256, kU);
-                    st4(CF + (2 * 2 + nt) * 256, u);
-                    st4(CF + (3 * 2 + nt) * 256, hr1);
-                    st4(CF + (4 * 2 + nt) * 256, r);
-                    gx[nt] = ng[nt];
+                    st4(CF + (0 * 2 + 0) * 256, kC);
+                    st4(CF + (1 * 2 + 0) * 256, kU);
+                    st4(CF + (2 * 2 + 0) * 256, u);
+                    st4(CF + (3 * 2 + 0) * 256, hr1);
+                    st4(CF + (4 * 2 + 0) * 256, r);
+                    gx = ng;
+                }
+                {
+                    const float one_u = 1.f - nu1;
+                    const float kC1 = act == 0 ? one_u * (1.f - nc1 * nc1) : (nc1 > 0.f ? one_u : 0.f);
+                    st4(CF1, (f32x4){kC1, (nh1 - nc1) * nu1 * one_u, nu1, nh1 * nr1 * (1.f - nr1)});
+                    *CFr1 = nr1;
+                    gx1 = ng1;
                 }
             };
             fetch(T - 1);
             __syncthreads();                                            // tiles cleared
             coef();                                                     // first step: its coefficients, DP = external gradient
             if (T > 1) fetch(T - 2);
-            st4(DP + odp[0], gx[0]);
-            if (lr < 4) st4(DP + odp[1], gx[1]);
+            st4(DP + odp0, gx);
+            DP[odp1] = gx1;
             f32x4 sb_r = zero4, sb_u = zero4, sb_c = zero4;
             EEG_LDS_BARRIER();                                          // (3) of an imaginary step T
             for (int t = T - 1; t >= 0; --t) {
@@ -945,7 +980,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                     if (t > 1) fetch(t - 2);                            // ... and the same registers request step t-2
                 }
                 f32x4 acc[1][2] = {{zero4, zero4}};
-                mfma_nodes32<1, KSG, true, 0, 2, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
+                mfma_nodes32<1, KSG, true, 0, 2, true, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
                 sb_c += ld4(EC + lds_sw(orow[0], col, KAP));
                 sb_u += ld4(EG + lds_sw(orow[0], H + col, KGP));
                 if (valid[1]) {
@@ -954,11 +989,11 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                 }
                 EEG_LDS_BARRIER();                                      // (2) P_m^T dR complete
                 EEG_SETPRIO(3);                                         // the dR half is on the chain
-                mfma_nodes32<1, KSG, true, 0, 1, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);
+                mfma_nodes32<1, KSG, true, 0, 1, true, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);
                 EEG_SETPRIO(0);
-                if (t > 0) { acc[0][0] += gx[0]; acc[0][1] += gx[1]; }
-                st4(DP + odp[0], acc[0][0]);
-                if (lr < 4) st4(DP + odp[1], acc[0][1]);
+                if (t > 0) { acc[0][0] += gx; acc[0][1][0] += gx1; }
+                st4(DP + odp0, acc[0][0]);
+                DP[odp1] = acc[0][1][0];
                 EEG_LDS_BARRIER();                                      // (3) DP and the coefficients of step t-1 complete
             }
             sb_r += ld4(EG + lds_sw(orow[0], col, KGP));                // dR of the last step (t = 0)
@@ -993,28 +1028,43 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     EEG_SETPRIO(3);                                                 // windows 0 and 1: the chain issues first
     float pf[poly_slots<M, NKS>()][NKS];
     load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
-    const int oxw[2] = {node[0] * (3 * H) + col, node[1] * (3 * H) + col};
+    const int oxw0 = node[0] * (3 * H) + col, oxw1 = node1 * (3 * H) + col1;
+    const int lc1 = lds_sw(node1, col1, KAP), lg1 = lds_sw(node1, col1, KGP), lu1 = lds_sw(node1, H + col1, KGP);
     const size_t boff = (size_t)b * N * H;
-    f32x4 dhn[2] = {zero4, zero4};                                  // A's elementwise part of dh
+    f32x4 dhn = zero4;                                              // A's elementwise part of dh (nodes 0..15)
+    float dhn1 = 0.f;                                               // ... of node 16 + lg
     EEG_LDS_BARRIER();                                              // (3) of an imaginary step T: first coefficients, DP
     const wbuf_t bX = make_wbuf(dXW);
     for (int t = T - 1; t >= 0; --t) {
         const unsigned sx = (unsigned)(((size_t)t * B + b) * N * (3 * H));
         // ---- E1: g = A's elementwise part + role B's GEMM2 of the step before (+ external gradient, added by B)
-        f32x4 hr1[2], rg[2];                                        // taken now: role B refills the slots in window 1
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const f32x4 g = valid[nt] ? dhn[nt] + ld4(DP + odp[nt]) : zero4;
-            const f32x4 dC = g * ld4(CF + (0 * 2 + nt) * 256), du_ = g * ld4(CF + (1 * 2 + nt) * 256);
-            st4(EC + lds_sw(node[nt], col, KAP), dC);               // zeros on padding nodes
-            st4(EG + lds_sw(node[nt], H + col, KGP), du_);
-            if (valid[nt]) {
-                wbuf_st4(bX, oxw[nt] + 2 * H, sx, dC);
-                wbuf_st4(bX, oxw[nt] + H, sx, du_);
+        f32x4 hr1, rg;                                              // taken now: role B refills the slots in window 1
+        float hr1_1, rg1;
+        {
+            const f32x4 g = valid[0] ? dhn + ld4(DP + odp0) : zero4;
+            const f32x4 dC = g * ld4(CF + (0 * 2 + 0) * 256), du_ = g * ld4(CF + (1 * 2 + 0) * 256);
+            st4(EC + lds_sw(lr, col, KAP), dC);                     // zeros on padding nodes
+            st4(EG + lds_sw(lr, H + col, KGP), du_);
+            if (valid[0]) {
+                wbuf_st4(bX, oxw0 + 2 * H, sx, dC);
+                wbuf_st4(bX, oxw0 + H, sx, du_);
             }
-            dhn[nt] = g * ld4(CF + (2 * 2 + nt) * 256);
-            hr1[nt] = ld4(CF + (3 * 2 + nt) * 256);
-            rg[nt] = ld4(CF + (4 * 2 + nt) * 256);
+            dhn = g * ld4(CF + (2 * 2 + 0) * 256);
+            hr1 = ld4(CF + (3 * 2 + 0) * 256);
+            rg = ld4(CF + (4 * 2 + 0) * 256);
+            // node 16 + lg, column ct*16 + lr: {kC, kU, u, hr1} in one 16-byte read
+            const float g1 = valid1 ? dhn1 + DP[odp1] : 0.f;
+            const f32x4 k1 = ld4(CF1);
+            const float dC1 = g1 * k1[0], du1 = g1 * k1[1];
+            EC[lc1] = dC1;
+            EG[lu1] = du1;
+            if (valid1) {
+                wbuf_st1(bX, oxw1 + 2 * H, sx, dC1);
+                wbuf_st1(bX, oxw1 + H, sx, du1);
+            }
+            dhn1 = g1 * k1[2];
+            hr1_1 = k1[3];
+            rg1 = *CFr1;
         }
         pp.mark(0);
         EEG_WAVE_SYNC();
@@ -1025,15 +1075,18 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
         pp.mark(1);
         // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T
         f32x4 acc[1][2] = {{zero4, zero4}};
-        mfma_nodes32<1, KS, true>(EC, KAP, lane, lr, lg, w1, acc, RS);
+        mfma_nodes32<1, KS, true, 0, 0, false, false, true>(EC, KAP, lane, lr, lg, w1, acc, RS);
         pp.mark(2);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const f32x4 drh = acc[0][nt];                           // exact 0 on padding nodes
-            const f32x4 dR = drh * hr1[nt];
-            dhn[nt] += drh * rg[nt];
-            st4(EG + lds_sw(node[nt], col, KGP), dR);
-            if (valid[nt]) wbuf_st4(bX, oxw[nt], sx, dR);
+        {
+            const f32x4 drh = acc[0][0];                            // exact 0 on padding nodes
+            const f32x4 dR = drh * hr1;
+            dhn += drh * rg;
+            st4(EG + lds_sw(lr, col, KGP), dR);
+            if (valid[0]) wbuf_st4(bX, oxw0, sx, dR);
+            const float drh1 = acc[0][1][0], dR1 = drh1 * hr1_1;
+            dhn1 += drh1 * rg1;
+            EG[lg1] = dR1;
+            if (valid1) wbuf_st1(bX, oxw1, sx, dR1);
         }
         pp.mark(3);
         EEG_WAVE_SYNC();
@@ -1048,9 +1101,8 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     // ---- epilogue: dh0; role B reduces the bias sums
     __syncthreads();                                                // all waves done with EG
     if (dh0 != nullptr) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            if (valid[nt]) st4(dh0 + boff + node[nt] * H + col, dhn[nt] + ld4(DP + odp[nt]));
+        if (valid[0]) st4(dh0 + boff + lr * H + col, dhn + ld4(DP + odp0));
+        if (valid1) dh0[boff + node1 * H + col1] = dhn1 + DP[odp1];
     }
     __syncthreads();
     }   // clips of this workgroup

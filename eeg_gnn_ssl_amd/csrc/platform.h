@@ -40,6 +40,17 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // EEG_USE: the value is needed here (keeps accumulators of ablated code paths alive).  No instructions.
 #define EEG_PIN(v) asm volatile("" : "+v"(v))
 #define EEG_USE(v) asm volatile("" ::"v"(v))
+// gfx950 cross-lane register swaps (VOP1, no LDS): v_permlane32_swap_b32 exchanges lanes 32..63 of `a` with lanes 0..31 of `b`;
+// v_permlane16_swap_b32 exchanges the odd 16-lane rows of `a` with the even rows of `b` (a.row1 <-> b.row0, a.row3 <-> b.row2).
+// Inline asm: ROCm 7.2's __builtin_amdgcn_permlane{16,32}_swap returns the FIRST result twice (checked in the ISA), and the
+// hazard recognizer does not look into asm, so the two wait states a VALU write -> permlane read needs are issued here
+// (the compiler emits the same s_nop in front of the builtin; nothing is needed behind it).
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ long long cycle_now() { return (long long)__builtin_readcyclecounter(); }
 __device__ __forceinline__ long long realtime_now() { return (long long)__builtin_amdgcn_s_memrealtime(); }   // 100 MHz, chip-wide
 

@@ -18,6 +18,25 @@ from .. import utils
 from .cell import DCGRUCell
 
 
+class _FusedDropout:
+    """Mixin of the two modules that own an `nn.Dropout` in the reference (model.py:191,267).  The module keeps its
+    `self.dropout = nn.Dropout(p)` attribute (same repr / `p` semantics), but the mask is generated inside the HIP kernel that
+    consumes the dropped tensor: a device-resident Philox4x32-10 generator state (int64 {seed, offset}; the seed is drawn from
+    torch's default generator at first use, so `torch.manual_seed` governs it) that every dropping forward advances on the
+    device -- a captured HIP graph therefore draws a fresh mask on every replay."""
+
+    def _drop_p(self) -> float:
+        return float(self.dropout.p) if self.training else 0.0
+
+    def _rng_state(self, device) -> torch.Tensor:
+        st = getattr(self, "_dropout_rng", None)
+        device = torch.device(device)
+        if st is None or st.device.type != device.type or (device.index is not None and st.device.index != device.index):
+            st = ops.make_rng_state(device)
+            self._dropout_rng = st
+        return st
+
+
 class DCRNNEncoder(nn.Module):
     """reference: model.py:48-109."""
 
@@ -67,7 +86,7 @@ class DCRNNEncoder(nn.Module):
         return torch.stack([c.init_hidden(batch_size) for c in self.encoding_cells], dim=0)
 
 
-class DCGRUDecoder(nn.Module):
+class DCGRUDecoder(_FusedDropout, nn.Module):
     """reference: model.py:112-204.  Time-major autoregressive loop; layers >= 1 share ONE cell
     object (model.py:126-143), so `decoding_cells.1` and `.2` alias the same parameters."""
 
@@ -93,13 +112,13 @@ class DCGRUDecoder(nn.Module):
         """inputs (T,B,N,Dout) targets, initial_hidden_state (L,B,N*H) -> (T,B,N*Dout).
 
         One native operator (eeg_dcrnn_decoder_fwd/bwd) runs the T autoregressive steps, the cells of
-        all layers and the projection; the teacher-forcing coin flips (model.py:194-200: one
+        all layers, the dropout in front of the projection (training, p > 0: a fresh mask per step, generated
+        inside the persistent kernel) and the projection; the teacher-forcing coin flips (model.py:194-200: one
         `random.random()` per step) are drawn here, in the reference's order."""
         t_len, b = inputs.shape[0], inputs.shape[1]
         self.decoding_cells[0]._check_supports(supports)
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
-        if self.training and self.dropout.p > 0:
-            return self._forward_stepwise(inputs, initial_hidden_state, p, p_batched, teacher_forcing_ratio)
+        drop_p = self._drop_p()
         teacher = None
         if teacher_forcing_ratio is not None:
             teacher = tuple(random.random() < teacher_forcing_ratio for _ in range(t_len))
@@ -110,33 +129,11 @@ class DCGRUDecoder(nn.Module):
         return ops.dcgru_decoder(inputs.reshape(t_len, b, -1), initial_hidden_state, p, p_batched, cell_params(first),
                                  None if shared is None else cell_params(shared), self.projection_layer.weight,
                                  self.projection_layer.bias, self.num_nodes, self.hid_dim, self.output_dim,
-                                 first.num_matrices, self.num_rnn_layers, first._activation_name, teacher)
-
-    def _forward_stepwise(self, inputs, initial_hidden_state, p, p_batched, teacher_forcing_ratio):
-        """Per-step composition (one T=1 layer operator per cell and step); only used when dropout is
-        active on the projection input during training (torch generates the dropout mask)."""
-        t_len, b = inputs.shape[0], inputs.shape[1]
-        targets = inputs.reshape(t_len, b, -1)
-        hidden = [initial_hidden_state[l] for l in range(self.num_rnn_layers)]
-        cur = torch.zeros(b, self.num_nodes * self.output_dim, device=inputs.device, dtype=inputs.dtype)  # GO symbol
-        outs = []
-        for t in range(t_len):
-            x = cur
-            for layer, cell in enumerate(self.decoding_cells):
-                xin = x.reshape(1, b, self.num_nodes, -1)
-                hidden[layer] = cell.run_sequence(xin, hidden[layer], p, p_batched).hsel
-                x = hidden[layer]
-            proj = self.projection_layer(self.dropout(x.reshape(b, self.num_nodes, self.hid_dim)))
-            proj = proj.reshape(b, self.num_nodes * self.output_dim)
-            outs.append(proj)
-            if teacher_forcing_ratio is not None and random.random() < teacher_forcing_ratio:
-                cur = targets[t]
-            else:
-                cur = proj
-        return torch.stack(outs, dim=0)
+                                 first.num_matrices, self.num_rnn_layers, first._activation_name, teacher,
+                                 dropout_p=drop_p, rng_state=self._rng_state(inputs.device) if drop_p > 0 else None)
 
 
-class DCRNNModel_classification(nn.Module):
+class DCRNNModel_classification(_FusedDropout, nn.Module):
     """Seizure detection / classification model (reference: model.py:208-272).
     forward(input_seq (B,T,N,Din), seq_lengths (B,), supports) -> (B, num_classes) logits."""
 
@@ -159,8 +156,10 @@ class DCRNNModel_classification(nn.Module):
         b = input_seq.shape[0]
         x = input_seq.transpose(0, 1)                         # (T,B,N,Din); made contiguous by the op
         _, _, last = self.encoder.run(x, None, supports, lengths=seq_lengths, want_finals=False)
-        last = self.dropout(last.view(b, self.num_nodes, self.rnn_units))
-        return ops.cls_head(last, self.fc.weight, self.fc.bias)    # relu -> fc -> max over nodes
+        drop_p = self._drop_p()
+        # dropout -> relu -> fc -> max over nodes in ONE launch (the mask is generated in the kernel, recomputed in its backward)
+        return ops.cls_head(last.view(b, self.num_nodes, self.rnn_units), self.fc.weight, self.fc.bias, drop_p,
+                            self._rng_state(last.device) if drop_p > 0 else None)
 
 
 class DCRNNModel_nextTimePred(nn.Module):

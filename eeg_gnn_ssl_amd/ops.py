@@ -10,7 +10,7 @@ dispatcher's "no kernel for the CPU backend" error, and the C-ABI stub refuses n
 
 Operators (namespace `eeg_dcrnn`):
     hop_polys, pack_cell, diffusion_hops, dconv (+ dconv_bwd), dcgru_layer (+ dcgru_layer_bwd),
-    dcgru_decoder (+ dcgru_decoder_bwd), cls_head (+ cls_head_bwd), gather_last, corr_graph,
+    dcgru_decoder (+ dcgru_decoder_bwd), cls_head (+ cls_head_bwd), rng_take_, dropout_mask, gather_last, corr_graph,
     fft_features, bce_logits, ce_logits, masked_loss, clip_adam_.
 The functions below them are the Python conveniences the modules in model/ and train_step.py call.
 """
@@ -126,11 +126,9 @@ def _pack_cell_impl(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
 
 
 def _pack_floats(fin, h, m):
-    """mirror of make_cell_pack (csrc/kernels_pack.h) for shape inference"""
-    r16 = lambda a: (a + 15) // 16 * 16   # noqa: E731
-    cx = h + (128 if fin <= 128 else (fin + 63) // 64 * 64)     # cell_pack_cx_cols (csrc/common.h)
-    return (m * fin * 3 * h + (3 * h + 63) // 64 * 64 + m * h * 2 * h + 2 * m * h * h + m * 2 * h * h + 3 * h * r16(m * fin)
-            + 3 * m * h * cx)
+    """size of a cell's weight pack for shape inference: `eeg_dcrnn_pack_floats` is a pure host computation of the library
+    (make_cell_pack, csrc/kernels_pack.h), so the fake implementations ask it instead of mirroring its layout"""
+    return int(_lib.get_lib().query("eeg_dcrnn_pack_floats", int(fin), int(h), int(m)))
 
 
 _define("pack_cell", "(Tensor wg, Tensor bg, Tensor wc, Tensor bc, int fin, int h, int m) -> Tensor", _pack_cell_impl,
@@ -330,10 +328,12 @@ def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_pla
     if not save:
         return hext, hsel, []
     # a non-contiguous x is copied time-major (kept for the backward) -- except the transposed view of a contiguous batch-major
-    # tensor at a layer without handed-over planes, which the kernels read through a row map (eeg_dcrnn_batch_major_ok = 2
-    # for every shape the streaming diffusion kernel covers: 19 nodes, Fin <= 512)
-    zero_copy = (not x.is_contiguous() and x_off == 0 and x_planes is None and x.transpose(0, 1).is_contiguous()
-                 and n == 19 and fin % 4 == 0 and fin <= 512)
+    # tensor at a layer without handed-over planes where the kernels read it through a row map: exactly when the library's host-side
+    # predicate eeg_dcrnn_batch_major_ok says 2 (1: the diffusion kernel emits the time-major copy, 0: torch copies; both keep xtm)
+    zero_copy = False
+    if not x.is_contiguous() and x_off == 0 and x_planes is None and x.transpose(0, 1).is_contiguous():
+        dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, False)
+        zero_copy = _lib.get_lib().query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)) == 2
     xtm = ne(t_len, b, n, fin) if (not x.is_contiguous() and not zero_copy) else ne(0)
     planes = ne(0) if x_planes is not None else ne(m - 1, t_len * b, n, fin)
     return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + \
@@ -434,16 +434,37 @@ torch.library.register_autograd(f"{NS}::dcgru_layer", _dcgru_layer_backward, set
 # =============================================================================================
 # decoder (model.py:160-204) as one operator
 # =============================================================================================
-def _dec_dims(meta):
+def _dec_dims(meta, dropout_p=0.0):
     t_len, b, n, h, dout, m, n_layers, act, p_batched = meta
-    return DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched)
+    return DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched, float(dropout_p))
+
+
+def make_rng_state(device) -> torch.Tensor:
+    """Device-resident state {seed, offset} (int64[2]) of the Philox4x32-10 generator behind the fused dropout masks
+    (csrc/common.h).  The seed is drawn from torch's default CPU generator, so `torch.manual_seed` governs it like it governs
+    `nn.Dropout`; every forward call that drops advances the offset ON THE DEVICE (a replayed HIP graph keeps drawing fresh
+    masks)."""
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+
+def _check_rng(lib, t, name):
+    _check(lib, t, name, torch.int64)
+    if t.numel() != 2:
+        raise RuntimeError(f"{name}: expected int64[2] {{seed, offset}}, got {tuple(t.shape)}")
 
 
 def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher: List[int],
-                        t_len: int, n: int, h: int, dout: int, m: int, n_layers: int, act: int):
+                        t_len: int, n: int, h: int, dout: int, m: int, n_layers: int, act: int, dropout_p: float, rng_used):
     """T autoregressive steps through L cells + the projection.  teacher: T ints (1 = feed targets[t] to step t+1,
-    all 0 = fully autoregressive); returns out (T,B,N*Dout) and [saved, pack0, pack1]."""
+    all 0 = fully autoregressive); dropout_p > 0: nn.Dropout in front of the projection (model.py:191), masks from the
+    {seed, offset} pair `rng_used` that `rng_take_` handed out for T*B*N*H/4 counters.  Returns out (T,B,N*Dout) and
+    [saved, pack0, pack1]."""
     lib = _lib.get_lib()
+    if dropout_p > 0:
+        if rng_used is None:
+            raise RuntimeError("dcgru_decoder: dropout_p > 0 needs rng_used (ops.rng_take)")
+        _check_rng(lib, rng_used, "rng_used")
     for fin in (dout, h):
         if not lib.query("eeg_dcrnn_supported", n, h, fin, m):
             raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
@@ -463,24 +484,27 @@ def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1,
     pack0 = torch.ops.eeg_dcrnn.pack_cell(wg0, bg0, wc0, bc0, dout, h, m)
     pack1 = torch.ops.eeg_dcrnn.pack_cell(wg1, bg1, wc1, bc1, h, h, m) if n_layers > 1 else _new((0,), h0)
     packs = [pack0] + [pack1] * (n_layers - 1)
-    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched))
+    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched), dropout_p)
     out = _new((t_len, b, n * dout), h0)
     saved = _new((lib.query("eeg_dcrnn_decoder_saved_floats", ctypes.byref(dims)),), h0)
     ws = _new((lib.query("eeg_dcrnn_decoder_fwd_ws_floats", ctypes.byref(dims)),), h0)
     tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if use_tf else None
     pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
     lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_arr, _p(h0), _p(p), pk_arr,
-             _p(wp), _p(bp), _p(out), _p(saved), _p(ws), _stream(h0))
+             _p(wp), _p(bp), _p(rng_used) if dropout_p > 0 else None, _p(out), _p(saved), _p(ws), _stream(h0))
     return out, [saved, pack0, pack1]
 
 
 def _dcgru_decoder_bwd_impl(d_out, p, p_batched: int, saved, pack0, pack1, wp, teacher: List[int], t_len: int, n: int, h: int,
-                            dout: int, m: int, n_layers: int, act: int, dwg0, dbg0, dwc0, dbc0, dwg1, dbg1, dwc1, dbc1, dwp, dbp):
+                            dout: int, m: int, n_layers: int, act: int, dropout_p: float, rng_used,
+                            dwg0, dbg0, dwc0, dbc0, dwg1, dbg1, dwc1, dbc1, dwp, dbp):
     lib = _lib.get_lib()
     d_out = d_out.contiguous()
     _check(lib, d_out, "grad of the decoder output")
     b = d_out.shape[1]
-    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched))
+    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched), dropout_p)
+    if dropout_p > 0:
+        _check_rng(lib, rng_used, "rng_used")
     packs = [pack0] + [pack1] * (n_layers - 1)
     g0, g1 = (dwg0, dbg0, dwc0, dbc0), (dwg1, dbg1, dwc1, dbc1)
     dh0 = _new((n_layers, b, n * h), saved)
@@ -490,7 +514,7 @@ def _dcgru_decoder_bwd_impl(d_out, p, p_batched: int, saved, pack0, pack1, wp, t
     arr = lambda k: (ctypes.c_void_p * n_layers)(*[(g0 if l == 0 else g1)[k].data_ptr() for l in range(n_layers)])  # noqa: E731
     pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
     lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_arr, _p(p), pk_arr, _p(wp.detach().contiguous()), _p(saved), _p(d_out),
-             _p(dh0), arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
+             _p(rng_used) if dropout_p > 0 else None, _p(dh0), arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
     return dh0
 
 
@@ -500,43 +524,46 @@ def _dec_saved_floats_fake(h0, t_len, n, h, dout, m, n_layers):
 
 _define("dcgru_decoder",
         "(Tensor? targets, Tensor h0, Tensor P, int p_batched, Tensor wg0, Tensor bg0, Tensor wc0, Tensor bc0, Tensor? wg1, Tensor? bg1, "
-        "Tensor? wc1, Tensor? bc1, Tensor wp, Tensor bp, int[] teacher, int t_len, int n, int h, int dout, int m, int n_layers, int act) "
-        "-> (Tensor out, Tensor[] saved)",
+        "Tensor? wc1, Tensor? bc1, Tensor wp, Tensor bp, int[] teacher, int t_len, int n, int h, int dout, int m, int n_layers, int act, "
+        "float dropout_p, Tensor? rng_used) -> (Tensor out, Tensor[] saved)",
         _dcgru_decoder_impl,
-        lambda targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act:
+        lambda targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act,
+        dropout_p, rng_used:
         (h0.new_empty((t_len, h0.shape[1], n * dout)),
          [_dec_saved_floats_fake(h0, t_len, n, h, dout, m, n_layers), h0.new_empty((_pack_floats(dout, h, m),)),
           h0.new_empty((_pack_floats(h, h, m) if n_layers > 1 else 0,))]))
 _define("dcgru_decoder_bwd",
         "(Tensor d_out, Tensor P, int p_batched, Tensor saved, Tensor pack0, Tensor pack1, Tensor wp, int[] teacher, int t_len, int n, "
-        "int h, int dout, int m, int n_layers, int act, Tensor(a!) dwg0, Tensor(b!) dbg0, Tensor(c!) dwc0, Tensor(d!) dbc0, "
-        "Tensor(e!)? dwg1, Tensor(f!)? dbg1, Tensor(g!)? dwc1, Tensor(h!)? dbc1, Tensor(i!) dwp, Tensor(j!) dbp) -> Tensor",
+        "int h, int dout, int m, int n_layers, int act, float dropout_p, Tensor? rng_used, Tensor(a!) dwg0, Tensor(b!) dbg0, "
+        "Tensor(c!) dwc0, Tensor(d!) dbc0, Tensor(e!)? dwg1, Tensor(f!)? dbg1, Tensor(g!)? dwc1, Tensor(h!)? dbc1, Tensor(i!) dwp, "
+        "Tensor(j!) dbp) -> Tensor",
         _dcgru_decoder_bwd_impl,
-        lambda d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m, n_layers, act, *grads:
+        lambda d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m, n_layers, act, dropout_p, rng_used, *grads:
         d_out.new_empty((n_layers, d_out.shape[1], n * h)))
 
 
 def _dcgru_decoder_setup(ctx, inputs, output):
-    (targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act) = inputs
+    (targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act,
+     dropout_p, rng_used) = inputs
     _, saved = output
     ctx.set_materialize_grads(False)
-    ctx.save_for_backward(p, wp, *saved)
+    ctx.save_for_backward(p, wp, rng_used, *saved)
     ctx.params = (wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp)
-    ctx.meta = (p_batched, list(teacher), t_len, n, h, dout, m, n_layers, act)
+    ctx.meta = (p_batched, list(teacher), t_len, n, h, dout, m, n_layers, act, float(dropout_p))
 
 
 def _dcgru_decoder_backward(ctx, d_out, d_saved):
-    p, wp, saved, pack0, pack1 = ctx.saved_tensors
-    p_batched, teacher, t_len, n, h, dout, m, n_layers, act = ctx.meta
+    p, wp, rng_used, saved, pack0, pack1 = ctx.saved_tensors
+    p_batched, teacher, t_len, n, h, dout, m, n_layers, act, dropout_p = ctx.meta
     if d_out is None:
-        return (None,) * 22
+        return (None,) * 24
     shapes = [None if q is None else tuple(q.shape) for q in ctx.params]
     sunk = [GradSink.take(q) if q is not None else None for q in ctx.params]
     bufs = [t if t is not None else (_new(sh, saved) if sh is not None else None) for t, sh in zip(sunk, shapes)]
     dh0 = torch.ops.eeg_dcrnn.dcgru_decoder_bwd(d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m,
-                                                n_layers, act, *bufs)
+                                                n_layers, act, dropout_p, rng_used if dropout_p > 0 else None, *bufs)
     ret = [None if (t is not None or g is None) else g for t, g in zip(sunk, bufs)]   # sunk: already in the caller's buffer
-    return (None, dh0, None, None, *ret, None, None, None, None, None, None, None, None)
+    return (None, dh0, None, None, *ret, None, None, None, None, None, None, None, None, None, None)
 
 
 torch.library.register_autograd(f"{NS}::dcgru_decoder", _dcgru_decoder_backward, setup_context=_dcgru_decoder_setup, lib=_libdef)
@@ -545,50 +572,82 @@ torch.library.register_autograd(f"{NS}::dcgru_decoder", _dcgru_decoder_backward,
 # =============================================================================================
 # heads, gather, graph construction, featurisation
 # =============================================================================================
-def _cls_head_impl(z, w, bias):
+def _cls_head_impl(z, w, bias, dropout_p: float, rng_used):
     lib = _lib.get_lib()
     z, w, bias = z.contiguous(), w.detach().contiguous(), bias.detach().contiguous()
     for t, nm in ((z, "last_out"), (w, "fc.weight"), (bias, "fc.bias")):
         _check(lib, t, nm)
     b, n, h = z.shape
     c = w.shape[0]
+    drop = dropout_p > 0
+    if drop:
+        if rng_used is None:
+            raise RuntimeError("cls_head: dropout_p > 0 needs rng_used (ops.rng_take)")
+        _check_rng(lib, rng_used, "rng_used")
     logits = _new((b, c), z)
     arg = _new((b, c), z, torch.int32)
-    lib.call("eeg_dcrnn_cls_head_fwd", _p(z), _p(w), _p(bias), b, n, h, c, _p(logits), _p(arg), _stream(z))
+    lib.call("eeg_dcrnn_cls_head_fwd", _p(z), _p(w), _p(bias), b, n, h, c, float(dropout_p), _p(rng_used) if drop else None,
+             _p(logits), _p(arg), _stream(z))
     return logits, arg
 
 
-def _cls_head_bwd_impl(z, w, dlogits, arg, dw, db):
+def _rng_take_impl(rng_state, groups: int):
+    """{seed, offset} of the device generator -> a fresh int64[2] tensor; the state's offset advances by `groups` counters on the
+    stream (so a replayed HIP graph keeps drawing fresh masks)"""
+    lib = _lib.get_lib()
+    _check_rng(lib, rng_state, "rng_state")
+    used = torch.empty_like(rng_state)
+    lib.call("eeg_dcrnn_rng_take", _p(rng_state), int(groups), _p(used), _stream(rng_state))
+    return used
+
+
+def _cls_head_bwd_impl(z, w, dlogits, arg, dropout_p: float, rng_used, dw, db):
     lib = _lib.get_lib()
     z, w, dlogits = z.contiguous(), w.detach().contiguous(), dlogits.contiguous()
     b, n, h = z.shape
     dz = torch.empty_like(z)
-    lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, w.shape[0], _p(dz), _p(dw), _p(db), _stream(z))
+    lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, w.shape[0], float(dropout_p),
+             _p(rng_used) if dropout_p > 0 else None, _p(dz), _p(dw), _p(db), _stream(z))
     return dz
 
 
-_define("cls_head", "(Tensor z, Tensor w, Tensor bias) -> (Tensor logits, Tensor arg)", _cls_head_impl,
-        lambda z, w, bias: (z.new_empty((z.shape[0], w.shape[0])), z.new_empty((z.shape[0], w.shape[0]), dtype=torch.int32)))
-_define("cls_head_bwd", "(Tensor z, Tensor w, Tensor dlogits, Tensor arg, Tensor(a!) dw, Tensor(b!) db) -> Tensor", _cls_head_bwd_impl,
-        lambda z, w, dlogits, arg, dw, db: torch.empty_like(z))
+def _dropout_mask_impl(rng_used, n: int, dropout_p: float):
+    """the mask x 1/(1-p) factors the fused kernels apply to elements 0..n-1 of a dropped tensor for the {seed, offset} pair a
+    forward call reported (tests: handed to the oracle)"""
+    lib = _lib.get_lib()
+    _check_rng(lib, rng_used, "rng_used")
+    mask = torch.empty((n,), dtype=torch.float32, device=rng_used.device)
+    lib.call("eeg_dcrnn_dropout_mask", _p(rng_used), n, float(dropout_p), _p(mask), _stream(rng_used))
+    return mask
+
+
+_define("rng_take_", "(Tensor(a!) rng_state, int groups) -> Tensor", _rng_take_impl, lambda rng_state, groups: torch.empty_like(rng_state))
+_define("cls_head", "(Tensor z, Tensor w, Tensor bias, float dropout_p, Tensor? rng_used) -> (Tensor logits, Tensor arg)",
+        _cls_head_impl,
+        lambda z, w, bias, dropout_p, rng_used: (z.new_empty((z.shape[0], w.shape[0])), z.new_empty((z.shape[0], w.shape[0]), dtype=torch.int32)))
+_define("cls_head_bwd", "(Tensor z, Tensor w, Tensor dlogits, Tensor arg, float dropout_p, Tensor? rng_used, Tensor(a!) dw, Tensor(b!) db) -> Tensor",
+        _cls_head_bwd_impl, lambda z, w, dlogits, arg, dropout_p, rng_used, dw, db: torch.empty_like(z))
+_define("dropout_mask", "(Tensor rng_used, int n, float dropout_p) -> Tensor", _dropout_mask_impl,
+        lambda rng_used, n, dropout_p: rng_used.new_empty((n,), dtype=torch.float32))
 
 
 def _cls_head_setup(ctx, inputs, output):
-    z, w, bias = inputs
-    ctx.save_for_backward(z, w, output[1])
+    z, w, bias, dropout_p, rng_used = inputs
+    ctx.save_for_backward(z, w, output[1], rng_used)
     ctx.params = (w, bias)
+    ctx.dropout_p = float(dropout_p)
     ctx.set_materialize_grads(False)
 
 
 def _cls_head_backward(ctx, dlogits, _darg):
-    z, w, arg = ctx.saved_tensors
+    z, w, arg, rng_used = ctx.saved_tensors
     if dlogits is None:
-        return None, None, None
+        return None, None, None, None, None
     sunk = [GradSink.take(q) for q in ctx.params]
     dw = sunk[0] if sunk[0] is not None else torch.empty_like(w)
     db = sunk[1] if sunk[1] is not None else _new((w.shape[0],), z)
-    dz = torch.ops.eeg_dcrnn.cls_head_bwd(z, w, dlogits, arg, dw, db)
-    return dz, (None if sunk[0] is not None else dw), (None if sunk[1] is not None else db)
+    dz = torch.ops.eeg_dcrnn.cls_head_bwd(z, w, dlogits, arg, ctx.dropout_p, rng_used if ctx.dropout_p > 0 else None, dw, db)
+    return dz, (None if sunk[0] is not None else dw), (None if sunk[1] is not None else db), None, None
 
 
 torch.library.register_autograd(f"{NS}::cls_head", _cls_head_backward, setup_context=_cls_head_setup, lib=_libdef)
@@ -830,21 +889,38 @@ def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh",
 
 
 def dcgru_decoder(targets, h0, p, p_batched, first_cell, shared_cell, wp, bp, n, h, dout, m, n_layers,
-                  activation="tanh", teacher=None):
-    """Run the whole decoder: returns (T,B,N*Dout).  first_cell / shared_cell = (wg, bg, wc, bc)."""
+                  activation="tanh", teacher=None, dropout_p=0.0, rng_state=None, return_rng_used=False):
+    """Run the whole decoder: returns (T,B,N*Dout).  first_cell / shared_cell = (wg, bg, wc, bc).  dropout_p > 0: nn.Dropout
+    in front of the projection, masks from the device generator rng_state (make_rng_state; advanced in place)."""
     act = ACT_CODES.get(activation, 1)
     t_len = targets.shape[0]
     sc = shared_cell if shared_cell is not None else (None, None, None, None)
     use_tf = teacher is not None and any(teacher)
     tf = [1 if v else 0 for v in teacher] if use_tf else [0] * t_len     # never an empty list: pytree leaf of the autograd glue
+    used = rng_take(rng_state, t_len * h0.shape[1] * n * h // 4) if dropout_p > 0 else None
     out, _ = torch.ops.eeg_dcrnn.dcgru_decoder(targets if use_tf else None, h0, p, int(p_batched), *first_cell, *sc, wp, bp, tf,
-                                               int(t_len), n, h, dout, m, n_layers, act)
-    return out
+                                               int(t_len), n, h, dout, m, n_layers, act, float(dropout_p), used)
+    return (out, used) if return_rng_used else out
 
 
-def cls_head(z, w, bias):
-    """model.py:267-270 after dropout: per-node Linear(H->C) on relu(z), max over nodes."""
-    return torch.ops.eeg_dcrnn.cls_head(z, w, bias)[0]
+def cls_head(z, w, bias, dropout_p=0.0, rng_state=None, return_rng_used=False):
+    """model.py:267-270: dropout (training) -> relu -> per-node Linear(H->C) -> max over nodes, one launch; the dropout mask
+    comes from the device generator rng_state (make_rng_state) and is recomputed, not stored, in the backward."""
+    used = rng_take(rng_state, z.numel() // 4) if dropout_p > 0 else None
+    logits, _ = torch.ops.eeg_dcrnn.cls_head(z, w, bias, float(dropout_p), used)
+    return (logits, used) if return_rng_used else logits
+
+
+def rng_take(rng_state, groups):
+    """hand out the generator's current {seed, offset} pair for `groups` Philox counters and advance the device state"""
+    if rng_state is None:
+        raise RuntimeError("dropout_p > 0 needs a device generator state (ops.make_rng_state)")
+    return torch.ops.eeg_dcrnn.rng_take_(rng_state, int(groups))
+
+
+def dropout_mask(rng_used, n, dropout_p):
+    """the keep-mask x 1/(1-p) factors of elements 0..n-1 for a forward call's {seed, offset} pair (tests)"""
+    return torch.ops.eeg_dcrnn.dropout_mask(rng_used, int(n), float(dropout_p))
 
 
 def gather_last(htop: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:

@@ -132,6 +132,9 @@ class TrainStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = self.forward_backward(x, y, seq_lengths, supports)
+        # one untimed replay: the first launch of an instantiated graph also uploads it to the device (torch exposes no
+        # hipGraphUpload); it recomputes the gradients of the captured batch, nothing else changes
+        graph.replay()
         self._graphs[slot] = (graph, loss, (x, y, seq_lengths, supports))
         return graph
 

@@ -48,6 +48,7 @@ typedef struct eeg_decoder_dims {
     int32_t Dout;        /* output_dim = input_dim of the first decoding cell (model.py:131-143) */
     int32_t M, L;        /* hop matrices; num_rnn_layers (layers >= 1 share ONE cell, model.py:126-143) */
     int32_t act, p_batched;
+    float dropout_p;     /* nn.Dropout in front of the projection (model.py:191), p when the module is training, else 0 */
 } eeg_decoder_dims;
 
 /* Human-readable text of the last error raised on the calling thread. */
@@ -160,22 +161,41 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
 size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d);
 size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d);
 size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d);
+/* d->dropout_p > 0 (model.py:191: `self.projection_layer(self.dropout(output))`, a fresh mask every step): the projection of step t
+ * reads mask_t * h_top_t, the recurrence keeps h_top_t.  rng_used = the {seed, offset} pair eeg_dcrnn_rng_take (below) handed out
+ * for T*B*N*H/4 counters: element e = ((t*B + b)*N + n)*H + h of the top-layer outputs takes word e%4 of counter offset + e/4.
+ * The masks are fused into the persistent kernels (nothing is stored but the dropped rows that dW_p needs) and recomputed in the
+ * backward from the same pair.  dropout_p == 0: rng_used may be NULL. */
 int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const int32_t* teacher,
                           const float* h0, const float* P, const float* const* packs, const float* Wp,
-                          const float* bp, float* out, float* saved, float* ws, void* stream);
+                          const float* bp, const uint64_t* rng_used, float* out, float* saved,
+                          float* ws, void* stream);
 int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, const float* P,
                           const float* const* packs, const float* Wp, const float* saved, const float* dOut,
-                          float* dh0, float* const* dWg, float* const* dbg, float* const* dWc,
-                          float* const* dbc, float* dWp, float* dbp, float* ws, void* stream);
+                          const uint64_t* rng_used, float* dh0, float* const* dWg, float* const* dbg,
+                          float* const* dWc, float* const* dbc, float* dWp, float* dbp, float* ws, void* stream);
 
 /* utils.last_relevant_pytorch (utils.py:346-357): last[b] = Htop[lengths[b]-1, b]. Htop (T,B,NH). */
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH,
                           float* last, void* stream);
-/* model.py:267-270: logits[b][c] = max_n fc(relu(z[b][n])); arg[b][c] = maximising node. */
+/* The generator behind the fused dropout masks (nn.Dropout of model.py:191,267): Philox4x32-10, state = device uint64[2]
+ * {seed, offset}.  rng_take copies the pair to rng_used (device uint64[2]) and advances the state's offset by `groups` counters --
+ * ON THE STREAM, so a replayed HIP graph draws fresh masks every time.  A forward entry point that drops is handed rng_used and
+ * keeps element e of its dropped tensor iff word e%4 of counter offset + e/4 under key seed is >= p * 2^32, scaled by 1/(1-p);
+ * nothing is stored, the backward entry point recomputes the mask from the same pair. */
+int eeg_dcrnn_rng_take(uint64_t* rng_state, uint64_t groups, uint64_t* rng_used, void* stream);
+/* model.py:267-270: logits[b][c] = max_n fc(relu(dropout(z[b][n]))); arg[b][c] = maximising node.
+ * dropout_p = nn.Dropout's p while the module is training (README.md:83 trains the 4-class model with --dropout 0.5), else 0;
+ * dropout_p > 0: rng_used = the pair rng_take handed out for B*N*H/4 counters (NULL allowed otherwise). */
 int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H,
-                           int C, float* logits, int32_t* arg, void* stream);
+                           int C, float dropout_p, const uint64_t* rng_used,
+                           float* logits, int32_t* arg, void* stream);
 int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg,
-                           int B, int N, int H, int C, float* dz, float* dW, float* dbias, void* stream);
+                           int B, int N, int H, int C, float dropout_p, const uint64_t* rng_used,
+                           float* dz, float* dW, float* dbias, void* stream);
+/* mask[e] = keep(e) / (1 - p) for e < n: the factors the fused kernels apply for the {seed, offset} pair in rng_used (a forward
+ * call's output), materialised -- the parity tests hand them to the oracle. */
+int eeg_dcrnn_dropout_mask(const uint64_t* rng_used, size_t n, float dropout_p, float* mask, void* stream);
 
 /* Losses that seed backward (train.py:203-206,266-268), value + gradient in one launch:
  * nn.BCEWithLogitsLoss() on logits (B,) / nn.CrossEntropyLoss() on logits (B,C); loss[0] = mean. */

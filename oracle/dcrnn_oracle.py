@@ -236,14 +236,16 @@ def encoder_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, inputs: Tensor,
 def decoder_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, targets: Tensor,
                     init_hidden: Tensor, supports: Sequence[Tensor],
                     teacher_force_mask: Optional[Sequence[bool]] = None,
-                    prefix: str = "decoder") -> Tensor:
+                    prefix: str = "decoder", dropout_masks: Optional[Tensor] = None) -> Tensor:
     """model.py:149-204 (DCGRUDecoder.forward): time-major autoregressive loop, GO = zeros,
     per-step Linear(H->Dout) per node, output fed back.  targets (T,B,N,Dout) are only used
     when teacher forcing; the reference draws `random.random() < ratio` per step — the draw
     is passed in here as an explicit per-step mask so the oracle stays deterministic.
     Q6: decoding_cells.l for every l >= 1 carry the same tensors in a reference state_dict
     (one shared cell object); the dict-of-names interface reproduces that automatically.
-    Dropout (model.py:192) is p=0 in every README command; the oracle is eval-mode / p=0."""
+    Dropout (model.py:191-192, `self.projection_layer(self.dropout(output...))`): nn.Dropout in training mode multiplies by a
+    Bernoulli keep-mask scaled by 1/(1-p), a fresh one every step.  The draw is an input here like the teacher-forcing flags:
+    dropout_masks (T,B,N,H) holds the mask x scale factors (None = eval mode / p = 0)."""
     t_len, b = targets.shape[0], targets.shape[1]
     tgt = targets.reshape(t_len, b, -1)
     w_proj = params[f"{prefix}.projection_layer.weight"]
@@ -258,7 +260,10 @@ def decoder_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, targets: Tensor
             hidden[layer] = dcgru_cell(supports, x, hidden[layer], wg, bg, wc, bc, cfg.num_nodes,
                                        cfg.rnn_units, cfg.max_diffusion_step, cfg.dcgru_activation)
             x = hidden[layer]
-        proj = torch.matmul(x.reshape(b, cfg.num_nodes, cfg.rnn_units), w_proj.t()) + b_proj
+        top = x.reshape(b, cfg.num_nodes, cfg.rnn_units)
+        if dropout_masks is not None:
+            top = top * dropout_masks[t].reshape(b, cfg.num_nodes, cfg.rnn_units)
+        proj = torch.matmul(top, w_proj.t()) + b_proj
         proj = proj.reshape(b, cfg.num_nodes * cfg.output_dim)
         outs.append(proj)
         if teacher_force_mask is not None and teacher_force_mask[t]:
@@ -275,28 +280,33 @@ def last_relevant(output: Tensor, lengths: Tensor) -> Tensor:
 
 
 def classification_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, input_seq: Tensor,
-                           seq_lengths: Tensor, supports: Sequence[Tensor]) -> Tensor:
+                           seq_lengths: Tensor, supports: Sequence[Tensor],
+                           dropout_mask: Optional[Tensor] = None) -> Tensor:
     """model.py:235-272 (DCRNNModel_classification.forward).  input_seq (B,T,N,Din) -> (B,C).
-    Q7: fc(relu(dropout(h_last))) per node, then max over nodes."""
+    Q7: fc(relu(dropout(h_last))) per node, then max over nodes.  dropout_mask (B,N,H): the training-mode nn.Dropout draw of
+    model.py:267 as mask x 1/(1-p) factors (README.md:83 trains the 4-class model with --dropout 0.5); None = eval / p = 0."""
     b = input_seq.shape[0]
     x = input_seq.transpose(0, 1)
     h0 = torch.zeros(cfg.num_rnn_layers, b, cfg.num_nodes * cfg.rnn_units, dtype=input_seq.dtype)
     _, top = encoder_forward(params, cfg, x, h0, supports)
     last = last_relevant(top.transpose(0, 1), seq_lengths).view(b, cfg.num_nodes, cfg.rnn_units)
+    if dropout_mask is not None:
+        last = last * dropout_mask.reshape(b, cfg.num_nodes, cfg.rnn_units)
     logits = torch.matmul(torch.relu(last), params["fc.weight"].t()) + params["fc.bias"]
     return logits.max(dim=1).values
 
 
 def next_time_pred_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, encoder_inputs: Tensor,
                            decoder_inputs: Tensor, supports: Sequence[Tensor],
-                           teacher_force_mask: Optional[Sequence[bool]] = None) -> Tensor:
-    """model.py:313-360 (DCRNNModel_nextTimePred.forward) -> (B,T_out,N,Dout)."""
+                           teacher_force_mask: Optional[Sequence[bool]] = None,
+                           dropout_masks: Optional[Tensor] = None) -> Tensor:
+    """model.py:313-360 (DCRNNModel_nextTimePred.forward) -> (B,T_out,N,Dout).  dropout_masks: see decoder_forward."""
     b, t_out, n, _ = decoder_inputs.shape
     enc_in = encoder_inputs.transpose(0, 1)
     dec_in = decoder_inputs.transpose(0, 1)
     h0 = torch.zeros(cfg.num_rnn_layers, b, cfg.num_nodes * cfg.rnn_units, dtype=encoder_inputs.dtype)
     enc_final, _ = encoder_forward(params, cfg, enc_in, h0, supports)
-    out = decoder_forward(params, cfg, dec_in, enc_final, supports, teacher_force_mask)
+    out = decoder_forward(params, cfg, dec_in, enc_final, supports, teacher_force_mask, dropout_masks=dropout_masks)
     return out.reshape(t_out, b, n, -1).transpose(0, 1)
 
 

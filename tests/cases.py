@@ -5,7 +5,7 @@ check against exactly the inputs the genuine reference was run on."""
 import numpy as np
 import torch
 
-from closed_form import cf, cf_adjacency, cf_params
+from closed_form import cf, cf_adjacency, cf_dropout_mask, cf_params
 from oracle import dcrnn_oracle as orc
 
 N = 19
@@ -195,3 +195,21 @@ def ssl_train_inputs(golden_train):
     y[0, 0, 0, :3] = -mean / std
     return dict(cfg=cfg, params=p, x=x, y=y, sup=dual_supports(b), steps=int(steps), lr=lr, wd=wd, clip=clip,
                 mean=mean, std=std)
+
+
+# ---- training-mode dropout (tests/golden/make_golden_dropout.py: the genuine reference run with closed-form masks) ----------
+DROPOUT_P = 0.5
+DROPOUT_CLS_TAGS = ("lap_small_ce_varlen", "dual_small_bce", "lap_default_ce_varlen")      # tags of CLS_CASES
+DROPOUT_SSL_TAGS = ("lap_small", "dual_small_L3", "dual_default")                          # tags of SSL_CASES
+
+
+def dropout_cls_mask(tag):
+    """mask x 1/(1-p) the reference's classification head was given in the golden run: (B,N,H)"""
+    _, _, h, _, _, b, _, _, _ = CLS_CASES[tag]
+    return T(cf_dropout_mask((b, N, h), DROPOUT_P, 0.9))
+
+
+def dropout_ssl_masks(tag):
+    """one mask per decoder step, in call order: (T_out,B,N,H)"""
+    _, _, h, _, b, _, t_out, _ = SSL_CASES[tag]
+    return torch.stack([T(cf_dropout_mask((b, N, h), DROPOUT_P, 1.3 + 0.37 * t)) for t in range(t_out)])

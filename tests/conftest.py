@@ -34,5 +34,10 @@ def golden_train():
 
 
 @pytest.fixture(scope="session")
+def golden_dropout():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_dropout_v1.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_fft():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_fft_v1.npz"))

@@ -11,6 +11,8 @@ struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } const float
 #define EEG_SET_MAX_LDS(kern, bytes) ((void)0)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::mfma4(a, b, c); }
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) { emu::permlane_swap(a, b, 32); }
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) { emu::permlane_swap(a, b, 16); }
 #define EEG_SCHED_FENCE() ((void)0)
 #define EEG_WAVE_SYNC() emu::wave_sync()
 #define EEG_SETPRIO(p) ((void)0)

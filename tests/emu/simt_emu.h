@@ -42,6 +42,8 @@ struct Fiber {
     bool mfma4 = false;          // this rendezvous is a v_mfma_f32_4x4x1_16B_f32
     int shfl_mask = -1;          // >= 0: this rendezvous is a __shfl_xor with that lane mask
     float shfl_val = 0.f;
+    int swap_rows = 0;           // 16 / 32: this rendezvous is a v_permlane16_swap / v_permlane32_swap of (swap_a, swap_b)
+    float swap_a = 0.f, swap_b = 0.f;
 };
 struct Ctx {
     dim3 tIdx, bIdx, bDim, gDim;
@@ -91,6 +93,17 @@ inline float shfl_xor(float v, int mask) {
     yield_to_sched();
     cur->shfl_mask = -1;
     return cur->shfl_val;
+}
+// gfx950 v_permlane32_swap_b32 (a's lanes 32..63 <-> b's lanes 0..31) / v_permlane16_swap_b32 (a's odd 16-lane rows <-> b's even rows)
+inline void permlane_swap(float& a, float& b, int rows) {
+    cur->swap_rows = rows;
+    cur->swap_a = a;
+    cur->swap_b = b;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    cur->swap_rows = 0;
+    a = cur->swap_a;
+    b = cur->swap_b;
 }
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 }  // namespace emu
@@ -163,6 +176,29 @@ static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
     }
     if (nshfl != 0) {
         fprintf(stderr, "emu: wave mixes shfl and mfma at one rendezvous\n");
+        abort();
+    }
+    unsigned nswap = 0;
+    for (unsigned l = 0; l < 64; ++l) nswap += f[w0 + l].swap_rows != 0;
+    if (nswap == 64) {
+        const int rows = f[w0].swap_rows;
+        for (unsigned l = 0; l < 64; ++l)
+            if (f[w0 + l].swap_rows != rows) { fprintf(stderr, "emu: divergent permlane swaps\n"); abort(); }
+        // a's upper half (rows == 32) / odd 16-lane rows (rows == 16) trade places with b's lower half / even rows
+        for (unsigned l = 0; l < 64; ++l) {
+            const bool a_side = rows == 32 ? l >= 32 : ((l >> 4) & 1) != 0;
+            if (a_side) {
+                const unsigned partner = rows == 32 ? l - 32 : l - 16;
+                const float t = f[w0 + l].swap_a;
+                f[w0 + l].swap_a = f[w0 + partner].swap_b;
+                f[w0 + partner].swap_b = t;
+            }
+        }
+        for (unsigned l = 0; l < 64; ++l) f[w0 + l].st = RUNNABLE;
+        return;
+    }
+    if (nswap != 0) {
+        fprintf(stderr, "emu: wave mixes permlane swaps and mfma at one rendezvous\n");
         abort();
     }
     unsigned n4 = 0;

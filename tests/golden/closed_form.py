@@ -67,3 +67,11 @@ def train_task(b=32, t=12, n=19, d=100):
     off = 0.1 * np.sin(2.1 * np.arange(b, dtype=np.float64) + 0.4)
     x[:, :, :, :10] += off[:, None, None, None]
     return x.astype(np.float32), (off > 0).astype(np.float32)
+
+
+def cf_dropout_mask(shape, p=0.5, phase=0.0):
+    """Closed-form stand-in for one nn.Dropout(p) draw in training mode: keep-mask x 1/(1-p) (hash noise thresholded at p)."""
+    i = np.arange(int(np.prod(shape)), dtype=np.float64)
+    h = np.sin(12.9898 * i + 78.233 + phase) * 43758.5453
+    keep = (h - np.floor(h)) >= p
+    return (keep.astype(np.float32) / np.float32(1.0 - p)).reshape(shape)

@@ -668,7 +668,14 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
                            nog[2].clone().requires_grad_(True), nog[3].clone().requires_grad_(True))),
         (E.cls_head.default, (torch.randn(b, n, h, generator=g).to(device).requires_grad_(True),
                               torch.randn(4, h, generator=g).to(device).requires_grad_(True),
-                              torch.randn(4, generator=g).to(device).requires_grad_(True))),
+                              torch.randn(4, generator=g).to(device).requires_grad_(True), 0.0, None)),
+        # training-mode dropout: the functional head takes the {seed, offset} pair that the (mutating) rng_take_ handed out
+        (E.cls_head.default, (torch.randn(b, n, h, generator=g).to(device).requires_grad_(True),
+                              torch.randn(4, h, generator=g).to(device).requires_grad_(True),
+                              torch.randn(4, generator=g).to(device).requires_grad_(True), 0.5,
+                              d(torch.tensor([1234567, 40], dtype=torch.int64)))),
+        (E.rng_take_.default, (d(torch.tensor([99, 0], dtype=torch.int64)), 12)),
+        (E.dropout_mask.default, (d(torch.tensor([99, 8], dtype=torch.int64)), 50, 0.25)),
         (E.bce_logits.default, (torch.randn(b, generator=g).to(device).requires_grad_(True), d(torch.tensor([1.0, 0.0, 1.0])))),
         (E.ce_logits.default, (torch.randn(b, 4, generator=g).to(device).requires_grad_(True), d(torch.tensor([1, 0, 3])))),
         (E.masked_loss.default, (torch.randn(b, 7, generator=g).to(device).requires_grad_(True), d(torch.randn(b, 7, generator=g)),
@@ -678,6 +685,15 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
         (E.clip_adam_.default, (d(torch.randn(64, generator=g)), d(torch.randn(64, generator=g)), d(torch.zeros(64)), d(torch.zeros(64)),
                                 1, 1e-3, 0.9, 0.999, 1e-8, 5e-4, 5.0, 1.0, d(torch.zeros(64)), d(torch.zeros(1)))),
     ]
+    # shapes where the fake implementations used to drift from the library: a 64-unit cell (quad packs bxq / bxtq exist from
+    # 64 units on) and a transposed batch-major input at a width the zero-copy row map does not cover (Fin = 8: the library
+    # keeps a time-major copy, eeg_dcrnn_batch_major_ok = 1)
+    rows64 = (100 + 64) * 3
+    samples.append((E.pack_cell.default, (d(0.1 * torch.randn(rows64, 128, generator=g)), d(torch.zeros(128)),
+                                          d(0.1 * torch.randn(rows64, 64, generator=g)), d(torch.zeros(64)), 100, 64, 3)))
+    x_bm = d(torch.randn(b, t_len, n, din, generator=g))
+    samples.append((E.dcgru_layer.default, (x_bm.transpose(0, 1).requires_grad_(True), 0, None, P, 1,
+                                            *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True)))
     for op, args in samples:
         res = torch.library.opcheck(op, args, test_utils=list(opcheck_utils), raise_exception=True)
         assert all(v == "SUCCESS" for v in res.values()), (str(op), res)
@@ -717,3 +733,150 @@ def check_batch_major_input(device, adj3d):
         assert torch.equal(res[0][0], res[1][0]), filt
         for a, b_, (nm, _) in zip(res[0][1], res[1][1], model.named_parameters()):
             assert torch.equal(a, b_), (filt, nm, (a - b_).abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------
+# training-mode dropout (model.py:191,267): masks generated inside the kernels (Philox4x32-10), recomputed in the backward
+def philox4x32_10_numpy(counters, seed):
+    """Philox4x32-10 (Salmon et al., SC'11) on an array of 64-bit counters under a 64-bit key: (n, 4) uint32 words.
+    Reference implementation for the tests (known answer: counter 0, key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8)."""
+    c = np.asarray(counters, dtype=np.uint64)
+    c0, c1 = (c & np.uint64(0xffffffff)), (c >> np.uint64(32))
+    c2, c3 = np.zeros_like(c0), np.zeros_like(c0)
+    k0, k1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    m32 = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0, n2 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m32, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m32
+        c1, c3 = p1 & m32, p0 & m32
+        c0, c2 = n0, n2
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack([c0, c1, c2, c3], axis=1).astype(np.uint32)
+
+
+def expected_mask(seed, offset, n, p):
+    """the documented function of (seed, offset): element e keeps iff word e%4 of counter offset + e/4 is >= p * 2^32"""
+    groups = (n + 3) // 4
+    words = philox4x32_10_numpy(np.uint64(offset) + np.arange(groups, dtype=np.uint64), int(seed)).reshape(-1)[:n]
+    thr = np.uint32(min(p * 4294967296.0, 4294967295.0))
+    return (words >= thr).astype(np.float32) / np.float32(1.0 - p)
+
+
+def check_dropout_generator(device):
+    """known-answer test of the generator + the rng_take_ / dropout_mask operators: the mask is the documented function of
+    (seed, offset), rng_take_ hands out consecutive counter ranges, keep rate within 3 sigma."""
+    from eeg_gnn_ssl_amd import ops
+    assert [f"{w:08x}" for w in philox4x32_10_numpy([0], 0)[0]] == ["6627e8d5", "e169c58d", "bc57ac4c", "9b00dbd8"]
+    torch.manual_seed(1234)
+    st = ops.make_rng_state(device)
+    seed = int(st[0].item())
+    assert int(st[1].item()) == 0
+    torch.manual_seed(1234)
+    assert int(ops.make_rng_state(device)[0].item()) == seed                  # torch.manual_seed governs the seed
+    n = 4 * 5000 + 4
+    u1 = ops.rng_take(st, n // 4)
+    u2 = ops.rng_take(st, 7)
+    assert u1.tolist() == [seed, 0] and u2.tolist() == [seed, n // 4] and st.tolist() == [seed, n // 4 + 7]
+    for p in (0.5, 0.3):
+        m = ops.dropout_mask(u2, n, p).cpu().numpy()
+        assert np.array_equal(m, expected_mask(seed, n // 4, n, p)), p
+        keep = float((m > 0).mean())
+        assert abs(keep - (1 - p)) <= 3 * np.sqrt(p * (1 - p) / n), (p, keep)
+    assert float(ops.dropout_mask(u2, 64, 1.0).abs().max()) == 0.0            # p = 1: everything dropped (like torch)
+    assert float((ops.dropout_mask(u2, 64, 0.0) - 1).abs().max()) == 0.0      # p = 0: identity
+
+
+def _dropout_args(cfg, p):
+    a = make_args(cfg)
+    a.dropout = p
+    return a
+
+
+def check_dropout_cls_case(tag, golden_dropout, adj3d, device):
+    """DCRNNModel_classification in train() mode with dropout 0.5 (README.md:83): the kernel draws its own mask; the mask the
+    kernel used is materialised from the generator pair (ops.dropout_mask) and handed to the oracle -> logits and every
+    gradient agree; in eval() mode the model is the p = 0 model; the GENUINE reference's training-mode logits (golden,
+    closed-form mask) are reproduced when the kernel's mask is replaced by that mask through the same operator."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, ops
+    c = cases.cls_inputs(tag, adj3d)
+    p_drop = cases.DROPOUT_P
+    model = DCRNNModel_classification(_dropout_args(c["cfg"], p_drop), c["classes"], device=device)
+    load(model, c["params"], device)
+    model.train()
+    sup = [t.to(device) for t in c["sup"]]
+    x, seq, y = c["x"].to(device), c["seq"].to(device), c["y"].to(device)
+    torch.manual_seed(7)
+    logits = model(x, seq, sup)
+    st = model._dropout_rng
+    b, n, h = x.shape[0], 19, c["cfg"].rnn_units
+    used = torch.tensor([int(st[0].item()), int(st[1].item()) - b * n * h // 4], dtype=torch.int64, device=device)
+    mask = ops.dropout_mask(used, b * n * h, p_drop).view(b, n, h)
+    keep = float((mask > 0).float().mean().item())
+    assert abs(keep - (1 - p_drop)) <= 3 * np.sqrt(p_drop * (1 - p_drop) / mask.numel()) + 1e-9, keep
+    assert float(mask.max().item()) == 1.0 / (1.0 - p_drop)
+    loss = (torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), y) if c["classes"] == 1
+            else torch.nn.functional.cross_entropy(logits, y))
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+    lo = orc.classification_forward(po, c["cfg"], c["x"], c["seq"], c["sup"], dropout_mask=mask.cpu())
+    lso = orc.bce_with_logits(lo, c["y"]) if c["classes"] == 1 else orc.cross_entropy(lo, c["y"])
+    lso.backward()
+    assert_close(logits.detach().cpu().numpy(), lo.detach().numpy(), f"dropout cls/{tag}/logits")
+    for k, q in model.named_parameters():
+        assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"dropout cls/{tag}/d_{k}")
+    # a second forward draws another mask (the device generator advanced), eval mode drops nothing
+    l2 = model(x, seq, sup)
+    assert int(model._dropout_rng[1].item()) == int(st[1].item()) and int(st[1].item()) == 2 * (b * n * h // 4)
+    assert float((l2 - logits).abs().max().item()) > 0
+    model.eval()
+    le = model(x, seq, sup)
+    le0 = orc.classification_forward(c["params"], c["cfg"], c["x"], c["seq"], c["sup"])
+    assert_close(le.detach().cpu().numpy(), le0.detach().numpy(), f"dropout cls/{tag}/eval logits")
+    assert int(model._dropout_rng[1].item()) == 2 * (b * n * h // 4)          # eval: the generator does not move
+
+
+def check_dropout_ssl_case(tag, adj3d, device, teacher=None):
+    """DCRNNModel_nextTimePred in train() mode with dropout 0.5 in front of the decoder's projection (model.py:191): a fresh
+    in-kernel mask per step; the masks the kernels used (materialised from the generator pair) go to the oracle -> predictions
+    and every gradient (incl. the shared decoder cell and dW_p, whose A operand is the dropped rows) agree."""
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred, ops
+    c = cases.ssl_inputs(tag, adj3d)
+    cfg = c["cfg"]
+    p_drop = cases.DROPOUT_P
+    model = DCRNNModel_nextTimePred(_dropout_args(cfg, p_drop), device=device)
+    load(model, c["params"], device)
+    model.train()
+    sup = [t.to(device) for t in c["sup"]]
+    x, y = c["x"].to(device), c["y"].to(device)
+    torch.manual_seed(11)
+    pred = model(x, y, sup, batches_seen=7)
+    st = model.decoder._dropout_rng
+    b, t_out, n, h = y.shape[0], y.shape[1], 19, cfg.rnn_units
+    groups = t_out * b * n * h // 4
+    assert int(st[1].item()) == groups
+    used = torch.tensor([int(st[0].item()), 0], dtype=torch.int64, device=device)
+    masks = ops.dropout_mask(used, 4 * groups, p_drop).view(t_out, b, n, h)
+    keep = float((masks > 0).float().mean().item())
+    assert abs(keep - (1 - p_drop)) <= 3 * np.sqrt(p_drop * (1 - p_drop) / masks.numel()) + 1e-9, keep
+    for t in range(1, t_out):
+        assert not torch.equal(masks[t], masks[0])                             # a fresh draw every step
+    from eeg_gnn_ssl_amd import utils
+    loss = utils.compute_regression_loss(y_true=y, y_predicted=pred, standard_scaler=utils.StandardScaler(cases.SSL_MEAN, cases.SSL_STD),
+                                         loss_fn="MAE")
+    loss.backward()
+    uniq, po = {}, {}
+    for k, v in c["params"].items():
+        if id(v) not in uniq:
+            uniq[id(v)] = v.clone().requires_grad_(True)
+        po[k] = uniq[id(v)]
+    pro = orc.next_time_pred_forward(po, cfg, c["x"], c["y"], c["sup"], dropout_masks=masks.cpu())
+    lso = orc.regression_loss(c["y"], pro, cases.SSL_MEAN, cases.SSL_STD, loss_fn="MAE")
+    lso.backward()
+    assert_close(pred.detach().cpu().numpy(), pro.detach().numpy(), f"dropout ssl/{tag}/pred")
+    assert abs(loss.item() - lso.item()) < 1e-5
+    for k, q in model.named_parameters():
+        assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"dropout ssl/{tag}/d_{k}")
+    model.eval()
+    pe = model(x, y, sup)
+    pe0 = orc.next_time_pred_forward(c["params"], cfg, c["x"], c["y"], c["sup"])
+    assert_close(pe.detach().cpu().numpy(), pe0.detach().numpy(), f"dropout ssl/{tag}/eval pred")

@@ -36,6 +36,20 @@ def test_ssl_model(tag, golden, adj3d):
     ps.check_ssl_case(tag, golden, adj3d, "cpu")
 
 
+def test_dropout_generator():
+    ps.check_dropout_generator("cpu")
+
+
+@pytest.mark.parametrize("tag", list(cases.DROPOUT_CLS_TAGS))
+def test_classification_model_training_dropout(tag, golden_dropout, adj3d):
+    ps.check_dropout_cls_case(tag, golden_dropout, adj3d, "cpu")
+
+
+@pytest.mark.parametrize("tag", list(cases.DROPOUT_SSL_TAGS))      # dual_default (64 units) runs the persistent decoder kernels
+def test_ssl_model_training_dropout(tag, adj3d):
+    ps.check_dropout_ssl_case(tag, adj3d, "cpu")
+
+
 def test_random_vs_oracle_h32_relu_varlen(adj3d):
     ps.check_vs_oracle_random("cpu", "dual_random_walk", 12, 32, 2, 4, 3, 4, adj3d, seed=3, lengths=[4, 2, 1], act="relu")
 

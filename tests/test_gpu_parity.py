@@ -242,6 +242,161 @@ def test_ssl_full_size_gradients_vs_oracle():
         assert err < 1e-4, f"{k}: {err:.2e}"
 
 
+def test_ssl_full_size_three_layers_vs_oracle():
+    """The reference's own SSL recipe (/root/reference/README.md:91: `--num_rnn_layers 3`, the shape of its shipped checkpoints) at
+    cfg5's FULL per-GPU size (B=512, 60-s encoder, 12-s decoder, correlation-graph supports): decoder layers 1 and 2 are ONE
+    cell object (model.py:126-143) whose gradient receives both contributions -- predictions, loss, every gradient."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred, utils
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS["cfg5"]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=8)
+    torch.manual_seed(12)
+    model = DCRNNModel_nextTimePred(bench.make_args(filt, layers=3), device=DEV).to(DEV).train()
+    assert model.decoder.decoding_cells[1] is model.decoder.decoding_cells[2]
+    pred = model(x.to(DEV), y.to(DEV), [s.to(DEV) for s in sup])
+    loss = utils.compute_regression_loss(y_true=y.to(DEV), y_predicted=pred, standard_scaler=None, loss_fn="MAE")
+    loss.backward()
+    cfg = orc.DCRNNConfig(filter_type=filt, num_rnn_layers=3)
+    uniq, po = {}, {}
+    for k, v in model.state_dict().items():                 # decoding_cells.2.* alias decoding_cells.1.*: one leaf
+        key = v.data_ptr()
+        if key not in uniq:
+            uniq[key] = v.detach().cpu().clone().requires_grad_(True)
+        po[k] = uniq[key]
+    assert po["decoder.decoding_cells.2.dconv_gate.weight"] is po["decoder.decoding_cells.1.dconv_gate.weight"]
+    torch.set_num_threads(16)
+    pr = orc.next_time_pred_forward(po, cfg, x, y, sup)
+    lo = orc.regression_loss(y, pr, loss_fn="MAE")
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    assert (pred.detach().cpu() - pr.detach()).abs().max().item() < 1e-4
+    for k, p in model.named_parameters():
+        ref = po[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 1e-4, f"{k}: {err:.2e}"
+
+
+def test_dropout_generator():
+    ps.check_dropout_generator(DEV)
+
+
+@pytest.mark.parametrize("tag", list(cases.DROPOUT_CLS_TAGS))
+def test_classification_model_training_dropout(tag, golden_dropout, adj3d):
+    ps.check_dropout_cls_case(tag, golden_dropout, adj3d, DEV)
+
+
+@pytest.mark.parametrize("tag", list(cases.DROPOUT_SSL_TAGS))
+def test_ssl_model_training_dropout(tag, adj3d):
+    ps.check_dropout_ssl_case(tag, adj3d, DEV)
+
+
+def test_full_size_gradients_vs_oracle_with_dropout(adj3d):
+    """BASELINE cfg4 at FULL per-GPU size trained the way the reference trains it (/root/reference/README.md:83:
+    `--task classification --num_classes 4 --dropout 0.5`): train() mode, the head's dropout mask generated inside
+    cls_head_fwd; the mask the kernel used goes to the oracle -> every logit and every parameter gradient within 1e-4."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, ops
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS["cfg4"]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=78)
+    args = bench.make_args(filt)
+    args.dropout = 0.5
+    torch.manual_seed(21)
+    model = DCRNNModel_classification(args, classes, device=DEV).to(DEV).train()
+    lg = model(x.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup])
+    ops.cross_entropy(lg, y.to(DEV)).backward()
+    st = model._dropout_rng
+    n_el = batch * 19 * 64
+    assert int(st[1].item()) == n_el // 4
+    mask = ops.dropout_mask(torch.tensor([int(st[0].item()), 0], dtype=torch.int64, device=DEV), n_el, 0.5).view(batch, 19, 64)
+    keep = float((mask > 0).float().mean().item())
+    assert abs(keep - 0.5) <= 3 * (0.25 / n_el) ** 0.5, keep
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
+    po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    torch.set_num_threads(16)
+    lo = orc.classification_forward(po, cfg, x, lengths, sup, dropout_mask=mask.cpu())
+    orc.cross_entropy(lo, y).backward()
+    assert (lg.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    for k, p in model.named_parameters():
+        ref = po[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 1e-4, f"{k}: {err:.2e}"
+
+
+def test_ssl_full_size_gradients_vs_oracle_with_dropout():
+    """BASELINE cfg5 at FULL per-GPU size (B=512) in train() mode with dropout 0.5 in front of the decoder's projection
+    (/root/reference/model/model.py:191): the 12 per-step masks are generated inside dec_fwd_persist_kernel and recomputed inside
+    dec_bwd_persist_kernel; materialised from the generator pair they go to the oracle -> predictions, loss, all gradients."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred, ops, utils
+    from oracle import dcrnn_oracle as orc
+    task, filt, t_len, batch, classes = bench.WORKLOADS["cfg5"]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=6)
+    args = bench.make_args(filt)
+    args.dropout = 0.5
+    torch.manual_seed(10)
+    model = DCRNNModel_nextTimePred(args, device=DEV).to(DEV).train()
+    pred = model(x.to(DEV), y.to(DEV), [s.to(DEV) for s in sup])
+    loss = utils.compute_regression_loss(y_true=y.to(DEV), y_predicted=pred, standard_scaler=None, loss_fn="MAE")
+    loss.backward()
+    st = model.decoder._dropout_rng
+    n_el = bench.T_OUT * batch * 19 * 64
+    assert int(st[1].item()) == n_el // 4
+    masks = ops.dropout_mask(torch.tensor([int(st[0].item()), 0], dtype=torch.int64, device=DEV), n_el, 0.5).view(bench.T_OUT, batch, 19, 64)
+    cfg = orc.DCRNNConfig(filter_type=filt)
+    uniq, po = {}, {}
+    for k, v in model.state_dict().items():
+        key = v.data_ptr()
+        if key not in uniq:
+            uniq[key] = v.detach().cpu().clone().requires_grad_(True)
+        po[k] = uniq[key]
+    torch.set_num_threads(16)
+    pr = orc.next_time_pred_forward(po, cfg, x, y, sup, dropout_masks=masks.cpu())
+    lo = orc.regression_loss(y, pr, loss_fn="MAE")
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5
+    assert (pred.detach().cpu() - pr.detach()).abs().max().item() < 1e-4
+    for k, p in model.named_parameters():
+        ref = po[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 1e-4, f"{k}: {err:.2e}"
+
+
+def test_dropout_draws_a_fresh_mask_on_every_graph_replay():
+    """The generator state lives on the device and is advanced by a node of the captured graph (rng_take): replay k of the HIP
+    graph uses counter range k -- same parameters, bit for bit, as eagerly launched steps that start from the same state."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, classes = "classification", "laplacian", 4
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, 9, 6, classes, seed=3)
+    xd, yd, ld, supd = x.to(DEV), y.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup]
+    args = bench.make_args(filt)
+    args.dropout = 0.5
+    finals, losses, offsets = [], [], []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        model = DCRNNModel_classification(args, classes, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3)
+        model._rng_state(torch.device(DEV))                 # (created at first use otherwise)
+        seed0 = torch.tensor([4242, 0], dtype=torch.int64, device=DEV)
+        if graphed:
+            st.capture(xd, yd, ld, supd)                    # warm-up launches and the upload replay draw masks too
+        model._dropout_rng.copy_(seed0)
+        ls = []
+        for _ in range(4):
+            ls.append(float((st.replay_step() if graphed else st.step(xd, yd, ld, supd)).item()))
+        torch.cuda.synchronize()
+        finals.append(st.fp.flat.detach().clone())
+        losses.append(ls)
+        offsets.append(int(model._dropout_rng[1].item()))
+    assert offsets[0] == offsets[1] == 4 * (6 * 19 * 64 // 4)
+    assert len(set(losses[1])) == 4                         # four different masks
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_full_size_hidden_sequence_vs_oracle(adj3d):
     """cfg2 shape: the top-layer hidden sequence (all 60 steps) of the first clips vs the oracle."""
     import bench

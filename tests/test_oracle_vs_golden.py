@@ -140,6 +140,52 @@ def test_ssl_model(tag, golden, adj3d):
         close_view(pred.detach().numpy(), ref_pred, step=7)
 
 
+@pytest.mark.parametrize("tag", list(cases.DROPOUT_CLS_TAGS))
+def test_classification_model_training_dropout(tag, golden_dropout, adj3d):
+    """model.py:267 in train() mode with p = 0.5 (README.md:83's recipe): the genuine reference was run with its nn.Dropout
+    swapped for a closed-form mask (make_golden_dropout.py); the oracle with the same mask must give its logits / gradients."""
+    c = cases.cls_inputs(tag, adj3d)
+    p = {k: v.clone().requires_grad_(True) for k, v in c["params"].items()}
+    logits = orc.classification_forward(p, c["cfg"], c["x"], c["seq"], c["sup"], dropout_mask=cases.dropout_cls_mask(tag))
+    close(logits.detach().numpy(), golden_dropout[f"cls/{tag}/logits"])
+    loss = orc.bce_with_logits(logits, c["y"]) if c["classes"] == 1 else orc.cross_entropy(logits, c["y"])
+    loss.backward()
+    assert abs(loss.item() - float(golden_dropout[f"cls/{tag}/loss"])) < 2e-6
+    for k, v in p.items():
+        ref = golden_dropout[f"cls/{tag}/d_{k}"]
+        if c["full"]:
+            close(v.grad.numpy(), ref, atol=5e-6)
+        else:
+            close_view(v.grad.numpy(), ref)
+
+
+@pytest.mark.parametrize("tag", list(cases.DROPOUT_SSL_TAGS))
+def test_ssl_model_training_dropout(tag, golden_dropout, adj3d):
+    """model.py:191 in train() mode with p = 0.5: a fresh mask in front of the projection at every decoder step."""
+    c = cases.ssl_inputs(tag, adj3d)
+    uniq, p = {}, {}
+    for k, v in c["params"].items():
+        if id(v) not in uniq:
+            uniq[id(v)] = v.clone().requires_grad_(True)
+        p[k] = uniq[id(v)]
+    pred = orc.next_time_pred_forward(p, c["cfg"], c["x"], c["y"], c["sup"], dropout_masks=cases.dropout_ssl_masks(tag))
+    loss = orc.regression_loss(c["y"], pred, cases.SSL_MEAN, cases.SSL_STD, loss_fn="MAE")
+    loss.backward()
+    assert abs(loss.item() - float(golden_dropout[f"ssl/{tag}/loss"])) < 5e-6
+    ref_pred = golden_dropout[f"ssl/{tag}/pred"]
+    if ref_pred.ndim == 4:
+        close(pred.detach().numpy(), ref_pred)
+    else:
+        close_view(pred.detach().numpy(), ref_pred, step=7)
+    for k in (kk for kk in golden_dropout.files if kk.startswith(f"ssl/{tag}/d_")):
+        name = k[len(f"ssl/{tag}/d_"):]
+        ref = golden_dropout[k]
+        if c["full"]:
+            close(p[name].grad.numpy(), ref, atol=5e-6)
+        else:
+            close_view(p[name].grad.numpy(), ref)
+
+
 def test_training_trajectory_matches_reference(golden_train, adj3d):
     """20 optimiser steps of the reference recipe (Adam + L2, clip_grad_norm_, BCE) on the closed-form
     task: the oracle follows the genuine reference's loss / gradient-norm trajectory."""

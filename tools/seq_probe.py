@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid (GPU box): per-phase shader-clock cycles of the recurrent kernels at cfg2 size.
-usage: python tools/seq_probe.py [workload]"""
+usage: python tools/seq_probe.py [workload] [dev-library path]"""
 import ctypes
 import os
 import sys
@@ -18,7 +18,7 @@ dev = torch.device("cuda", 0)
 x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123)
 model = DCRNNModel_classification(bench.make_args(filt), classes, device=dev).to(dev).train()
 x, y, lengths, sup = x.to(dev), y.to(dev), lengths.to(dev), [s.to(dev) for s in sup]
-_lib._LIB = _lib.EegDcrnnLib(_lib.DEV_LIB_PATH)   # cycle probe: dev build only
+_lib._LIB = _lib.EegDcrnnLib(os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else _lib.DEV_LIB_PATH, strict=False)   # cycle probe: dev build only
 lib = _lib.get_lib()
 
 
