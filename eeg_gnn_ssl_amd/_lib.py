@@ -38,6 +38,7 @@ _SIGNATURES = {
     "eeg_dcrnn_abi_version": (c_int, []),
     "eeg_dcrnn_is_device_build": (c_int, []),
     "eeg_dcrnn_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "eeg_dcrnn_zero": (c_int, [_FP, c_size_t, c_void_p]),
     "eeg_dcrnn_prof_enable": (c_int, [c_int]),
     "eeg_dcrnn_prof_report": (c_int, [ctypes.c_char_p, c_size_t]),
     "eeg_dcrnn_prof_clock_probe": (c_int, [_FP, c_void_p]),

@@ -555,6 +555,11 @@ int eeg_dcrnn_prof_clock_probe(int64_t* out2, void* stream) {
     return check_launch("clock_probe");
 }
 int eeg_dcrnn_supported(int N, int H, int Fin, int M) { return check_dims(N, H, Fin, M) == 0 ? 1 : 0; }
+int eeg_dcrnn_zero(void* p, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    if (p == nullptr) return fail("zero: null pointer");
+    return hipMemsetAsync(p, 0, bytes, S_(stream)) == hipSuccess ? 0 : fail("zero: memset failed");
+}
 
 int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K, float* P_out,
                         void* stream) {

@@ -310,6 +310,11 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int oxw[CT][2], oh[CT][2];              // 32-bit element offsets inside one time step
+    // REM4: the remainder nodes 16..19 are handled one element per lane (mfma_nodes32 L1): lane (lr, lg) <-> node 16 + lg,
+    // column ct*16 + lr; oxw[.][1] / oh[.][1] / l1[.] are then that element's offsets
+    const int node1 = 16 + lg;
+    const bool valid1 = node1 < N;
+    int l1[CT];
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
@@ -317,6 +322,11 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
             const int ct = wave + 4 * i < NCT ? wave + 4 * i : 0;
             oxw[i][nt] = nodec[nt] * (3 * H) + ct * 16 + 4 * lg;
             oh[i][nt] = nodec[nt] * H + ct * 16 + 4 * lg;
+            if (REM4 && nt == 1) {
+                oxw[i][1] = (valid1 ? node1 : N - 1) * (3 * H) + ct * 16 + lr;
+                oh[i][1] = (valid1 ? node1 : N - 1) * H + ct * 16 + lr;
+                l1[i] = lds_sw(node1, ct * 16 + lr, KAP);
+            }
         }
 
     // hop-diffuse this wave's own column tiles of buf; planes != nullptr: the hop rows of step t also go to
@@ -341,6 +351,12 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                if (REM4 && nt == 1) {             // one element per lane: component 0
+                    nxr[i][1] = (f32x4){wbuf_ld(bx, oxw[i][1], 0u), 0.f, 0.f, 0.f};
+                    nxu[i][1] = (f32x4){wbuf_ld(bx, oxw[i][1] + H, 0u), 0.f, 0.f, 0.f};
+                    nxc[i][1] = (f32x4){wbuf_ld(bx, oxw[i][1] + 2 * H, 0u), 0.f, 0.f, 0.f};
+                    continue;
+                }
                 nxr[i][nt] = wbuf_ld4(bx, oxw[i][nt], 0u);
                 nxu[i][nt] = wbuf_ld4(bx, oxw[i][nt] + H, 0u);
                 nxc[i][nt] = wbuf_ld4(bx, oxw[i][nt] + 2 * H, 0u);
@@ -351,19 +367,18 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         const size_t s = (size_t)t * B + b;
         f32x4 ag[2 * CT][2], ac[CT][2], ug[CT][2];
         // the accumulators start from the hoisted pre-activations (no zero fill, no add behind the GEMM); with the 4x4x1
-        // remainder the second tile's accumulator is read on lanes lr < 4 only
+        // remainder the second tile's accumulator is one value per lane (component 0)
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const bool keep = !(REM4 && nt == 1) || lr < 4;
-                ag[i][nt] = keep ? nxr[i][nt] : zero4; ag[CT + i][nt] = keep ? nxu[i][nt] : zero4; ac[i][nt] = keep ? nxc[i][nt] : zero4;
+                ag[i][nt] = nxr[i][nt]; ag[CT + i][nt] = nxu[i][nt]; ac[i][nt] = nxc[i][nt];
             }
         EEG_LDS_BARRIER();                                            // (1) hops(h) complete
         pp.mark(0);
 
         // gate GEMM: (2H cols) x (32 nodes), K = M*H
-        mfma_nodes32<2 * CT, KS, REM4>(A, KAP, lane, lr, lg, wg, ag, RS);
+        mfma_nodes32<2 * CT, KS, REM4, 0, 0, false, false, REM4>(A, KAP, lane, lr, lg, wg, ag, RS);
         pp.mark(1);
         const wbuf_t bR = make_wbuf((save ? Rs : Hseq) + s * N * H), bRH = make_wbuf((save ? RHs : Hseq) + s * N * H),
                      bU = make_wbuf((save ? Us : Hseq) + s * N * H);
@@ -374,6 +389,18 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                 const int col = ct * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
+                    if (REM4 && nt == 1) {                           // node 16 + lg, column ct*16 + lr
+                        const float rg1 = sigmoidf_(ag[i][1][0]), u1 = sigmoidf_(ag[CT + i][1][0]);
+                        ug[i][1] = (f32x4){u1, 0.f, 0.f, 0.f};
+                        const float rh1 = valid1 ? rg1 * A[l1[i]] : 0.f;
+                        A2[l1[i]] = rh1;
+                        if (save && valid1) {
+                            wbuf_st1(bR, oh[i][1], 0u, rg1);
+                            wbuf_st1(bRH, oh[i][1], 0u, rh1);
+                            wbuf_st1(bU, oh[i][1], 0u, u1);
+                        }
+                        continue;
+                    }
                     const f32x4 rg = sigmoid4_(ag[i][nt]), u = sigmoid4_(ag[CT + i][nt]);
                     ug[i][nt] = u;
                     f32x4 rh = rg * ld4(A + lds_sw(node[nt], col, KAP));
@@ -395,7 +422,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         if (t + 1 < T) fetch_xw(t + 1);
 
         // candidate GEMM: (H cols) x (32 nodes), K = M*H
-        mfma_nodes32<CT, KS, REM4>(A2, KAP, lane, lr, lg, wc, ac, RS);
+        mfma_nodes32<CT, KS, REM4, 0, 0, false, false, REM4>(A2, KAP, lane, lr, lg, wc, ac, RS);
         pp.mark(4);
         const wbuf_t bH = make_wbuf(Hseq + s * N * H), bC = make_wbuf((save ? Cs : Hseq) + s * N * H);
 #pragma unroll
@@ -405,6 +432,17 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
                 const int col = ct * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
+                    if (REM4 && nt == 1) {
+                        const float u1 = ug[i][1][0], h1 = A[l1[i]];
+                        const float c1 = act == 0 ? tanhf_(ac[i][1][0]) : fmaxf(ac[i][1][0], 0.f);
+                        const float hn1 = valid1 ? u1 * h1 + (1.f - u1) * c1 : 0.f;
+                        A[l1[i]] = hn1;
+                        if (valid1) {
+                            wbuf_st1(bH, oh[i][1], 0u, hn1);
+                            if (save) wbuf_st1(bC, oh[i][1], 0u, c1);
+                        }
+                        continue;
+                    }
                     const f32x4 u = ug[i][nt], h = ld4(A + lds_sw(node[nt], col, KAP));
                     const f32x4 c = act == 0 ? tanh4_(ac[i][nt]) : relu4_(ac[i][nt]);
                     f32x4 hn = u * h + (1.f - u) * c;
@@ -519,6 +557,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1) hops(h) complete
             pp.mark(0);
+
             mfma_nodes32<1, KS, true, 0, 0, false, false, true>(A, KAP, lane, lr, lg, w0, ar, RS);
             pp.mark(1);
             {
@@ -662,6 +701,12 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int oh[CT][2], oxw[CT][2];              // 32-bit element offsets inside one time step
     bool own[CT];
+    // REM4: the remainder nodes 16..19 are handled one element per lane (mfma_nodes32 L1): lane (lr, lg) <-> node 16 + lg,
+    // column ct*16 + lr -- oh[.][1] / oxw[.][1] are then that element's offsets and every nt = 1 quantity below lives in
+    // component 0 of its vector
+    const int node1 = 16 + lg;
+    const bool valid1 = node1 < N;
+    int lc1[CT], lg1[CT], lu1[CT];          // LDS offsets of the element in the dC / dR / dU slots
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
         own[i] = wave + 4 * i < NCT;
@@ -671,14 +716,23 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             oh[i][nt] = nodec[nt] * H + ct * 16 + 4 * lg;
             oxw[i][nt] = node[nt] * (3 * H) + ct * 16 + 4 * lg;
         }
+        if (REM4) {
+            oh[i][1] = (valid1 ? node1 : N - 1) * H + ct * 16 + lr;
+            oxw[i][1] = node1 * (3 * H) + ct * 16 + lr;
+            lc1[i] = lds_sw(node1, ct * 16 + lr, KAP);
+            lg1[i] = lds_sw(node1, ct * 16 + lr, KGP);
+            lu1[i] = lds_sw(node1, H + ct * 16 + lr, KGP);
+        }
     }
 
     f32x4 dh[CT][2], sb_r[CT], sb_u[CT], sb_c[CT];
+    float sb1_r[CT], sb1_u[CT], sb1_c[CT];  // REM4: bias sums of the remainder element
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
         dh[i][0] = zero4;
         dh[i][1] = zero4;
         sb_r[i] = sb_u[i] = sb_c[i] = zero4;
+        sb1_r[i] = sb1_u[i] = sb1_c[i] = 0.f;
     }
 
     const size_t tstride = (size_t)B * N * H;
@@ -694,6 +748,17 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int o = oh[i][nt];
+                if (REM4 && nt == 1) {
+                    nh[i][1] = (f32x4){hs != nullptr ? hs[o] : 0.f, 0.f, 0.f, 0.f};
+                    nr[i][1] = (f32x4){Rs[so + o], 0.f, 0.f, 0.f};
+                    nu[i][1] = (f32x4){Us[so + o], 0.f, 0.f, 0.f};
+                    nc[i][1] = (f32x4){Cs[so + o], 0.f, 0.f, 0.f};
+                    float g1 = dHseq != nullptr ? dHseq[so + o] : 0.f;
+                    if (d_at_end != nullptr && t == T - 1) g1 += d_at_end[boff + o];
+                    if (t == t_len) g1 += d_at_len[boff + o];
+                    ng[i][1] = (f32x4){g1, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 nh[i][nt] = hs != nullptr ? ld4(hs + o) : zero4;
                 nr[i][nt] = ld4(Rs + so + o);
                 nu[i][nt] = ld4(Us + so + o);
@@ -722,6 +787,24 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             const int col = (own[i] ? wave + 4 * i : 0) * 16 + 4 * lg;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                if (REM4 && nt == 1) {                               // node 16 + lg, column ct*16 + lr
+                    const bool ok1 = valid1 && own[i];
+                    const float h1 = hp[i][1][0], u1 = uu[i][1][0], c1 = cc[i][1][0];
+                    const float g1 = ok1 ? dh[i][1][0] + gg[i][1][0] : 0.f;
+                    const float dc1 = g1 * (1.f - u1);
+                    const float dC1 = act == 0 ? dc1 * (1.f - c1 * c1) : (c1 > 0.f ? dc1 : 0.f);
+                    const float du1 = g1 * (h1 - c1) * u1 * (1.f - u1);
+                    if (own[i]) EC[lc1[i]] = dC1;                    // zeros on padding nodes
+                    if (ok1) {
+                        dxw[oxw[i][1] + 2 * H] = dC1;
+                        dxw[oxw[i][1] + H] = du1;
+                    }
+                    sb1_c[i] += dC1;
+                    sb1_u[i] += du1;
+                    dU[i][1] = (f32x4){du1, 0.f, 0.f, 0.f};
+                    dhn[i][1] = (f32x4){g1 * u1, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 const bool ok = valid[nt] && own[i];
                 const f32x4 h = hp[i][nt], u = uu[i][nt], c = cc[i][nt];
                 const f32x4 g = ok ? dh[i][nt] + gg[i][nt] : zero4;
@@ -759,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             acc[i][0] = zero4;
             acc[i][1] = zero4;
         }
-        mfma_nodes32<CT, KS, REM4>(EC, KAP, lane, lr, lg, w1, acc, RS);
+        mfma_nodes32<CT, KS, REM4, 0, 0, false, false, REM4>(EC, KAP, lane, lr, lg, w1, acc, RS);
         pp.mark(2);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -767,6 +850,16 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
                 const int col = (wave + 4 * i) * 16 + 4 * lg;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
+                    if (REM4 && nt == 1) {
+                        const float drh1 = acc[i][1][0], rg1 = rr[i][1][0];       // exact 0 on padding nodes
+                        const float dR1 = drh1 * hp[i][1][0] * rg1 * (1.f - rg1);
+                        dhn[i][1][0] += drh1 * rg1;
+                        EG[lg1[i]] = dR1;
+                        EG[lu1[i]] = dU[i][1][0];
+                        if (valid1) dxw[oxw[i][1]] = dR1;
+                        sb1_r[i] += dR1;
+                        continue;
+                    }
                     const f32x4 drh = acc[i][nt], rg = rr[i][nt];    // exact 0 on padding nodes
                     const f32x4 dR = drh * hp[i][nt] * rg * (1.f - rg);
                     dhn[i][nt] += drh * rg;
@@ -791,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
-        mfma_nodes32<CT, KSG, REM4>(EG, KGP, lane, lr, lg, w2, dhn, RS);
+        mfma_nodes32<CT, KSG, REM4, 0, 0, false, false, REM4>(EG, KGP, lane, lr, lg, w2, dhn, RS);
         pp.mark(5);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -802,21 +895,31 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 
     // ---- epilogue: dh0 and the per-clip bias-gradient partial sums (fixed-order node reduction)
     __syncthreads();                                                // all waves done with EG
-    float* red = EG;                                                // [3H][16]
+    float* red = EG;                                                // [3H][16] (+ REM4: [3H][4] partials of the remainder elements)
+    float* red1 = EG + 3 * H * 16;
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
         if (own[i]) {
             const int col = (wave + 4 * i) * 16 + 4 * lg;
             if (dh0 != nullptr) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    if (valid[nt]) st4(dh0 + boff + node[nt] * H + col, dh[i][nt]);
+                if (valid[0]) st4(dh0 + boff + node[0] * H + col, dh[i][0]);
+                if (REM4) {
+                    if (valid1) dh0[boff + node1 * H + (wave + 4 * i) * 16 + lr] = dh[i][1][0];
+                } else if (valid[1]) {
+                    st4(dh0 + boff + node[1] * H + col, dh[i][1]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 red[(0 * H + col + r) * 16 + lr] = sb_r[i][r];
                 red[(1 * H + col + r) * 16 + lr] = sb_u[i][r];
                 red[(2 * H + col + r) * 16 + lr] = sb_c[i][r];
+            }
+            if (REM4) {
+                const int c1 = (wave + 4 * i) * 16 + lr;
+                red1[(0 * H + c1) * 4 + lg] = sb1_r[i];
+                red1[(1 * H + c1) * 4 + lg] = sb1_u[i];
+                red1[(2 * H + c1) * 4 + lg] = sb1_c[i];
             }
         }
     }
@@ -825,6 +928,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         float sacc = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
+        if (REM4) sacc += (red1[j * 4] + red1[j * 4 + 1]) + (red1[j * 4 + 2] + red1[j * 4 + 3]);
         dbias_part[(size_t)b * 3 * H + j] = sacc;
     }
     }   // clips of this workgroup

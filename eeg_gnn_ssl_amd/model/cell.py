@@ -93,13 +93,13 @@ class DCGRUCell(nn.Module):
             raise RuntimeError(f"filter_type={self._filter_type!r} expects {self._num_supports} support(s), "
                                f"got {len(supports)}")
 
-    def run_sequence(self, x, h0, p, p_batched, lengths=None, x_off=0, x_planes=None):
+    def run_sequence(self, x, h0, p, p_batched, lengths=None, x_off=0, x_planes=None, want_hsel=True):
         """x (T + x_off, B, N, Din) -> ops.LayerOut (hext (T+1,B,N*H), hsel (B,N*H), hpl); used by the encoder /
         decoder loops.  x_off = 1 with x_planes: x is the `hext` of the layer below and x_planes its `hpl`."""
         return ops.dcgru_layer_ex(x, x_off, h0, p, p_batched, self.dconv_gate.weight, self.dconv_gate.biases,
                                   self.dconv_candidate.weight, self.dconv_candidate.biases,
                                   self._num_nodes, self._num_units, self.num_matrices,
-                                  self._activation_name, lengths, x_planes)
+                                  self._activation_name, lengths, x_planes, want_hsel)
 
     def forward(self, supports, inputs, state):
         self._check_supports(supports)

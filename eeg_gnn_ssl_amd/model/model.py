@@ -67,12 +67,14 @@ class DCRNNEncoder(nn.Module):
             h0 = None if initial_hidden_state is None else initial_hidden_state[layer]
             is_top = layer == self.num_rnn_layers - 1
             # layers >= 1 read the `hext` of the layer below (slots 1..T) and take its hop planes as their own
-            out = cell.run_sequence(cur, h0, p, p_batched, lengths if is_top else None, x_off, planes)
+            # (a layer's final state is only copied out when somebody reads it: `finals`, or the top state at len-1)
+            out = cell.run_sequence(cur, h0, p, p_batched, lengths if is_top else None, x_off, planes,
+                                    want_hsel=want_finals or (is_top and lengths is not None))
             if is_top and lengths is not None:
                 top_sel = out.hsel
                 finals.append(out.hext[t_len] if want_finals else None)
             else:
-                finals.append(out.hsel)
+                finals.append(out.hsel if want_finals else None)
             cur, x_off, planes = out.hext.view(t_len + 1, b, self.num_nodes, self.hid_dim), 1, out.hpl
         return (torch.stack(finals, dim=0) if want_finals else None), out.hseq, top_sel
 

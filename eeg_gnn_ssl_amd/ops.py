@@ -69,6 +69,24 @@ def _define(name: str, schema: str, impl, fake):
     torch.library.register_fake(f"{NS}::{name}", fake, lib=_libdef)
 
 
+def _zero_impl(t) -> None:
+    """t <- 0 as ONE memset on the stream (no framework fill kernel in the captured step)"""
+    lib = _lib.get_lib()
+    if not t.is_contiguous():
+        raise RuntimeError("zero_: tensor must be contiguous")
+    if lib.is_device_build and not t.is_cuda:
+        raise RuntimeError("zero_: eeg_gnn_ssl_amd runs only on an MI355X (HIP) device and has no CPU path")
+    lib.call("eeg_dcrnn_zero", _p(t), t.numel() * t.element_size(), _stream(t))
+
+
+_define("zero_", "(Tensor(a!) t) -> ()", _zero_impl, lambda t: None)
+
+
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    torch.ops.eeg_dcrnn.zero_(t)
+    return t
+
+
 def num_matrices(filter_type: str, max_diffusion_step: int) -> int:
     """cell.py:35,151-158."""
     return (2 if filter_type == "dual_random_walk" else 1) * max_diffusion_step + 1
@@ -254,7 +272,7 @@ def _layer_dims(t_len, b, n, h, fin, m, act, p_batched, planes_ready):
 
 
 def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, lengths, x_planes, n: int, h: int, m: int,
-                      act: int, save: bool):
+                      act: int, save: bool, want_hsel: bool):
     """x: (T + x_off, B, N, Fin) — x_off = 1 when x is the `hext` of the layer below (its slot 0 is that layer's
     initial state), whose `hpl` output is then passed as x_planes.  Returns hext (T+1, B, N*H) (slot 0 = initial
     state, slot t+1 = h_t), hsel (B, N*H) = h at t = lengths-1 (T-1 without lengths) and the tensors the backward
@@ -314,17 +332,19 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
         lengths = lengths.to(device=x.device, dtype=torch.int64).contiguous()
         hsel = _new((b, n * h), x)
         lib.call("eeg_dcrnn_gather_last", _p(hext[1:]), _p(lengths), t_len, b, n * h, _p(hsel), _stream(x))
-    else:
+    elif want_hsel:
         hsel = hext[t_len].clone()
+    else:
+        hsel = _new((0,), x)           # nobody reads the final state of this layer (a lower layer of the classification model)
     if not save:
         return hext, hsel, []
     return hext, hsel, [xtm if xtm is not None else empty, pack, planes, rs, us, cs, rhs, hpl, rhpl]
 
 
-def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save):
+def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel):
     t_len, b, fin = x.shape[0] - x_off, x.shape[1], x.shape[3]
     ne = lambda *shape: x.new_empty(shape)   # noqa: E731
-    hext, hsel = ne(t_len + 1, b, n * h), ne(b, n * h)
+    hext, hsel = ne(t_len + 1, b, n * h), (ne(b, n * h) if (want_hsel or lengths is not None) else ne(0))
     if not save:
         return hext, hsel, []
     # a non-contiguous x is copied time-major (kept for the backward) -- except the transposed view of a contiguous batch-major
@@ -370,7 +390,7 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
         # x is the `hext` of the layer below: its slot 0 is that layer's INITIAL state, which this layer never reads.  The
         # kernels fill slots x_off.. only; the gradient of slot 0 is exactly zero (and must be a defined value: it flows
         # through autograd accumulation, hooks and anomaly detection)
-        dx[:x_off].zero_()
+        lib.call("eeg_dcrnn_zero", _p(dx), 4 * x_off * b * n * fin, _stream(dx))
     dx_ptr = ctypes.c_void_p(dx.data_ptr() + 4 * x_off * b * n * fin) if need_dx else None
     dh0 = _new((b, n * h), hext) if (need_dh0 and has_h0) else _new((0,), hext)
     ws = _new((lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),), hext)
@@ -389,7 +409,7 @@ def _dcgru_layer_bwd_fake(d_hext, d_hsel, x, x_off, p, p_batched, pack, planes, 
 
 _define("dcgru_layer",
         "(Tensor x, int x_off, Tensor? h0, Tensor P, int p_batched, Tensor wg, Tensor bg, Tensor wc, Tensor bc, Tensor? lengths, "
-        "Tensor? x_planes, int n, int h, int m, int act, bool save) -> (Tensor hext, Tensor hsel, Tensor[] saved)",
+        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel) -> (Tensor hext, Tensor hsel, Tensor[] saved)",
         _dcgru_layer_impl, _dcgru_layer_fake)
 _define("dcgru_layer_bwd",
         "(Tensor? d_hext, Tensor? d_hsel, Tensor x, int x_off, Tensor P, int p_batched, Tensor pack, Tensor planes, Tensor? x_planes, "
@@ -399,7 +419,7 @@ _define("dcgru_layer_bwd",
 
 
 def _dcgru_layer_setup(ctx, inputs, output):
-    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save) = inputs
+    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel) = inputs
     hext, _, saved = output
     ctx.set_materialize_grads(False)
     ctx.saved_ok = bool(save) and len(saved) == 9
@@ -425,7 +445,7 @@ def _dcgru_layer_backward(ctx, d_hext, d_hsel, d_saved):
     dx, dh0 = torch.ops.eeg_dcrnn.dcgru_layer_bwd(d_hext, d_hsel, xk, x_off, p, p_batched, pack, planes, x_planes, hext,
                                                   rs, us, cs, rhs, hpl, rhpl, lens, has_h0, n, h, m, act, need_dx, need_dh0, *bufs)
     ret = [None if t is not None else g for t, g in zip(sunk, bufs)]
-    return (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None)
+    return (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None, None)
 
 
 torch.library.register_autograd(f"{NS}::dcgru_layer", _dcgru_layer_backward, setup_context=_dcgru_layer_setup, lib=_libdef)
@@ -869,16 +889,18 @@ class LayerOut:
         return self.hext[1:]
 
 
-def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None, x_planes=None) -> LayerOut:
+def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None, x_planes=None,
+                   want_hsel=True) -> LayerOut:
     """One DCGRU layer over x (T + x_off, B, N, Fin).  x_off = 1 / x_planes: x is the `hext` of the layer below and
-    x_planes its `hpl` (the layer then skips its own diffusion pass)."""
+    x_planes its `hpl` (the layer then skips its own diffusion pass).  want_hsel=False: the caller does not read the layer's
+    final state (hsel comes back empty; saves one copy per step)."""
     act = ACT_CODES.get(activation, 1)
     save = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, h0, wg, bg, wc, bc))
     if x_planes is not None:
         global hop_plane_handovers
         hop_plane_handovers += 1
     hext, hsel, saved = torch.ops.eeg_dcrnn.dcgru_layer(x, int(x_off), h0, p, int(p_batched), wg, bg, wc, bc, lengths, x_planes,
-                                                        n, h, m, act, save)
+                                                        n, h, m, act, save, bool(want_hsel))
     return LayerOut(hext, hsel, saved[7].detach() if save else None)
 
 

@@ -45,7 +45,7 @@ class FlatParameters:
         self.flat_param.grad = self.flat_grad
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        ops.zero_(self.flat_grad)          # one memset node on the stream (no framework fill kernel in the captured step)
 
 
 class TrainStep:
@@ -93,6 +93,17 @@ class TrainStep:
         sc = None if self.scaler_mean is None else utils.StandardScaler(self.scaler_mean, self.scaler_std)
         return utils.compute_regression_loss(y_true=y, y_predicted=out, standard_scaler=sc, loss_fn="MAE")
 
+    def loss_and_grad(self, out, y):
+        """(loss, d loss / d out) of the task's criterion from the fused HIP loss kernels (same values as `self.loss`)"""
+        if self.task == "detection":
+            return torch.ops.eeg_dcrnn.bce_logits(out.view(-1), y)
+        if self.task == "classification":
+            return torch.ops.eeg_dcrnn.ce_logits(out, y)
+        scaled = self.scaler_mean is not None
+        # train_ssl.py:165-170: loss_fn "MAE" != "mae" selects the masked RMSE (kind 1), Q9
+        return torch.ops.eeg_dcrnn.masked_loss(out, y, scaled, float(self.scaler_mean) if scaled else 0.0,
+                                               float(self.scaler_std) if scaled else 1.0, 0.0, 1)
+
     def forward_backward(self, x, y, seq_lengths, supports):
         """supports=None: build the per-clip correlation graph and its dual random-walk supports from
         the clips on the device (the DataLoader-side `_get_indiv_graphs` of the reference)."""
@@ -103,9 +114,12 @@ class TrainStep:
             out = self.model(x, y, supports, batches_seen=self.samples_seen)    # train_ssl.py:163
         else:
             out = self.model(x, seq_lengths, supports)
-        loss = self.loss(out, y)
+        # The loss kernels return value AND gradient (d loss / d out) from one pass: backward is seeded with that gradient
+        # directly -- `loss.backward()` would first fill a ones tensor and multiply the saved gradient by it (two framework
+        # kernels per step for a factor of exactly 1).  `self.loss(out, y).backward()` remains the equivalent public path.
+        loss, seed = self.loss_and_grad(out.detach(), y)
         with ops.GradSink(self.fp.params):       # backward operators write into the flat gradient bucket
-            loss.backward()
+            out.backward(seed.view_as(out))
         return loss.detach()
 
     # -- HIP-graph replay of forward + loss + backward -------------------------------------------

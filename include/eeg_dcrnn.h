@@ -60,6 +60,10 @@ int eeg_dcrnn_is_device_build(void);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
 int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 
+/* Clears `bytes` bytes at p on the stream (one memset node in a captured graph): `optimizer.zero_grad()` on the flat gradient
+ * bucket (train.py:262) and the never-read slot 0 of an upper layer's input gradient, without a framework fill kernel. */
+int eeg_dcrnn_zero(void* p, size_t bytes, void* stream);
+
 /* Hop polynomials from the supports (replaces the per-step `torch.matmul(support, x)` chain of
  * cell.py:83-93 incl. the carried-x0 quirk): P_out (G, n_supports*K, N, N). */
 int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K,

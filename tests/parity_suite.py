@@ -639,7 +639,7 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
     assert tuple(P.shape) == (b, 2 * k, n, n)
     leaf = [d(t).clone().requires_grad_(True) for t in (x, h0, wg, bg, wc, bc)]
     xd, h0d, wgd, bgd, wcd, bcd = leaf
-    hext, hsel, saved = E.dcgru_layer(xd, 0, h0d, P, 1, wgd, bgd, wcd, bcd, None, None, n, h, 2 * k + 1, 0, True)
+    hext, hsel, saved = E.dcgru_layer(xd, 0, h0d, P, 1, wgd, bgd, wcd, bcd, None, None, n, h, 2 * k + 1, 0, True, True)
     assert tuple(hext.shape) == (t_len + 1, b, n * h) and len(saved) == 9
     assert_close(hext[1:].detach().cpu().numpy(), top.detach().numpy(), "torch.ops dcgru_layer hseq")
     assert_close(hsel.detach().cpu().numpy(), top[-1].detach().numpy(), "torch.ops dcgru_layer hsel")
@@ -653,8 +653,8 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
     w2 = [d(t) for t in (0.1 * torch.randn((h + h) * 5, 2 * h, generator=g), torch.zeros(2 * h),
                          0.1 * torch.randn((h + h) * 5, h, generator=g), torch.zeros(h))]
     xin = hext.detach().view(t_len + 1, b, n, h)
-    a1 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, saved[7].detach(), n, h, 5, 0, False)[0]
-    a2 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, None, n, h, 5, 0, False)[0]
+    a1 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, saved[7].detach(), n, h, 5, 0, False, True)[0]
+    a2 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, None, n, h, 5, 0, False, True)[0]
     assert_close(a1.cpu().numpy(), a2.cpu().numpy(), "x_planes hand-over", tol=1e-6)
     # opcheck: schema + aliasing annotations, autograd registration, fake (meta) implementations
     nog = [t.detach() for t in leaf]
@@ -663,7 +663,7 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
         (E.pack_cell.default, (nog[2], nog[3], nog[4], nog[5], din, h, 5)),
         (E.diffusion_hops.default, (nog[0].reshape(t_len * b, n, din), P, 1, b)),
         (E.dcgru_layer.default, (xd.detach().requires_grad_(True), 0, h0d.detach().requires_grad_(True), P, 1,
-                                 *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True)),
+                                 *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True, True)),
         (E.dconv.default, (torch.randn(b, n, din + h, generator=g).to(device).requires_grad_(True), P, 1,
                            nog[2].clone().requires_grad_(True), nog[3].clone().requires_grad_(True))),
         (E.cls_head.default, (torch.randn(b, n, h, generator=g).to(device).requires_grad_(True),
@@ -693,7 +693,7 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
                                           d(0.1 * torch.randn(rows64, 64, generator=g)), d(torch.zeros(64)), 100, 64, 3)))
     x_bm = d(torch.randn(b, t_len, n, din, generator=g))
     samples.append((E.dcgru_layer.default, (x_bm.transpose(0, 1).requires_grad_(True), 0, None, P, 1,
-                                            *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True)))
+                                            *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True, False)))
     for op, args in samples:
         res = torch.library.opcheck(op, args, test_utils=list(opcheck_utils), raise_exception=True)
         assert all(v == "SUCCESS" for v in res.values()), (str(op), res)
