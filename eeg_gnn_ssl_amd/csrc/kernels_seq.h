@@ -968,7 +968,10 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     using G = SeqGeom<H, M>;
     static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
     constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, NCT = G::NCT, ROWS = 32, DPS = 20;
-    constexpr int kCoefTile = 5 * 2 * 256;                             // [kC, kU, u, hr1, r][node tile][64 lanes x 4]
+    // coefficient block of one (column tile, buffer): [kC, kU, u, hr1, r][64 lanes x 4] of nodes 0..15, one float4 {kC, kU, u, hr1}
+    // per lane + one dword r per lane of the remainder element.  TWO buffers (step parity): role B fills the block of step t-1
+    // in window 0 of step t, while role A reads the block of step t
+    constexpr int kCoefTile = 5 * 256 + 256 + 64;
     PhaseProbe<PROBE> pp;
     pp.start();
     EEG_DYN_SMEM(sm);
@@ -977,10 +980,10 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     float* EG = EC + ROWS * KAP;            // [32][KGP]  slot m = [P_m^T dR | P_m^T dU]
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, ct = wave8 & 3;
     const int lr = lane & 15, lg = lane >> 4;
-    float* RS = EG + ROWS * KGP + wave8 * kRemTile;                    // this wave's 4x4x1 hand-over scratch
-    float* DP = EG + ROWS * KGP + 8 * kRemTile + ct * (20 * DPS);      // [20][DPS] GEMM2 result + external gradient, tile ct
-    float* CF = EG + ROWS * KGP + 8 * kRemTile + 4 * 20 * DPS + ct * kCoefTile + 4 * lane;   // this lane's coefficient slots
-    constexpr int kZero = ROWS * (KAP + KGP) + 8 * kRemTile + 4 * 20 * DPS + 4 * kCoefTile;   // floats cleared per clip
+    float* RS = nullptr;                                               // (the remainder is reduced in registers: no hand-over scratch)
+    float* DP = EG + ROWS * KGP + ct * (20 * DPS);                     // [20][DPS] GEMM2 result + external gradient, tile ct
+    float* CF0 = EG + ROWS * KGP + 4 * 20 * DPS + ct * kCoefTile;      // this column tile's coefficient block, buffer 0 (buffer 1: + 4 * kCoefTile)
+    constexpr int kZero = ROWS * (KAP + KGP) + 4 * 20 * DPS + 2 * 4 * kCoefTile;   // floats cleared per clip
     const int node[2] = {lr, 16 + lr};
     const bool valid[2] = {lr < N, 16 + lr < N};
     const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
@@ -992,8 +995,8 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     const int odp0 = lr * DPS + 4 * lg, odp1 = node1 * DPS + lr;               // lane <-> lane hand-over ([20][DPS] = [node][col])
     // coefficient slots of the remainder element: one float4 {kC, kU, u, hr1} per lane in the nt = 1 slot of coefficient 0, r in
     // the nt = 1 slot of coefficient 1 (lane-linear dwords); the nt = 1 slots of coefficients 2..4 are unused
-    float* CF1 = CF + (0 * 2 + 1) * 256;
-    float* CFr1 = CF - 4 * lane + (1 * 2 + 1) * 256 + lane;
+    // this lane's slots inside a block: float4 k of nodes 0..15 at 256*k + 4*lane, the remainder float4 at 1280 + 4*lane, its r at 1536 + lane
+    auto cf_buf = [&](int t) { return CF0 + (t & 1) * (4 * kCoefTile); };
 
     if (role == 1) {
         // ================= role B =================
@@ -1039,7 +1042,8 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             // of that step is kept (gx) and added to the GEMM2 result that becomes its incoming gradient
             f32x4 gx;
             float gx1;
-            auto coef = [&]() {
+            auto coef = [&](int t_of) {                                 // operands in registers belong to step t_of
+                float* CF = cf_buf(t_of) + 4 * lane;
                 {
                     const f32x4 h = nh, u = nu, c = nc, r = nr;
                     f32x4 kC, kU, hr1;
@@ -1050,24 +1054,24 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                         kU[e] = (h[e] - c[e]) * u[e] * one_u;
                         hr1[e] = h[e] * r[e] * (1.f - r[e]);
                     }
-                    st4(CF + (0 * 2 + 0) * 256, kC);
-                    st4(CF + (1 * 2 + 0) * 256, kU);
-                    st4(CF + (2 * 2 + 0) * 256, u);
-                    st4(CF + (3 * 2 + 0) * 256, hr1);
-                    st4(CF + (4 * 2 + 0) * 256, r);
+                    st4(CF + 0 * 256, kC);
+                    st4(CF + 1 * 256, kU);
+                    st4(CF + 2 * 256, u);
+                    st4(CF + 3 * 256, hr1);
+                    st4(CF + 4 * 256, r);
                     gx = ng;
                 }
                 {
                     const float one_u = 1.f - nu1;
                     const float kC1 = act == 0 ? one_u * (1.f - nc1 * nc1) : (nc1 > 0.f ? one_u : 0.f);
-                    st4(CF1, (f32x4){kC1, (nh1 - nc1) * nu1 * one_u, nu1, nh1 * nr1 * (1.f - nr1)});
-                    *CFr1 = nr1;
+                    st4(CF + 5 * 256, (f32x4){kC1, (nh1 - nc1) * nu1 * one_u, nu1, nh1 * nr1 * (1.f - nr1)});
+                    CF[6 * 256 - 3 * lane] = nr1;                       // (block + 1536 + lane)
                     gx1 = ng1;
                 }
             };
             fetch(T - 1);
             __syncthreads();                                            // tiles cleared
-            coef();                                                     // first step: its coefficients, DP = external gradient
+            coef(T - 1);                                                // first step: its coefficients, DP = external gradient
             if (T > 1) fetch(T - 2);
             st4(DP + odp0, gx);
             DP[odp1] = gx1;
@@ -1078,11 +1082,13 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                     sb_r += ld4(EG + lds_sw(orow[0], col, KGP));
                     if (valid[1]) sb_r += ld4(EG + lds_sw(orow[1], col, KGP));
                 }
-                EEG_LDS_BARRIER();                                      // (1) P_m^T dC and P_m^T dU complete; A has read its coefficients
+                // window 0 (role A: elementwise work and node mixes, no GEMM on the pipe): the coefficients of step t-1 go to the
+                // OTHER buffer -- VALU instructions issued beside a wave that streams MFMAs wait out a whole MFMA each
                 if (t > 0) {
-                    coef();                                             // coefficients of step t-1 (operands requested a step ago)
+                    coef(t - 1);                                        // (operands requested a step ago)
                     if (t > 1) fetch(t - 2);                            // ... and the same registers request step t-2
                 }
+                EEG_LDS_BARRIER();                                      // (1) P_m^T dC and P_m^T dU complete
                 f32x4 acc[1][2] = {{zero4, zero4}};
                 mfma_nodes32<1, KSG, true, 0, 2, true, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
                 sb_c += ld4(EC + lds_sw(orow[0], col, KAP));
@@ -1098,7 +1104,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                 if (t > 0) { acc[0][0] += gx; acc[0][1][0] += gx1; }
                 st4(DP + odp0, acc[0][0]);
                 DP[odp1] = acc[0][1][0];
-                EEG_LDS_BARRIER();                                      // (3) DP and the coefficients of step t-1 complete
+                EEG_LDS_BARRIER();                                      // (3) DP complete
             }
             sb_r += ld4(EG + lds_sw(orow[0], col, KGP));                // dR of the last step (t = 0)
             if (valid[1]) sb_r += ld4(EG + lds_sw(orow[1], col, KGP));
@@ -1142,23 +1148,24 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     for (int t = T - 1; t >= 0; --t) {
         const unsigned sx = (unsigned)(((size_t)t * B + b) * N * (3 * H));
         // ---- E1: g = A's elementwise part + role B's GEMM2 of the step before (+ external gradient, added by B)
-        f32x4 hr1, rg;                                              // taken now: role B refills the slots in window 1
+        f32x4 hr1, rg;
         float hr1_1, rg1;
         {
+            const float* CF = cf_buf(t) + 4 * lane;                 // block of step t (role B is filling the other one)
             const f32x4 g = valid[0] ? dhn + ld4(DP + odp0) : zero4;
-            const f32x4 dC = g * ld4(CF + (0 * 2 + 0) * 256), du_ = g * ld4(CF + (1 * 2 + 0) * 256);
+            const f32x4 dC = g * ld4(CF + 0 * 256), du_ = g * ld4(CF + 1 * 256);
             st4(EC + lds_sw(lr, col, KAP), dC);                     // zeros on padding nodes
             st4(EG + lds_sw(lr, H + col, KGP), du_);
             if (valid[0]) {
                 wbuf_st4(bX, oxw0 + 2 * H, sx, dC);
                 wbuf_st4(bX, oxw0 + H, sx, du_);
             }
-            dhn = g * ld4(CF + (2 * 2 + 0) * 256);
-            hr1 = ld4(CF + (3 * 2 + 0) * 256);
-            rg = ld4(CF + (4 * 2 + 0) * 256);
+            dhn = g * ld4(CF + 2 * 256);
+            hr1 = ld4(CF + 3 * 256);
+            rg = ld4(CF + 4 * 256);
             // node 16 + lg, column ct*16 + lr: {kC, kU, u, hr1} in one 16-byte read
             const float g1 = valid1 ? dhn1 + DP[odp1] : 0.f;
-            const f32x4 k1 = ld4(CF1);
+            const f32x4 k1 = ld4(CF + 5 * 256);
             const float dC1 = g1 * k1[0], du1 = g1 * k1[1];
             EC[lc1] = dC1;
             EG[lu1] = du1;
@@ -1168,7 +1175,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             }
             dhn1 = g1 * k1[2];
             hr1_1 = k1[3];
-            rg1 = *CFr1;
+            rg1 = CF[6 * 256 - 3 * lane];
         }
         pp.mark(0);
         EEG_WAVE_SYNC();

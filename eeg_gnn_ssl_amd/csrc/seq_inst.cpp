@@ -75,7 +75,8 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
 #endif
     if constexpr (H == 64 && NKS == 5 && M <= 3) {   // two waves per SIMD: role A holds w1 + half of w2 (M >= 4: > 256 registers)
         if (a.variant == 1 && (double)a.T * a.B * a.N * 3 * H * sizeof(float) < 2147483648.0) {   // (32-bit buffer offsets)
-            const size_t lds2 = ((size_t)(M - 1) * kPFloats + 32 * (SeqGeom<H, M>::KAP + SeqGeom<H, M>::KGP) + 8 * kRemTile + 4 * 20 * 20 + 4 * 5 * 2 * 256) * sizeof(float);
+            // tiles + DP [4][20][20] + two coefficient buffers of 4 x (5*256 + 256 + 64) floats (seq_bwd2_kernel)
+            const size_t lds2 = ((size_t)(M - 1) * kPFloats + 32 * (SeqGeom<H, M>::KAP + SeqGeom<H, M>::KGP) + 4 * 20 * 20 + 2 * 4 * (5 * 256 + 256 + 64)) * sizeof(float);
 #if defined(EEG_DEV)
             if constexpr (M == 3) {
                 if (a.probe != nullptr) {
