@@ -33,10 +33,10 @@ thread_local char g_err[512] = "";
 // include/eeg_dcrnn_dev.h).  In the product build the knobs are compile-time zeros and there is no probe.
 #if defined(EEG_DEV)
 long long* g_seq_probe = nullptr;  // see eeg_dcrnn_set_seq_probe
-int g_tune[16] = {0};               // see eeg_dcrnn_set_tuning
+int g_tune[24] = {0};               // see eeg_dcrnn_set_tuning
 #else
 constexpr long long* g_seq_probe = nullptr;
-constexpr int g_tune[16] = {0};
+constexpr int g_tune[24] = {0};
 #endif
 
 int fail(const char* fmt, ...) {
@@ -332,7 +332,7 @@ struct BwdWs {
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
     if ((g_tune[2] & 2) != 0 || g_tune[1] != 0 || R < q_min_rows()) return TnqPlan{};
-    return tnq_plan(nseg, F, R, O, bt, num_cus());
+    return tnq_plan(nseg, F, R, O, bt, g_tune[16] > 0 ? g_tune[16] / 2 : num_cus());    // dev knob 16: target workgroups of the whole-block TN GEMM
 }
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     BwdWs w;
@@ -519,7 +519,7 @@ int eeg_dcrnn_abi_version(void) { return 3; }
 int eeg_dcrnn_is_device_build(void) { return kPlatformIsDevice; }
 #if defined(EEG_DEV)
 int eeg_dcrnn_set_tuning(int key, int value) {
-    if (key < 0 || key >= 16) return fail("set_tuning: key %d out of range", key);
+    if (key < 0 || key >= 24) return fail("set_tuning: key %d out of range", key);
     g_tune[key] = value;
     return 0;
 }
@@ -558,7 +558,13 @@ int eeg_dcrnn_supported(int N, int H, int Fin, int M) { return check_dims(N, H, 
 int eeg_dcrnn_zero(void* p, size_t bytes, void* stream) {
     if (bytes == 0) return 0;
     if (p == nullptr) return fail("zero: null pointer");
-    return hipMemsetAsync(p, 0, bytes, S_(stream)) == hipSuccess ? 0 : fail("zero: memset failed");
+    if (reinterpret_cast<uintptr_t>(p) % 16 != 0)                       // (torch allocations are 256-byte aligned; views may not be)
+        return hipMemsetAsync(p, 0, bytes, S_(stream)) == hipSuccess ? 0 : fail("zero: memset failed");
+    const size_t n16 = bytes / 16;
+    const int blocks = (int)(n16 / 256 < 1 ? 1 : (n16 / 256 > 1024 ? 1024 : n16 / 256));
+    EEG_LAUNCH_P("zero", zero_kernel, dim3(blocks), dim3(256), 0, S_(stream), reinterpret_cast<float4*>(p), n16,
+                 reinterpret_cast<unsigned char*>(p) + 16 * n16, (int)(bytes - 16 * n16));
+    return check_launch("zero");
 }
 
 int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_graphs, int N, int K, float* P_out,

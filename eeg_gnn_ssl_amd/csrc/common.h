@@ -150,4 +150,14 @@ __host__ __device__ inline f32x4 dropout_mask4(unsigned long long seed, unsigned
     for (int j = 0; j < 4; ++j) m[j] = (scale != 0.f && w[j] >= thr) ? scale : 0.f;
     return m;
 }
+// the same for ONE element e (the one-value-per-lane remainder epilogues)
+__host__ __device__ inline float dropout_mask1(unsigned long long seed, unsigned long long offset, unsigned long long e,
+                                               unsigned thr, float scale) {
+    const unsigned long long c = offset + (e >> 2);
+    unsigned w[4];
+    philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+    const unsigned k = (unsigned)e & 3u;
+    const unsigned word = k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+    return (scale != 0.f && word >= thr) ? scale : 0.f;
+}
 }  // namespace eeg

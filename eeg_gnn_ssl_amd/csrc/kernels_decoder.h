@@ -49,8 +49,10 @@ struct DecFwdArgs {
 };
 
 // ---- GEMMs with streamed weights -------------------------------------------------------------------------------
-// acc[i][nt] += (weight tile wt[i])^T x X^T, issued transposed like mfma_nodes32 (lane: node lr / 16 + lr, 4 consecutive
-// columns), remainder nodes 16..19 on v_mfma_f32_4x4x1 with the hand-over through `scratch` (NT * kRemTile floats).
+// acc[i][0] += (weight tile wt[i])^T x X^T for nodes 0..15, issued transposed like mfma_nodes32 (lane: node lr, 4 consecutive
+// columns); remainder nodes 16..19 on v_mfma_f32_4x4x1, reduced in registers to ONE element per lane (mfma_nodes32 L1): lane
+// (lr, lg) gets acc[i][1][0] += out[node 16 + lg][column lr of tile wt[i]]; components 1..3 of acc[i][1] are not touched
+// (`scratch` is unused).
 // Plain K order (pack index ks = k/4, k = slot*KPP*4 + f): the operand tile has `nslots` hop slots of `slotw` columns of
 // which the first 4*KPP are real; SWZ: the tile is an XOR-swizzled state tile (lds_sw), else a plain [rows][stride] one.
 // The weights of group g+1 (D k-steps x NT tiles, one coalesced dword per lane each) are requested before the MFMAs
@@ -147,20 +149,13 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
         }
     }
     if (NT == 1) acc[0][0] += alt;
-    // remainder hand-over (see mfma_nodes32)
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            scratch[i * kRemTile + lg * 80 + r * 16 + lr] = (rem[i][0][r] + rem[i][1][r]) + (rem[i][2][r] + rem[i][3][r]);
-    EEG_WAVE_SYNC();
+    // remainder: reduce-scatter in registers, one element per lane (mfma_nodes32 L1; common.h rem4_reduce)
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const float* q = scratch + i * kRemTile + (lr & 3) * 16 + 4 * lg;
-        const f32x4 s = (ld4(q) + ld4(q + 80)) + (ld4(q + 160) + ld4(q + 240));
-        if (lr < 4) acc[i][1] += s;
+        f32x4 t = (rem[i][0] + rem[i][1]) + (rem[i][2] + rem[i][3]);
+        EEG_PIN(t);
+        acc[i][1][0] += rem4_reduce(t);
     }
-    EEG_WAVE_SYNC();
 }
 template <int NT, int D, bool SWZ>
 __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile, int stride, int slotw, int kpp, int nslots,
@@ -235,18 +230,11 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
     }
     if (NT == 1) acc[0][0] += alt;
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            scratch[i * kRemTile + lg * 80 + r * 16 + lr] = (rem[i][0][r] + rem[i][1][r]) + (rem[i][2][r] + rem[i][3][r]);
-    EEG_WAVE_SYNC();
-#pragma unroll
     for (int i = 0; i < NT; ++i) {
-        const float* q = scratch + i * kRemTile + (lr & 3) * 16 + 4 * lg;
-        const f32x4 s = (ld4(q) + ld4(q + 80)) + (ld4(q + 160) + ld4(q + 240));
-        if (lr < 4) acc[i][1] += s;
+        f32x4 t = (rem[i][0] + rem[i][1]) + (rem[i][2] + rem[i][3]);
+        EEG_PIN(t);
+        acc[i][1][0] += rem4_reduce(t);
     }
-    EEG_WAVE_SYNC();
 }
 template <int NT, int NQ, int PD>
 __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile, int stride, const float* __restrict__ wp,
@@ -296,10 +284,14 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
         __syncthreads();
         float pf[poly_slots<M, NKS>()][NKS];
         load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
-        const int node[2] = {lr, 16 + lr};
         const bool valid[2] = {lr < N, 16 + lr < N};
         const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
         const int oh[2] = {nodec[0] * H + col, nodec[1] * H + col};
+        // remainder nodes 16..19: one element per lane -- lane (lr, lg) <-> node 16 + lg, column lr of the wave's column tile
+        const int node1 = 16 + lg, col1 = ct * 16 + lr;
+        const bool valid1 = node1 < N;
+        const int oh1 = (valid1 ? node1 : N - 1) * H + col1;
+        const int l1 = lds_sw(node1, col1, KAP);
         // initial states (encoder finals; the host has copied them into hext slot 0) and their hop rows (hpl slot 0)
         for (int l = 0; l < L; ++l) {
             float* Al = A0 + l * ROWS * KAP;
@@ -331,9 +323,8 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                 const int wt3[3] = {ct, NCT + ct, 2 * NCT + ct};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const f32x4 bv = ld4(lp.bias + wt3[i] * 16 + 4 * lg);
-                    ag[i][0] = bv;
-                    ag[i][1] = lr < 4 ? bv : zero4;
+                    ag[i][0] = ld4(lp.bias + wt3[i] * 16 + 4 * lg);
+                    ag[i][1] = (f32x4){lp.bias[wt3[i] * 16 + lr], 0.f, 0.f, 0.f};
                 }
                 if (l == 0)
                     gemm_stream_plain<3, DX, false>(XA, XS, FP, Dout / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag, RS);
@@ -352,23 +343,27 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     ag[0][0] = g2[0][0]; ag[0][1] = g2[0][1]; ag[1][0] = g2[1][0]; ag[1][1] = g2[1][1];
                 }
                 quad_prefetch<1, NQ, PDC>(lp.bhc, NCT, wt1, lane, wqc);
-                f32x4 ug[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    f32x4 rg, u;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        rg[r] = sigmoidf_(ag[0][nt][r]);
-                        u[r] = sigmoidf_(ag[1][nt][r]);
+                f32x4 ug0;
+                float ug1;
+                {
+                    const f32x4 rg = sigmoid4_(ag[0][0]), u = sigmoid4_(ag[1][0]);
+                    ug0 = u;
+                    f32x4 rh = rg * ld4(Al + lds_sw(lr, col, KAP));
+                    rh = valid[0] ? rh : zero4;
+                    st4(A2 + lds_sw(lr, col, KAP), rh);
+                    if (valid[0]) {
+                        st4(lp.rs + s * N * H + oh[0], rg);
+                        st4(lp.rhs + s * N * H + oh[0], rh);
+                        st4(lp.us + s * N * H + oh[0], u);
                     }
-                    ug[nt] = u;
-                    f32x4 rh = rg * ld4(Al + lds_sw(nt == 0 ? lr : 16 + (lr & 3), col, KAP));
-                    rh = valid[nt] ? rh : zero4;
-                    if (nt == 0 || lr < 4) st4(A2 + lds_sw(nt == 0 ? lr : 16 + lr, col, KAP), rh);
-                    if (valid[nt]) {
-                        st4(lp.rs + s * N * H + oh[nt], rg);
-                        st4(lp.rhs + s * N * H + oh[nt], rh);
-                        st4(lp.us + s * N * H + oh[nt], u);
+                    const float rg1 = sigmoidf_(ag[0][1][0]), u1 = sigmoidf_(ag[1][1][0]);
+                    ug1 = u1;
+                    const float rh1 = valid1 ? rg1 * Al[l1] : 0.f;
+                    A2[l1] = rh1;
+                    if (valid1) {
+                        lp.rs[s * N * H + oh1] = rg1;
+                        lp.rhs[s * N * H + oh1] = rh1;
+                        lp.us[s * N * H + oh1] = u1;
                     }
                 }
                 EEG_WAVE_SYNC();
@@ -380,27 +375,31 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     gemm_stream_quad<1, NQ, PDC, true>(A2, KAP, lp.bhc, NCT, wt1, lane, lr, lg, c1, RS, wqc);
                     ag[2][0] = c1[0][0]; ag[2][1] = c1[0][1];
                 }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int row = nt == 0 ? lr : 16 + (lr & 3);
-                    const f32x4 u = ug[nt], h = ld4(Al + lds_sw(row, col, KAP));
-                    f32x4 c, hn;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pre = ag[2][nt][r];
-                        c[r] = act == 0 ? tanhf_(pre) : fmaxf(pre, 0.f);
-                        hn[r] = u[r] * h[r] + (1.f - u[r]) * c[r];
+                {
+                    const f32x4 u = ug0, h = ld4(Al + lds_sw(lr, col, KAP));
+                    const f32x4 c = act == 0 ? tanh4_(ag[2][0]) : relu4_(ag[2][0]);
+                    f32x4 hn = u * h + (1.f - u) * c;
+                    hn = valid[0] ? hn : zero4;
+                    st4(Al + lds_sw(lr, col, KAP), hn);
+                    if (valid[0]) {
+                        st4(lp.hext + (s + B) * N * H + oh[0], hn);              // hext slot t+1
+                        st4(lp.cs + s * N * H + oh[0], c);
                     }
-                    hn = valid[nt] ? hn : zero4;
-                    if (nt == 0 || lr < 4) st4(Al + lds_sw(nt == 0 ? lr : 16 + lr, col, KAP), hn);
-                    if (valid[nt]) {
-                        st4(lp.hext + (s + B) * N * H + oh[nt], hn);             // hext slot t+1
-                        st4(lp.cs + s * N * H + oh[nt], c);
+                    const float h1 = Al[l1], pre1 = ag[2][1][0];
+                    const float c1 = act == 0 ? tanhf_(pre1) : fmaxf(pre1, 0.f);
+                    const float hn1 = valid1 ? ug1 * h1 + (1.f - ug1) * c1 : 0.f;
+                    Al[l1] = hn1;
+                    if (valid1) {
+                        lp.hext[(s + B) * N * H + oh1] = hn1;
+                        lp.cs[s * N * H + oh1] = c1;
                     }
                     if (drop.on && l == L - 1) {                                 // what the projection reads (model.py:191)
-                        const f32x4 hd = hn * dropout_mask4(dseed, doff, (s * N * H + oh[nt]) >> 2, drop.thr, drop.scale);
-                        if (nt == 0 || lr < 4) st4(HD + lds_sw(nt == 0 ? lr : 16 + lr, col, 64), hd);
-                        if (valid[nt]) st4(a.hd + s * N * H + oh[nt], hd);
+                        const f32x4 hd = hn * dropout_mask4(dseed, doff, (s * N * H + oh[0]) >> 2, drop.thr, drop.scale);
+                        st4(HD + lds_sw(lr, col, 64), hd);
+                        if (valid[0]) st4(a.hd + s * N * H + oh[0], hd);
+                        const float hd1 = hn1 * dropout_mask1(dseed, doff, s * N * H + oh1, drop.thr, drop.scale);
+                        HD[lds_sw(node1, col1, 64)] = hd1;
+                        if (valid1) a.hd[s * N * H + oh1] = hd1;
                     }
                 }
                 EEG_WAVE_SYNC();
@@ -417,25 +416,31 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     const int wt2[2] = {j0, two ? j0 + 4 : j0};
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const f32x4 bv = ld4(a.pbias + wt2[i] * 16 + 4 * lg);
-                        po[i][0] = bv;
-                        po[i][1] = lr < 4 ? bv : zero4;
+                        po[i][0] = ld4(a.pbias + wt2[i] * 16 + 4 * lg);
+                        po[i][1] = (f32x4){a.pbias[wt2[i] * 16 + lr], 0.f, 0.f, 0.f};
                     }
                     gemm_stream_plain<2, 16, true>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po, RS);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (i == 1 && !two) continue;
-                        const int c0 = wt2[i] * 16 + 4 * lg;
-                        if (c0 >= Dout) continue;                       // Dout % 4 == 0: whole float4 pieces
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            if (!valid[nt]) continue;
-                            const size_t o = (s * N + node[nt]) * Dout + c0;
-                            st4(a.out + o, po[i][nt]);
+                        const int c0 = wt2[i] * 16 + 4 * lg, c1 = wt2[i] * 16 + lr;
+                        if (c0 < Dout && valid[0]) {                    // Dout % 4 == 0: whole float4 pieces
+                            const size_t o = (s * N + lr) * Dout + c0;
+                            st4(a.out + o, po[i][0]);
                             if (t + 1 < T) {
-                                const f32x4 nxt = tf ? ld4(a.targets + o) : po[i][nt];
+                                const f32x4 nxt = tf ? ld4(a.targets + o) : po[i][0];
                                 st4(a.xin + o + xstep, nxt);
-                                st4(XA + node[nt] * XS + c0, nxt);      // X0 slot 0 of the next step
+                                st4(XA + lr * XS + c0, nxt);            // X0 slot 0 of the next step
+                            }
+                        }
+                        if (c1 < Dout && valid1) {                      // node 16 + lg, one column per lane
+                            const size_t o = (s * N + node1) * Dout + c1;
+                            const float v = po[i][1][0];
+                            a.out[o] = v;
+                            if (t + 1 < T) {
+                                const float nxt = tf ? a.targets[o] : v;
+                                a.xin[o + xstep] = nxt;
+                                XA[node1 * XS + c1] = nxt;
                             }
                         }
                     }
@@ -523,11 +528,16 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
         float pf[poly_slots<M, NKS>()][NKS];
         load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
         const int node[2] = {lr, 16 + lr};
-        const int rowt[2] = {lr, 16 + (lr & 3)};                       // tile rows (second node tile: 4 rows)
         const bool valid[2] = {lr < N, 16 + lr < N};
         const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
         const int oh[2] = {nodec[0] * H + col, nodec[1] * H + col};
         const int oxw[2] = {node[0] * (3 * H) + col, node[1] * (3 * H) + col};
+        // remainder nodes 16..19: one element per lane -- lane (lr, lg) <-> node 16 + lg, column ct*16 + lr; every nt = 1
+        // quantity below lives in component 0 of its vector
+        const int node1 = 16 + lg, col1 = ct * 16 + lr;
+        const bool valid1 = node1 < N;
+        const int oh1 = (valid1 ? node1 : N - 1) * H + col1, oxw1 = node1 * (3 * H) + col1;
+        const int lc1 = lds_sw(node1, col1, KAP), lg1 = lds_sw(node1, col1, KGP), lu1 = lds_sw(node1, H + col1, KGP);
         float* dhl = DH + (wave * 2) * 256 + 4 * lane;                 // + l * 2048 + nt * 256
         const size_t boff = (size_t)b * N * H;
         // operands of one (layer, step) pair; the next pair's are requested while the current one is processed
@@ -535,13 +545,14 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
         auto fetch = [&](int l, int t) {
             const DecBwdLayerPtrs& lp = a.l[l];
             const size_t so = (size_t)t * state + boff;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                nh[nt] = ld4(lp.hext + so + oh[nt]);                   // hext slot t = h_{t-1}
-                nr[nt] = ld4(lp.rs + so + oh[nt]);
-                nu[nt] = ld4(lp.us + so + oh[nt]);
-                nc[nt] = ld4(lp.cs + so + oh[nt]);
-            }
+            nh[0] = ld4(lp.hext + so + oh[0]);                         // hext slot t = h_{t-1}
+            nr[0] = ld4(lp.rs + so + oh[0]);
+            nu[0] = ld4(lp.us + so + oh[0]);
+            nc[0] = ld4(lp.cs + so + oh[0]);
+            nh[1] = (f32x4){lp.hext[so + oh1], 0.f, 0.f, 0.f};
+            nr[1] = (f32x4){lp.rs[so + oh1], 0.f, 0.f, 0.f};
+            nu[1] = (f32x4){lp.us[so + oh1], 0.f, 0.f, 0.f};
+            nc[1] = (f32x4){lp.cs[so + oh1], 0.f, 0.f, 0.f};
         };
         // column tiles of a pair: 1 (no input gradient wanted), 2 (layers above the first / narrow outputs) or 3
         auto pair_nt = [&](int l, int t) {
@@ -574,6 +585,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
             }
         };
         f32x4 sb0[3] = {zero4, zero4, zero4}, sb1[3] = {zero4, zero4, zero4};   // bias-gradient sums [r, u, c]: layer 0, layers above
+        float sr0[3] = {0.f, 0.f, 0.f}, sr1[3] = {0.f, 0.f, 0.f};               // ... of the remainder element
         fetch(L - 1, T - 1);
         plain_wload<1, DT>(a.tpack, nct_h, wt1, lane, 0, wpt);
         for (int t = T - 1; t >= 0; --t) {
@@ -596,9 +608,8 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 gext[0] = pa[0][0];
                 gext[1] = pa[0][1];
                 if (a.drop.on) {      // through the dropout in front of the projection: the forward's mask, recomputed
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        gext[nt] *= dropout_mask4(a.rng_used[0], a.rng_used[1], (s * N * H + oh[nt]) >> 2, a.drop.thr, a.drop.scale);
+                    gext[0] *= dropout_mask4(a.rng_used[0], a.rng_used[1], (s * N * H + oh[0]) >> 2, a.drop.thr, a.drop.scale);
+                    gext[1][0] *= dropout_mask1(a.rng_used[0], a.rng_used[1], s * N * H + oh1, a.drop.thr, a.drop.scale);
                 }
             }
             prefetch1(L - 1, pair_nt(L - 1, t));
@@ -612,10 +623,9 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 if (l > 0) fetch(l - 1, t); else if (t > 0) fetch(L - 1, t - 1);
                 // ---- E1: blend backward (cell.py:182-210 reversed)
                 f32x4 dU[2], dhn[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const f32x4 h = hp[nt], u = uu[nt], c = cc[nt];
-                    const f32x4 g = valid[nt] ? ld4(dhl + l * 2048 + nt * 256) + gext[nt] : zero4;
+                {
+                    const f32x4 h = hp[0], u = uu[0], c = cc[0];
+                    const f32x4 g = valid[0] ? ld4(dhl + l * 2048) + gext[0] : zero4;
                     f32x4 dC, du_;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -623,14 +633,28 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                         dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
                         du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
                     }
-                    if (nt == 0 || lr < 4) st4(EC + lds_sw(rowt[nt], col, KAP), dC);      // zeros on padding nodes
-                    if (valid[nt]) {
-                        st4(dxw + oxw[nt] + 2 * H, dC);
-                        st4(dxw + oxw[nt] + H, du_);
+                    st4(EC + lds_sw(lr, col, KAP), dC);                               // zeros on padding nodes
+                    if (valid[0]) {
+                        st4(dxw + oxw[0] + 2 * H, dC);
+                        st4(dxw + oxw[0] + H, du_);
                     }
-                    dU[nt] = du_;
-                    dhn[nt] = g * u;
+                    dU[0] = du_;
+                    dhn[0] = g * u;
                     if (l == 0) { sb0[1] += du_; sb0[2] += dC; } else { sb1[1] += du_; sb1[2] += dC; }
+                    // node 16 + lg, column ct*16 + lr
+                    const float h1 = hp[1][0], u1 = uu[1][0], c1 = cc[1][0];
+                    const float g1 = valid1 ? dhl[l * 2048 + 256] + gext[1][0] : 0.f;
+                    const float dc1 = g1 * (1.f - u1);
+                    const float dC1 = act == 0 ? dc1 * (1.f - c1 * c1) : (c1 > 0.f ? dc1 : 0.f);
+                    const float du1 = g1 * (h1 - c1) * u1 * (1.f - u1);
+                    EC[lc1] = dC1;
+                    if (valid1) {
+                        dxw[oxw1 + 2 * H] = dC1;
+                        dxw[oxw1 + H] = du1;
+                    }
+                    dU[1] = (f32x4){du1, 0.f, 0.f, 0.f};
+                    dhn[1] = (f32x4){g1 * u1, 0.f, 0.f, 0.f};
+                    if (l == 0) { sr0[1] += du1; sr0[2] += dC1; } else { sr1[1] += du1; sr1[2] += dC1; }
                 }
                 EEG_WAVE_SYNC();
                 lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
@@ -648,18 +672,23 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     for (int i = 0; i < NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
                     gemm_stream_quad<NT, NQ, PD, true, 3>(EC, KAP, lp.c1, nct, wtn, lane, lr, lg, acc, RS, wq1);
                     quad_prefetch<NT, 2 * NQ, PD, 3>(lp.c2, nct, wtn, lane, wq2);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        const f32x4 drh = acc[0][nt], rg = rr[nt];       // exact 0 on padding nodes
-                        const f32x4 dR = drh * hp[nt] * rg * (1.f - rg);
-                        dhn[nt] += drh * rg;
-                        if (nt == 0 || lr < 4) {
-                            st4(EG + lds_sw(rowt[nt], col, KGP), dR);
-                            st4(EG + lds_sw(rowt[nt], H + col, KGP), dU[nt]);
-                        }
-                        if (valid[nt]) st4(dxw + oxw[nt], dR);
+                    {
+                        const f32x4 drh = acc[0][0], rg = rr[0];         // exact 0 on padding nodes
+                        const f32x4 dR = drh * hp[0] * rg * (1.f - rg);
+                        dhn[0] += drh * rg;
+                        st4(EG + lds_sw(lr, col, KGP), dR);
+                        st4(EG + lds_sw(lr, H + col, KGP), dU[0]);
+                        if (valid[0]) st4(dxw + oxw[0], dR);
                         if (l == 0) sb0[0] += dR; else sb1[0] += dR;
-                        acc[0][nt] = dhn[nt];
+                        acc[0][0] = dhn[0];
+                        const float drh1 = acc[0][1][0], rg1 = rr[1][0];
+                        const float dR1 = drh1 * hp[1][0] * rg1 * (1.f - rg1);
+                        dhn[1][0] += drh1 * rg1;
+                        EG[lg1] = dR1;
+                        EG[lu1] = dU[1][0];
+                        if (valid1) dxw[oxw1] = dR1;
+                        if (l == 0) sr0[0] += dR1; else sr1[0] += dR1;
+                        acc[0][1] = (f32x4){dhn[1][0], 0.f, 0.f, 0.f};
                     }
                     EEG_WAVE_SYNC();
                     lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
@@ -686,9 +715,8 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     for (int i = 0; i < 2; ++i) {
                         const int j = wave + 4 * i;
                         if (j >= nct_o || i + 1 >= ntp) continue;
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-                            if (nt == 0 || lr < 4) st4(DX + rowt[nt] * FS + j * 16 + 4 * lg, dx[i][nt]);
+                        st4(DX + lr * FS + j * 16 + 4 * lg, dx[i][0]);
+                        DX[node1 * FS + j * 16 + lr] = dx[i][1][0];
                     }
                 }
                 __syncthreads();                                         // (3) tiles free for the next pair; DX complete
@@ -696,25 +724,29 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
         }
         // ---- gradients of the initial states (the encoder's final states)
         if (a.dh0 != nullptr) {
-            for (int l = 0; l < L; ++l)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    if (valid[nt]) st4(a.dh0 + (size_t)l * state + boff + node[nt] * H + col, ld4(dhl + l * 2048 + nt * 256));
+            for (int l = 0; l < L; ++l) {
+                if (valid[0]) st4(a.dh0 + (size_t)l * state + boff + lr * H + col, ld4(dhl + l * 2048));
+                if (valid1) a.dh0[(size_t)l * state + boff + node1 * H + col1] = dhl[l * 2048 + 256];
+            }
         }
         // ---- per-clip bias-gradient sums (fixed-order node reduction through the free dC / [dR|dU] tiles)
-        float* red = EC;                                             // [3H][16]
+        float* red = EC;                                             // [3H][16] + [3H][4] (the remainder elements)
+        float* red1 = EC + 3 * H * 16;
         for (int set = 0; set < (L > 1 ? 2 : 1); ++set) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[(k * H + col + r) * 16 + lr] = set == 0 ? sb0[k][r] : sb1[k][r];
+                red1[(k * H + col1) * 4 + lg] = set == 0 ? sr0[k] : sr1[k];
+            }
             __syncthreads();
             float* dst = (set == 0 ? a.dbias0 : a.dbias1) + (size_t)b * 3 * H;
             for (int j = tid; j < 3 * H; j += 256) {
                 float sacc = 0.f;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
+                sacc += (red1[j * 4] + red1[j * 4 + 1]) + (red1[j * 4 + 2] + red1[j * 4 + 3]);
                 dst[j] = sacc;
             }
         }

@@ -62,29 +62,45 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
         for (int e = tid; e < TILES; e += 256) EC[e] = 0.f;
         __syncthreads();
         const int node[2] = {lr, 16 + lr};
-        const int rowt[2] = {lr, 16 + (lr & 3)};
         const bool valid[2] = {lr < N, 16 + lr < N};
         const int nodec[2] = {valid[0] ? lr : N - 1, valid[1] ? 16 + lr : N - 1};
         const int oh[2] = {nodec[0] * H + col, nodec[1] * H + col};
         const int oxw[2] = {node[0] * (3 * H) + col, node[1] * (3 * H) + col};
+        // remainder nodes 16..19: one element per lane (mfma_nodes32 L1) -- lane (lr, lg) <-> node 16 + lg, column ct*16 + lr;
+        // every nt = 1 quantity below lives in component 0 of its vector
+        const int node1 = 16 + lg, col1 = ct * 16 + lr;
+        const bool valid1 = node1 < N;
+        const int oh1 = (valid1 ? node1 : N - 1) * H + col1, oxw1 = node1 * (3 * H) + col1;
+        const int lc1 = lds_sw(node1, col1, KAP), lg1 = lds_sw(node1, col1, KGP), lu1 = lds_sw(node1, H + col1, KGP);
         f32x4 dh[2] = {zero4, zero4}, sb_r = zero4, sb_u = zero4, sb_c = zero4;
+        float s1_r = 0.f, s1_u = 0.f, s1_c = 0.f;
         const size_t tstride = (size_t)B * N * H, boff = (size_t)b * N * H;
         // operands through buffer descriptors: one per-lane VGPR offset per node tile, the step offset in an SGPR
         // (64-bit per-lane addresses of six arrays would not fit next to the weight stream in 256 registers)
         f32x4 nh[2], nr[2], nu[2], nc[2], ng[2];
         auto fetch = [&](int t) {
             const unsigned so = (unsigned)((size_t)t * tstride + boff);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const unsigned o = oh[nt];
-                nh[nt] = t > 0 ? wbuf_ld4(bH, o, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld4(bH0, o, (unsigned)boff) : zero4);
-                nr[nt] = wbuf_ld4(bR, o, so);
-                nu[nt] = wbuf_ld4(bU, o, so);
-                nc[nt] = wbuf_ld4(bC, o, so);
+            {
+                const unsigned o = oh[0];
+                nh[0] = t > 0 ? wbuf_ld4(bH, o, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld4(bH0, o, (unsigned)boff) : zero4);
+                nr[0] = wbuf_ld4(bR, o, so);
+                nu[0] = wbuf_ld4(bU, o, so);
+                nc[0] = wbuf_ld4(bC, o, so);
                 f32x4 g = dHseq != nullptr ? wbuf_ld4(bG, o, so) : zero4;
                 if (d_at_end != nullptr && t == T - 1) g += ld4(d_at_end + boff + o);
                 if (t == t_len) g += ld4(d_at_len + boff + o);
-                ng[nt] = g;
+                ng[0] = g;
+            }
+            {
+                const unsigned o = oh1;
+                nh[1] = (f32x4){t > 0 ? wbuf_ld(bH, o, so - (unsigned)tstride) : (h0 != nullptr ? wbuf_ld(bH0, o, (unsigned)boff) : 0.f), 0.f, 0.f, 0.f};
+                nr[1] = (f32x4){wbuf_ld(bR, o, so), 0.f, 0.f, 0.f};
+                nu[1] = (f32x4){wbuf_ld(bU, o, so), 0.f, 0.f, 0.f};
+                nc[1] = (f32x4){wbuf_ld(bC, o, so), 0.f, 0.f, 0.f};
+                float g1 = dHseq != nullptr ? wbuf_ld(bG, o, so) : 0.f;
+                if (d_at_end != nullptr && t == T - 1) g1 += d_at_end[boff + o];
+                if (t == t_len) g1 += d_at_len[boff + o];
+                ng[1] = (f32x4){g1, 0.f, 0.f, 0.f};
             }
         };
         fetch(T - 1);
@@ -98,10 +114,9 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
             if (t > 0) fetch(t - 1);
             // ---- E1: gate blend backward on the owned elements (padding nodes zeroed)
             f32x4 dU[2], dhn[2];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 h = hp[nt], u = uu[nt], c = cc[nt];
-                const f32x4 g = valid[nt] ? dh[nt] + gg[nt] : zero4;
+            {
+                const f32x4 h = hp[0], u = uu[0], c = cc[0];
+                const f32x4 g = valid[0] ? dh[0] + gg[0] : zero4;
                 f32x4 dC, du_;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -109,15 +124,29 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
                     dC[r] = act == 0 ? dc * (1.f - c[r] * c[r]) : (c[r] > 0.f ? dc : 0.f);
                     du_[r] = g[r] * (h[r] - c[r]) * u[r] * (1.f - u[r]);
                 }
-                if (nt == 0 || lr < 4) st4(EC + lds_sw(rowt[nt], col, KAP), dC);
-                if (valid[nt]) {
-                    wbuf_st4(bX, oxw[nt] + 2 * H, sx, dC);
-                    wbuf_st4(bX, oxw[nt] + H, sx, du_);
+                st4(EC + lds_sw(lr, col, KAP), dC);
+                if (valid[0]) {
+                    wbuf_st4(bX, oxw[0] + 2 * H, sx, dC);
+                    wbuf_st4(bX, oxw[0] + H, sx, du_);
                 }
                 sb_c += dC;
                 sb_u += du_;
-                dU[nt] = du_;
-                dhn[nt] = g * u;
+                dU[0] = du_;
+                dhn[0] = g * u;
+                const float h1 = hp[1][0], u1 = uu[1][0], c1 = cc[1][0];
+                const float g1 = valid1 ? dh[1][0] + gg[1][0] : 0.f;
+                const float dc1 = g1 * (1.f - u1);
+                const float dC1 = act == 0 ? dc1 * (1.f - c1 * c1) : (c1 > 0.f ? dc1 : 0.f);
+                const float du1 = g1 * (h1 - c1) * u1 * (1.f - u1);
+                EC[lc1] = dC1;
+                if (valid1) {
+                    wbuf_st1(bX, oxw1 + 2 * H, sx, dC1);
+                    wbuf_st1(bX, oxw1 + H, sx, du1);
+                }
+                s1_c += dC1;
+                s1_u += du1;
+                dU[1] = (f32x4){du1, 0.f, 0.f, 0.f};
+                dhn[1] = (f32x4){g1 * u1, 0.f, 0.f, 0.f};
             }
             EEG_WAVE_SYNC();
             lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
@@ -126,18 +155,23 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
             f32x4 acc[1][2] = {{zero4, zero4}};
             gemm_stream_quad<1, NQ, PD, true>(EC, KAP, b1p, NCT, wt1, lane, lr, lg, acc, RS, wq1);
             quad_prefetch<1, 2 * NQ, PD>(b2p, NCT, wt1, lane, wq2);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 drh = acc[0][nt], rg = rr[nt];               // exact 0 on padding nodes
-                const f32x4 dR = drh * hp[nt] * rg * (1.f - rg);
-                dhn[nt] += drh * rg;
-                if (nt == 0 || lr < 4) {
-                    st4(EG + lds_sw(rowt[nt], col, KGP), dR);
-                    st4(EG + lds_sw(rowt[nt], H + col, KGP), dU[nt]);
-                }
-                if (valid[nt]) wbuf_st4(bX, oxw[nt], sx, dR);
+            {
+                const f32x4 drh = acc[0][0], rg = rr[0];                 // exact 0 on padding nodes
+                const f32x4 dR = drh * hp[0] * rg * (1.f - rg);
+                dhn[0] += drh * rg;
+                st4(EG + lds_sw(lr, col, KGP), dR);
+                st4(EG + lds_sw(lr, H + col, KGP), dU[0]);
+                if (valid[0]) wbuf_st4(bX, oxw[0], sx, dR);
                 sb_r += dR;
-                acc[0][nt] = dhn[nt];
+                acc[0][0] = dhn[0];
+                const float drh1 = acc[0][1][0], rg1 = rr[1][0];
+                const float dR1 = drh1 * hp[1][0] * rg1 * (1.f - rg1);
+                dhn[1][0] += drh1 * rg1;
+                EG[lg1] = dR1;
+                EG[lu1] = dU[1][0];
+                if (valid1) wbuf_st1(bX, oxw1, sx, dR1);
+                s1_r += dR1;
+                acc[0][1] = (f32x4){dhn[1][0], 0.f, 0.f, 0.f};
             }
             EEG_WAVE_SYNC();
             lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
@@ -151,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
         }
         // ---- epilogue: dh0 and the per-clip bias-gradient partial sums (fixed-order node reduction)
         __syncthreads();                                                // all waves done with the tiles
-        float* red = EC;                                                // [3H][16]
+        float* red = EC;                                                // [3H][16] + [3H][4] (the remainder elements)
+        float* red1 = EC + 3 * H * 16;
         if (dh0 != nullptr) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                if (valid[nt]) st4(dh0 + boff + node[nt] * H + col, dh[nt]);
+            if (valid[0]) st4(dh0 + boff + lr * H + col, dh[0]);
+            if (valid1) dh0[boff + node1 * H + col1] = dh[1][0];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -163,11 +197,15 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
             red[(1 * H + col + r) * 16 + lr] = sb_u[r];
             red[(2 * H + col + r) * 16 + lr] = sb_c[r];
         }
+        red1[(0 * H + col1) * 4 + lg] = s1_r;
+        red1[(1 * H + col1) * 4 + lg] = s1_u;
+        red1[(2 * H + col1) * 4 + lg] = s1_c;
         __syncthreads();
         for (int j = tid; j < 3 * H; j += 256) {
             float sacc = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) sacc += red[j * 16 + q];
+            sacc += (red1[j * 4] + red1[j * 4 + 1]) + (red1[j * 4 + 2] + red1[j * 4 + 3]);
             dbias_part[(size_t)b * 3 * H + j] = sacc;
         }
     }

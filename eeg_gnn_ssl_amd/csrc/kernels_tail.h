@@ -149,6 +149,14 @@ __global__ __launch_bounds__(256) void masked_loss_grad_kernel(const float* __re
         for (size_t e = 4 * n4; e < n; ++e) dpred[e] = grad(pred[e], y[e]);
 }
 
+// p[0 .. n16) <- 0 in 16-byte pieces, then the < 16 trailing bytes (optimizer.zero_grad() on the flat bucket; a memset node of the
+// runtime costs ~4.7 us per call in a replayed graph, this kernel ~2 us)
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 // stage 1: per-block partial sums of g^2 (fixed assignment of elements to blocks/threads)
 __global__ void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     EEG_DYN_SMEM(sm);

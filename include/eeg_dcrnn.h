@@ -60,7 +60,7 @@ int eeg_dcrnn_is_device_build(void);
 /* 1 if kernels are instantiated for this (N, H, Fin, M); else 0 and last_error says why. */
 int eeg_dcrnn_supported(int N, int H, int Fin, int M);
 
-/* Clears `bytes` bytes at p on the stream (one memset node in a captured graph): `optimizer.zero_grad()` on the flat gradient
+/* Clears `bytes` bytes at p on the stream (one small kernel node in a captured graph): `optimizer.zero_grad()` on the flat gradient
  * bucket (train.py:262) and the never-read slot 0 of an upper layer's input gradient, without a framework fill kernel. */
 int eeg_dcrnn_zero(void* p, size_t bytes, void* stream);
 
