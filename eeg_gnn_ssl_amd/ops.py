@@ -229,37 +229,42 @@ torch.library.register_autograd(f"{NS}::dconv", _dconv_backward, setup_context=_
 # one DCGRU layer over a whole sequence (model.py:93-96 around cell.py:182-210)
 # =============================================================================================
 class GradSink:
-    """Lets the backward operators write parameter gradients straight into caller-owned buffers
-    (TrainStep's flat gradient bucket) instead of returning fresh tensors that autograd then adds into
-    `p.grad` with one small kernel per parameter.  Active only inside `with GradSink(params): ...`;
-    a parameter that receives a second gradient in the same pass falls back to the returned-tensor path
-    (autograd accumulates), so results never depend on the sink."""
-    _active: Optional["GradSink"] = None
+    """Lets the backward operators write parameter gradients straight into caller-owned buffers (TrainStep's flat gradient
+    bucket) instead of returning fresh tensors that autograd then adds into `p.grad` with one small kernel per parameter.
+
+    No process-global state: the sink belongs to the object that owns the buffers (train_step.FlatParameters creates one and
+    attaches it to each of ITS parameters as `param._eeg_grad_sink = (sink, index)`); a backward formula finds it through the
+    parameter it was handed.  It is armed only inside `with sink: ...` (one backward pass); a parameter that receives a second
+    gradient in the same pass falls back to the returned-tensor path (autograd accumulates), so results never depend on it."""
 
     def __init__(self, params: Sequence[torch.Tensor]):
-        self.targets = {p.data_ptr(): p.grad for p in params if p.grad is not None}
-        self.seen = set()
+        self.params = list(params)
+        self.armed = False
+        self.written = [False] * len(self.params)
+        for i, p in enumerate(self.params):
+            p._eeg_grad_sink = (self, i)
 
     def __enter__(self):
-        GradSink._active = self
-        self.seen.clear()
+        self.armed = True
+        self.written = [False] * len(self.params)
         return self
 
     def __exit__(self, *exc):
-        GradSink._active = None
+        self.armed = False
         return False
 
     @staticmethod
     def take(param: torch.Tensor) -> Optional[torch.Tensor]:
         """the buffer to write `param`'s gradient into, or None (-> allocate and return it to autograd)"""
-        sink = GradSink._active
-        if sink is None:
+        ref = getattr(param, "_eeg_grad_sink", None)
+        if ref is None:
             return None
-        key = param.data_ptr()
-        tgt = sink.targets.get(key)
-        if tgt is None or key in sink.seen or not tgt.is_contiguous() or tgt.shape != param.shape:
+        sink, i = ref
+        tgt = param.grad
+        if (not sink.armed or sink.written[i] or sink.params[i] is not param or tgt is None or not tgt.is_contiguous()
+                or tgt.shape != param.shape):
             return None
-        sink.seen.add(key)
+        sink.written[i] = True
         return tgt
 
 

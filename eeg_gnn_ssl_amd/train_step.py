@@ -43,6 +43,8 @@ class FlatParameters:
                 off += n
         self.flat_param = torch.nn.Parameter(self.flat, requires_grad=True)
         self.flat_param.grad = self.flat_grad
+        # the backward operators write these parameters' gradients straight into the bucket while `with self.sink:` is open
+        self.sink = ops.GradSink(params)
 
     def zero_grad(self):
         ops.zero_(self.flat_grad)          # one memset node on the stream (no framework fill kernel in the captured step)
@@ -118,7 +120,7 @@ class TrainStep:
         # directly -- `loss.backward()` would first fill a ones tensor and multiply the saved gradient by it (two framework
         # kernels per step for a factor of exactly 1).  `self.loss(out, y).backward()` remains the equivalent public path.
         loss, seed = self.loss_and_grad(out.detach(), y)
-        with ops.GradSink(self.fp.params):       # backward operators write into the flat gradient bucket
+        with self.fp.sink:                       # backward operators write into the flat gradient bucket
             out.backward(seed.view_as(out))
         return loss.detach()
 
