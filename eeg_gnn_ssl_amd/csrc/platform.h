@@ -97,6 +97,9 @@ __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsig
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff_bytes, soff_bytes, 0, 0);
 }
 
+// device-scope 64-bit fetch-and-add (the clock probe's sums)
+__device__ __forceinline__ unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+
 namespace eeg {
 // Fast activations for the recurrent epilogues: v_exp_f32 / v_rcp_f32 (1 ulp each); absolute
 // error of sigmoid/tanh ~2e-7, far inside the 1e-4 parity budget (tests assert 2e-5).

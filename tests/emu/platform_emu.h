@@ -48,6 +48,12 @@ __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsig
     memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
 }
 
+__device__ __forceinline__ unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) {
+    const unsigned long long o = *p;      // fibers run one at a time
+    *p = o + v;
+    return o;
+}
+
 namespace eeg {
 __device__ __forceinline__ float fast_exp(float x) { return expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
