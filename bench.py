@@ -482,15 +482,25 @@ def main():
         log(f"streamed inputs: {streamed['ms_per_step']} ms/step")
 
     prof = {}
+    kernel_clock_mhz = {}
     if not args.no_prof:
         # per-kernel durations: the SAME K steps once more, launched eagerly with a HIP-event pair
         # around every launch on the launch stream (events cannot be read back from a graph replay;
         # the pairs themselves cost ~0.2 ms/step, which is why they are kept out of the timed region)
+        clk = torch.zeros(4, dtype=torch.int64, device=dev)     # in-kernel clock samples of the two-wave recurrent kernels
+        has_clk = hasattr(lib._dll, "eeg_dcrnn_prof_clock_samples") and not lib.is_dev_build
+        if has_clk:
+            lib.call("eeg_dcrnn_prof_clock_samples", ctypes.c_void_p(clk.data_ptr()))
         lib.query("eeg_dcrnn_prof_enable", 1)
         for _ in range(args.steps):
             stepper.step(x, y, lengths, supports)
         torch.cuda.synchronize()
         lib.query("eeg_dcrnn_prof_enable", 0)
+        if has_clk:
+            lib.call("eeg_dcrnn_prof_clock_samples", None)
+            c = clk.tolist()
+            kernel_clock_mhz = {"seq_fwd": round(c[0] / c[1] * 100.0, 1) if c[1] > 0 else None,
+                                "seq_bwd": round(c[2] / c[3] * 100.0, 1) if c[3] > 0 else None}
         buf = ctypes.create_string_buffer(1 << 16)
         lib.call("eeg_dcrnn_prof_report", buf, len(buf))
         for line in buf.value.decode().strip().splitlines():
@@ -584,18 +594,25 @@ def main():
                         "frac": round(v["work"] / (v["ms_per_step"] * 1e-3) / (PEAK_HBM_GBS * 1e9 if v["bound"] == "hbm" else PEAK_MFMA_F32_TFLOPS * 1e12), 4)}
                     for k, v in classes_ms.items()}
         flops = sum(v for k, v in work.items() if "diffuse" not in k and k != "corr_gram" and not k.endswith("_persist"))
-        held = (sclk_mhz / PEAK_CLOCK_MHZ) if sclk_mhz else None
-        if held:
-            for v in kernels.values():
-                if v.get("bound") == "mfma":
-                    v["frac_at_held_clock"] = round(v["frac"] / held, 4)
+        # frac_at_held_clock: the fraction of the cycles the chip actually ran.  For the two-wave recurrent kernels the clock is
+        # sampled INSIDE the kernel (eeg_dcrnn_prof_clock_samples), for the others by the MFMA-burn probe behind the timed steps.
+        # In steady state both read 2.37-2.42 GHz (the peak is a 2.4 GHz figure); a process that has just started runs its first
+        # tens of milliseconds at 1.9-2.2 GHz, which is what the few-step PMC passes see (profiles/README.md) and what first5_ms shows.
+        for k, v in kernels.items():
+            if v.get("bound") != "mfma":
+                continue
+            mhz = kernel_clock_mhz.get(k) or sclk_mhz
+            if mhz:
+                v["clock_mhz"] = mhz
+                v["clock_source"] = "in-kernel sample" if kernel_clock_mhz.get(k) else "MFMA-burn probe behind the step"
+                v["frac_at_held_clock"] = round(v["frac"] * PEAK_CLOCK_MHZ / mhz, 4)
         roofline = {"kernel": dom, "symbol": d.get("symbol"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                     "unit": d["unit"], "frac": d["frac"],
                     # the MFMA peak is a 2.4 GHz figure; the part holds less under sustained fp32 matrix load.  frac_at_held_clock =
                     # frac x 2400 / (shader clock measured right behind the last timed step): the share of the cycles the chip
                     # actually ran.  `frac` (against the spec-sheet peak) stays the reported figure.
-                    "shader_clock_mhz_under_load": sclk_mhz,
-                    "frac_at_held_clock": d.get("frac_at_held_clock"),
+                    "shader_clock_mhz_under_load": sclk_mhz, "kernel_clock_mhz": kernel_clock_mhz or None,
+                    "frac_at_held_clock": d.get("frac_at_held_clock"), "clock_source": d.get("clock_source"),
                     "traffic": (traffic or {}).get(dom), "traffic_note": traffic_note, "avg_launch_ms": d["avg_launch_ms"],
                     "top_class": max(by_class, key=lambda k: by_class[k]["ms_per_step"]), "by_class": by_class,
                     "kernels": kernels,

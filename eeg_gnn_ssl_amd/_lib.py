@@ -42,6 +42,7 @@ _SIGNATURES = {
     "eeg_dcrnn_prof_enable": (c_int, [c_int]),
     "eeg_dcrnn_prof_report": (c_int, [ctypes.c_char_p, c_size_t]),
     "eeg_dcrnn_prof_clock_probe": (c_int, [_FP, c_void_p]),
+    "eeg_dcrnn_prof_clock_samples": (c_int, [_FP]),
     "eeg_dcrnn_hop_polys": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_fft_features": (c_int, [_FP, c_int, c_int, c_int, c_int, _FP, _FP, c_float, c_float, _FP, _FP, c_void_p]),
     "eeg_dcrnn_corr_graph_ws_floats": (c_size_t, [c_int, c_int]),

@@ -35,9 +35,19 @@ thread_local char g_err[512] = "";
 long long* g_seq_probe = nullptr;  // see eeg_dcrnn_set_seq_probe
 int g_tune[24] = {0};               // see eeg_dcrnn_set_tuning
 #else
-constexpr long long* g_seq_probe = nullptr;
 constexpr int g_tune[24] = {0};
 #endif
+
+long long* g_clock_samples = nullptr;   // eeg_dcrnn_prof_clock_samples (measurement hook, like the event recorder)
+// the `probe` argument of the recurrent launches: the dev build's phase probe (which selects the probe instantiations), else the
+// product's clock-sample buffer (4 x int64; dev builds leave it alone: a non-null probe means 32 slots per wave there)
+long long* seq_probe_arg() {
+#if defined(EEG_DEV)
+    return g_seq_probe;
+#else
+    return g_clock_samples;
+#endif
+}
 
 int fail(const char* fmt, ...) {
     va_list ap;
@@ -561,6 +571,10 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(long long ticks, long 
     }
 }
 }  // namespace
+int eeg_dcrnn_prof_clock_samples(int64_t* buf4) {
+    g_clock_samples = reinterpret_cast<long long*>(buf4);
+    return 0;
+}
 int eeg_dcrnn_prof_clock_probe(int64_t* out2, void* stream) {
     if (out2 == nullptr) return fail("prof_clock_probe: null output");
     // 200 us of full-chip fp32-MFMA load; the caller zeroes out2 (3 x int64) first
@@ -664,7 +678,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
-                 (size_t)(d->T + 1) * state, d->T, d->B, d->N, d->act, g_seq_probe};
+                 (size_t)(d->T + 1) * state, d->T, d->B, d->N, d->act, seq_probe_arg()};
     a.variant = g_tune[12] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 12 = 1: off)
     return seq_fwd(H, M, a, st);
 }
@@ -688,7 +702,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     // 1. BPTT through the recurrence: dXW = [dR|dU|dC] per step, dh0, per-clip bias partials
     SeqBwdArgs a{Hext + state, Hext, Rs, Us, Cs, dHseq, d_at_end, d_at_len,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
-                 dXW, dh0, dbias, d->T, d->B, N, d->act, g_seq_probe};
+                 dXW, dh0, dbias, d->T, d->B, N, d->act, seq_probe_arg()};
     a.variant = g_tune[13] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 13 = 1: off)
     if (seq_bwd(H, M, a, st)) return 1;
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);

@@ -223,14 +223,33 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
 // branch directly behind an MFMA chain lets the compiler sink the first VALU read of the MFMA
 // result below the branch, where its hazard recognizer no longer pads the XDL-write -> VALU-read
 // wait states (observed on gfx950 / ROCm 7.2: components 2,3 of the accumulator read stale).
+// Clock sample of a product launch (eeg_dcrnn_prof_clock_samples): ONE lane of the chip reads the shader-clock and the 100 MHz
+// real-time counters in front of and behind its time loop and adds the differences to clk[0] / clk[1] -- the clock the part holds
+// INSIDE this kernel (2.37-2.39 GHz in steady state, 1.9-2.2 GHz while a fresh process ramps up).  Outside the step loop.
+struct ClockSample {
+    long long c0, r0;
+    __device__ __forceinline__ void begin(const long long* clk, bool me) {
+        if (clk != nullptr && me) { c0 = cycle_now(); r0 = realtime_now(); }
+    }
+    __device__ __forceinline__ void end(long long* clk, bool me) {
+        if (clk != nullptr && me) {
+            atomic_add_u64(reinterpret_cast<unsigned long long*>(clk), (unsigned long long)(cycle_now() - c0));
+            atomic_add_u64(reinterpret_cast<unsigned long long*>(clk) + 1, (unsigned long long)(realtime_now() - r0));
+        }
+    }
+};
+
 template <bool ON>
 struct PhaseProbe {
     long long acc[8];
     long long last;
+    long long rt[4];            // chip-wide 100 MHz counter at kernel entry / first step / behind the last step / kernel exit
     __device__ __forceinline__ void start() {
         if (ON) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = 0;
+            rt[0] = realtime_now();
+            rt[1] = rt[2] = rt[3] = 0;
             last = cycle_now();
         }
     }
@@ -241,12 +260,19 @@ struct PhaseProbe {
             last = t;
         }
     }
+    __device__ __forceinline__ void stamp(int k) {
+        if (ON) rt[k] = realtime_now();
+    }
     __device__ __forceinline__ void dump(long long* p, int slot0) {
         if (ON) {
+            rt[3] = realtime_now();
             if (p != nullptr && (threadIdx.x & 63) == 0) {
                 long long* d = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 32 + slot0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) d[i] = acc[i];
+                long long* e = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 32 + 16 + slot0 / 2;     // 16..19 forward, 20..23 backward
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = rt[i];
             }
         }
     }
@@ -549,6 +575,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             nxc = wbuf_ld4(bx, oxw0 + 2 * H, 0u);
         };
         fetch_xw(0);
+        pp.stamp(1);
+        pp.last = PROBE ? cycle_now() : 0;
+        ClockSample cs;
+        const bool cs_me = !PROBE && b == 0 && tid == 0;         // (the probe instantiation uses `probe` for its own records)
+        cs.begin(probe, cs_me);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
             // the accumulators start from the hoisted pre-activations (no zero fill, no add behind the GEMM); the
@@ -603,6 +634,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);
             pp.mark(6);
         }
+        cs.end(probe, cs_me);
+        pp.stamp(2);
     } else {
         f32x4 nxu0;
         float nxu1, nxc1;
@@ -1147,6 +1180,11 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     float dhn1 = 0.f;                                               // ... of node 16 + lg
     EEG_LDS_BARRIER();                                              // (3) of an imaginary step T: first coefficients, DP
     const wbuf_t bX = make_wbuf(dXW);
+    pp.stamp(1);
+    pp.last = PROBE ? cycle_now() : 0;
+    ClockSample cs;
+    const bool cs_me = !PROBE && b == 0 && tid == 0;
+    cs.begin(probe == nullptr ? nullptr : probe + 2, cs_me);
     for (int t = T - 1; t >= 0; --t) {
         const unsigned sx = (unsigned)(((size_t)t * B + b) * N * (3 * H));
         // ---- E1: g = A's elementwise part + role B's GEMM2 of the step before (+ external gradient, added by B)
@@ -1211,6 +1249,8 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
         EEG_SETPRIO(3);
         pp.mark(6);
     }
+    cs.end(probe == nullptr ? nullptr : probe + 2, cs_me);
+    pp.stamp(2);
     // ---- epilogue: dh0; role B reduces the bias sums
     __syncthreads();                                                // all waves done with EG
     if (dh0 != nullptr) {

@@ -24,6 +24,12 @@ int eeg_dcrnn_prof_report(char* buf, size_t cap);
  * load at that point of the stream.  bench.py launches it right behind the timed steps (outside the timed region): the MFMA peak
  * the roofline fractions are priced against is a 2.4 GHz figure (`frac_at_held_clock`). */
 int eeg_dcrnn_prof_clock_probe(int64_t* out2, void* stream);
+/* buf4 (device, 4 x int64, zeroed by the caller; NULL switches it off again): while set, every launch of the two-wave recurrent
+ * kernels adds {shader-clock cycles, 100 MHz ticks} of ONE lane's time loop to buf4[0..1] (forward) / buf4[2..3] (backward):
+ * cycles / ticks * 100 = the clock in MHz the part holds INSIDE those kernels (steady state on the boxes of round 4: 2.37-2.39 GHz
+ * against the 2.4 GHz the MFMA peak is quoted at; a process that has just started runs its first tens of milliseconds at
+ * 1.9-2.2 GHz -- the ramp behind the slower first steps of a fresh bench run).  Process-global like the event recorder. */
+int eeg_dcrnn_prof_clock_samples(int64_t* buf4);
 
 #ifdef __cplusplus
 }

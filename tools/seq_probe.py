@@ -46,3 +46,17 @@ for title, off, names in (("seq_fwd", 0, names_f), ("seq_bwd", 8, names_b)):
         v = p[:, :, off + k] / t_len
         print(f"   {nm:22s} mean {v.mean().item():8.0f}  min {v.min().item():8.0f}  max {v.max().item():8.0f}   per-wave means "
               + " ".join(f"{v[:, w].mean().item():7.0f}" for w in range(4)))
+
+# chip-wide 100 MHz stamps of the chain waves: kernel entry / first step / behind the last step / kernel exit
+for title, off in (("seq_fwd", 16), ("seq_bwd", 20)):
+    r = p[:, :, off:off + 4]
+    if float(r[:, :, 1].min()) <= 0:
+        continue
+    t0 = r[:, :, 0].min()
+    pro = (r[:, :, 1] - r[:, :, 0]) / 100.0
+    loop = (r[:, :, 2] - r[:, :, 1]) / 100.0
+    epi = (r[:, :, 3] - r[:, :, 2]) / 100.0
+    cyc = p[:, :, (0 if off == 16 else 8):(8 if off == 16 else 16)].sum(-1)
+    print(f"{title}: prologue {pro.mean().item():6.1f} us (max {pro.max().item():.1f}), time loop {loop.mean().item():6.1f} us, epilogue {epi.mean().item():5.1f} us; "
+          f"first entry -> last exit {(r[:, :, 3].max() - t0).item() / 100.0:6.1f} us, entry spread {((r[:, :, 0].max() - t0) / 100.0).item():.1f} us; "
+          f"shader clock inside the loop {(cyc / (loop * 1e-6)).mean().item() / 1e6:7.1f} MHz")
