@@ -178,8 +178,6 @@ def kernel_sources_sha256():
     h = hashlib.sha256()
     for d in (os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc"), os.path.join(ROOT, "include")):
         for f in sorted(os.listdir(d)):
-            if f == "torch_ops.cpp":            # host-only operator shim (libeeg_dcrnn_torch.so), not part of the HIP library
-                continue
             if f.endswith((".h", ".cpp", ".hip")) or f == "Makefile":
                 h.update(f.encode())
                 h.update(open(os.path.join(d, f), "rb").read())

@@ -674,34 +674,3 @@ def test_lengths_out_of_range_agree_between_forward_and_backward():
 
 def test_batch_major_input_without_copy(adj3d):
     ps.check_batch_major_input(DEV, adj3d)
-
-
-def test_cpp_operator_library_equals_python_operators(adj3d):
-    """torch.ops.eeg_dcrnn_cpp.* (TORCH_LIBRARY shim over the C ABI) against torch.ops.eeg_dcrnn.* on the same inputs:
-    both call the same C entry points, so the results are identical bit for bit (the Python operators are the ones the
-    oracle parity tests of this file pin)."""
-    from eeg_gnn_ssl_amd import native_ops, ops
-    cpp = native_ops.load()
-    g = torch.Generator().manual_seed(5)
-    b, n, f, o, k = 37, 19, 164, 128, 2
-    sup = [torch.rand(b, n, n, generator=g).to(DEV), torch.rand(n, n, generator=g).to(DEV)]
-    p_py, pb = ops.hop_polys(sup, k, b)
-    p_cpp = cpp.hop_polys(sup, k, b)
-    assert torch.equal(p_py, p_cpp)
-    x = torch.randn(b, n, f, generator=g).to(DEV)
-    m = p_py.shape[1] + 1
-    w = (0.1 * torch.randn(f * m, o, generator=g)).to(DEV)
-    bias = torch.randn(o, generator=g).to(DEV)
-    y_py = torch.ops.eeg_dcrnn.dconv(x, p_py, pb, w, bias)
-    y_cpp = cpp.dconv(x, p_cpp, pb, w, bias)
-    assert torch.equal(y_py, y_cpp)
-    dout = torch.randn(b, n, o, generator=g).to(DEV)
-    for a, c in zip(torch.ops.eeg_dcrnn.dconv_bwd(dout, x, p_py, pb, w, True), cpp.dconv_bwd(dout, x, p_cpp, pb, w, True)):
-        assert torch.equal(a, c)
-    xs = torch.randn(8 * b, n, 100, generator=g).to(DEV)
-    assert torch.equal(torch.ops.eeg_dcrnn.diffusion_hops(xs, p_py, pb, b), cpp.diffusion_hops(xs, p_cpp, pb, b))
-    h, fin = 64, 100
-    wg = torch.randn((fin + h) * m, 2 * h, generator=g).to(DEV)
-    wc = torch.randn((fin + h) * m, h, generator=g).to(DEV)
-    bg, bc = torch.randn(2 * h, generator=g).to(DEV), torch.randn(h, generator=g).to(DEV)
-    assert torch.equal(torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m), cpp.pack_cell(wg, bg, wc, bc, fin, h, m))
