@@ -21,9 +21,12 @@ import os
 import sys
 import time
 
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
     # the CPU baseline leg (oracle on the host cores) is reported with pinned threads: its rate moved 131.9 <-> 162.7 clips/s
     # between boxes of the pool with floating threads.  Must be set before the OpenMP runtime starts (= before torch).
+    # Only when run as the benchmark: `import bench` (tests, smoke) must not touch the environment -- a process that imports this
+    # module after torch and later loads a second OpenMP runtime (scikit-learn's) ends up with every thread bound to the same
+    # cores, and its torch-eager code crawls (the CPU test suite lost half an hour in one oracle test to exactly that).
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
 

@@ -90,9 +90,12 @@ constexpr int rem_ahead(int i) {
     return l;
 }
 
-template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false, bool TWOPASS = false, bool L1 = false>
+// QB (TWOPASS only): the stream starts at quad QB -- the quads before it were run earlier by mfma_tile_quads, whose chain state comes
+// in through `carry` (carry[0..3] = the four 4x4x1 chains, carry[4] = the second 16x16x4 chain; acc[0][0] holds the first).
+template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false, bool TWOPASS = false, bool L1 = false, int QB = 0>
 __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
-                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch) {
+                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch,
+                                             const f32x4* carry = nullptr) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
     static_assert(MODE == 0 || REM4, "split modes exist for the 4x4x1 remainder only");
     static_assert(!L1 || REM4, "the one-value-per-lane remainder layout exists for the 4x4x1 remainder only");
@@ -123,21 +126,26 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
         // A wave that has the matrix pipe to itself (role B's dR half in window 2 of the BPTT kernel): all 16x16x4 MFMAs of
         // the GEMM, then all its 4x4x1 MFMAs -- one change of shape (~43 cycles) instead of one per quad.
         static_assert(REM4 && NT == 1, "two-pass stream: one column tile, 4x4x1 remainder");
-        constexpr int N16 = DO16 ? NQ : 0, N4 = DO4 ? NQ : 0, NI = N16 + N4;
+        constexpr int N16 = DO16 ? NQ - QB : 0, N4 = DO4 ? NQ - QB : 0, NI = N16 + N4;
+        if (QB > 0 && carry != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rem[0][j] = carry[j];
+            alt[0] = carry[4];
+        }
         float4 xb[NI];
         static_for<0, rem_ahead<N16, N4>(0) + 1>([&](auto L) __attribute__((always_inline)) {
             constexpr int l = decltype(L)::value;
-            xb[l] = l < N16 ? frag(p0, s0, l) : frag(p1, s1, l - N16);
+            xb[l] = l < N16 ? frag(p0, s0, QB + l) : frag(p1, s1, QB + l - N16);
         });
         static_for<0, NI>([&](auto IT) __attribute__((always_inline)) {
             constexpr int it = decltype(IT)::value;
             constexpr int lo = it > 0 ? rem_ahead<N16, N4>(it > 0 ? it - 1 : 0) + 1 : 0, hi = it > 0 ? rem_ahead<N16, N4>(it) + 1 : 0;
             static_for<lo, hi>([&](auto L) __attribute__((always_inline)) {
                 constexpr int l = decltype(L)::value;
-                xb[l] = l < N16 ? frag(p0, s0, l) : frag(p1, s1, l - N16);
+                xb[l] = l < N16 ? frag(p0, s0, QB + l) : frag(p1, s1, QB + l - N16);
             });
             EEG_SCHED_FENCE();
-            constexpr int q = it < N16 ? it : it - N16;
+            constexpr int q = QB + (it < N16 ? it : it - N16);
             constexpr int qw4 = 4 * (WQ ? qmap(q) : q);
             const float x[4] = {xb[it].x, xb[it].y, xb[it].z, xb[it].w};
 #pragma unroll
@@ -215,6 +223,39 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
             if (lr < 4) acc[i][1] += s;
         }
         EEG_WAVE_SYNC();        // the next call may overwrite the scratch
+    }
+}
+
+// Quads [Q0, Q1) of a one-column-tile GEMM over a swizzled tile with the accumulator chains held by the caller: acc / alt = the two
+// 16x16x4 chains of nodes 0..15, rem[4] = the four 4x4x1 chains of the remainder (not reduced here).  Lets a wave run a slice
+// of a GEMM in one window and the rest in another (the hop-0 slot of the next step's update gate: seq_fwd2_kernel, role B).
+template <int NKS, int Q0, int Q1>
+__device__ __forceinline__ void mfma_tile_quads(const float* __restrict__ X, int stride, int lane, int lr, int lg, const float (&w)[NKS],
+                                                f32x4& acc, f32x4& alt, f32x4 (&rem)[4]) {
+    const int s0 = lg ^ sigma4(lr), s1 = lg ^ sigma4(lane & 3);
+    const float* p0 = X + lr * stride;
+    const float* p1 = X + (16 + (lane & 3)) * stride;
+    auto frag = [&](const float* rowp, int sx, int q) {
+        return *reinterpret_cast<const float4*>(rowp + 64 * (q >> 2) + 4 * ((4 * (q & 3)) ^ sx));
+    };
+    if constexpr (Q0 >= Q1) return;
+    float4 a0 = frag(p0, s0, Q0), a1 = frag(p1, s1, Q0);
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+        float4 n0 = a0, n1 = a1;
+        if (q + 1 < Q1) { n0 = frag(p0, s0, q + 1); n1 = frag(p1, s1, q + 1); }
+        EEG_SCHED_FENCE();
+        const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j & 1) alt = mfma16(w[4 * q + j], x0[j], alt);
+            else acc = mfma16(w[4 * q + j], x0[j], acc);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rem[j] = mfma4(x1[j], w[4 * q + j], rem[j]);
+        EEG_SCHED_FENCE();
+        a0 = n0;
+        a1 = n1;
     }
 }
 
@@ -580,6 +621,12 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         ClockSample cs;
         const bool cs_me = !PROBE && b == 0 && tid == 0;         // (the probe instantiation uses `probe` for its own records)
         cs.begin(probe, cs_me);
+        // Like role B's update gate (below), the hop-0 slot of the NEXT step's r GEMM runs ahead, behind this wave's node mix in the
+        // third window (its LDS writes drain meanwhile); the two-pass stream of the other slots picks the chains up (QB / carry).
+        constexpr int QSA = KS / 4 / M;
+        f32x4 rc[5] = {zero4, zero4, zero4, zero4, zero4};
+        f32x4 ra = zero4;
+        bool pre_r = false;
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
             // the accumulators start from the hoisted pre-activations (no zero fill, no add behind the GEMM); the
@@ -591,7 +638,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
 
             // all 16x16x4 MFMAs of the r GEMM, then all its 4x4x1 MFMAs (TWOPASS: one change of MFMA shape instead of one per quad;
             // round 4, with the register-reduced remainder: seq_fwd 0.527 -> 0.512 ms; the same order for role B's u GEMM loses)
-            mfma_nodes32<1, KS, true, 0, 0, false, true, true>(A, KAP, lane, lr, lg, w0, ar, RS);
+            if (M > 1 && pre_r) {
+                ar[0][0] = ra;
+                mfma_nodes32<1, KS, true, 0, 0, false, true, true, (M > 1 ? QSA : 0)>(A, KAP, lane, lr, lg, w0, ar, RS, rc);
+            } else
+                mfma_nodes32<1, KS, true, 0, 0, false, true, true>(A, KAP, lane, lr, lg, w0, ar, RS);
             pp.mark(1);
             {
                 const f32x4 rg = sigmoid4_(ar[0][0]);
@@ -632,6 +683,14 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             pp.mark(5);
             EEG_LDS_BARRIER();                                        // (3) h' complete (rows 16..19 come from role B)
             if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);
+            pre_r = M > 1 && t + 1 < T;
+            if (pre_r) {      // hop-0 slot of the next step's r GEMM (seq_fwd -2.8 %, profiles/r04_d_*)
+                ra = nxr0;
+                rc[0] = rc[1] = rc[2] = rc[3] = rc[4] = zero4;
+                f32x4 rr4[4] = {zero4, zero4, zero4, zero4};
+                mfma_tile_quads<KS, 0, QSA>(A, KAP, lane, lr, lg, w0[0], ra, rc[4], rr4);
+                rc[0] = rr4[0]; rc[1] = rr4[1]; rc[2] = rr4[2]; rc[3] = rr4[3];
+            }
             pp.mark(6);
         }
         cs.end(probe, cs_me);
@@ -646,13 +705,31 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             nxc1 = wbuf_ld(bx, oxw1 + 2 * H, 0u);
         };
         fetch_x(0);
+        // The hop-0 slot of the NEXT step's update-gate GEMM (the first K quads: h' itself, complete at barrier 3) runs in the third
+        // window, where role A mixes h' and the matrix pipe is otherwise idle; the other hop slots follow behind barrier (1).
+        // (Round 3 measured this move as a loss; with the register-reduced remainder it wins: seq_fwd -3..4 %, profiles/r04_d_*.)
+        constexpr int QS = KS / 4 / M;                               // quads of one hop slot
+        f32x4 ua = zero4, ub = zero4, urem[4] = {zero4, zero4, zero4, zero4};
+        float ux1 = 0.f;
+        bool pre = false;
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
             f32x4 au[1][2] = {{nxu0, (f32x4){nxu1, 0.f, 0.f, 0.f}}}, ac[1][2] = {{zero4, (f32x4){nxc1, 0.f, 0.f, 0.f}}};
             const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1)
+            if (!pre) {                                               // first step: nothing was run ahead
+                ua = nxu0; ub = zero4; ux1 = nxu1;
+                urem[0] = urem[1] = urem[2] = urem[3] = zero4;
+            }
             if (t + 1 < T) fetch_x(t + 1);
-            mfma_nodes32<1, KS, true, 0, 0, false, false, true>(A, KAP, lane, lr, lg, w0, au, RS);
+            if (!pre) mfma_tile_quads<KS, 0, QS>(A, KAP, lane, lr, lg, w0[0], ua, ub, urem);
+            mfma_tile_quads<KS, QS, KS / 4>(A, KAP, lane, lr, lg, w0[0], ua, ub, urem);
+            {
+                f32x4 tt = (urem[0] + urem[1]) + (urem[2] + urem[3]);
+                EEG_PIN(tt);
+                au[0][0] = ua + ub;
+                au[0][1][0] = ux1 + rem4_reduce(tt);
+            }
             float u1;                                                // node 16 + lg: stays in a register for the blend
             {
                 const f32x4 u0 = sigmoid4_(au[0][0]);
@@ -677,6 +754,13 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 }
             }
             EEG_LDS_BARRIER();                                        // (3)
+            pre = t + 1 < T;
+            if (pre) {                                                // hop-0 slot of step t+1's update gate, from h' (slot 0 of A)
+                ua = nxu0; ub = zero4; ux1 = nxu1;
+                urem[0] = urem[1] = urem[2] = urem[3] = zero4;
+                // (nxc1 of step t+1 stays in its register until the top of the next iteration; the registers of nxu are free now)
+                mfma_tile_quads<KS, 0, QS>(A, KAP, lane, lr, lg, w0[0], ua, ub, urem);
+            }
         }
     }
     }   // clips of this workgroup

@@ -10,6 +10,7 @@
 //   C/D: lane l, reg r holds element (row = 4*(l>>4) + r, col = l&15);  D = C + sum_k A.B as an
 //   fmaf chain in k order.
 #pragma once
+#include <setjmp.h>
 #include <ucontext.h>
 
 #include <cmath>
@@ -32,7 +33,9 @@ struct dim3 {
 };
 enum State { RUNNABLE, WAIT_BLOCK, WAIT_WAVE, DONE };
 struct Fiber {
-    ucontext_t ctx;
+    ucontext_t ctx;              // first entry only (makecontext); every later switch is _setjmp / _longjmp: swapcontext costs two
+    jmp_buf jb;                  // sigprocmask system calls per switch, and a kernel switches fibers millions of times
+    bool started = false;
     char* stack = nullptr;
     State st = RUNNABLE;
     unsigned tid = 0;
@@ -51,8 +54,10 @@ struct Ctx {
 };
 extern Ctx g;
 extern Fiber* cur;
-extern ucontext_t sched_ctx;
-inline void yield_to_sched() { swapcontext(&cur->ctx, &sched_ctx); }
+extern jmp_buf sched_jb;
+inline void yield_to_sched() {
+    if (_setjmp(cur->jb) == 0) _longjmp(sched_jb, 1);
+}
 inline void sync_block() {
     cur->st = WAIT_BLOCK;
     yield_to_sched();
@@ -141,13 +146,26 @@ inline hipError_t hipMemcpyAsyncD2D(void* d, const void* s, size_t n, hipStream_
 namespace emu {
 Ctx g;
 Fiber* cur = nullptr;
-ucontext_t sched_ctx;
+jmp_buf sched_jb;
 static const std::function<void()>* body_ptr = nullptr;
 static void trampoline() {
     (*body_ptr)();
     cur->st = DONE;
-    swapcontext(&cur->ctx, &sched_ctx);
+    _longjmp(sched_jb, 1);
 }
+// run fiber f until it yields (or finishes)
+static void resume(Fiber& f) {
+    if (_setjmp(sched_jb) == 0) {
+        if (!f.started) {
+            f.started = true;
+            setcontext(&f.ctx);          // does not return
+        }
+        _longjmp(f.jb, 1);
+    }
+}
+// fiber stacks / LDS image: allocated once and reused (a value-initialised vector would clear 128 MB per launch)
+static char* g_stacks = nullptr;
+static size_t g_stacks_bytes = 0;
 static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
     unsigned nsync = 0;
     for (unsigned l = 0; l < 64; ++l) nsync += f[w0 + l].sync_only;
@@ -239,7 +257,13 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     }
     const size_t STACK = 256 * 1024;
     std::vector<Fiber> fibers(nt);
-    std::vector<char> stacks((size_t)nt * STACK);
+    if (g_stacks_bytes < (size_t)nt * STACK) {
+        free(g_stacks);
+        g_stacks_bytes = (size_t)nt * STACK;
+        g_stacks = static_cast<char*>(malloc(g_stacks_bytes));
+        if (g_stacks == nullptr) { fprintf(stderr, "emu: out of memory for fiber stacks\n"); abort(); }
+    }
+    char* const stacks = g_stacks;
     std::vector<char> smem(smem_bytes + 64);
     body_ptr = &body;
     g.bDim = block;
@@ -254,10 +278,11 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
                     Fiber& f = fibers[t];
                     f.st = RUNNABLE;
                     f.tid = t;
+                    f.started = false;
                     getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = stacks.data() + (size_t)t * STACK;
+                    f.ctx.uc_stack.ss_sp = stacks + (size_t)t * STACK;
                     f.ctx.uc_stack.ss_size = STACK;
-                    f.ctx.uc_link = &sched_ctx;
+                    f.ctx.uc_link = nullptr;
                     makecontext(&f.ctx, (void (*)())trampoline, 0);
                 }
                 unsigned done = 0;
@@ -269,7 +294,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
                         cur = &f;
                         g.bIdx = dim3(bx, by, bz);
                         g.tIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                        swapcontext(&sched_ctx, &f.ctx);
+                        resume(f);
                         progressed = true;
                         if (f.st == DONE) ++done;
                     }
