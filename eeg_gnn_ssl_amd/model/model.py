@@ -139,13 +139,18 @@ class DCRNNModel_classification(_FusedDropout, nn.Module):
     """Seizure detection / classification model (reference: model.py:208-272).
     forward(input_seq (B,T,N,Din), seq_lengths (B,), supports) -> (B, num_classes) logits."""
 
-    def __init__(self, args, num_classes, device=None):
+    def __init__(self, args, num_classes, device=None, strict_lengths=False):
+        """strict_lengths: check `seq_lengths` on the host like the reference does (`utils.last_relevant_pytorch` moves them to
+        the CPU and gathers at len-1: a length outside 1..T raises there, utils.py:346-357).  Off by default: the check costs the
+        device-to-host synchronisation the reference pays every step; without it an out-of-range length selects the clamped step,
+        in forward and backward alike."""
         super().__init__()
         self.num_nodes = args.num_nodes
         self.num_rnn_layers = args.num_rnn_layers
         self.rnn_units = args.rnn_units
         self._device = device
         self.num_classes = num_classes
+        self.strict_lengths = bool(strict_lengths)
         self.encoder = DCRNNEncoder(input_dim=args.input_dim, max_diffusion_step=args.max_diffusion_step,
                                     hid_dim=args.rnn_units, num_nodes=args.num_nodes,
                                     num_rnn_layers=args.num_rnn_layers,
@@ -156,6 +161,8 @@ class DCRNNModel_classification(_FusedDropout, nn.Module):
 
     def forward(self, input_seq, seq_lengths, supports):
         b = input_seq.shape[0]
+        if self.strict_lengths:
+            utils.check_seq_lengths(seq_lengths, input_seq.shape[1])
         x = input_seq.transpose(0, 1)                         # (T,B,N,Din); made contiguous by the op
         _, _, last = self.encoder.run(x, None, supports, lengths=seq_lengths, want_finals=False)
         drop_p = self._drop_p()

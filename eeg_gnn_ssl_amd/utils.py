@@ -141,6 +141,17 @@ def masked_mse_loss(y_pred, y_true, mask_val=0.0):
     return torch.sqrt(_masked(y_pred, y_true, mask_val, lambda d: d * d).mean())
 
 
+def check_seq_lengths(seq_lengths, max_len):
+    """The reference's error behaviour for bad `seq_lengths` (utils.py:346-357: `output.gather(1, lengths - 1)` on host-side
+    lengths raises for a length outside 1..T), as an explicit host-side check (one device-to-host synchronisation)."""
+    ln = torch.as_tensor(seq_lengths).detach().to("cpu", torch.int64)
+    bad = (ln < 1) | (ln > int(max_len))
+    if bool(bad.any()):
+        i = int(torch.nonzero(bad)[0])
+        raise RuntimeError(f"index {int(ln[i]) - 1} is out of bounds for dimension 1 with size {int(max_len)} "
+                           f"(seq_lengths[{i}] = {int(ln[i])}, valid: 1..{int(max_len)})")
+
+
 def compute_regression_loss(y_true, y_predicted, standard_scaler=None, device=None, loss_fn="mae",
                             mask_val=0.0, is_tensor=True):
     """reference utils.py:460-495.  Only the exact string 'mae' selects the MAE; the SSL trainer

@@ -110,6 +110,18 @@ def test_product_sources_do_not_know_the_emulator():
     assert '#define EEG_PLATFORM_HEADER "platform.h"' in common and "#include EEG_PLATFORM_HEADER" in common
 
 
+def test_strict_lengths_raise_like_the_reference():
+    """`utils.last_relevant_pytorch` (utils.py:346-357) gathers at len-1 on host-side lengths: out-of-range lengths raise.  The
+    opt-in host check reproduces that (the default path clamps without a host synchronisation)."""
+    import pytest
+    import torch
+    from eeg_gnn_ssl_amd import utils
+    utils.check_seq_lengths(torch.tensor([1, 12, 7]), 12)
+    for bad in ([0, 3], [13, 1], [-2, 5]):
+        with pytest.raises(RuntimeError, match="out of bounds"):
+            utils.check_seq_lengths(torch.tensor(bad), 12)
+
+
 def test_cosine_schedule_matches_torch():
     """utils.cosine_annealing_lr == CosineAnnealingLR(T_max=num_epochs) stepped per epoch (train.py:224,329)."""
     import torch
