@@ -74,8 +74,8 @@ int check_dims(int N, int H, int Fin, int M) {
     if (Fin < 4 || Fin % 4 != 0) return fail("per-node input dim=%d unsupported (must be a positive multiple of 4)", Fin);
     if (!m_supported(M)) return fail("num hop matrices M=%d unsupported (1,2,3,4,5,7)", M);
     // LDS of the BPTT kernel (SeqGeom::bwd_lds_floats): the widest case (H=64, M=7) only fits montages of <= 20 nodes
-    const int ka = M * H, rows = N <= 20 ? 20 : 32, ct = ceil_div(H / 16, 4);
-    const size_t bwd = ((size_t)(M - 1) * kPFloats + (size_t)rows * (lds_stride_x(ka) + lds_stride_x(2 * ka)) + 4 * 2 * ct * kRemTile) * sizeof(float);
+    const int ka = M * H, rows = N <= 20 ? 20 : 32;
+    const size_t bwd = ((size_t)(M - 1) * kPFloats + (size_t)rows * (lds_stride_x(ka) + lds_stride_x(2 * ka))) * sizeof(float);
     if (bwd > kMaxLdsBytes)
         return fail("rnn_units=%d with %d hop matrices and %d nodes needs %zu KB of LDS for the backward pass (160 available)",
                     H, M, N, bwd / 1024);

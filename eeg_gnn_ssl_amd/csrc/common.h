@@ -55,9 +55,6 @@ __host__ __device__ constexpr int sigma4(int r) { return ((r & 1) << 2) ^ (r & 2
 __host__ __device__ constexpr int lds_sw(int row, int col, int stride) {
     return row * stride + ((((col >> 2) & ~15) | (((col >> 2) ^ sigma4(row)) & 15)) << 2) + (col & 3);
 }
-// per-tile stride of the 4x4x1 remainder hand-over scratch: [4 lane groups][4 nodes][16 cols] with the lane groups
-// 80 floats apart (80 = 16 mod 32: the two lane groups of a half-wave write different bank halves)
-constexpr int kRemTile = 4 * 80;
 
 // Reduce-scatter of a 4x4x1 remainder chain inside the wave, no LDS: register r of lane (lr, lg) holds lane group lg's partial of
 // out[node 16 + r][col lr]; the return value of lane (lr, lg) is the complete out[node 16 + lg][col lr] -- every lane ends up with

@@ -51,8 +51,7 @@ struct DecFwdArgs {
 // ---- GEMMs with streamed weights -------------------------------------------------------------------------------
 // acc[i][0] += (weight tile wt[i])^T x X^T for nodes 0..15, issued transposed like mfma_nodes32 (lane: node lr, 4 consecutive
 // columns); remainder nodes 16..19 on v_mfma_f32_4x4x1, reduced in registers to ONE element per lane (mfma_nodes32 L1): lane
-// (lr, lg) gets acc[i][1][0] += out[node 16 + lg][column lr of tile wt[i]]; components 1..3 of acc[i][1] are not touched
-// (`scratch` is unused).
+// (lr, lg) gets acc[i][1][0] += out[node 16 + lg][column lr of tile wt[i]]; components 1..3 of acc[i][1] are not touched.
 // Plain K order (pack index ks = k/4, k = slot*KPP*4 + f): the operand tile has `nslots` hop slots of `slotw` columns of
 // which the first 4*KPP are real; SWZ: the tile is an XOR-swizzled state tile (lds_sw), else a plain [rows][stride] one.
 // The weights of group g+1 (D k-steps x NT tiles, one coalesced dword per lane each) are requested before the MFMAs
@@ -72,7 +71,7 @@ __device__ __forceinline__ void plain_wload(const float* __restrict__ wp, int nc
 template <int NT, int D, bool SWZ, bool PRE = false, bool XP = true>
 __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile, int stride, int slotw, int kpp, int nslots,
                                                   const float* __restrict__ wp, int nct_total, const int (&wt)[NT],
-                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2], float* scratch,
+                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2],
                                                   float (&wa)[D][NT], const float* __restrict__ tile_last = nullptr,
                                                   int stride_last = 0) {
     const int ngroups = nslots * kpp / D;
@@ -160,9 +159,9 @@ __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile
 template <int NT, int D, bool SWZ>
 __device__ __forceinline__ void gemm_stream_plain(const float* __restrict__ tile, int stride, int slotw, int kpp, int nslots,
                                                   const float* __restrict__ wp, int nct_total, const int (&wt)[NT],
-                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2], float* scratch) {
+                                                  int lane, int lr, int lg, f32x4 (&acc)[NT][2]) {
     float wa[D][NT];
-    gemm_stream_plain<NT, D, SWZ, false, false>(tile, stride, slotw, kpp, nslots, wp, nct_total, wt, lane, lr, lg, acc, scratch, wa);
+    gemm_stream_plain<NT, D, SWZ, false, false>(tile, stride, slotw, kpp, nslots, wp, nct_total, wt, lane, lr, lg, acc, wa);
 }
 
 // Same for the recurrent packs (quad-permuted K order, ds_read_b128 fragments of a swizzled state tile): NQ quads
@@ -182,7 +181,7 @@ __device__ __forceinline__ void quad_prefetch(const float* __restrict__ wp, int 
 template <int NT, int NQ, int PD, bool PRE = false, int NTW = NT>
 __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile, int stride, const float* __restrict__ wp,
                                                  int nct_total, const int (&wt)[NT], int lane, int lr, int lg,
-                                                 f32x4 (&acc)[NT][2], float* scratch, float (&w)[PD + 1][4][NTW]) {
+                                                 f32x4 (&acc)[NT][2], float (&w)[PD + 1][4][NTW]) {
     const int s0 = lg ^ sigma4(lr), s1 = lg ^ sigma4(lane & 3);
     const float* p0 = tile + lr * stride;
     const float* p1 = tile + (16 + (lane & 3)) * stride;
@@ -239,9 +238,9 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
 template <int NT, int NQ, int PD>
 __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile, int stride, const float* __restrict__ wp,
                                                  int nct_total, const int (&wt)[NT], int lane, int lr, int lg,
-                                                 f32x4 (&acc)[NT][2], float* scratch) {
+                                                 f32x4 (&acc)[NT][2]) {
     float w[PD + 1][4][NT];
-    gemm_stream_quad<NT, NQ, PD, false>(tile, stride, wp, nct_total, wt, lane, lr, lg, acc, scratch, w);
+    gemm_stream_quad<NT, NQ, PD, false>(tile, stride, wp, nct_total, wt, lane, lr, lg, acc, w);
 }
 
 constexpr int kDecRows = 20;     // node rows of the LDS tiles (montages of at most 20 nodes)
@@ -249,7 +248,7 @@ constexpr int kDecRows = 20;     // node rows of the LDS tiles (montages of at m
 // LDS floats of dec_fwd_persist_kernel<64, M>
 __host__ __device__ constexpr size_t dec_fwd_lds_floats(int M, int L, int Dout) {
     const int H = 64, KAP = M * H, XS = lds_stride_q(M * round_up(Dout, 16));
-    return (size_t)(M - 1) * kPFloats + (size_t)L * kDecRows * KAP + (size_t)kDecRows * (XS > KAP ? XS : KAP) + 4 * 3 * kRemTile
+    return (size_t)(M - 1) * kPFloats + (size_t)L * kDecRows * KAP + (size_t)kDecRows * (XS > KAP ? XS : KAP)
            + (size_t)kDecRows * 64;      // + the dropped copy of the top state the projection reads (swizzled [rows][64])
 }
 
@@ -266,10 +265,8 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
     float* Pl = sm;
     float* A0 = Pl + (M - 1) * kPFloats;            // L state tiles [ROWS][KAP]: slot 0 = h^l, slots m = P_m h^l
     float* XA = A0 + L * ROWS * KAP;                // step-input tile X0 [ROWS][XS] (plain)  |  r*h tile A2 [ROWS][KAP] (swizzled)
-    float* RS0 = XA + ROWS * XK;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
-    float* RS = RS0 + wave * (3 * kRemTile);
-    float* HD = RS0 + 4 * 3 * kRemTile;             // [ROWS][64] swizzled: drop(h^{L-1}_t), written and read only when a.drop.on
+    float* HD = XA + ROWS * XK;                     // [ROWS][64] swizzled: drop(h^{L-1}_t), written and read only when a.drop.on
     const int ct = wave, col = ct * 16 + 4 * lg;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int nct_o = ceil_div(Dout, 16);
@@ -327,9 +324,9 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     ag[i][1] = (f32x4){lp.bias[wt3[i] * 16 + lr], 0.f, 0.f, 0.f};
                 }
                 if (l == 0)
-                    gemm_stream_plain<3, DX, false>(XA, XS, FP, Dout / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag, RS);
+                    gemm_stream_plain<3, DX, false>(XA, XS, FP, Dout / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag);
                 else
-                    gemm_stream_plain<3, 16, true>(A0 + (l - 1) * ROWS * KAP, KAP, H, H / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag, RS);
+                    gemm_stream_plain<3, 16, true>(A0 + (l - 1) * ROWS * KAP, KAP, H, H / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag);
                 // the first quads of the gate / candidate weights are requested before the barrier / the epilogue in front of their GEMM
                 constexpr int PDG = NQ < 6 ? NQ : 6, PDC = NQ < 10 ? NQ : 10;
                 const int wt2[2] = {ct, NCT + ct}, wt1[1] = {ct};
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                 // gate h-part: hops(h^l) x Wg^h
                 {
                     f32x4 g2[2][2] = {{ag[0][0], ag[0][1]}, {ag[1][0], ag[1][1]}};
-                    gemm_stream_quad<2, NQ, PDG, true>(Al, KAP, lp.bhg, NGT, wt2, lane, lr, lg, g2, RS, wqg);
+                    gemm_stream_quad<2, NQ, PDG, true>(Al, KAP, lp.bhg, NGT, wt2, lane, lr, lg, g2, wqg);
                     ag[0][0] = g2[0][0]; ag[0][1] = g2[0][1]; ag[1][0] = g2[1][0]; ag[1][1] = g2[1][1];
                 }
                 quad_prefetch<1, NQ, PDC>(lp.bhc, NCT, wt1, lane, wqc);
@@ -372,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                 // candidate h-part: hops(r*h) x Wc^h
                 {
                     f32x4 c1[1][2] = {{ag[2][0], ag[2][1]}};
-                    gemm_stream_quad<1, NQ, PDC, true>(A2, KAP, lp.bhc, NCT, wt1, lane, lr, lg, c1, RS, wqc);
+                    gemm_stream_quad<1, NQ, PDC, true>(A2, KAP, lp.bhc, NCT, wt1, lane, lr, lg, c1, wqc);
                     ag[2][0] = c1[0][0]; ag[2][1] = c1[0][1];
                 }
                 {
@@ -419,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                         po[i][0] = ld4(a.pbias + wt2[i] * 16 + 4 * lg);
                         po[i][1] = (f32x4){a.pbias[wt2[i] * 16 + lr], 0.f, 0.f, 0.f};
                     }
-                    gemm_stream_plain<2, 16, true>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po, RS);
+                    gemm_stream_plain<2, 16, true>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (i == 1 && !two) continue;
@@ -490,7 +487,7 @@ struct DecBwdArgs {
 __host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) {
     const int H = 64, FS = lds_stride_q(round_up(Dout, 16));
     return (size_t)(M - 1) * kPFloats + (size_t)kDecRows * (M * H + M * 2 * H) + 2 * (size_t)kDecRows * FS
-           + (size_t)L * 4 * 2 * 256 + 4 * 3 * kRemTile;
+           + (size_t)L * 4 * 2 * 256;
 }
 
 template <int H, int M, int DT>
@@ -508,9 +505,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
     float* DO = EG + ROWS * KGP;             // [ROWS][FS]   total gradient of out_t
     float* DX = DO + ROWS * FS;              // [ROWS][FS]   input gradient of layer 0 at step t (feeds dO_{t-1})
     float* DH = DX + ROWS * FS;              // [L][4 waves][2][64 lanes] float4: recurrent gradients dh^l, lane-linear
-    float* RS0 = DH + L * 4 * 2 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
-    float* RS = RS0 + wave * (3 * kRemTile);
     const int ct = wave, col = ct * 16 + 4 * lg;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const size_t state = (size_t)B * N * H;
@@ -604,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
             f32x4 gext[2];
             {
                 f32x4 pa[1][2] = {{zero4, zero4}};
-                gemm_stream_plain<1, DT, false, true>(DO, FS, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, RS, wpt);
+                gemm_stream_plain<1, DT, false, true>(DO, FS, FP, Dout / 4, 1, a.tpack, nct_h, wt1, lane, lr, lg, pa, wpt);
                 gext[0] = pa[0][0];
                 gext[1] = pa[0][1];
                 if (a.drop.on) {      // through the dropout in front of the projection: the forward's mask, recomputed
@@ -670,7 +665,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     f32x4 acc[NT][2];
 #pragma unroll
                     for (int i = 0; i < NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
-                    gemm_stream_quad<NT, NQ, PD, true, 3>(EC, KAP, lp.c1, nct, wtn, lane, lr, lg, acc, RS, wq1);
+                    gemm_stream_quad<NT, NQ, PD, true, 3>(EC, KAP, lp.c1, nct, wtn, lane, lr, lg, acc, wq1);
                     quad_prefetch<NT, 2 * NQ, PD, 3>(lp.c2, nct, wtn, lane, wq2);
                     {
                         const f32x4 drh = acc[0][0], rg = rr[0];         // exact 0 on padding nodes
@@ -695,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
                     __syncthreads();                                     // (2) P_m^T [dR|dU] complete
                     // ---- GEMM2: [dh | dX] += [P_m^T dG]_m @ [Wg^h | Wg^x]^T -> recurrent gradient for step t-1, input gradient
-                    gemm_stream_quad<NT, 2 * NQ, PD, true, 3>(EG, KGP, lp.c2, nct, wtn, lane, lr, lg, acc, RS, wq2);
+                    gemm_stream_quad<NT, 2 * NQ, PD, true, 3>(EG, KGP, lp.c2, nct, wtn, lane, lr, lg, acc, wq2);
                     st4(dhl + l * 2048 + 0 * 256, acc[0][0]);
                     st4(dhl + l * 2048 + 1 * 256, acc[0][1]);
 #pragma unroll

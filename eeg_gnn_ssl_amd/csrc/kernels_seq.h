@@ -38,12 +38,11 @@ struct SeqGeom {
     static constexpr int KG = M * 2 * H, KGP = lds_stride_x(KG), KSG = KG / 4;   // 2H-wide hop tile (bwd)
     static constexpr int NGT = 2 * H / 16, NCT = H / 16;                         // gate / cand col tiles
     static constexpr int GT = ceil_div(NGT, 4), CT = ceil_div(NCT, 4);           // per wave (4 waves)
-    static constexpr int kRemScratch = 4 * 2 * CT * kRemTile;                    // 4 waves x up to 2*CT tiles x [4 groups][4 nodes][16 cols] (REM4 hand-over)
-    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP + kRemScratch; }
+    static constexpr size_t fwd_lds_floats() { return (size_t)(M - 1) * kPFloats + 2 * 32 * KAP; }
     // Node rows of the backward kernel's LDS tiles: 32 (two MFMA node tiles), or -- where 32 rows exceed the
     // 160 KB of a CU (H=64, M=7) and the montage has at most 20 nodes, so that the second tile runs on the
     // 4x4x1 MFMA and only rows 16..19 are ever read -- 20.
-    static constexpr size_t bwd_lds_floats(int rows) { return (size_t)(M - 1) * kPFloats + (size_t)rows * (KAP + KGP) + kRemScratch; }
+    static constexpr size_t bwd_lds_floats(int rows) { return (size_t)(M - 1) * kPFloats + (size_t)rows * (KAP + KGP); }
     static constexpr int bwd_rows(int nks) { return (nks == 5 && bwd_lds_floats(32) * sizeof(float) > kMaxLdsBytes) ? 20 : 32; }
 };
 
@@ -60,9 +59,8 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float
 // of a second 16x16x4 stream (100 % extra matrix work for 3 nodes) it is computed with
 // v_mfma_f32_4x4x1 (16 independent 4x4 outer products per instruction = 25 % extra): block = (lane
 // group lg, column quad), B operand = the SAME weight register, A operand = X[node 16 + (lane&3)][k];
-// register r of a lane is then the lane group's partial of out[node 16 + r][col lr].  The partials
-// are handed through `scratch` (per-wave LDS, NT*256 floats) to the lanes that own these nodes in the
-// tile layout (lane (lr < 4, lg): node 16 + lr, columns 4*lg..4*lg+3), which also sums the 4 groups.
+// register r of a lane is then the lane group's partial of out[node 16 + r][col lr].  The partials are
+// reduce-scattered in registers (L1 below: common.h rem4_reduce), one element of the 4 x 16 remainder tile per lane.
 // MODE (REM4 only): 0 = both node tiles; 1 = only the 16-node tile (acc[.][0]); 2 = only the 4x4x1 remainder
 // (acc[.][1]) -- the two-wave forward kernel splits a GEMM between its waves that way.
 // QM (the two-role BPTT kernel splits its K = M*2H gate GEMM by column half): 0: weight quad q' reads tile quad q';
@@ -94,11 +92,11 @@ constexpr int rem_ahead(int i) {
 // in through `carry` (carry[0..3] = the four 4x4x1 chains, carry[4] = the second 16x16x4 chain; acc[0][0] holds the first).
 template <int NT, int NKS, bool REM4, int MODE = 0, int QM = 0, bool WQ = false, bool TWOPASS = false, bool L1 = false, int QB = 0>
 __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int stride, int lane, int lr, int lg,
-                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], float* scratch,
-                                             const f32x4* carry = nullptr) {
+                                             const float (&w)[NT][NKS], f32x4 (&acc)[NT][2], const f32x4* carry = nullptr) {
     static_assert(NKS % 4 == 0, "K must be a multiple of 16");
     static_assert(MODE == 0 || REM4, "split modes exist for the 4x4x1 remainder only");
     static_assert(!L1 || REM4, "the one-value-per-lane remainder layout exists for the 4x4x1 remainder only");
+    static_assert(!(REM4 && MODE != 1) || L1, "the 4x4x1 remainder always leaves in the one-value-per-lane layout");
     constexpr bool DO16 = MODE != 2, DO4 = REM4 && MODE != 1;
     // swizzled tile (common.h): quad q of row r is the 16-byte piece 16*(q>>2) + ((4*(q&3) + lg) ^ sigma4(r))
     const int s0 = lg ^ sigma4(lr), s1 = REM4 ? (lg ^ sigma4(lane & 3)) : s0;
@@ -124,7 +122,9 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
     for (int i = 0; i < NT; ++i) alt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (TWOPASS) {
         // A wave that has the matrix pipe to itself (role B's dR half in window 2 of the BPTT kernel): all 16x16x4 MFMAs of
-        // the GEMM, then all its 4x4x1 MFMAs -- one change of shape (~43 cycles) instead of one per quad.
+        // the GEMM, then all its 4x4x1 MFMAs -- one change of shape (~43 cycles) instead of one per quad.  It pays in the
+        // two-wave kernels only: in the single-wave kernels (one or two column tiles per wave, M = 5) the same stream measured
+        // 3 % (forward) to 13-30 % (BPTT) SLOWER than the quad-interleaved order (profiles/r04_h_singlewave_twopass.txt).
         static_assert(REM4 && NT == 1, "two-pass stream: one column tile, 4x4x1 remainder");
         constexpr int N16 = DO16 ? NQ - QB : 0, N4 = DO4 ? NQ - QB : 0, NI = N16 + N4;
         if (QB > 0 && carry != nullptr) {
@@ -205,24 +205,6 @@ __device__ __forceinline__ void mfma_nodes32(const float* __restrict__ X, int st
             EEG_PIN(t);                                  // (keeps the three adds packed)
             acc[i][1][0] += rem4_reduce(t);
         }
-    } else if (DO4) {
-        // scratch[i][lg][r][lr] <- partial of (node 16 + r, col lr) (lane groups 80 floats apart);  reader (lr < 4, lg):
-        // sum over the 4 groups of the float4 at [i][g][r = lr][4*lg .. 4*lg+3]
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            f32x4 t = (rem[i][0] + rem[i][1]) + (rem[i][2] + rem[i][3]);
-            EEG_PIN(t);                                  // (keeps the three adds packed: 6 v_pk_add_f32, not 12 v_add_f32)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) scratch[i * kRemTile + lg * 80 + r * 16 + lr] = t[r];
-        }
-        EEG_WAVE_SYNC();
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const float* q = scratch + i * kRemTile + (lr & 3) * 16 + 4 * lg;
-            const f32x4 s = (ld4(q) + ld4(q + 80)) + (ld4(q + 160) + ld4(q + 240));
-            if (lr < 4) acc[i][1] += s;
-        }
-        EEG_WAVE_SYNC();        // the next call may overwrite the scratch
     }
 }
 
@@ -336,7 +318,6 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
     constexpr bool REM4 = NKS == 5;         // at most 20 nodes: the second node tile runs as 4x4x1 MFMAs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = A2 + 32 * KAP + wave * (2 * CT * kRemTile);   // this wave's REM4 hand-over scratch
     const bool save = Rs != nullptr;
 
     // Wave w owns column tiles ct = w + 4*i of r, u, c and h (so gate tiles ct and NCT+ct): the
@@ -445,7 +426,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         pp.mark(0);
 
         // gate GEMM: (2H cols) x (32 nodes), K = M*H
-        mfma_nodes32<2 * CT, KS, REM4, 0, 0, false, false, REM4>(A, KAP, lane, lr, lg, wg, ag, RS);
+        mfma_nodes32<2 * CT, KS, REM4, 0, 0, false, false, REM4>(A, KAP, lane, lr, lg, wg, ag);
         pp.mark(1);
         const wbuf_t bR = make_wbuf((save ? Rs : Hseq) + s * N * H), bRH = make_wbuf((save ? RHs : Hseq) + s * N * H),
                      bU = make_wbuf((save ? Us : Hseq) + s * N * H);
@@ -489,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
         if (t + 1 < T) fetch_xw(t + 1);
 
         // candidate GEMM: (H cols) x (32 nodes), K = M*H
-        mfma_nodes32<CT, KS, REM4, 0, 0, false, false, REM4>(A2, KAP, lane, lr, lg, wc, ac, RS);
+        mfma_nodes32<CT, KS, REM4, 0, 0, false, false, REM4>(A2, KAP, lane, lr, lg, wc, ac);
         pp.mark(4);
         const wbuf_t bH = make_wbuf(Hseq + s * N * H), bC = make_wbuf((save ? Cs : Hseq) + s * N * H);
 #pragma unroll
@@ -559,8 +540,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, wave = wave8 & 3;
     const int lr = lane & 15, lg = lane >> 4;
-    float* RS = A2 + 32 * KAP + wave8 * kRemTile;     // this wave's hand-over scratch (one column tile)
-    float* U = A2 + 32 * KAP + 8 * kRemTile;          // [16][UST] update gate of nodes 0..15 of the current step
+    float* U = A2 + 32 * KAP;                      // [16][UST] update gate of nodes 0..15 of the current step
     const bool save = Rs != nullptr;
     const int ct = wave;                               // NCT == 4 == waves per role
     // results leave through buffer descriptors (one VGPR offset per node tile, the step offset in an SGPR): the 64-bit
@@ -640,9 +620,9 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             // round 4, with the register-reduced remainder: seq_fwd 0.527 -> 0.512 ms; the same order for role B's u GEMM loses)
             if (M > 1 && pre_r) {
                 ar[0][0] = ra;
-                mfma_nodes32<1, KS, true, 0, 0, false, true, true, (M > 1 ? QSA : 0)>(A, KAP, lane, lr, lg, w0, ar, RS, rc);
+                mfma_nodes32<1, KS, true, 0, 0, false, true, true, (M > 1 ? QSA : 0)>(A, KAP, lane, lr, lg, w0, ar, rc);
             } else
-                mfma_nodes32<1, KS, true, 0, 0, false, true, true>(A, KAP, lane, lr, lg, w0, ar, RS);
+                mfma_nodes32<1, KS, true, 0, 0, false, true, true>(A, KAP, lane, lr, lg, w0, ar);
             pp.mark(1);
             {
                 const f32x4 rg = sigmoid4_(ar[0][0]);
@@ -667,7 +647,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             EEG_LDS_BARRIER();                                        // (2) hops(r*h) and u of nodes 0..15 complete
             pp.mark(3);
             if (t + 1 < T) fetch_xw(t + 1);
-            mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac, RS);
+            mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac);
             pp.mark(4);
             {
                 const f32x4 u = ld4(U + lds_sw(lr, col, UST)), h = ld4(A + lds_sw(lr, col, KAP));
@@ -739,7 +719,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             }
             EEG_LDS_BARRIER();                                        // (2)
             // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend, one element per lane
-            mfma_nodes32<1, KS, true, 2, 0, false, false, true>(A2, KAP, lane, lr, lg, w1, ac, RS);
+            mfma_nodes32<1, KS, true, 2, 0, false, false, true>(A2, KAP, lane, lr, lg, w1, ac);
             {
                 const float h1 = A[l1];
                 const float c1 = act == 0 ? tanhf_(ac[0][1][0]) : fmaxf(ac[0][1][0], 0.f);
@@ -787,7 +767,6 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
     float* EG = EC + ROWS * KAP;            // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
     constexpr bool REM4 = NKS == 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    float* RS = EG + ROWS * KGP + wave * (2 * CT * kRemTile);
 
     // wave w owns column tiles ct = w + 4*i of every H-wide quantity (and dR tile ct / dU tile ct of
     // the 2H-wide gate gradient): all elementwise -> diffusion hand-offs are wave-local.
@@ -961,7 +940,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
             acc[i][0] = zero4;
             acc[i][1] = zero4;
         }
-        mfma_nodes32<CT, KS, REM4, 0, 0, false, false, REM4>(EC, KAP, lane, lr, lg, w1, acc, RS);
+        mfma_nodes32<CT, KS, REM4, 0, 0, false, false, REM4>(EC, KAP, lane, lr, lg, w1, acc);
         pp.mark(2);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -1003,7 +982,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
         pp.mark(4);
 
         // ---- GEMM2: dh = dhn + [P_m^T dG]_m (32 x M*2H) @ Wg^h^T (M*2H x H)
-        mfma_nodes32<CT, KSG, REM4, 0, 0, false, false, REM4>(EG, KGP, lane, lr, lg, w2, dhn, RS);
+        mfma_nodes32<CT, KSG, REM4, 0, 0, false, false, REM4>(EG, KGP, lane, lr, lg, w2, dhn);
         pp.mark(5);
 #pragma unroll
         for (int i = 0; i < CT; ++i) {
@@ -1099,7 +1078,6 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     float* EG = EC + ROWS * KAP;            // [32][KGP]  slot m = [P_m^T dR | P_m^T dU]
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, ct = wave8 & 3;
     const int lr = lane & 15, lg = lane >> 4;
-    float* RS = nullptr;                                               // (the remainder is reduced in registers: no hand-over scratch)
     float* DP = EG + ROWS * KGP + ct * (20 * DPS);                     // [20][DPS] GEMM2 result + external gradient, tile ct
     float* CF0 = EG + ROWS * KGP + 4 * 20 * DPS + ct * kCoefTile;      // this column tile's coefficient block, buffer 0 (buffer 1: + 4 * kCoefTile)
     constexpr int kZero = ROWS * (KAP + KGP) + 4 * 20 * DPS + 2 * 4 * kCoefTile;   // floats cleared per clip
@@ -1209,7 +1187,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                 }
                 EEG_LDS_BARRIER();                                      // (1) P_m^T dC and P_m^T dU complete
                 f32x4 acc[1][2] = {{zero4, zero4}};
-                mfma_nodes32<1, KSG, true, 0, 2, true, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);     // dU half: off the chain
+                mfma_nodes32<1, KSG, true, 0, 2, true, true, true>(EG, KGP, lane, lr, lg, w2, acc);     // dU half: off the chain
                 sb_c += ld4(EC + lds_sw(orow[0], col, KAP));
                 sb_u += ld4(EG + lds_sw(orow[0], H + col, KGP));
                 if (valid[1]) {
@@ -1218,7 +1196,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
                 }
                 EEG_LDS_BARRIER();                                      // (2) P_m^T dR complete
                 EEG_SETPRIO(3);                                         // the dR half is on the chain
-                mfma_nodes32<1, KSG, true, 0, 1, true, true, true>(EG, KGP, lane, lr, lg, w2, acc, RS);
+                mfma_nodes32<1, KSG, true, 0, 1, true, true, true>(EG, KGP, lane, lr, lg, w2, acc);
                 EEG_SETPRIO(0);
                 if (t > 0) { acc[0][0] += gx; acc[0][1][0] += gx1; }
                 st4(DP + odp0, acc[0][0]);
@@ -1310,7 +1288,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
         pp.mark(1);
         // ---- GEMM1: d(r*h) = [P_m^T dC]_m (32 x M*H) @ Wc^h^T
         f32x4 acc[1][2] = {{zero4, zero4}};
-        mfma_nodes32<1, KS, true, 0, 0, false, false, true>(EC, KAP, lane, lr, lg, w1, acc, RS);   // (TWOPASS here: seq_bwd +2.5 %, measured)
+        mfma_nodes32<1, KS, true, 0, 0, false, false, true>(EC, KAP, lane, lr, lg, w1, acc);   // (TWOPASS here: seq_bwd +2.5 %, measured)
         pp.mark(2);
         {
             const f32x4 drh = acc[0][0];                            // exact 0 on padding nodes

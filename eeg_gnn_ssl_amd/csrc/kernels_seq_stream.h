@@ -15,10 +15,10 @@
 namespace eeg {
 
 // (the hop polynomials are only staged through the tile area: after load_poly_frags they live in registers -- at M = 5
-//  the tiles and the hand-over scratch of two workgroups fill the 160 KB of a CU exactly)
+//  the tiles of two workgroups take 150 of the 160 KB of a CU)
 __host__ __device__ constexpr size_t seq_stream_bwd_lds_floats(int M) {
     const size_t tiles = (size_t)kDecRows * (M * 64 + M * 128), polys = (size_t)(M - 1) * kPFloats;
-    return (tiles > polys ? tiles : polys) + 4 * kRemTile;
+    return tiles > polys ? tiles : polys;
 }
 
 // BPTT, same contract as seq_bwd_kernel (operands one step ahead, d_at_end / d_at_len / lengths, dXW, dh0 and the
@@ -34,12 +34,11 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
     constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, KGP = M * 2 * H, NCT = H / 16, NQ = M * H / 16;
     constexpr int PD = NQ < 3 ? NQ : 3;           // quads of weights in flight: deeper costs registers, and spills are costly here (2: +1 %, 4: +1 %, 6: +12 %)
     EEG_DYN_SMEM(sm);
-    constexpr int TILES = ROWS * (KAP + KGP), POLYS = (M - 1) * kPFloats;
+    constexpr int TILES = ROWS * (KAP + KGP);
     float* Pl = sm;                         // staging only (aliases the tiles)
     float* EC = sm;                         // [ROWS][KAP]  slot 0 = dC, slots m = P_m^T dC
     float* EG = EC + ROWS * KAP;            // [ROWS][KGP]  slot 0 = [dR|dU], slots m = P_m^T [dR|dU]
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
-    float* RS = sm + (TILES > POLYS ? TILES : POLYS) + wave * kRemTile;
     const int ct = wave, col = ct * 16 + 4 * lg;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int wt1[1] = {ct};
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
             __syncthreads();                                             // (1) P_m^T dC complete
             // ---- GEMM1: d(r*h) = [P_m^T dC]_m @ Wc^h^T
             f32x4 acc[1][2] = {{zero4, zero4}};
-            gemm_stream_quad<1, NQ, PD, true>(EC, KAP, b1p, NCT, wt1, lane, lr, lg, acc, RS, wq1);
+            gemm_stream_quad<1, NQ, PD, true>(EC, KAP, b1p, NCT, wt1, lane, lr, lg, acc, wq1);
             quad_prefetch<1, 2 * NQ, PD>(b2p, NCT, wt1, lane, wq2);
             {
                 const f32x4 drh = acc[0][0], rg = rr[0];                 // exact 0 on padding nodes
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void seq_bwd_stream_kernel(
             lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
             __syncthreads();                                             // (2) P_m^T [dR|dU] complete
             // ---- GEMM2: dh = dhn + [P_m^T dG]_m @ Wg^h^T
-            gemm_stream_quad<1, 2 * NQ, PD, true>(EG, KGP, b2p, NCT, wt1, lane, lr, lg, acc, RS, wq2);
+            gemm_stream_quad<1, 2 * NQ, PD, true>(EG, KGP, b2p, NCT, wt1, lane, lr, lg, acc, wq2);
             if (t > 0) quad_prefetch<1, NQ, PD>(b1p, NCT, wt1, lane, wq1);
             dh[0] = acc[0][0];
             dh[1] = acc[0][1];

@@ -9,7 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "eeg_gnn_ssl_amd", "csrc")
-OUT_DIR = os.path.join(ROOT, "tests", "_emu_build")
+# EEG_EMU_XFLAGS: extra -D switches (the experiment knobs of development A/B builds, csrc/Makefile XFLAGS) -> their own build directory
+XFLAGS = os.environ.get("EEG_EMU_XFLAGS", "").split()
+OUT_DIR = os.path.join(ROOT, "tests", "_emu_build" + ("_" + "".join(c if c.isalnum() else "_" for c in "".join(XFLAGS)) if XFLAGS else ""))
 OUT = os.path.join(OUT_DIR, "libeeg_dcrnn_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
@@ -32,7 +34,7 @@ def build(force=False):
         return OUT
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
     common = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-DEEG_PLATFORM_HEADER=\"platform_emu.h\"", "-DEEG_DEV", "-I", HERE, "-I", CSRC,
-              "-Wno-unused-function", "-Wno-unknown-attributes"]
+              "-Wno-unused-function", "-Wno-unknown-attributes"] + XFLAGS
     objs = []
     jobs = []
     units = [("api", os.path.join(CSRC, "api.cpp"), []),
