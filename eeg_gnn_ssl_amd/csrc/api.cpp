@@ -49,6 +49,15 @@ long long* seq_probe_arg() {
 #endif
 }
 
+// the dev build's phase probe is armed (its instantiations exist for the register-resident kernels only)
+bool phase_probe_armed() {
+#if defined(EEG_DEV)
+    return g_seq_probe != nullptr;
+#else
+    return false;
+#endif
+}
+
 int fail(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -322,7 +331,7 @@ bool seq_stream_wanted(int H, int M, int B, int N) {
     return g_tune[3] == 1 || (M >= 4 && B >= 384);
 }
 int seq_bwd(int H, int M, const SeqBwdArgs& a, hipStream_t st) {
-    if (a.variant != 0 && a.probe == nullptr && seq_stream_wanted(H, M, a.B, a.N)) {
+    if (a.variant != 0 && !phase_probe_armed() && seq_stream_wanted(H, M, a.B, a.N)) {   // (the streamed kernel takes no clock samples either)
         const int rs = launch_seq_bwd_stream(M, a, st);
         if (rs == 0) return 0;
         if (rs == 2) return fail("seq_bwd: streamed kernel launch failed (M=%d)", M);
@@ -813,15 +822,14 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
     //      apply (hidden size, montage > 20 nodes, LDS) the per-step launches below run
     {
         const int q4 = Dout / 4;
-        int dx = q4 % 25 == 0 ? 25 : (q4 % 16 == 0 ? 16 : (q4 % 5 == 0 ? 5 : (q4 % 4 == 0 ? 4 : 0)));
-        if (g_tune[8] > 0 && q4 % g_tune[8] == 0) dx = g_tune[8];   // dev knob 8: weight-group size of the layer-0 x-part
+        const bool bwd_covers = q4 % 5 == 0 || q4 % 4 == 0;        // (the weight-group sizes of the backward's projection transpose)
         const size_t lds = dec_fwd_lds_floats(M, L, Dout) * sizeof(float);
         // (Dout <= 128 like the backward: the two persistent kernels always pair up over the shared `saved` layout)
-        if (g_tune[11] == 0 && H == 64 && N <= kDecRows && L <= 4 && d->T <= 64 && Dout <= 128 && dx != 0 && lds <= kMaxLdsBytes) {
+        if (g_tune[11] == 0 && H == 64 && N <= kDecRows && L <= 4 && d->T <= 64 && Dout <= 128 && bwd_covers && lds <= kMaxLdsBytes) {
             DecFwdArgs a;
             for (int l = 0; l < L; ++l) {
                 const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);
-                a.l[l] = DecLayerPtrs{packs[l] + p.bx, packs[l] + p.bias, packs[l] + p.bhg, packs[l] + p.bhc,
+                a.l[l] = DecLayerPtrs{packs[l] + p.bxq, packs[l] + p.bias, packs[l] + p.bhg, packs[l] + p.bhc,
                                       saved + y.hext[l], saved + y.rs[l], saved + y.us[l], saved + y.cs[l], saved + y.rhs[l],
                                       saved + y.hpl[l], saved + y.rpl[l]};
             }
@@ -834,8 +842,8 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
             for (int t = 0; t < d->T; ++t)
                 if (teacher != nullptr && teacher[t] != 0) a.teacher_mask |= 1ull << t;
             a.p_batched = d->p_batched; a.T = d->T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
-            a.drop = drop; a.rng_used = used; a.hd = saved + y.hd;
-            const int rc = launch_dec_fwd_persist(M, dx, a, lds, st);
+            a.drop = drop; a.rng_used = used; a.hd = saved + y.hd; a.probe = seq_probe_arg();
+            const int rc = launch_dec_fwd_persist(M, a, lds, st);
             if (rc == 0) return 0;
             if (rc == 2) return fail("decoder_fwd: persistent kernel launch failed");
         }
@@ -923,7 +931,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
             for (int t = 0; t < T; ++t)
                 if (feeds_back(t)) a.feeds_mask |= 1ull << t;
             a.p_batched = d->p_batched; a.T = T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
-            a.drop = drop; a.rng_used = used;
+            a.drop = drop; a.rng_used = used; a.probe = seq_probe_arg();
             const int rc = launch_dec_bwd_persist(M, dt, a, lds, st);
             if (rc == 2) return fail("decoder_bwd: persistent kernel launch failed");
             persistent = rc == 0;

@@ -23,11 +23,12 @@
 #include "common.h"
 #include "kernels_seq.h"
 #include "lds_diffuse.h"
+#include "nnq_order.h"
 
 namespace eeg {
 
 struct DecLayerPtrs {
-    const float *bx, *bias, *bhg, *bhc;                       // weight packs of the layer's cell (kernels_pack.h)
+    const float *bxq, *bias, *bhg, *bhc;                      // weight packs of the layer's cell (kernels_pack.h; bxq: the x-part in quad order)
     float *hext, *rs, *us, *cs, *rhs, *hpl, *rpl;             // saved for the backward (decoder `saved` layout)
 };
 struct DecFwdArgs {
@@ -46,6 +47,39 @@ struct DecFwdArgs {
     DropCfg drop;
     const unsigned long long* rng_used;
     float* hd;
+    long long* probe;             // phase cycles (development builds with -DEEG_DEC_PROBE: tools/dec_probe.py), else unused
+};
+#if defined(EEG_DEV) && defined(EEG_DEC_PROBE)
+constexpr bool kDecProbe = true;
+#else
+constexpr bool kDecProbe = false;
+#endif
+// shader-clock cycles per phase, 16 slots per wave (layer 0: slots 0..7, layers above: 8..15), as PhaseProbe (kernels_seq.h)
+template <bool ON>
+struct DecProbe {
+    long long acc[16];
+    long long last;
+    __device__ __forceinline__ void start() {
+        if (ON) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0;
+            last = cycle_now();
+        }
+    }
+    __device__ __forceinline__ void mark(int k, int l = 0) {
+        if (ON) {
+            const long long t = cycle_now();
+            if (l == 0) acc[k] += t - last; else acc[8 + k] += t - last;
+            last = t;
+        }
+    }
+    __device__ __forceinline__ void dump(long long* p) {
+        if (ON && p != nullptr && (threadIdx.x & 63) == 0) {
+            long long* d = p + ((size_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)) * 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = acc[i];
+        }
+    }
 };
 
 // ---- GEMMs with streamed weights -------------------------------------------------------------------------------
@@ -243,17 +277,133 @@ __device__ __forceinline__ void gemm_stream_quad(const float* __restrict__ tile,
     gemm_stream_quad<NT, NQ, PD, false>(tile, stride, wp, nct_total, wt, lane, lr, lg, acc, w);
 }
 
+// The x-part of a cell with the weights in the quad pack of gemm_nnr_kernel (kernels_pack.h bxq: chunk order of make_nnq_order over
+// nseg hop slots x F features; [(c * nct_total + ct) * 64 + lane][4], zero chunks appended up to a multiple of 4): per 16-deep
+// chunk ONE 16-byte weight load per lane and column tile and ONE ds_read_b128 per node tile feed four k-steps -- a quarter of the
+// vector-memory and LDS instructions of gemm_stream_plain, whose 4-byte loads (3 + 2 per k-step beside 6 MFMAs, ~200 registers of
+// look-ahead at 25 k-steps per group) left the x-part at half the MFMA rate (profiles/r04_i_dec_probe.txt).
+// The stream is BRANCH-FREE: groups of 4 chunks (= the weight ring: 3 chunks requested ahead), every body issues its loads
+// unconditionally (past the end: the last chunk again, into a slot nothing reads any more), so the compiler's own s_waitcnt
+// counts are the steady-state ones; with a conditional load in the body it waited for ALL loads, i.e. one L2 round trip per chunk.
+// Operand tile, SWZ = true: the XOR-swizzled state tile of the layer below (slots of 64 = 4 whole chunks, no tail: chunk c is
+// quad c of gemm_stream_quad).  SWZ = false: the plain step-input tile (slots of slotw columns, F real); the column of lane
+// group lg's 16-byte piece of chunk c comes from a table in LDS (nnq_col_table: tail chunks gather the leftover pieces of the
+// slots; padding chunks and missing pieces point at column 0: zero weights, any finite operand does).
+constexpr int kNnqPD = 3;
+__host__ __device__ inline int nnq_padded_chunks(int nseg, int F) { return round_up(make_nnq_order(nseg, F).nch, 4); }
+// tab[c * 4 + g], c < nnq_padded_chunks: float column of piece g of chunk c in a tile with hop slots of slotw columns
+__device__ __forceinline__ void nnq_col_table(int* tab, int nseg, int F, int slotw) {
+    const NnqOrder ko = make_nnq_order(nseg, F);
+    const int n = 4 * round_up(ko.nch, 4);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int c = e >> 2, g = e & 3;
+        int col = 0;
+        if (c < ko.nmain) {
+            const int seg = c / ko.a;
+            col = seg * slotw + (c - seg * ko.a) * 16 + 4 * g;
+        } else {
+            const int tp = (c - ko.nmain) * 4 + g;
+            if (tp < ko.nseg * ko.b) col = (tp / ko.b) * slotw + ko.a * 16 + (tp % ko.b) * 4;
+        }
+        tab[e] = col;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void nnq_prefetch(const float* __restrict__ Bq, int nct_total, const int (&wt)[NT], int lane,
+                                             f32x4 (&w)[kNnqPD + 1][NT]) {
+    const wbuf_t wb = make_wbuf(Bq);
+#pragma unroll
+    for (int c = 0; c < kNnqPD; ++c)             // (a pack has at least 4 chunks)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) w[c][i] = wbuf_ld4(wb, (unsigned)(wt[i] * 64 + lane) * 4u, (unsigned)(c * nct_total) * 256u);
+}
+// nchp = nnq_padded_chunks; the first 3 chunks of weights are in w[0..2] (nnq_prefetch); tab: nnq_col_table (SWZ = false only)
+template <int NT, bool SWZ>
+__device__ __forceinline__ void gemm_stream_nnq(const float* __restrict__ tile, int stride, const int* __restrict__ tab, int nchp,
+                                                const float* __restrict__ Bq, int nct_total, const int (&wt)[NT],
+                                                int lane, int lr, int lg, f32x4 (&acc)[NT][2], f32x4 (&w)[kNnqPD + 1][NT]) {
+    constexpr int PD = kNnqPD, R = PD + 1;
+    const int row1 = 16 + (lane & 3);
+    const wbuf_t wb = make_wbuf(Bq);
+    unsigned wv[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) wv[i] = (unsigned)(wt[i] * 64 + lane) * 4u;
+    // SWZ: piece 4j + lg of quad-group Q of row r sits at 64 Q + 4 ((4j + lg) ^ sigma4(r)); the 4 j-offsets are lane constants
+    const float* p0 = tile + lr * stride;
+    const float* p1 = tile + row1 * stride;
+    int k0[4], k1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        k0[j] = SWZ ? 4 * ((4 * j + lg) ^ sigma4(lr)) : 0;
+        k1[j] = SWZ ? 4 * ((4 * j + lg) ^ sigma4(lane & 3)) : 0;
+    }
+    f32x4 rem[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rem[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 alt = {0.f, 0.f, 0.f, 0.f};            // second 16x16x4 chain of a lone column tile
+    int tc = SWZ ? 0 : tab[lg], tn = SWZ ? 0 : tab[4 + lg];         // piece columns of chunks 0 and 1 (plain tile)
+    float4 a0 = *reinterpret_cast<const float4*>(p0 + (SWZ ? k0[0] : tc));
+    float4 a1 = *reinterpret_cast<const float4*>(p1 + (SWZ ? k1[0] : tc));
+    const int ngroups = nchp / R;
+    for (int g = 0; g < ngroups; ++g) {
+        static_for<0, R>([&](auto J) __attribute__((always_inline)) {
+            constexpr int j = decltype(J)::value, slot = j, slot_n = (j + PD) % R;
+            const int c = g * R + j;
+            const int cl = c + PD < nchp ? c + PD : nchp - 1;        // (scalar)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) w[slot_n][i] = wbuf_ld4(wb, wv[i], (unsigned)(cl * nct_total) * 256u);
+            // fragments of chunk c + 1 (past the end: chunk nchp - 1 again)
+            float4 n0, n1;
+            if constexpr (SWZ) {
+                const int cn = c + 1 < nchp ? c + 1 : nchp - 1, qn = 64 * (cn >> 2);
+                constexpr int jn = (j + 1) % R;
+                n0 = *reinterpret_cast<const float4*>(p0 + qn + k0[jn]);
+                n1 = *reinterpret_cast<const float4*>(p1 + qn + k1[jn]);
+            } else {
+                n0 = *reinterpret_cast<const float4*>(p0 + tn);
+                n1 = *reinterpret_cast<const float4*>(p1 + tn);
+                const int c2 = c + 2 < nchp ? c + 2 : nchp - 1;
+                tn = tab[c2 * 4 + lg];
+            }
+            const float x0[4] = {a0.x, a0.y, a0.z, a0.w}, x1[4] = {a1.x, a1.y, a1.z, a1.w};
+            EEG_SCHED_FENCE();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (NT == 1 && (jj & 1)) alt = mfma16(w[slot][i][jj], x0[jj], alt);
+                    else acc[i][0] = mfma16(w[slot][i][jj], x0[jj], acc[i][0]);
+                }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) rem[i][jj] = mfma4(x1[jj], w[slot][i][jj], rem[i][jj]);
+            a0 = n0;
+            a1 = n1;
+        });
+    }
+    if (NT == 1) acc[0][0] += alt;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        f32x4 t = (rem[i][0] + rem[i][1]) + (rem[i][2] + rem[i][3]);
+        EEG_PIN(t);
+        acc[i][1][0] += rem4_reduce(t);
+    }
+}
+
 constexpr int kDecRows = 20;     // node rows of the LDS tiles (montages of at most 20 nodes)
 
 // LDS floats of dec_fwd_persist_kernel<64, M>
 __host__ __device__ constexpr size_t dec_fwd_lds_floats(int M, int L, int Dout) {
     const int H = 64, KAP = M * H, XS = lds_stride_q(M * round_up(Dout, 16));
     return (size_t)(M - 1) * kPFloats + (size_t)L * kDecRows * KAP + (size_t)kDecRows * (XS > KAP ? XS : KAP)
-           + (size_t)kDecRows * 64;      // + the dropped copy of the top state the projection reads (swizzled [rows][64])
+           + (size_t)kDecRows * 64       // + the dropped copy of the top state the projection reads (swizzled [rows][64])
+           + 4 * (size_t)nnq_padded_chunks(M, Dout);   // + the piece-column table of the layer-0 x-part (gemm_stream_nnq)
 }
 
-// DX = k-steps per weight group of the layer-0 x-part ((Dout/4) % DX == 0; the larger, the further ahead the weights are requested).
-template <int H, int M, int DX>
+template <int H, int M>
 __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
     static_assert(H == 64, "one column tile per wave");
     constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, NCT = H / 16, NGT = 2 * NCT, NQ = M * H / 16;
@@ -273,6 +423,15 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
     const size_t xstep = (size_t)B * N * Dout;
     const DropCfg drop = a.drop;
     const unsigned long long dseed = drop.on ? a.rng_used[0] : 0ull, doff = drop.on ? a.rng_used[1] : 0ull;
+    const int wt3[3] = {ct, NCT + ct, 2 * NCT + ct};
+    f32x4 wx[kNnqPD + 1][3];       // weight ring of the x-part (gemm_stream_nnq)
+    int* XT = reinterpret_cast<int*>(HD + ROWS * 64);               // piece columns of the layer-0 x-part chunks in X0
+    const int nchp0 = nnq_padded_chunks(M, Dout), nchp1 = nnq_padded_chunks(M, H);
+    nnq_col_table(XT, M, Dout, FP);                                 // (first read behind the barriers of the clip set-up)
+    float wpp[8][2];               // first weight group (8 of the 16 k-steps) of the projection; 16: spills at M = 5
+    bool xpre = false;
+    DecProbe<kDecProbe> pp;        // 0 input node mix + planes, 1 x-part GEMM, 2 barrier, 3 gate GEMM, 4 gate epilogue + node mix + barrier,
+    pp.start();                    // 5 candidate GEMM, 6 its epilogue + node mix + barrier, 7 projection + barrier
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
@@ -299,40 +458,42 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
             lds_diffuse_tile<M, NKS, ROWS>(A0 + l * ROWS * KAP, KAP, ct * 16, H, pf, lr, lg,
                                            a.l[l].hpl + (size_t)b * N * H, a.hplane_stride, N);
         __syncthreads();
+        pp.mark(7);
         for (int t = 0; t < T; ++t) {
             const size_t s = (size_t)t * B + b;
             // ---- hop rows of the step input (X0 slot 0 holds it: zeros at t = 0, GO symbol) -> slots 1..M-1, and to planes0
-            lds_diffuse_tiles<false>(XA, XS, 0, FP, FP, FP, Pl, M, N, ROWS);
+            // (register-resident polynomial fragments, one 16-column tile at a time as for the state tiles; the generic work-list
+            //  routine lds_diffuse_tiles + a copy loop took 15.5 k of the 115 k cycles of a step: profiles/r04_i_dec_probe.txt)
+            nnq_prefetch<3>(a.l[0].bxq, 3 * NCT, wt3, lane, wx);
+            xpre = true;
+            for (int j = wave; j < FP / 16; j += 4)
+                lds_diffuse_tile_plain<M, NKS, ROWS>(XA, XS, j * 16, FP, pf, lr, lg, a.planes0 + s * N * Dout, a.planes0_stride, Dout, N);
             __syncthreads();
-            for (int m1 = 0; m1 < M - 1; ++m1) {
-                float* dst = a.planes0 + (size_t)m1 * a.planes0_stride + s * N * Dout;
-                for (int e = tid; e < N * (Dout / 4); e += 256) {
-                    const int n = e / (Dout / 4), c4 = e % (Dout / 4);
-                    *reinterpret_cast<float4*>(dst + n * Dout + 4 * c4) =
-                        *reinterpret_cast<const float4*>(XA + n * XS + (m1 + 1) * FP + 4 * c4);
-                }
-            }
+            pp.mark(0);
             for (int l = 0; l < L; ++l) {
                 const DecLayerPtrs& lp = a.l[l];
                 float* Al = A0 + l * ROWS * KAP;
                 float* A2 = XA;
                 f32x4 ag[3][2];          // pre-activations of this wave's r, u, c tiles: x-part + bias, then + h-part
-                const int wt3[3] = {ct, NCT + ct, 2 * NCT + ct};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     ag[i][0] = ld4(lp.bias + wt3[i] * 16 + 4 * lg);
                     ag[i][1] = (f32x4){lp.bias[wt3[i] * 16 + lr], 0.f, 0.f, 0.f};
                 }
-                if (l == 0)
-                    gemm_stream_plain<3, DX, false>(XA, XS, FP, Dout / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag);
-                else
-                    gemm_stream_plain<3, 16, true>(A0 + (l - 1) * ROWS * KAP, KAP, H, H / 4, M, lp.bx, 3 * NCT, wt3, lane, lr, lg, ag);
+                {
+                    if (!xpre) nnq_prefetch<3>(lp.bxq, 3 * NCT, wt3, lane, wx);
+                    xpre = false;
+                    if (l == 0) gemm_stream_nnq<3, false>(XA, XS, XT, nchp0, lp.bxq, 3 * NCT, wt3, lane, lr, lg, ag, wx);
+                    else gemm_stream_nnq<3, true>(A0 + (l - 1) * ROWS * KAP, KAP, nullptr, nchp1, lp.bxq, 3 * NCT, wt3, lane, lr, lg, ag, wx);
+                }
                 // the first quads of the gate / candidate weights are requested before the barrier / the epilogue in front of their GEMM
                 constexpr int PDG = NQ < 6 ? NQ : 6, PDC = NQ < 10 ? NQ : 10;
                 const int wt2[2] = {ct, NCT + ct}, wt1[1] = {ct};
                 float wqg[PDG + 1][4][2], wqc[PDC + 1][4][1];
                 quad_prefetch<2, NQ, PDG>(lp.bhg, NGT, wt2, lane, wqg);
+                pp.mark(1, l);
                 __syncthreads();                                     // layer 0: every wave has read X0 (A2 aliases it)
+                pp.mark(2, l);
                 // gate h-part: hops(h^l) x Wg^h
                 {
                     f32x4 g2[2][2] = {{ag[0][0], ag[0][1]}, {ag[1][0], ag[1][1]}};
@@ -340,6 +501,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     ag[0][0] = g2[0][0]; ag[0][1] = g2[0][1]; ag[1][0] = g2[1][0]; ag[1][1] = g2[1][1];
                 }
                 quad_prefetch<1, NQ, PDC>(lp.bhc, NCT, wt1, lane, wqc);
+                pp.mark(3, l);
                 f32x4 ug0;
                 float ug1;
                 {
@@ -366,12 +528,14 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                 EEG_WAVE_SYNC();
                 lds_diffuse_tile<M, NKS, ROWS>(A2, KAP, ct * 16, H, pf, lr, lg, lp.rpl + s * N * H, a.hplane_stride, N);
                 __syncthreads();                                     // hops(r*h) complete
+                pp.mark(4, l);
                 // candidate h-part: hops(r*h) x Wc^h
                 {
                     f32x4 c1[1][2] = {{ag[2][0], ag[2][1]}};
                     gemm_stream_quad<1, NQ, PDC, true>(A2, KAP, lp.bhc, NCT, wt1, lane, lr, lg, c1, wqc);
                     ag[2][0] = c1[0][0]; ag[2][1] = c1[0][1];
                 }
+                pp.mark(5, l);
                 {
                     const f32x4 u = ug0, h = ld4(Al + lds_sw(lr, col, KAP));
                     const f32x4 c = act == 0 ? tanh4_(ag[2][0]) : relu4_(ag[2][0]);
@@ -400,8 +564,16 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                     }
                 }
                 EEG_WAVE_SYNC();
+                if (l + 1 < L) {                                     // the next layer's first x-part weights, behind this node mix and barrier
+                    nnq_prefetch<3>(a.l[l + 1].bxq, 3 * NCT, wt3, lane, wx);
+                    xpre = true;
+                } else if (wave < nct_o) {                           // the projection's weights (this wave's tiles wave, wave + 4)
+                    const int wtp[2] = {wave, wave + 4 < nct_o ? wave + 4 : wave};
+                    plain_wload<2, 8>(a.ppack, nct_o, wtp, lane, 0, wpp);
+                }
                 lds_diffuse_tile<M, NKS, ROWS>(Al, KAP, ct * 16, H, pf, lr, lg, lp.hpl + (s + B) * N * H, a.hplane_stride, N);
                 __syncthreads();                                     // h^l of this step and its hop rows complete
+                pp.mark(6, l);
             }
             // ---- projection (model.py:188-190) and the next step's input (model.py:194-200)
             {
@@ -416,7 +588,10 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                         po[i][0] = ld4(a.pbias + wt2[i] * 16 + 4 * lg);
                         po[i][1] = (f32x4){a.pbias[wt2[i] * 16 + lr], 0.f, 0.f, 0.f};
                     }
-                    gemm_stream_plain<2, 16, true>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po);
+                        if (j0 == wave)         // first pair of tiles: weights requested in front of the last barrier
+                        gemm_stream_plain<2, 8, true, true, false>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po, wpp);
+                    else
+                        gemm_stream_plain<2, 16, true>(drop.on ? HD : Atop, drop.on ? 64 : KAP, H, H / 4, 1, a.ppack, nct_o, wt2, lane, lr, lg, po);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         if (i == 1 && !two) continue;
@@ -444,8 +619,10 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
                 }
             }
             __syncthreads();                                         // X0 slot 0 of the next step complete
+            pp.mark(7);
         }
     }
+    pp.dump(a.probe);
 }
 
 }  // namespace eeg
@@ -482,6 +659,7 @@ struct DecBwdArgs {
     int p_batched, T, B, N, Dout, L, act;
     DropCfg drop;                      // dropout in front of the projection (DecFwdArgs): d h_top = mask * (dO W_p), mask recomputed
     const unsigned long long* rng_used;
+    long long* probe;                  // phase cycles (development builds with -DEEG_DEC_PROBE), else unused
 };
 
 __host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) {
@@ -515,6 +693,8 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
     const int wt0[3] = {ct, NCT + (wave < nct_o ? wave : 0), NCT + (wave + 4 < nct_o ? wave + 4 : 0)};
     const int wtu[3] = {ct, NCT + ct, NCT + ct};                    // layers above: input = 64 hidden units of the layer below
 
+    DecProbe<kDecProbe> pp;        // 0 output-gradient tile, 1 projection transpose, 2 blend backward + node mix + barrier, 3 GEMM1, 4 its epilogue
+    pp.start();                    // + node mixes + barrier, 5 GEMM2, 6 hand-over of dX + barrier, 7 clip set-up / bias sums
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();
         for (int e = tid; e < (int)(ROWS * (KAP + KGP) + 2 * ROWS * FS + L * 4 * 2 * 256); e += 256) EC[e] = 0.f;
@@ -583,6 +763,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
         float sr0[3] = {0.f, 0.f, 0.f}, sr1[3] = {0.f, 0.f, 0.f};               // ... of the remainder element
         fetch(L - 1, T - 1);
         plain_wload<1, DT>(a.tpack, nct_h, wt1, lane, 0, wpt);
+        pp.mark(7);
         for (int t = T - 1; t >= 0; --t) {
             const size_t s = (size_t)t * B + b;
             const bool fb = ((a.feeds_mask >> t) & 1ull) != 0;       // out_t feeds step t+1: its gradient gets DX of that step
@@ -595,6 +776,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 st4(a.dOtot + (s * N + n) * Dout + 4 * c4, g);
             }
             __syncthreads();
+            pp.mark(0);
             // ---- gradient of h^{L-1}_t through the projection (model.py:188-190): dA = dO W_p
             f32x4 gext[2];
             {
@@ -608,6 +790,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 }
             }
             prefetch1(L - 1, pair_nt(L - 1, t));
+            pp.mark(1);
             for (int l = L - 1; l >= 0; --l) {
                 const DecBwdLayerPtrs& lp = a.l[l];
                 float* dxw = lp.dxw + s * N * (3 * H);
@@ -654,6 +837,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 EEG_WAVE_SYNC();
                 lds_diffuse_tile<M, NKS, ROWS>(EC, KAP, ct * 16, H, pf, lr, lg);
                 __syncthreads();                                         // (1) P_m^T dC complete
+                pp.mark(2, l);
                 const int ntp = pair_nt(l, t);
                 f32x4 dx[2][2] = {{zero4, zero4}, {zero4, zero4}};      // this wave's input-gradient tiles
                 auto cell = [&](auto ntag) {
@@ -667,6 +851,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     for (int i = 0; i < NT; ++i) { acc[i][0] = zero4; acc[i][1] = zero4; }
                     gemm_stream_quad<NT, NQ, PD, true, 3>(EC, KAP, lp.c1, nct, wtn, lane, lr, lg, acc, wq1);
                     quad_prefetch<NT, 2 * NQ, PD, 3>(lp.c2, nct, wtn, lane, wq2);
+                    pp.mark(3, l);
                     {
                         const f32x4 drh = acc[0][0], rg = rr[0];         // exact 0 on padding nodes
                         const f32x4 dR = drh * hp[0] * rg * (1.f - rg);
@@ -689,8 +874,10 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, ct * 16, 2 * H, pf, lr, lg);
                     lds_diffuse_tile<M, NKS, ROWS>(EG, KGP, H + ct * 16, 2 * H, pf, lr, lg);
                     __syncthreads();                                     // (2) P_m^T [dR|dU] complete
+                    pp.mark(4, l);
                     // ---- GEMM2: [dh | dX] += [P_m^T dG]_m @ [Wg^h | Wg^x]^T -> recurrent gradient for step t-1, input gradient
                     gemm_stream_quad<NT, 2 * NQ, PD, true, 3>(EG, KGP, lp.c2, nct, wtn, lane, lr, lg, acc, wq2);
+                    pp.mark(5, l);
                     st4(dhl + l * 2048 + 0 * 256, acc[0][0]);
                     st4(dhl + l * 2048 + 1 * 256, acc[0][1]);
 #pragma unroll
@@ -715,6 +902,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                     }
                 }
                 __syncthreads();                                         // (3) tiles free for the next pair; DX complete
+                pp.mark(6, l);
             }
         }
         // ---- gradients of the initial states (the encoder's final states)
@@ -745,7 +933,9 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
                 dst[j] = sacc;
             }
         }
+        pp.mark(7);
     }
+    pp.dump(a.probe);
 }
 
 }  // namespace eeg

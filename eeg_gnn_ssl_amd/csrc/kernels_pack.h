@@ -52,9 +52,9 @@ __host__ __device__ inline CellPack make_cell_pack(int Fin, int H, int M) {
     p.bxt = o;  o += (size_t)3 * H * round_up(M * Fin, 16);
     p.c1 = o;   o += (size_t)M * H * cell_pack_cx_cols(Fin, H);
     p.c2 = o;   o += (size_t)M * 2 * H * cell_pack_cx_cols(Fin, H);
-    p.has_bxq = (3 * H) % 192 == 0 && make_nnq_order(M, Fin).ntail <= 2;
+    p.has_bxq = (3 * H) % 192 == 0;     // (any tail count: gemm_nnr_kernel takes <= 2 tail chunks, the decoder kernels any)
     p.has_bxtq = (M * Fin) % 192 == 0 && (3 * H) % 4 == 0 && make_nnq_order(1, 3 * H).ntail <= 2;
-    p.bxq = o;  o += p.has_bxq ? (size_t)make_nnq_order(M, Fin).nch * (3 * H / 16) * 256 : 0;
+    p.bxq = o;  o += p.has_bxq ? (size_t)round_up(make_nnq_order(M, Fin).nch, 4) * (3 * H / 16) * 256 : 0;   // (zero chunks up to a multiple of 4: kernels_decoder.h gemm_stream_nnq)
     p.bxtq = o; o += p.has_bxtq ? (size_t)make_nnq_order(1, 3 * H).nch * (M * Fin / 16) * 256 : 0;
     p.total = o;
     return p;

@@ -169,4 +169,42 @@ __device__ __forceinline__ void lds_diffuse_tile(float* buf, int stride, int src
     }
 }
 
+// The same for a PLAIN [rows][stride] tile whose hop slots are slot_w columns wide (the step-input tile of the persistent decoder:
+// kernels_decoder.h): source buf[:, src_col : src_col + 16) -> slot m at column m * slot_w + src_col, m = 1..M-1.  gout != nullptr: hop
+// plane m also goes to gout + (m-1) * gplane, element (node, col) at node * g_ld + col, for the columns below g_ld (g_ld % 4 == 0).
+template <int M, int NKS, int ROWS>
+__device__ __forceinline__ void lds_diffuse_tile_plain(float* buf, int stride, int src_col, int slot_w,
+                                                       const float (&pf)[poly_slots<M, NKS>()][NKS], int lr, int lg,
+                                                       float* __restrict__ gout, size_t gplane, int g_ld, int n_nodes) {
+    constexpr int NC = poly_chains<M, NKS>();
+    if constexpr (NC == 0) return;
+    constexpr int NA = NC > 0 ? NC : 1;
+    float b[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) b[ks] = buf[(4 * ks + lg) * stride + src_col + lr];
+    f32x4 acc[NA];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(b[ks], pf[c][ks], acc[c]);
+    const int col = src_col + 4 * lg;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        int node, hop;
+        bool live = true;
+        if constexpr (NKS == 5) {
+            if (c < M - 1) { node = lr; hop = c; }
+            else { node = 16 + (lr & 3); hop = 4 * (c - (M - 1)) + (lr >> 2); live = hop < M - 1; }
+        } else {
+            node = (c & 1) * 16 + lr; hop = c >> 1;
+        }
+        const float4 v = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+        if (live && (ROWS == 32 || node < ROWS)) *reinterpret_cast<float4*>(buf + node * stride + (hop + 1) * slot_w + col) = v;
+        if (gout != nullptr && live && node < n_nodes && col < g_ld)
+            *reinterpret_cast<float4*>(gout + (size_t)hop * gplane + node * g_ld + col) = v;
+    }
+}
+
 }  // namespace eeg

@@ -41,7 +41,7 @@ bool seq_m_supported(int M);
 int launch_seq_bwd_stream(int M, const SeqBwdArgs& a, hipStream_t st);
 struct DecFwdArgs;
 struct DecBwdArgs;
-int launch_dec_fwd_persist(int M, int dx, const DecFwdArgs& a, size_t lds, hipStream_t st);
+int launch_dec_fwd_persist(int M, const DecFwdArgs& a, size_t lds, hipStream_t st);
 int launch_dec_bwd_persist(int M, int dt, const DecBwdArgs& a, size_t lds, hipStream_t st);
 
 

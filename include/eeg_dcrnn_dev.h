@@ -22,7 +22,7 @@ int eeg_dcrnn_set_seq_probe(int64_t* probe);
  * key 9 = 1: LDS/MFMA adjoint diffusion; key 12 = 1: single-wave-per-SIMD forward recurrent kernel also
  * where the two-wave one exists (64 units, M <= 3); key 13 = 1: the same for the BPTT kernel; key 11 = 1: per-step
  * launches in the decoder forward instead of the persistent kernel, key 10 = 1: the same for the decoder backward;
- * key 8 = n: k-steps per weight group of the layer-0 input part in the persistent decoder forward; key 3: the
+ * key 8: unused (round 1-3: k-steps per weight group of the layer-0 input part in the persistent decoder forward); key 3: the
  * streamed-weight BPTT kernel with two workgroups per CU (1 = wherever it exists, 2 = never; default: batches beyond
  * 1.5 clips per CU at M >= 4); keys 14 / 15: 8-wave TN GEMM from this dY width up / its workgroup target;
  * keys 5 / 6 / 7: target workgroup counts of the streaming diffusion (forward / adjoint) and the correlation-Gram launches.

@@ -116,6 +116,7 @@ def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ("dual_random_walk", 20, 2, 2, 2, None, 20, 1),     # 20 nodes: the 4x4 remainder tile full, M = 3
     ("laplacian", 16, 2, 3, 2, 0.5, 19, 0),             # max_diffusion_step = 0: M = 1, no hop slots
     ("dual_random_walk", 20, 4, 2, 1, None, 5, 1),      # four layers (three uses of the shared cell), 5 nodes
+    ("dual_random_walk", 60, 2, 2, 2, None, 19, 2),     # Dout = 60, M = 5: three leftover 16-byte pieces per hop slot -> 4 tail chunks of the quad pack
 ])
 def test_persistent_decoder_edge_shapes(filt, dout, layers, t_out, b, ratio, n, order, adj3d):
     """the persistent decoder kernels (forward and BPTT, kernels_decoder.h) at the edges of their range"""

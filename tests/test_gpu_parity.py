@@ -602,6 +602,7 @@ def test_streamed_weight_bptt_kernel_large_batch(adj3d):
     ("dual_random_walk", 20, 2, 2, 2, None, 20, 1),     # 20 nodes: the 4x4 remainder tile full, M = 3
     ("laplacian", 16, 2, 3, 2, 0.5, 19, 0),             # max_diffusion_step = 0: M = 1, no hop slots
     ("dual_random_walk", 20, 4, 2, 1, None, 5, 1),      # four layers (three uses of the shared cell), 5 nodes
+    ("dual_random_walk", 60, 2, 2, 2, None, 19, 2),     # Dout = 60, M = 5: three leftover 16-byte pieces per hop slot -> 4 tail chunks of the quad pack
     ("dual_random_walk", 100, 2, 2, 300, None, 19, 2),  # more clips than workgroups: the clip loop of a workgroup
     ("laplacian", 128, 2, 4, 2, 0.5, 19, 2),            # widest output the persistent kernels take (Dout = 128)
 ])
