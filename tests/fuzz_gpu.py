@@ -58,8 +58,9 @@ def _close_scaled(a, b, what, tol=ps.TOL):
     _strict_close_scaled(a, b, what, tol)
 
 
-def run(seconds=None, cases=None, seed=0, dev="cuda"):
-    """draw and check cases until `seconds` have passed or `cases` cases were checked; returns the counts"""
+def run(seconds=None, cases=None, seed=0, dev="cuda", small=False):
+    """draw and check cases until `seconds` have passed or `cases` cases were checked; returns the counts.  small: shapes the CPU emulator of
+    the kernel sources (tests/emu) gets through in a second or two each (the same generator, narrower ranges)"""
     ps.assert_close_scaled = _close_scaled
     adj3d = np.load(os.path.join(ROOT, "tests", "golden", "adj_mx_3d.npy"))
     rng = random.Random(seed)
@@ -77,12 +78,16 @@ def run(seconds=None, cases=None, seed=0, dev="cuda"):
         if kind == "model":
             p = dict(n=n, h=h, filt=filt, k=k, din=rng.choice([4, 8, 12, 20, 100]), layers=rng.choice([1, 2, 3]),
                      t_len=rng.choice([1, 2, 3, 5, 9]), b=rng.choice([1, 2, 3, 5]), classes=rng.choice([1, 4]), seed=case_seed)
-            if rng.random() < 0.04:      # more clips than workgroups: the resident workgroups walk clips; from 384 clips on, the streamed BPTT kernel (M >= 4)
+            if small:
+                p.update(h=rng.choice([16, 32, 64]), din=rng.choice([4, 8, 12]), layers=rng.choice([1, 2]), t_len=rng.choice([1, 2, 3]), b=rng.choice([1, 2]))
+            elif rng.random() < 0.04:      # more clips than workgroups: the resident workgroups walk clips; from 384 clips on, the streamed BPTT kernel (M >= 4)
                 p.update(b=rng.choice([257, 300, 385, 520]), t_len=rng.choice([1, 2, 3]), layers=rng.choice([1, 2]), din=rng.choice([4, 20]))
         else:
             p = dict(filt=filt, dout=rng.choice([4, 8, 12, 16, 20, 28, 40, 60, 100]), h=h, layers=rng.choice([1, 2, 3, 4]),
                      t_out=rng.choice([1, 2, 3, 6]), b=rng.choice([1, 2, 4]), seed=case_seed, ratio=rng.choice([None, None, 0.5]),
                      act=rng.choice(["tanh", "relu"]), n=n, order=k)
+            if small:
+                p.update(dout=rng.choice([4, 8, 20]), layers=rng.choice([1, 2]), t_out=rng.choice([1, 2]), b=rng.choice([1, 2]))
         try:
             if kind == "model":
                 ps.check_shape_sweep(dev, **p)
@@ -110,7 +115,8 @@ def run(seconds=None, cases=None, seed=0, dev="cuda"):
                 continue
             print("FAILED (mismatch)", kind, p, flush=True)
             raise
-        torch.cuda.synchronize()
+        if dev != "cpu":
+            torch.cuda.synchronize()
     print(f"fuzz: {done['model']} model cases + {done['decoder']} decoder cases passed, {refused} refused loudly, {kinks} on a ReLU kink, "
           f"{time.time() - t0:.0f} s, seed {seed}")
     return done, refused, kinks

@@ -169,3 +169,10 @@ def test_zero_diffusion_steps_model_and_dconv(adj3d):
     ps.assert_close(out.detach().numpy(), ref.numpy(), "dconv K=0")
     out.sum().backward()
     assert x.grad is not None and mod.weight.grad is not None and tuple(mod.weight.shape) == (24, 32)
+
+
+def test_randomized_small_shapes_vs_oracle(emulator):
+    """the randomized parity generator of the GPU suite (tests/fuzz_gpu.py) on the emulator build of the kernel sources, small shapes"""
+    import fuzz_gpu
+    done, refused, kinks = fuzz_gpu.run(cases=40, seed=11, dev="cpu", small=True)
+    assert done["model"] + done["decoder"] == 40 and kinks <= 1
