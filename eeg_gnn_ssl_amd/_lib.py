@@ -15,7 +15,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip.so")
 DEV_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip_dev.so")     # `make dev`: tools/ and `bench.py --tune` only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class LayerDims(ctypes.Structure):
@@ -28,7 +28,8 @@ class LayerDims(ctypes.Structure):
 class DecoderDims(ctypes.Structure):
     """mirror of `eeg_decoder_dims` (include/eeg_dcrnn.h)."""
     _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Dout", c_int32),
-                ("M", c_int32), ("L", c_int32), ("act", c_int32), ("p_batched", c_int32), ("dropout_p", c_float)]
+                ("M", c_int32), ("L", c_int32), ("act", c_int32), ("p_batched", c_int32), ("dropout_p", c_float),
+                ("teacher_on_device", c_int32)]
 
 
 _FP = c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -63,11 +64,14 @@ _SIGNATURES = {
     "eeg_dcrnn_decoder_saved_floats": (c_size_t, [POINTER(DecoderDims)]),
     "eeg_dcrnn_decoder_fwd_ws_floats": (c_size_t, [POINTER(DecoderDims)]),
     "eeg_dcrnn_decoder_bwd_ws_floats": (c_size_t, [POINTER(DecoderDims)]),
-    "eeg_dcrnn_decoder_fwd": (c_int, [POINTER(DecoderDims), _FP, POINTER(c_int32), _FP, _FP, POINTER(c_void_p), _FP, _FP,
+    "eeg_dcrnn_decoder_is_persistent": (c_int, [POINTER(DecoderDims)]),
+    # (`teacher` travels as a void*: a host int32[T] array or, with dims.teacher_on_device = 1, a device pointer)
+    "eeg_dcrnn_decoder_fwd": (c_int, [POINTER(DecoderDims), _FP, c_void_p, _FP, _FP, POINTER(c_void_p), _FP, _FP,
                                       _FP, _FP, _FP, _FP, c_void_p]),
-    "eeg_dcrnn_decoder_bwd": (c_int, [POINTER(DecoderDims), POINTER(c_int32), _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP,
+    "eeg_dcrnn_decoder_bwd": (c_int, [POINTER(DecoderDims), c_void_p, _FP, POINTER(c_void_p), _FP, _FP, _FP, _FP, _FP,
                                       POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                       _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_teacher_flags": (c_int, [_FP, _FP, c_int64, ctypes.c_double, c_int, _FP, c_void_p]),
     "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_rng_take": (c_int, [_FP, ctypes.c_uint64, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, _FP, _FP, _FP, c_void_p]),
@@ -80,6 +84,8 @@ _SIGNATURES = {
     "eeg_dcrnn_clip_adam_ws_floats": (c_size_t, []),
     "eeg_dcrnn_clip_adam": (c_int, [_FP, _FP, _FP, _FP, c_size_t, c_float, c_float, c_float, c_float, c_float, c_float,
                                     c_int, c_float, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_clip_adam_dev": (c_int, [_FP, _FP, _FP, _FP, c_size_t, c_float, _FP, c_float, c_float, c_float, c_float,
+                                        _FP, c_float, _FP, _FP, c_void_p]),
 }
 
 
@@ -118,7 +124,9 @@ class EegDcrnnLib:
             for name, (res, args) in _SIGNATURES_DEV.items():
                 fn = getattr(self._dll, name)
                 fn.restype, fn.argtypes = res, args
-        if strict and self._dll.eeg_dcrnn_abi_version() != ABI_VERSION:
+        # strict=False tolerates MISSING entry points only: a library of another ABI version has entry points with other
+        # signatures (shifted arguments = wild pointers), so it is refused in both modes
+        if self._dll.eeg_dcrnn_abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {self._dll.eeg_dcrnn_abi_version()} != {ABI_VERSION}; rebuild")
         self.is_device_build = bool(self._dll.eeg_dcrnn_is_device_build())
 

@@ -1,4 +1,5 @@
 // C ABI of libeeg_dcrnn_hip.so (see include/eeg_dcrnn.h): argument checking + kernel orchestration.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -38,14 +39,19 @@ int g_tune[24] = {0};               // see eeg_dcrnn_set_tuning
 constexpr int g_tune[24] = {0};
 #endif
 
-long long* g_clock_samples = nullptr;   // eeg_dcrnn_prof_clock_samples (measurement hook, like the event recorder)
+std::atomic<long long*> g_clock_samples{nullptr};   // eeg_dcrnn_prof_clock_samples (measurement hook, like the event recorder)
 // the `probe` argument of the recurrent launches: the dev build's phase probe (which selects the probe instantiations), else the
-// product's clock-sample buffer (4 x int64; dev builds leave it alone: a non-null probe means 32 slots per wave there)
-long long* seq_probe_arg() {
+// product's clock-sample buffer (4 x int64; dev builds leave it alone: a non-null probe means 32 slots per wave there).
+// A launch that is being CAPTURED into a graph never gets the clock-sample buffer: the graph would keep the pointer and go on
+// adding to it on every replay, after the buffer was disarmed and freed.
+long long* seq_probe_arg(hipStream_t st) {
 #if defined(EEG_DEV)
+    (void)st;
     return g_seq_probe;
 #else
-    return g_clock_samples;
+    long long* p = g_clock_samples.load(std::memory_order_acquire);
+    if (p != nullptr && eeg::platform_stream_is_capturing(st)) return nullptr;
+    return p;
 #endif
 }
 
@@ -534,7 +540,7 @@ int copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
 extern "C" {
 
 const char* eeg_dcrnn_last_error(void) { return g_err; }
-int eeg_dcrnn_abi_version(void) { return 3; }
+int eeg_dcrnn_abi_version(void) { return 4; }
 int eeg_dcrnn_is_device_build(void) { return kPlatformIsDevice; }
 #if defined(EEG_DEV)
 int eeg_dcrnn_set_tuning(int key, int value) {
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256) void clock_probe_kernel(long long ticks, long 
 }
 }  // namespace
 int eeg_dcrnn_prof_clock_samples(int64_t* buf4) {
-    g_clock_samples = reinterpret_cast<long long*>(buf4);
+    g_clock_samples.store(reinterpret_cast<long long*>(buf4), std::memory_order_release);
     return 0;
 }
 int eeg_dcrnn_prof_clock_probe(int64_t* out2, void* stream) {
@@ -687,7 +693,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
-                 (size_t)(d->T + 1) * state, d->T, d->B, d->N, d->act, seq_probe_arg()};
+                 (size_t)(d->T + 1) * state, d->T, d->B, d->N, d->act, seq_probe_arg(st)};
     a.variant = g_tune[12] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 12 = 1: off)
     return seq_fwd(H, M, a, st);
 }
@@ -711,7 +717,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     // 1. BPTT through the recurrence: dXW = [dR|dU|dC] per step, dh0, per-clip bias partials
     SeqBwdArgs a{Hext + state, Hext, Rs, Us, Cs, dHseq, d_at_end, d_at_len,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
-                 dXW, dh0, dbias, d->T, d->B, N, d->act, seq_probe_arg()};
+                 dXW, dh0, dbias, d->T, d->B, N, d->act, seq_probe_arg(st)};
     a.variant = g_tune[13] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 13 = 1: off)
     if (seq_bwd(H, M, a, st)) return 1;
     EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
@@ -795,6 +801,21 @@ size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d) { return dec_la
 size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d) { return (size_t)d->B * d->N * 3 * d->H; }
 size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d) { return dec_layout(d).bwd_total; }
 
+// the persistent decoder kernels (kernels_decoder.h) cover this shape: forward and backward always pair up over the shared `saved`
+// layout (64 units, <= 20 nodes, <= 4 layers, horizon <= 64, Dout <= 128 with Dout/4 divisible by 4 or 5 = the weight-group
+// sizes of the backward's projection transpose, both LDS budgets)
+static bool dec_persistent_ok(const eeg_decoder_dims* d) {
+    const int q4 = d->Dout / 4;
+    return d->H == 64 && d->N <= kDecRows && d->L >= 1 && d->L <= 4 && d->T >= 1 && d->T <= 64 && d->Dout <= 128
+           && (q4 % 5 == 0 || q4 % 4 == 0) && m_supported(d->M)
+           && dec_fwd_lds_floats(d->M, d->L, d->Dout) * sizeof(float) <= kMaxLdsBytes
+           && dec_bwd_lds_floats(d->M, d->L, d->Dout) * sizeof(float) <= kMaxLdsBytes;
+}
+int eeg_dcrnn_decoder_is_persistent(const eeg_decoder_dims* d) {
+    if (check_decoder_dims(d)) return 0;
+    return dec_persistent_ok(d) ? 1 : 0;
+}
+
 int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const int32_t* teacher, const float* h0,
                           const float* P, const float* const* packs, const float* Wp, const float* bp,
                           const uint64_t* rng_used, float* out, float* saved, float* ws, void* stream) {
@@ -805,6 +826,8 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
     const DropCfg drop = make_drop_cfg(d->dropout_p);
     const unsigned long long* used = reinterpret_cast<const unsigned long long*>(rng_used);
     if (drop.on && rng_used == nullptr) return fail("decoder_fwd: dropout_p > 0 needs the {seed, offset} pair of eeg_dcrnn_rng_take");
+    const bool tf_dev = d->teacher_on_device != 0 && teacher != nullptr;
+    if (tf_dev && targets == nullptr) return fail("decoder_fwd: teacher flags on the device need the target sequence");
     const int B = d->B, N = d->N, H = d->H, M = d->M, Dout = d->Dout, L = d->L, RB = B * N;
     const size_t state = (size_t)RB * H, xstep = (size_t)RB * Dout;
     const int nct_o = ceil_div(Dout, 16);
@@ -821,11 +844,8 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
     // ---- persistent path: ONE launch for all T steps, layers and the projection (kernels_decoder.h); where it does not
     //      apply (hidden size, montage > 20 nodes, LDS) the per-step launches below run
     {
-        const int q4 = Dout / 4;
-        const bool bwd_covers = q4 % 5 == 0 || q4 % 4 == 0;        // (the weight-group sizes of the backward's projection transpose)
         const size_t lds = dec_fwd_lds_floats(M, L, Dout) * sizeof(float);
-        // (Dout <= 128 like the backward: the two persistent kernels always pair up over the shared `saved` layout)
-        if (g_tune[11] == 0 && H == 64 && N <= kDecRows && L <= 4 && d->T <= 64 && Dout <= 128 && bwd_covers && lds <= kMaxLdsBytes) {
+        if (g_tune[11] == 0 && dec_persistent_ok(d)) {
             DecFwdArgs a;
             for (int l = 0; l < L; ++l) {
                 const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);
@@ -839,15 +859,18 @@ int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const
             a.planes0_stride = (size_t)d->T * RB * Dout;
             a.hplane_stride = (size_t)(d->T + 1) * state;
             a.teacher_mask = 0;
-            for (int t = 0; t < d->T; ++t)
+            a.teacher_dev = tf_dev ? reinterpret_cast<const int*>(teacher) : nullptr;
+            for (int t = 0; t < d->T && !tf_dev; ++t)
                 if (teacher != nullptr && teacher[t] != 0) a.teacher_mask |= 1ull << t;
             a.p_batched = d->p_batched; a.T = d->T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
-            a.drop = drop; a.rng_used = used; a.hd = saved + y.hd; a.probe = seq_probe_arg();
+            a.drop = drop; a.rng_used = used; a.hd = saved + y.hd; a.probe = seq_probe_arg(st);
             const int rc = launch_dec_fwd_persist(M, a, lds, st);
             if (rc == 0) return 0;
             if (rc == 2) return fail("decoder_fwd: persistent kernel launch failed");
         }
     }
+    if (tf_dev) return fail("decoder_fwd: teacher_on_device needs the persistent decoder kernel, which does not cover this shape "
+                            "(H=%d, N=%d, L=%d, T=%d, Dout=%d, M=%d): pass the flags as a host array", H, N, L, d->T, Dout, M);
     float* XW = ws;
     for (int t = 0; t < d->T; ++t) {
         for (int l = 0; l < L; ++l) {
@@ -900,6 +923,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
     const DropCfg drop = make_drop_cfg(d->dropout_p);
     const unsigned long long* used = reinterpret_cast<const unsigned long long*>(rng_used);
     if (drop.on && rng_used == nullptr) return fail("decoder_bwd: dropout_p > 0 needs the rng_used pair of the forward call");
+    const bool tf_dev = d->teacher_on_device != 0 && teacher != nullptr;
     const int B = d->B, N = d->N, H = d->H, M = d->M, Dout = d->Dout, L = d->L, RB = B * N, T = d->T;
     const size_t state = (size_t)RB * H, xstep = (size_t)RB * Dout, Rall = (size_t)T * RB;
     const int nct_h = ceil_div(H, 16);
@@ -909,7 +933,8 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
     float* dOtot = ws + y.dotot;
     float* dA = ws + y.da;
     float* Z = ws + y.z;
-    auto feeds_back = [&](int t) { return t + 1 < T && !(teacher != nullptr && teacher[t] != 0); };   // out_t is step t+1's input
+    // out_t is step t+1's input (host flags; with device flags the persistent kernel derives the same mask itself)
+    auto feeds_back = [&](int t) { return t + 1 < T && !(!tf_dev && teacher != nullptr && teacher[t] != 0); };
     // ---- persistent path: ONE launch walks the T steps backwards (kernels_decoder.h); it leaves dXW of every
     //      (layer, step), dOtot and dh0 -- the hoisted parameter gradients below are common to both paths
     bool persistent = false;
@@ -917,7 +942,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
         const int q4 = Dout / 4;
         const int dt = q4 % 5 == 0 ? 5 : (q4 % 4 == 0 ? 4 : 0);
         const size_t lds = dec_bwd_lds_floats(M, L, Dout) * sizeof(float);
-        if (g_tune[10] == 0 && H == 64 && N <= kDecRows && L <= 4 && T <= 64 && Dout <= 128 && dt != 0 && lds <= kMaxLdsBytes) {
+        if (g_tune[10] == 0 && dec_persistent_ok(d)) {
             DecBwdArgs a;
             for (int l = 0; l < L; ++l) {
                 const CellPack p = make_cell_pack(l == 0 ? Dout : H, H, M);
@@ -928,15 +953,18 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
             a.P = P; a.tpack = tpack; a.dOut = dOut; a.dOtot = dOtot; a.dh0 = dh0;
             a.dbias0 = ws + y.dbias[0]; a.dbias1 = ws + y.dbias[L > 1 ? 1 : 0];
             a.feeds_mask = 0;
+            a.teacher_dev = tf_dev ? reinterpret_cast<const int*>(teacher) : nullptr;
             for (int t = 0; t < T; ++t)
                 if (feeds_back(t)) a.feeds_mask |= 1ull << t;
             a.p_batched = d->p_batched; a.T = T; a.B = B; a.N = N; a.Dout = Dout; a.L = L; a.act = d->act;
-            a.drop = drop; a.rng_used = used; a.probe = seq_probe_arg();
+            a.drop = drop; a.rng_used = used; a.probe = seq_probe_arg(st);
             const int rc = launch_dec_bwd_persist(M, dt, a, lds, st);
             if (rc == 2) return fail("decoder_bwd: persistent kernel launch failed");
             persistent = rc == 0;
         }
     }
+    if (tf_dev && !persistent) return fail("decoder_bwd: teacher_on_device needs the persistent decoder kernel, which does not cover "
+                                           "this shape (H=%d, N=%d, L=%d, T=%d, Dout=%d, M=%d)", H, N, L, T, Dout, M);
     for (int t = persistent ? -1 : T - 1; t >= 0; --t) {
         // total gradient of out_t: the loss term, plus (autoregressive feedback) dx of layer 0 at step t+1, which
         // the adjoint diffusion of that step has already added into dOtot[t]
@@ -1023,6 +1051,15 @@ int eeg_dcrnn_rng_take(uint64_t* rng_state, uint64_t groups, uint64_t* rng_used,
                  reinterpret_cast<unsigned long long*>(rng_used), (unsigned long long)groups);
     return check_launch("rng_take");
 }
+int eeg_dcrnn_teacher_flags(uint64_t* rng_state, int64_t* samples_seen, int64_t increment, double cl_decay_steps, int T,
+                            int32_t* flags, void* stream) {
+    if (rng_state == nullptr || samples_seen == nullptr || flags == nullptr) return fail("teacher_flags: null state / counter / output");
+    if (T < 1 || T > 64) return fail("teacher_flags: T=%d unsupported (1..64)", T);
+    if (!(cl_decay_steps > 0.0)) return fail("teacher_flags: cl_decay_steps must be positive");
+    EEG_LAUNCH_P("teacher_flags", teacher_flags_kernel, dim3(1), dim3(64), 0, S_(stream), reinterpret_cast<unsigned long long*>(rng_state),
+                 reinterpret_cast<long long*>(samples_seen), (long long)increment, cl_decay_steps, T, reinterpret_cast<int*>(flags));
+    return check_launch("teacher_flags");
+}
 int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, int B, int N, int H, int C, float dropout_p,
                            const uint64_t* rng_used, float* logits, int32_t* arg, void* stream) {
     if (N > 64) return fail("cls_head: num_nodes=%d unsupported (<= 64)", N);
@@ -1030,7 +1067,11 @@ int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, in
     if (check_dropout_p("cls_head", dropout_p)) return 1;
     const DropCfg drop = make_drop_cfg(dropout_p);
     if (drop.on && rng_used == nullptr) return fail("cls_head: dropout_p > 0 needs the {seed, offset} pair of eeg_dcrnn_rng_take");
-    EEG_LAUNCH_P("cls_head_fwd", cls_head_fwd_kernel, dim3(B), dim3(64), (size_t)N * (C + H) * sizeof(float), S_(stream), z, W, bias, B, N, H, C, drop,
+    // LDS: [N][C] node logits + [N][H] masked relu(z) rows
+    const size_t head_lds = (size_t)N * (C + H) * sizeof(float);
+    if (B < 1 || C < 1 || head_lds > kMaxLdsBytes) return fail("cls_head: B=%d, N=%d x (classes=%d + rnn_units=%d) floats do not fit the %zu-byte LDS", B, N, C, H, (size_t)kMaxLdsBytes);
+    EEG_SET_MAX_LDS(cls_head_fwd_kernel, head_lds);
+    EEG_LAUNCH_P("cls_head_fwd", cls_head_fwd_kernel, dim3(B), dim3(64), head_lds, S_(stream), z, W, bias, B, N, H, C, drop,
                  reinterpret_cast<const unsigned long long*>(rng_used), logits, arg);
     return check_launch("cls_head_fwd");
 }
@@ -1137,20 +1178,36 @@ int eeg_dcrnn_masked_loss(const float* pred, const float* y, size_t n, int use_s
     return 0;
 }
 size_t eeg_dcrnn_clip_adam_ws_floats(void) { return 64; }
-int eeg_dcrnn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
-                        float grad_scale, float* ws, float* norm_out, void* stream) {
-    if (step < 1) return fail("clip_adam: step must be >= 1");
+static int clip_adam_launch(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* ws,
+                            float* norm_out, int32_t* step_dev, const float* lr_dev, void* stream) {
     const int nparts = 64;
-    EEG_LAUNCH_P("grad_sqnorm", sqnorm_partial_kernel, dim3(nparts), dim3(256), 256 * sizeof(float), S_(stream), grads, n, ws);
+    EEG_LAUNCH_P("grad_sqnorm", sqnorm_partial_kernel, dim3(nparts), dim3(256), 256 * sizeof(float), S_(stream), grads, n, ws, reinterpret_cast<int*>(step_dev));
     if (check_launch("grad_sqnorm")) return 1;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // torch.optim.Adam forms `1 - beta ** step` and its square root as Python (fp64) scalars
+    const float bc1 = step_dev ? 1.f : (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = step_dev ? 1.f : (float)sqrt(1.0 - pow((double)beta2, (double)step));
     int blocks = (int)((n + 1023) / 1024);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     EEG_LAUNCH_P("clip_adam", clip_adam_kernel, dim3(blocks), dim3(256), 0, S_(stream), params, grads, exp_avg, exp_avg_sq, n,
-                 ws, nparts, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, norm_out);
+                 ws, nparts, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale, norm_out,
+                 reinterpret_cast<const int*>(step_dev), lr_dev);
     return check_launch("clip_adam");
+}
+int eeg_dcrnn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                        float grad_scale, float* ws, float* norm_out, void* stream) {
+    if (step < 1) return fail("clip_adam: step must be >= 1");
+    return clip_adam_launch(params, grads, exp_avg, exp_avg_sq, n, max_norm, lr, beta1, beta2, eps, weight_decay, step, grad_scale, ws,
+                            norm_out, nullptr, nullptr, stream);
+}
+int eeg_dcrnn_clip_adam_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float max_norm,
+                            const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, int32_t* step_dev,
+                            float grad_scale, float* ws, float* norm_out, void* stream) {
+    if (lr_dev == nullptr || step_dev == nullptr) return fail("clip_adam_dev: null learning-rate / step-counter pointer");
+    return clip_adam_launch(params, grads, exp_avg, exp_avg_sq, n, max_norm, 0.f, beta1, beta2, eps, weight_decay, 0, grad_scale, ws,
+                            norm_out, step_dev, lr_dev, stream);
 }
 
 }  // extern "C"

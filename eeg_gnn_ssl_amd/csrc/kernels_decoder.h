@@ -40,6 +40,8 @@ struct DecFwdArgs {
     size_t planes0_stride;        // floats between two planes of planes0
     size_t hplane_stride;         // floats between two planes of hpl / rpl = (T+1)*B*N*H
     unsigned long long teacher_mask;   // bit t: step t+1 is fed targets[t] instead of out[t] (model.py:194-200)
+    const int* teacher_dev;            // nullable DEVICE int32[T]: when set, the flags are read from it at launch instead (a captured
+                                       // graph then replays with whatever eeg_dcrnn_teacher_flags drew in front of it)
     int p_batched, T, B, N, Dout, L, act;
     // nn.Dropout in front of the projection (model.py:191, training): the projection reads drop(h_top_t) = mask * h_top_t; the
     // recurrence keeps h_top_t.  Element ((t*B + b)*N + n)*H + h of the (T,B,N,H) top outputs takes word e % 4 of Philox counter
@@ -405,6 +407,12 @@ __host__ __device__ constexpr size_t dec_fwd_lds_floats(int M, int L, int Dout) 
 
 template <int H, int M>
 __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
+    unsigned long long teacher_mask = a.teacher_mask;
+    if (a.teacher_dev != nullptr) {                 // flags drawn on the device (uniform scalar loads, once per launch)
+        teacher_mask = 0;
+        for (int t = 0; t < a.T; ++t)
+            if (a.teacher_dev[t] != 0) teacher_mask |= 1ull << t;
+    }
     static_assert(H == 64, "one column tile per wave");
     constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, NCT = H / 16, NGT = 2 * NCT, NQ = M * H / 16;
     EEG_DYN_SMEM(sm);
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void dec_fwd_persist_kernel(DecFwdArgs a) {
             // ---- projection (model.py:188-190) and the next step's input (model.py:194-200)
             {
                 float* Atop = A0 + (L - 1) * ROWS * KAP;
-                const bool tf = ((a.teacher_mask >> t) & 1ull) != 0;
+                const bool tf = ((teacher_mask >> t) & 1ull) != 0;
                 for (int j0 = wave; j0 < nct_o; j0 += 8) {              // this wave's tiles j0 and j0 + 4
                     const bool two = j0 + 4 < nct_o;
                     f32x4 po[2][2];
@@ -656,6 +664,7 @@ struct DecBwdArgs {
     float* dh0;                   // (L,B,N,H)
     float *dbias0, *dbias1;       // (B,3H) per-clip bias-gradient sums [r|u|c] over steps and nodes: layer 0, layers >= 1 (one shared cell)
     unsigned long long feeds_mask;     // bit t: out_t is the input of step t+1 (no teacher forcing there, t+1 < T)
+    const int* teacher_dev;            // nullable DEVICE int32[T] teacher-forcing flags: when set, feeds_mask is derived from it at launch
     int p_batched, T, B, N, Dout, L, act;
     DropCfg drop;                      // dropout in front of the projection (DecFwdArgs): d h_top = mask * (dO W_p), mask recomputed
     const unsigned long long* rng_used;
@@ -670,6 +679,12 @@ __host__ __device__ constexpr size_t dec_bwd_lds_floats(int M, int L, int Dout) 
 
 template <int H, int M, int DT>
 __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
+    unsigned long long feeds_mask = a.feeds_mask;
+    if (a.teacher_dev != nullptr) {                 // flags drawn on the device: out_t feeds step t+1 unless teacher-forced
+        feeds_mask = 0;
+        for (int t = 0; t + 1 < a.T; ++t)
+            if (a.teacher_dev[t] == 0) feeds_mask |= 1ull << t;
+    }
     static_assert(H == 64, "one column tile per wave");
     constexpr int NKS = 5, ROWS = kDecRows, KAP = M * H, KGP = M * 2 * H, NCT = H / 16, NQ = M * H / 16;
     constexpr int PD = NQ < 3 ? NQ : 3;              // quads of weights in flight ahead of the MFMAs
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
         // column tiles of a pair: 1 (no input gradient wanted), 2 (layers above the first / narrow outputs) or 3
         auto pair_nt = [&](int l, int t) {
             if (l > 0) return 2;
-            return t > 0 && ((a.feeds_mask >> (t - 1)) & 1ull) != 0 ? 1 + nx0 : 1;
+            return t > 0 && ((feeds_mask >> (t - 1)) & 1ull) != 0 ? 1 + nx0 : 1;
         };
         // weights requested ahead of their GEMM: the first group of the projection transpose, the first PD quads of GEMM1 / GEMM2
         const int wt1[1] = {ct};
@@ -766,7 +781,7 @@ __global__ __launch_bounds__(256, 1) void dec_bwd_persist_kernel(DecBwdArgs a) {
         pp.mark(7);
         for (int t = T - 1; t >= 0; --t) {
             const size_t s = (size_t)t * B + b;
-            const bool fb = ((a.feeds_mask >> t) & 1ull) != 0;       // out_t feeds step t+1: its gradient gets DX of that step
+            const bool fb = ((feeds_mask >> t) & 1ull) != 0;       // out_t feeds step t+1: its gradient gets DX of that step
             // ---- S0: total gradient of out_t -> DO tile and dOtot
             for (int e = tid; e < N * (Dout / 4); e += 256) {
                 const int n = e / (Dout / 4), c4 = e % (Dout / 4);

@@ -126,6 +126,26 @@ __global__ void rng_take_kernel(unsigned long long* __restrict__ state, unsigned
         state[1] = off + groups;
     }
 }
+// Scheduled sampling on the device (model.py:194-200 + utils.py:385-390 `compute_sampling_threshold`): the reference draws one
+// `random.random() < k / (k + exp(batches_seen / k))` per decoder step on the host; here the T flags of a forward call come from the
+// same Philox generator as the dropout masks (flag t = word t % 4 of counter offset + t / 4, u = word / 2^32 in fp64), and both the
+// generator offset and the `samples_seen` counter advance ON THE STREAM -- a captured training step replays with a fresh draw and
+// the decayed threshold.  seen[0] (int64) is read, then incremented by `inc` (the global batch: train_ssl.py:178 `step += batch_size`).
+__global__ void teacher_flags_kernel(unsigned long long* __restrict__ state, long long* __restrict__ seen, long long inc,
+                                     double decay_steps, int T, int* __restrict__ flags) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const unsigned long long seed = state[0], off = state[1];
+    const long long n = seen[0];
+    const double ratio = decay_steps / (decay_steps + exp((double)n / decay_steps));
+    for (int t0 = 0; t0 < T; t0 += 4) {
+        unsigned w[4];
+        const unsigned long long c = off + (unsigned long long)(t0 >> 2);
+        philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+        for (int j = 0; j < 4 && t0 + j < T; ++j) flags[t0 + j] = ((double)w[j] * (1.0 / 4294967296.0) < ratio) ? 1 : 0;
+    }
+    state[1] = off + (unsigned long long)((T + 3) / 4);
+    seen[0] = n + inc;
+}
 // mask[e] = keep(e) * scale for e < n: the values the fused kernels multiply with, materialised (tests hand them to the oracle)
 __global__ void dropout_mask_kernel(const unsigned long long* __restrict__ used, size_t n, DropCfg drop, float* __restrict__ mask) {
     const size_t groups = (n + 3) / 4;
@@ -136,8 +156,9 @@ __global__ void dropout_mask_kernel(const unsigned long long* __restrict__ used,
             if (4 * g + j < n) mask[4 * g + j] = m[j];
     }
 }
-// y = x * mask (per-step decoder path: the projection input) / x *= mask (its gradient); e0 = index of x[0] in the dropped tensor
-__global__ void dropout_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, size_t e0,
+// y = x * mask (per-step decoder path: the projection input) / x *= mask (its gradient: launched IN PLACE, x == y, hence no
+// __restrict__ on the two; every thread reads its own 16 bytes before it writes them); e0 = index of x[0] in the dropped tensor
+__global__ void dropout_apply_kernel(const float* x, float* y, size_t n, size_t e0,
                                      const unsigned long long* __restrict__ used, DropCfg drop) {
     const size_t groups = n / 4;        // n % 4 == 0, e0 % 4 == 0
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {

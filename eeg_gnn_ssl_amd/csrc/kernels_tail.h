@@ -158,8 +158,11 @@ __global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, size_
 }
 
 // stage 1: per-block partial sums of g^2 (fixed assignment of elements to blocks/threads)
-__global__ void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+// step_dev (nullable): the optimiser's step counter on the device, advanced here -- one launch AHEAD of clip_adam_kernel, every
+// block of which reads it -- so that a captured graph of the whole step counts its own replays
+__global__ void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part, int* __restrict__ step_dev) {
     EEG_DYN_SMEM(sm);
+    if (step_dev != nullptr && blockIdx.x == 0 && threadIdx.x == 0) step_dev[0] += 1;
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         acc = fmaf(g[i], g[i], acc);
@@ -178,7 +181,14 @@ __global__ void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, flo
 __global__ void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, size_t n, const float* __restrict__ part, int nparts,
                                  float max_norm, float lr, float b1, float b2, float eps, float wd,
-                                 float bc1, float bc2_sqrt, float grad_scale, float* __restrict__ norm_out) {
+                                 float bc1, float bc2_sqrt, float grad_scale, float* __restrict__ norm_out,
+                                 const int* __restrict__ step_dev, const float* __restrict__ lr_dev) {
+    if (step_dev != nullptr) {      // step count and learning rate live on the device (eeg_dcrnn_clip_adam_dev): the bias corrections
+        const int step = step_dev[0];   // are formed here, in fp64 like torch.optim.Adam's Python scalars
+        bc1 = (float)(1.0 - pow((double)b1, (double)step));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+        lr = lr_dev[0];
+    }
     float tot = 0.f;
     for (int i = 0; i < nparts; ++i) tot += part[i];
     const float norm = sqrtf(tot) * grad_scale;        // grad_scale: 1/world after a summed all-reduce

@@ -128,4 +128,9 @@ inline int platform_num_cus() {
 inline bool platform_copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
     return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
 }
+// true while launches on `st` are being recorded into a graph instead of executed
+inline bool platform_stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 }  // namespace eeg

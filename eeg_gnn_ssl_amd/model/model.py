@@ -21,19 +21,41 @@ from .cell import DCGRUCell
 class _FusedDropout:
     """Mixin of the two modules that own an `nn.Dropout` in the reference (model.py:191,267).  The module keeps its
     `self.dropout = nn.Dropout(p)` attribute (same repr / `p` semantics), but the mask is generated inside the HIP kernel that
-    consumes the dropped tensor: a device-resident Philox4x32-10 generator state (int64 {seed, offset}; the seed is drawn from
-    torch's default generator at first use, so `torch.manual_seed` governs it) that every dropping forward advances on the
-    device -- a captured HIP graph therefore draws a fresh mask on every replay."""
+    consumes the dropped tensor from a device-resident Philox4x32-10 generator state (int64 {seed, offset}) that every
+    dropping forward advances on the device -- a captured HIP graph therefore draws a fresh mask on every replay.
+
+    The state is a NON-persistent buffer `_dropout_rng`, created in the constructor (so `.to(device)` moves it with the
+    parameters and nothing is allocated or copied inside a forward that may be under graph capture).  Its seed derives from
+    `torch.initial_seed()` -- `torch.manual_seed` before construction governs it -- without drawing from the global generator
+    (later host-side draws, e.g. DataLoader shuffles, are where they would be in a reference run).  It is outside `state_dict`
+    on purpose (reference checkpoints load with strict=True); a run that wants mask-reproducible resumption saves
+    `dropout_rng_state()` next to the checkpoint and restores it with `set_dropout_seed(seed, offset)`."""
+
+    def _init_dropout_rng(self, stream_id: int):
+        self.register_buffer("_dropout_rng", ops.make_rng_state("cpu", stream_id), persistent=False)
 
     def _drop_p(self) -> float:
         return float(self.dropout.p) if self.training else 0.0
 
+    def set_dropout_seed(self, seed: int, offset: int = 0):
+        """Re-seed the fused dropout generator (in place: captured graphs keep reading the same tensor)."""
+        st = self._dropout_rng
+        st.copy_(torch.tensor([int(seed), int(offset)], dtype=torch.int64), non_blocking=False)
+
+    def dropout_rng_state(self):
+        """(seed, offset) of the generator right now (synchronises with the device)."""
+        seed, offset = self._dropout_rng.tolist()
+        return int(seed), int(offset)
+
     def _rng_state(self, device) -> torch.Tensor:
-        st = getattr(self, "_dropout_rng", None)
+        st = self._dropout_rng
         device = torch.device(device)
-        if st is None or st.device.type != device.type or (device.index is not None and st.device.index != device.index):
-            st = ops.make_rng_state(device)
-            self._dropout_rng = st
+        if st.device.type != device.type or (device.index is not None and st.device.index != device.index):
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the fused dropout generator state is not on the device of the inputs: move the model "
+                                   "with .to(device) before capturing its forward into a HIP graph")
+            st = st.to(device)
+            self._buffers["_dropout_rng"] = st
         return st
 
 
@@ -109,9 +131,13 @@ class DCGRUDecoder(_FusedDropout, nn.Module):
         self.decoding_cells = nn.ModuleList([first] + [shared] * (num_rnn_layers - 1))
         self.projection_layer = nn.Linear(hid_dim, output_dim)
         self.dropout = nn.Dropout(p=dropout)
+        self._init_dropout_rng(1)
 
-    def forward(self, inputs, initial_hidden_state, supports, teacher_forcing_ratio=None):
+    def forward(self, inputs, initial_hidden_state, supports, teacher_forcing_ratio=None, teacher_flags=None):
         """inputs (T,B,N,Dout) targets, initial_hidden_state (L,B,N*H) -> (T,B,N*Dout).
+        teacher_flags (extension): a DEVICE int32[T] tensor of teacher-forcing flags (`ops.teacher_flags`) instead of the
+        host-side coin flips -- the persistent kernels read it when they start, so a captured HIP graph replays curriculum
+        learning with a fresh draw every step.
 
         One native operator (eeg_dcrnn_decoder_fwd/bwd) runs the T autoregressive steps, the cells of
         all layers, the dropout in front of the projection (training, p > 0: a fresh mask per step, generated
@@ -121,8 +147,8 @@ class DCGRUDecoder(_FusedDropout, nn.Module):
         self.decoding_cells[0]._check_supports(supports)
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
         drop_p = self._drop_p()
-        teacher = None
-        if teacher_forcing_ratio is not None:
+        teacher = teacher_flags
+        if teacher is None and teacher_forcing_ratio is not None:
             teacher = tuple(random.random() < teacher_forcing_ratio for _ in range(t_len))
         first = self.decoding_cells[0]
         shared = self.decoding_cells[1] if self.num_rnn_layers > 1 else None
@@ -158,6 +184,7 @@ class DCRNNModel_classification(_FusedDropout, nn.Module):
         self.fc = nn.Linear(args.rnn_units, num_classes)
         self.dropout = nn.Dropout(args.dropout)
         self.relu = nn.ReLU()
+        self._init_dropout_rng(0)
 
     def forward(self, input_seq, seq_lengths, supports):
         b = input_seq.shape[0]
@@ -185,6 +212,8 @@ class DCRNNModel_nextTimePred(nn.Module):
         self.output_dim = args.output_dim
         self.cl_decay_steps = args.cl_decay_steps
         self.use_curriculum_learning = bool(args.use_curriculum_learning)
+        # device-side scheduled sampling (see forward): what one forward adds to a `batches_seen` counter tensor
+        self.batches_seen_increment = 0
         self.encoder = DCRNNEncoder(input_dim=args.input_dim, max_diffusion_step=args.max_diffusion_step,
                                     hid_dim=args.rnn_units, num_nodes=args.num_nodes,
                                     num_rnn_layers=args.num_rnn_layers,
@@ -196,13 +225,20 @@ class DCRNNModel_nextTimePred(nn.Module):
                                     device=device, dropout=args.dropout)
 
     def forward(self, encoder_inputs, decoder_inputs, supports, batches_seen=None):
+        """batches_seen: the reference's host integer (model.py:336-343: the threshold and `random.random()` per decoder step
+        are evaluated on the host) -- or, as an extension, a DEVICE int64[1] counter tensor: threshold and coin flips are then
+        evaluated by `eeg_dcrnn_teacher_flags` on the stream from the decoder's Philox generator, and the counter advances
+        by `self.batches_seen_increment` (train_ssl.py:178 `step += batch_size`), so that the forward is graph-replayable."""
         b, t_out, n, _ = decoder_inputs.shape
         enc_in = encoder_inputs.transpose(0, 1)
         dec_in = decoder_inputs.transpose(0, 1)
         enc_final, _, _ = self.encoder.run(enc_in, None, supports)
+        ratio, flags = None, None
         if self.training and self.use_curriculum_learning and batches_seen is not None:
-            ratio = utils.compute_sampling_threshold(self.cl_decay_steps, batches_seen)
-        else:
-            ratio = None
-        out = self.decoder(dec_in, enc_final, supports, teacher_forcing_ratio=ratio)
+            if torch.is_tensor(batches_seen):
+                flags = ops.teacher_flags(self.decoder._rng_state(batches_seen.device), batches_seen,
+                                          self.batches_seen_increment, self.cl_decay_steps, t_out)
+            else:
+                ratio = utils.compute_sampling_threshold(self.cl_decay_steps, batches_seen)
+        out = self.decoder(dec_in, enc_final, supports, teacher_forcing_ratio=ratio, teacher_flags=flags)
         return out.reshape(t_out, b, n, -1).transpose(0, 1)

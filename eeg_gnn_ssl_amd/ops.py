@@ -11,7 +11,7 @@ dispatcher's "no kernel for the CPU backend" error, and the C-ABI stub refuses n
 Operators (namespace `eeg_dcrnn`):
     hop_polys, pack_cell, diffusion_hops, dconv (+ dconv_bwd), dcgru_layer (+ dcgru_layer_bwd),
     dcgru_decoder (+ dcgru_decoder_bwd), cls_head (+ cls_head_bwd), rng_take_, dropout_mask, gather_last, corr_graph,
-    fft_features, bce_logits, ce_logits, masked_loss, clip_adam_.
+    fft_features, bce_logits, ce_logits, masked_loss, clip_adam_, clip_adam_dev_, teacher_flags_.
 The functions below them are the Python conveniences the modules in model/ and train_step.py call.
 """
 from __future__ import annotations
@@ -459,17 +459,32 @@ torch.library.register_autograd(f"{NS}::dcgru_layer", _dcgru_layer_backward, set
 # =============================================================================================
 # decoder (model.py:160-204) as one operator
 # =============================================================================================
-def _dec_dims(meta, dropout_p=0.0):
+def _dec_dims(meta, dropout_p=0.0, teacher_on_device=False):
     t_len, b, n, h, dout, m, n_layers, act, p_batched = meta
-    return DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched, float(dropout_p))
+    return DecoderDims(t_len, b, n, h, dout, m, n_layers, act, p_batched, float(dropout_p), 1 if teacher_on_device else 0)
 
 
-def make_rng_state(device) -> torch.Tensor:
-    """Device-resident state {seed, offset} (int64[2]) of the Philox4x32-10 generator behind the fused dropout masks
-    (csrc/common.h).  The seed is drawn from torch's default CPU generator, so `torch.manual_seed` governs it like it governs
-    `nn.Dropout`; every forward call that drops advances the offset ON THE DEVICE (a replayed HIP graph keeps drawing fresh
-    masks)."""
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+def _teacher_arg(lib, teacher, teacher_dev, t_len):
+    """the `teacher` argument of eeg_dcrnn_decoder_fwd / _bwd: (void* value, keep-alive object, flags on the device?)"""
+    if teacher_dev is not None:
+        _check(lib, teacher_dev, "teacher_dev", torch.int32)
+        if teacher_dev.numel() != t_len:
+            raise RuntimeError(f"teacher_dev: expected int32[{t_len}], got {tuple(teacher_dev.shape)}")
+        return _p(teacher_dev), teacher_dev, True
+    if len(teacher) > 0 and any(teacher):
+        arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)])
+        return ctypes.cast(arr, ctypes.c_void_p), arr, False
+    return None, None, False
+
+
+def make_rng_state(device, stream_id: int = 0) -> torch.Tensor:
+    """State {seed, offset} (int64[2]) of the Philox4x32-10 generator behind the fused dropout masks (csrc/common.h).  The seed
+    is a function of `torch.initial_seed()` (so `torch.manual_seed` governs it like it governs `nn.Dropout`) and of `stream_id`
+    (the classification head and the decoder use different ones), drawn from a DEDICATED generator: the global CPU generator
+    is not advanced.  Every forward call that drops advances the offset ON THE DEVICE (a replayed HIP graph keeps drawing
+    fresh masks)."""
+    g = torch.Generator().manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * int(stream_id)) % (1 << 63))
+    seed = int(torch.randint(0, 2 ** 62, (1,), generator=g).item())
     return torch.tensor([seed, 0], dtype=torch.int64, device=device)
 
 
@@ -480,9 +495,11 @@ def _check_rng(lib, t, name):
 
 
 def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher: List[int],
-                        t_len: int, n: int, h: int, dout: int, m: int, n_layers: int, act: int, dropout_p: float, rng_used):
+                        t_len: int, n: int, h: int, dout: int, m: int, n_layers: int, act: int, dropout_p: float, rng_used,
+                        teacher_dev=None):
     """T autoregressive steps through L cells + the projection.  teacher: T ints (1 = feed targets[t] to step t+1,
-    all 0 = fully autoregressive); dropout_p > 0: nn.Dropout in front of the projection (model.py:191), masks from the
+    all 0 = fully autoregressive) -- or teacher_dev: the same flags as a DEVICE int32[T] tensor (`teacher_flags_`), read by the
+    persistent kernel when it starts (graph-replayable curriculum learning); dropout_p > 0: nn.Dropout in front of the projection (model.py:191), masks from the
     {seed, offset} pair `rng_used` that `rng_take_` handed out for T*B*N*H/4 counters.  Returns out (T,B,N*Dout) and
     [saved, pack0, pack1]."""
     lib = _lib.get_lib()
@@ -500,7 +517,8 @@ def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1,
         _check(lib, t, nm)
     if tuple(wp.shape) != (dout, h) or tuple(bp.shape) != (dout,):
         raise RuntimeError(f"projection_layer shapes {tuple(wp.shape)}, {tuple(bp.shape)} do not match ({dout}, {h})")
-    use_tf = len(teacher) > 0 and any(teacher)
+    tf_ptr, tf_keep, tf_dev = _teacher_arg(lib, teacher, teacher_dev, t_len)
+    use_tf = tf_ptr is not None
     if use_tf:
         if targets is None:
             raise RuntimeError("teacher forcing needs the target sequence")
@@ -509,36 +527,34 @@ def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1,
     pack0 = torch.ops.eeg_dcrnn.pack_cell(wg0, bg0, wc0, bc0, dout, h, m)
     pack1 = torch.ops.eeg_dcrnn.pack_cell(wg1, bg1, wc1, bc1, h, h, m) if n_layers > 1 else _new((0,), h0)
     packs = [pack0] + [pack1] * (n_layers - 1)
-    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched), dropout_p)
+    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched), dropout_p, tf_dev)
     out = _new((t_len, b, n * dout), h0)
     saved = _new((lib.query("eeg_dcrnn_decoder_saved_floats", ctypes.byref(dims)),), h0)
     ws = _new((lib.query("eeg_dcrnn_decoder_fwd_ws_floats", ctypes.byref(dims)),), h0)
-    tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if use_tf else None
     pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
-    lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_arr, _p(h0), _p(p), pk_arr,
+    lib.call("eeg_dcrnn_decoder_fwd", ctypes.byref(dims), _p(targets) if use_tf else None, tf_ptr, _p(h0), _p(p), pk_arr,
              _p(wp), _p(bp), _p(rng_used) if dropout_p > 0 else None, _p(out), _p(saved), _p(ws), _stream(h0))
     return out, [saved, pack0, pack1]
 
 
 def _dcgru_decoder_bwd_impl(d_out, p, p_batched: int, saved, pack0, pack1, wp, teacher: List[int], t_len: int, n: int, h: int,
                             dout: int, m: int, n_layers: int, act: int, dropout_p: float, rng_used,
-                            dwg0, dbg0, dwc0, dbc0, dwg1, dbg1, dwc1, dbc1, dwp, dbp):
+                            dwg0, dbg0, dwc0, dbc0, dwg1, dbg1, dwc1, dbc1, dwp, dbp, teacher_dev=None):
     lib = _lib.get_lib()
     d_out = d_out.contiguous()
     _check(lib, d_out, "grad of the decoder output")
     b = d_out.shape[1]
-    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched), dropout_p)
+    tf_ptr, tf_keep, tf_dev = _teacher_arg(lib, teacher, teacher_dev, t_len)
+    dims = _dec_dims((t_len, b, n, h, dout, m, n_layers, act, p_batched), dropout_p, tf_dev)
     if dropout_p > 0:
         _check_rng(lib, rng_used, "rng_used")
     packs = [pack0] + [pack1] * (n_layers - 1)
     g0, g1 = (dwg0, dbg0, dwc0, dbc0), (dwg1, dbg1, dwc1, dbc1)
     dh0 = _new((n_layers, b, n * h), saved)
     ws = _new((lib.query("eeg_dcrnn_decoder_bwd_ws_floats", ctypes.byref(dims)),), saved)
-    use_tf = len(teacher) > 0 and any(teacher)
-    tf_arr = (ctypes.c_int32 * t_len)(*[1 if teacher[i] else 0 for i in range(t_len)]) if use_tf else None
     arr = lambda k: (ctypes.c_void_p * n_layers)(*[(g0 if l == 0 else g1)[k].data_ptr() for l in range(n_layers)])  # noqa: E731
     pk_arr = (ctypes.c_void_p * n_layers)(*[q.data_ptr() for q in packs])
-    lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_arr, _p(p), pk_arr, _p(wp.detach().contiguous()), _p(saved), _p(d_out),
+    lib.call("eeg_dcrnn_decoder_bwd", ctypes.byref(dims), tf_ptr, _p(p), pk_arr, _p(wp.detach().contiguous()), _p(saved), _p(d_out),
              _p(rng_used) if dropout_p > 0 else None, _p(dh0), arr(0), arr(1), arr(2), arr(3), _p(dwp), _p(dbp), _p(ws), _stream(saved))
     return dh0
 
@@ -550,10 +566,10 @@ def _dec_saved_floats_fake(h0, t_len, n, h, dout, m, n_layers):
 _define("dcgru_decoder",
         "(Tensor? targets, Tensor h0, Tensor P, int p_batched, Tensor wg0, Tensor bg0, Tensor wc0, Tensor bc0, Tensor? wg1, Tensor? bg1, "
         "Tensor? wc1, Tensor? bc1, Tensor wp, Tensor bp, int[] teacher, int t_len, int n, int h, int dout, int m, int n_layers, int act, "
-        "float dropout_p, Tensor? rng_used) -> (Tensor out, Tensor[] saved)",
+        "float dropout_p, Tensor? rng_used, Tensor? teacher_dev) -> (Tensor out, Tensor[] saved)",
         _dcgru_decoder_impl,
         lambda targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act,
-        dropout_p, rng_used:
+        dropout_p, rng_used, teacher_dev=None:
         (h0.new_empty((t_len, h0.shape[1], n * dout)),
          [_dec_saved_floats_fake(h0, t_len, n, h, dout, m, n_layers), h0.new_empty((_pack_floats(dout, h, m),)),
           h0.new_empty((_pack_floats(h, h, m) if n_layers > 1 else 0,))]))
@@ -561,7 +577,7 @@ _define("dcgru_decoder_bwd",
         "(Tensor d_out, Tensor P, int p_batched, Tensor saved, Tensor pack0, Tensor pack1, Tensor wp, int[] teacher, int t_len, int n, "
         "int h, int dout, int m, int n_layers, int act, float dropout_p, Tensor? rng_used, Tensor(a!) dwg0, Tensor(b!) dbg0, "
         "Tensor(c!) dwc0, Tensor(d!) dbc0, Tensor(e!)? dwg1, Tensor(f!)? dbg1, Tensor(g!)? dwc1, Tensor(h!)? dbc1, Tensor(i!) dwp, "
-        "Tensor(j!) dbp) -> Tensor",
+        "Tensor(j!) dbp, Tensor? teacher_dev) -> Tensor",
         _dcgru_decoder_bwd_impl,
         lambda d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m, n_layers, act, dropout_p, rng_used, *grads:
         d_out.new_empty((n_layers, d_out.shape[1], n * h)))
@@ -569,26 +585,26 @@ _define("dcgru_decoder_bwd",
 
 def _dcgru_decoder_setup(ctx, inputs, output):
     (targets, h0, p, p_batched, wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp, teacher, t_len, n, h, dout, m, n_layers, act,
-     dropout_p, rng_used) = inputs
+     dropout_p, rng_used, teacher_dev) = inputs
     _, saved = output
     ctx.set_materialize_grads(False)
-    ctx.save_for_backward(p, wp, rng_used, *saved)
+    ctx.save_for_backward(p, wp, rng_used, teacher_dev, *saved)
     ctx.params = (wg0, bg0, wc0, bc0, wg1, bg1, wc1, bc1, wp, bp)
     ctx.meta = (p_batched, list(teacher), t_len, n, h, dout, m, n_layers, act, float(dropout_p))
 
 
 def _dcgru_decoder_backward(ctx, d_out, d_saved):
-    p, wp, rng_used, saved, pack0, pack1 = ctx.saved_tensors
+    p, wp, rng_used, teacher_dev, saved, pack0, pack1 = ctx.saved_tensors
     p_batched, teacher, t_len, n, h, dout, m, n_layers, act, dropout_p = ctx.meta
     if d_out is None:
-        return (None,) * 24
+        return (None,) * 25
     shapes = [None if q is None else tuple(q.shape) for q in ctx.params]
     sunk = [GradSink.take(q) if q is not None else None for q in ctx.params]
     bufs = [t if t is not None else (_new(sh, saved) if sh is not None else None) for t, sh in zip(sunk, shapes)]
     dh0 = torch.ops.eeg_dcrnn.dcgru_decoder_bwd(d_out, p, p_batched, saved, pack0, pack1, wp, teacher, t_len, n, h, dout, m,
-                                                n_layers, act, dropout_p, rng_used if dropout_p > 0 else None, *bufs)
+                                                n_layers, act, dropout_p, rng_used if dropout_p > 0 else None, *bufs, teacher_dev)
     ret = [None if (t is not None or g is None) else g for t, g in zip(sunk, bufs)]   # sunk: already in the caller's buffer
-    return (None, dh0, None, None, *ret, None, None, None, None, None, None, None, None, None, None)
+    return (None, dh0, None, None, *ret, None, None, None, None, None, None, None, None, None, None, None)
 
 
 torch.library.register_autograd(f"{NS}::dcgru_decoder", _dcgru_decoder_backward, setup_context=_dcgru_decoder_setup, lib=_libdef)
@@ -820,6 +836,37 @@ _define("clip_adam_",
         _clip_adam_impl, lambda *a: None)
 
 
+def _clip_adam_dev_impl(params, grads, exp_avg, exp_avg_sq, step_dev, lr_dev, beta1: float, beta2: float, eps: float,
+                        weight_decay: float, max_norm: float, grad_scale: float, ws, norm_out):
+    lib = _lib.get_lib()
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (lr_dev, "lr_dev")):
+        _check(lib, t, nm)
+    _check(lib, step_dev, "step_dev", torch.int32)
+    lib.call("eeg_dcrnn_clip_adam_dev", _p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), params.numel(), float(max_norm),
+             _p(lr_dev), float(beta1), float(beta2), float(eps), float(weight_decay), _p(step_dev), float(grad_scale),
+             _p(ws), _p(norm_out), _stream(params))
+
+
+_define("clip_adam_dev_",
+        "(Tensor(a!) params, Tensor(b!) grads, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, Tensor(g!) step_dev, Tensor lr_dev, float beta1, "
+        "float beta2, float eps, float weight_decay, float max_norm, float grad_scale, Tensor(e!) ws, Tensor(f!)? norm_out) -> ()",
+        _clip_adam_dev_impl, lambda *a: None)
+
+
+def _teacher_flags_impl(rng_state, samples_seen, increment: int, cl_decay_steps: float, t_len: int):
+    lib = _lib.get_lib()
+    _check_rng(lib, rng_state, "rng_state")
+    _check(lib, samples_seen, "samples_seen", torch.int64)
+    flags = _new((t_len,), rng_state, torch.int32)
+    lib.call("eeg_dcrnn_teacher_flags", _p(rng_state), _p(samples_seen), int(increment), float(cl_decay_steps), int(t_len),
+             _p(flags), _stream(rng_state))
+    return flags
+
+
+_define("teacher_flags_", "(Tensor(a!) rng_state, Tensor(b!) samples_seen, int increment, float cl_decay_steps, int t_len) -> Tensor",
+        _teacher_flags_impl, lambda rng_state, samples_seen, increment, cl_decay_steps, t_len: rng_state.new_empty((t_len,), dtype=torch.int32))
+
+
 # =============================================================================================
 # Python conveniences used by model/, utils.py and train_step.py
 # =============================================================================================
@@ -922,11 +969,13 @@ def dcgru_decoder(targets, h0, p, p_batched, first_cell, shared_cell, wp, bp, n,
     act = ACT_CODES.get(activation, 1)
     t_len = targets.shape[0]
     sc = shared_cell if shared_cell is not None else (None, None, None, None)
-    use_tf = teacher is not None and any(teacher)
-    tf = [1 if v else 0 for v in teacher] if use_tf else [0] * t_len     # never an empty list: pytree leaf of the autograd glue
+    # teacher: a sequence of T host flags, or a DEVICE int32[T] tensor (ops.teacher_flags: drawn on the stream, graph-replayable)
+    tf_dev = teacher if torch.is_tensor(teacher) else None
+    use_tf = tf_dev is not None or (teacher is not None and any(teacher))
+    tf = [1 if v else 0 for v in teacher] if (use_tf and tf_dev is None) else [0] * t_len     # never an empty list: pytree leaf of the autograd glue
     used = rng_take(rng_state, t_len * h0.shape[1] * n * h // 4) if dropout_p > 0 else None
     out, _ = torch.ops.eeg_dcrnn.dcgru_decoder(targets if use_tf else None, h0, p, int(p_batched), *first_cell, *sc, wp, bp, tf,
-                                               int(t_len), n, h, dout, m, n_layers, act, float(dropout_p), used)
+                                               int(t_len), n, h, dout, m, n_layers, act, float(dropout_p), used, tf_dev)
     return (out, used) if return_rng_used else out
 
 
@@ -971,6 +1020,27 @@ def bce_with_logits(logits, y):
 def cross_entropy(logits, y):
     """nn.CrossEntropyLoss() (mean) on (B,C) logits and int64 class targets (train.py:205-206)."""
     return torch.ops.eeg_dcrnn.ce_logits(logits, y)[0]
+
+
+def decoder_is_persistent(t_len, batch, n, h, dout, m, n_layers) -> bool:
+    """the persistent decoder kernels cover this shape (then device-resident teacher-forcing flags are available)"""
+    lib = _lib.get_lib()
+    dims = _dec_dims((int(t_len), int(batch), int(n), int(h), int(dout), int(m), int(n_layers), 0, 0))
+    return bool(lib.query("eeg_dcrnn_decoder_is_persistent", ctypes.byref(dims)))
+
+
+def teacher_flags(rng_state, samples_seen, increment, cl_decay_steps, t_len):
+    """Scheduled-sampling flags of one decoder forward drawn ON THE DEVICE (model.py:194-200, utils.py:385-390): int32[t_len],
+    flag t = u_t < k / (k + exp(samples_seen / k)); advances the generator and adds `increment` to samples_seen on the stream."""
+    return torch.ops.eeg_dcrnn.teacher_flags_(rng_state, samples_seen, int(increment), float(cl_decay_steps), int(t_len))
+
+
+def clip_adam_step_dev(params, grads, exp_avg, exp_avg_sq, step_dev, lr_dev, betas, eps, weight_decay, max_norm, grad_scale, ws,
+                       norm_out=None):
+    """clip_adam_step with the step counter (int32[1], incremented on the stream) and the learning rate (float32[1]) in device
+    memory: capturable into a HIP graph together with the rest of the step."""
+    torch.ops.eeg_dcrnn.clip_adam_dev_(params, grads, exp_avg, exp_avg_sq, step_dev, lr_dev, float(betas[0]), float(betas[1]),
+                                       float(eps), float(weight_decay), float(max_norm), float(grad_scale), ws, norm_out)
 
 
 def clip_adam_step(params, grads, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, max_norm, grad_scale, ws,

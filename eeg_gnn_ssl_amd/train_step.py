@@ -69,14 +69,43 @@ class TrainStep:
         self.ws = torch.zeros(64, device=self.fp.flat.device, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=self.fp.flat.device, dtype=torch.float32)
         self.step_count = 0
+        # the optimiser's step count and learning rate also live on the device (eeg_dcrnn_clip_adam_dev reads / advances them on
+        # the stream): the update is then a graph node like everything else.  `step_count` / `lr` are the host mirrors.
+        dev = self.fp.flat.device
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
         # samples seen so far = the reference's `step += batch_size` (train_ssl.py:163,178): drives the scheduled-
         # sampling threshold of the SSL model under curriculum learning (global batch: every rank advances alike)
         self.samples_seen = 0
+        self.samples_seen_dev = torch.zeros(1, device=dev, dtype=torch.int64)
         has_pg = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if has_pg else 1
         self.reduce = has_pg and (self.world > 1 or always_reduce)
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
         self._graphs = {}
+        # curriculum learning (SSL, model.py:194-200): where the persistent decoder kernels apply, the teacher-forcing flags are
+        # drawn on the device (`eeg_dcrnn_teacher_flags`) -- in eager steps and graph replays alike; elsewhere on the host
+        self.device_curriculum = None     # decided at the first batch (needs the shapes)
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if hasattr(self, "lr_dev"):
+            self.lr_dev.fill_(self._lr)   # (outside any captured graph: the graph reads the tensor)
+
+    def _use_device_curriculum(self, y) -> bool:
+        m = self.model
+        if self.task != "ssl" or not getattr(m, "use_curriculum_learning", False):
+            return False
+        if self.device_curriculum is None:
+            dec = m.decoder
+            self.device_curriculum = ops.decoder_is_persistent(y.shape[1], y.shape[0], dec.num_nodes, dec.hid_dim, dec.output_dim,
+                                                               dec.decoding_cells[0].num_matrices, dec.num_rnn_layers)
+        return self.device_curriculum
 
     def set_epoch(self, epoch: int, num_epochs: int, eta_min: float = 0.0):
         """Cosine learning-rate schedule of the reference, stepped per epoch (train.py:224,329)."""
@@ -113,7 +142,11 @@ class TrainStep:
         if supports is None:
             supports = ops.correlation_supports(x, top_k=3)
         if self.task == "ssl":
-            out = self.model(x, y, supports, batches_seen=self.samples_seen)    # train_ssl.py:163
+            if self._use_device_curriculum(y):
+                self.model.batches_seen_increment = x.shape[0] * self.world
+                out = self.model(x, y, supports, batches_seen=self.samples_seen_dev)
+            else:
+                out = self.model(x, y, supports, batches_seen=self.samples_seen)    # train_ssl.py:163
         else:
             out = self.model(x, seq_lengths, supports)
         # The loss kernels return value AND gradient (d loss / d out) from one pass: backward is seeded with that gradient
@@ -125,8 +158,13 @@ class TrainStep:
         return loss.detach()
 
     # -- HIP-graph replay of forward + loss + backward -------------------------------------------
-    def capture(self, x, y, seq_lengths, supports, warmup: int = 2, slot: int = 0):
-        """Capture zero_grad -> forward -> loss -> backward on the given (static) input tensors into
+    def capture(self, x, y, seq_lengths, supports, warmup: int = 2, slot: int = 0, include_update: bool = False):
+        """include_update: also capture the exchange + optimiser tail (the RCCL all-reduce of the flat bucket when a process
+        group exists -- RCCL collectives are capturable -- and the fused clip + Adam, whose step count and learning rate are
+        device-resident): the WHOLE optimisation step is then one graph launch per rank.  The warm-up launches and the upload
+        replay below then apply real updates; a caller that minds restores the state afterwards (`snapshot()` / `restore()`).
+
+        Capture zero_grad -> forward -> loss -> backward on the given (static) input tensors into
         one HIP graph (torch.cuda.CUDAGraph: the library launches on torch's current stream, never
         synchronises and allocates only through torch, so the ~60 launches of a step replay as one
         graph launch).  The exchange + optimiser tail stay outside the graph: the RCCL all-reduce is
@@ -134,42 +172,77 @@ class TrainStep:
         copying into the captured tensors (`x.copy_(batch)`) -- or, without any device-side copy, by capturing the step
         on TWO input sets (`slot` 0 and 1) and alternating `replay_step(slot)`: the host-to-device copy of batch k+1
         then lands directly in the tensors the next replay reads while batch k computes."""
-        if self.task == "ssl" and getattr(self.model, "use_curriculum_learning", False):
-            # the teacher-forcing coin flips (model.py:194-200) are host-side `random.random()` draws that select
-            # which launches are issued: a captured graph would freeze one draw for ever
-            raise RuntimeError("TrainStep.capture: curriculum learning draws teacher-forcing flags on the host every "
-                               "step; use step() (eager launches) for this configuration")
+        if self.task == "ssl" and getattr(self.model, "use_curriculum_learning", False) and not self._use_device_curriculum(y):
+            # host-side teacher-forcing coin flips (model.py:194-200) select which launches are issued: a captured graph would
+            # freeze one draw for ever.  (Where the persistent decoder kernels apply the flags are drawn on the device instead.)
+            raise RuntimeError("TrainStep.capture: this decoder shape is outside the persistent decoder kernels, so curriculum "
+                               "learning draws its teacher-forcing flags on the host every step; use step() (eager launches)")
+        keep = self.snapshot() if self.task == "ssl" and self._use_device_curriculum(y) and not include_update else None
+
+        def body():
+            loss = self.forward_backward(x, y, seq_lengths, supports)
+            if include_update:
+                self.reduce_and_update(count=False)
+            return loss
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                       # populate the allocator before capture
-                self.forward_backward(x, y, seq_lengths, supports)
+                body()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss = self.forward_backward(x, y, seq_lengths, supports)
+            loss = body()
         # one untimed replay: the first launch of an instantiated graph also uploads it to the device (torch exposes no
-        # hipGraphUpload); it recomputes the gradients of the captured batch, nothing else changes
+        # hipGraphUpload); it recomputes the gradients of the captured batch (and, with include_update, applies one more update)
         graph.replay()
-        self._graphs[slot] = (graph, loss, (x, y, seq_lengths, supports))
+        if include_update:
+            self.step_count += warmup + 1
+            self.samples_seen += (warmup + 1) * x.shape[0] * self.world
+        elif keep is not None:
+            self.restore(keep, counters_only=True)        # the warm-up draws advanced the device-side sample counter
+        self._graphs[slot] = (graph, loss, (x, y, seq_lengths, supports), include_update)
         return graph
+
+    def snapshot(self):
+        """everything a step changes besides the gradients: parameters, Adam moments, counters (device and host)"""
+        return {"flat": self.fp.flat.detach().clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "step_dev": self.step_dev.clone(), "samples_seen_dev": self.samples_seen_dev.clone(),
+                "step_count": self.step_count, "samples_seen": self.samples_seen}
+
+    def restore(self, snap, counters_only: bool = False):
+        with torch.no_grad():
+            if not counters_only:
+                self.fp.flat.copy_(snap["flat"])
+                self.exp_avg.copy_(snap["exp_avg"])
+                self.exp_avg_sq.copy_(snap["exp_avg_sq"])
+                self.step_dev.copy_(snap["step_dev"])
+                self.step_count = snap["step_count"]
+            self.samples_seen_dev.copy_(snap["samples_seen_dev"])
+            self.samples_seen = snap["samples_seen"]
 
     def replay_step(self, slot: int = 0):
         """One optimisation step on the captured tensors of `slot`: graph replay + all-reduce + clip/Adam."""
-        graph, loss, inputs = self._graphs[slot]
+        graph, loss, inputs, whole = self._graphs[slot]
         graph.replay()
         self.samples_seen += inputs[0].shape[0] * self.world
-        self.reduce_and_update()
+        if whole:
+            self.step_count += 1
+        else:
+            self.reduce_and_update()
         return loss
 
-    def reduce_and_update(self):
+    def reduce_and_update(self, count: bool = True):
         g = self.fp.flat_grad
         if self.reduce:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)        # RCCL over xGMI: one flat bucket
-        self.step_count += 1
-        # mean over ranks (grad_scale), clip_grad_norm_(max_norm) and Adam in one pass over the buffers
-        ops.clip_adam_step(self.fp.flat, g, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas,
-                           self.eps, self.weight_decay, self.max_grad_norm, 1.0 / self.world, self.ws, self.grad_norm)
+        if count:
+            self.step_count += 1
+        # mean over ranks (grad_scale), clip_grad_norm_(max_norm) and Adam in one pass over the buffers; the kernel advances
+        # the device-resident step count itself
+        ops.clip_adam_step_dev(self.fp.flat, g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr_dev, self.betas,
+                               self.eps, self.weight_decay, self.max_grad_norm, 1.0 / self.world, self.ws, self.grad_norm)
         return self.grad_norm
 
     def step(self, x, y, seq_lengths, supports):
@@ -185,6 +258,8 @@ class TrainStep:
     def load_state_dict(self, state):
         self.step_count, self.lr = int(state["step"]), float(state["lr"])
         self.samples_seen = int(state.get("samples_seen", 0))
+        self.step_dev.fill_(self.step_count)
+        self.samples_seen_dev.fill_(self.samples_seen)
         self.exp_avg.copy_(state["exp_avg"])
         self.exp_avg_sq.copy_(state["exp_avg_sq"])
 
@@ -225,6 +300,42 @@ def predict(model, batches, task: str = "detection"):
         prob, lab = _all_gather_uneven(prob), _all_gather_uneven(lab)
     model.train(was_training)
     return prob.cpu().numpy(), lab.cpu().numpy()
+
+
+@torch.no_grad()
+def evaluate_ssl(model, batches, scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None,
+                 return_predictions: bool = False):
+    """The reference's SSL evaluation pass (train_ssl.py:232-280): eval mode (no dropout, no teacher forcing -- `model(x, y,
+    supports)` without `batches_seen`), per batch the masked MAE in original units (`loss_fn="mae"` with the StandardScaler,
+    utils.py:431-495) from the HIP loss kernel, averaged over the data set weighted by batch size (the reference's
+    `AverageMeter`, train_ssl.py:262-263,276).  Launched data-parallel, every rank evaluates its shard and all ranks
+    return the loss of the union (all-reduce of the weighted sum and the count; no host round trip per batch).
+    batches: iterable of (x, y, supports) or (x, y, seq_lengths, supports) device tensors (supports None: built on the
+    device).  Returns eval_loss (float) -- and, with return_predictions, the predictions and targets of THIS rank's shard
+    as the reference collects them (train_ssl.py:266-274)."""
+    was_training = model.training
+    model.eval()
+    tot, preds, truths = None, [], []
+    for batch in batches:
+        x, y, supports = batch[0], batch[1], batch[-1]
+        if supports is None:
+            supports = ops.correlation_supports(x, top_k=3)
+        pred = model(x, y, supports)
+        loss = ops.masked_regression_loss(pred, y, scaler_mean, scaler_std, loss_fn="mae")
+        w = torch.stack([loss.reshape(()).double() * x.shape[0], torch.tensor(float(x.shape[0]), device=x.device, dtype=torch.float64)])
+        tot = w if tot is None else tot + w
+        if return_predictions:
+            preds.append(pred)
+            truths.append(y)
+    if tot is None:
+        raise ValueError("evaluate_ssl: no batches")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(tot)
+    model.train(was_training)
+    eval_loss = float((tot[0] / tot[1]).item())
+    if return_predictions:
+        return eval_loss, torch.cat(preds).cpu().numpy(), torch.cat(truths).cpu().numpy()
+    return eval_loss
 
 
 @torch.no_grad()

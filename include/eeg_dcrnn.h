@@ -49,6 +49,9 @@ typedef struct eeg_decoder_dims {
     int32_t M, L;        /* hop matrices; num_rnn_layers (layers >= 1 share ONE cell, model.py:126-143) */
     int32_t act, p_batched;
     float dropout_p;     /* nn.Dropout in front of the projection (model.py:191), p when the module is training, else 0 */
+    int32_t teacher_on_device;  /* 1: `teacher` of decoder_fwd / _bwd is a DEVICE int32[T] array (e.g. written by
+                                   eeg_dcrnn_teacher_flags earlier on the stream) that the persistent kernels read when they
+                                   start -- a captured HIP graph then replays with fresh curriculum-learning flags; 0: HOST array */
 } eeg_decoder_dims;
 
 /* Human-readable text of the last error raised on the calling thread. */
@@ -161,7 +164,10 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
  * The recurrence cannot be hoisted (the input of step t+1 is the output of step t), so the forward
  * launches per step; the backward runs BPTT per step and ALL parameter gradients as GEMMs hoisted
  * over the T steps.  dWg/dbg/dWc/dbc: HOST arrays of L device pointers (entries 1..L-1 equal:
- * gradients of the shared cell are summed); dh0 (L,B,N,H); dWp (Dout,H); dbp (Dout). */
+ * gradients of the shared cell are summed); dh0 (L,B,N,H); dWp (Dout,H); dbp (Dout).
+ * d->teacher_on_device = 1: `teacher` is a device array (targets must then be given); available where the persistent decoder
+ * kernels run (64 units, <= 20 nodes, <= 4 layers, T <= 64, Dout <= 128 with Dout/4 divisible by 4 or 5), refused elsewhere:
+ * the per-step launch sequence is selected by the flags and cannot depend on device memory. */
 size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d);
 size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d);
 size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d);
@@ -170,6 +176,8 @@ size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d);
  * for T*B*N*H/4 counters: element e = ((t*B + b)*N + n)*H + h of the top-layer outputs takes word e%4 of counter offset + e/4.
  * The masks are fused into the persistent kernels (nothing is stored but the dropped rows that dW_p needs) and recomputed in the
  * backward from the same pair.  dropout_p == 0: rng_used may be NULL. */
+/* 1 if the persistent decoder kernels cover this shape (then d->teacher_on_device = 1 is available), else 0. */
+int eeg_dcrnn_decoder_is_persistent(const eeg_decoder_dims* d);
 int eeg_dcrnn_decoder_fwd(const eeg_decoder_dims* d, const float* targets, const int32_t* teacher,
                           const float* h0, const float* P, const float* const* packs, const float* Wp,
                           const float* bp, const uint64_t* rng_used, float* out, float* saved,
@@ -178,6 +186,15 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
                           const float* const* packs, const float* Wp, const float* saved, const float* dOut,
                           const uint64_t* rng_used, float* dh0, float* const* dWg, float* const* dbg,
                           float* const* dWc, float* const* dbc, float* dWp, float* dbp, float* ws, void* stream);
+
+/* Scheduled sampling drawn on the device (model.py:194-200: one `random.random() < teacher_forcing_ratio` per decoder step;
+ * utils.py:385-390: ratio = k / (k + exp(batches_seen / k)), k = cl_decay_steps): flags[t] (DEVICE int32[T]) = 1 iff
+ * u_t < ratio, u_t = word t%4 of Philox counter offset + t/4 of rng_state (the dropout generator's {seed, offset} pair) / 2^32,
+ * evaluated in fp64.  ON THE STREAM: rng_state's offset advances by ceil(T/4) and samples_seen[0] (DEVICE int64, the
+ * reference's `step`, train_ssl.py:163,178) by `increment` (the global batch), so every replay of a captured step draws fresh
+ * flags against the decayed threshold. */
+int eeg_dcrnn_teacher_flags(uint64_t* rng_state, int64_t* samples_seen, int64_t increment, double cl_decay_steps, int T,
+                            int32_t* flags, void* stream);
 
 /* utils.last_relevant_pytorch (utils.py:346-357): last[b] = Htop[lengths[b]-1, b]. Htop (T,B,NH). */
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH,
@@ -222,6 +239,15 @@ size_t eeg_dcrnn_clip_adam_ws_floats(void);
 int eeg_dcrnn_clip_adam(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                         int step, float grad_scale, float* ws, float* norm_out, void* stream);
+
+/* The same update with the optimiser's step count and learning rate in DEVICE memory: step_dev[0] (int32, the number of updates
+ * applied so far) is incremented on the stream and the bias corrections 1 - beta^step are formed in the kernel; lr_dev[0] is the
+ * current learning rate (the host rewrites it between epochs, train.py:224,329 cosine schedule).  With these two the whole
+ * optimisation step -- zero_grad ... backward, [all-reduce], clip, Adam -- is capturable as ONE HIP graph. */
+int eeg_dcrnn_clip_adam_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                            float max_norm, const float* lr_dev, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t* step_dev, float grad_scale, float* ws, float* norm_out,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,4 +66,5 @@ inline bool platform_copy_floats(float* dst, const float* src, size_t n, hipStre
     memcpy(dst, src, n * sizeof(float));
     return true;
 }
+inline bool platform_stream_is_capturing(hipStream_t) { return false; }
 }  // namespace eeg

@@ -321,7 +321,11 @@ def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed
     h0 = 0.5 * torch.randn(layers, b, n * h, generator=g)
     wout = torch.randn(t_out, b, n * dout, generator=g)
     mask = None
-    if ratio is not None:
+    device_flags = ratio == "device"        # the flags as a DEVICE int32[T] tensor (read by the persistent kernels when they start)
+    if device_flags:
+        mask = [(3 * i + seed) % 5 in (0, 3) for i in range(t_out)]
+        ratio = None
+    elif ratio is not None:
         random.seed(seed)
         mask = [random.random() < ratio for _ in range(t_out)]
         assert any(mask) and not all(mask[:-1]), mask
@@ -342,7 +346,8 @@ def check_decoder_vs_oracle(device, filt, dout, h, layers, t_out, b, adj3d, seed
     h0d = h0.clone().to(device).requires_grad_(True)
     if ratio is not None:
         random.seed(seed)
-    out = dec(targets.to(device), h0d, [s.to(device) for s in sup], teacher_forcing_ratio=ratio)
+    flags = torch.tensor([1 if v else 0 for v in mask], dtype=torch.int32, device=device) if device_flags else None
+    out = dec(targets.to(device), h0d, [s.to(device) for s in sup], teacher_forcing_ratio=ratio, teacher_flags=flags)
     (out * wout.to(device)).sum().backward()
     assert_close(out.detach().cpu().numpy(), oo.detach().numpy(), "decoder outputs vs oracle")
     assert_close_scaled(h0d.grad.cpu().numpy(), h0o.grad.numpy(), "d_initial_hidden_state vs oracle", tol=5e-5)
@@ -567,6 +572,39 @@ def check_eval_driver(device, adj3d):
         assert np.abs(y_prob - ref_prob).max() < 1e-5 and (y_true == yy.numpy()).all()
 
 
+def check_ssl_eval_driver(device, adj3d):
+    """train_step.evaluate_ssl (train_ssl.py:232-280): eval-mode predictions, masked MAE in original units per batch,
+    batch-size-weighted average -- against the same quantities from the oracle."""
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import evaluate_ssl
+    g = torch.Generator().manual_seed(21)
+    cfg = orc.DCRNNConfig(filter_type="dual_random_walk", input_dim=20, output_dim=20, rnn_units=64, num_rnn_layers=2)
+    params = orc.init_params(cfg, "ssl", seed=4)
+    a = make_args(cfg)
+    a.dropout, a.use_curriculum_learning = 0.5, True      # both must be inert in eval mode
+    model = DCRNNModel_nextTimePred(a, device=device)
+    load(model, params, device)
+    model.train()
+    batches, num, den, ref_preds = [], 0.0, 0, []
+    for b in (4, 2, 3):
+        x = torch.randn(b, 5, 19, 20, generator=g)
+        y = torch.randn(b, 3, 19, 20, generator=g)
+        y[0, 1, 5, :7] = -cases.SSL_MEAN / cases.SSL_STD                              # entries that un-scale to 0 are masked out
+        sup = cases.supports_for("dual_random_walk", adj3d, b)
+        batches.append((x.to(device), y.to(device), [s.to(device) for s in sup]))
+        pr = orc.next_time_pred_forward(params, cfg, x, y, sup)
+        ref_preds.append(pr)
+        num += orc.regression_loss(y, pr, cases.SSL_MEAN, cases.SSL_STD, loss_fn="mae").item() * b
+        den += b
+    loss, preds, truths = evaluate_ssl(model, batches, cases.SSL_MEAN, cases.SSL_STD, return_predictions=True)
+    assert model.training
+    assert abs(loss - num / den) < 1e-5 * max(1.0, abs(num / den)), (loss, num / den)
+    assert preds.shape == (9, 3, 19, 20) and truths.shape == preds.shape
+    assert_close(preds, torch.cat(ref_preds).detach().numpy(), "evaluate_ssl predictions")
+    assert abs(evaluate_ssl(model, batches[:1], cases.SSL_MEAN, cases.SSL_STD) -
+               orc.regression_loss(batches[0][1].cpu(), ref_preds[0], cases.SSL_MEAN, cases.SSL_STD, loss_fn="mae").item()) < 1e-5
+
+
 def check_fft_features(device, golden_fft):
     """On-device featurisation (1-s windows -> log|FFT| -> reflection / amplitude jitter -> z-score) vs the
     goldens of the genuine reference pipeline and, for the augmented variant and a ragged shape, the oracle."""
@@ -784,6 +822,137 @@ def check_dropout_generator(device):
         assert abs(keep - (1 - p)) <= 3 * np.sqrt(p * (1 - p) / n), (p, keep)
     assert float(ops.dropout_mask(u2, 64, 1.0).abs().max()) == 0.0            # p = 1: everything dropped (like torch)
     assert float((ops.dropout_mask(u2, 64, 0.0) - 1).abs().max()) == 0.0      # p = 0: identity
+
+
+def expected_teacher_flags(seed, offset, seen, decay, t_len):
+    """numpy restatement of eeg_dcrnn_teacher_flags: flag t = u_t < k / (k + exp(seen / k)) (utils.py:385-390,
+    model.py:194-200), u_t = word t%4 of Philox counter offset + t/4, / 2^32"""
+    import math
+    groups = (t_len + 3) // 4
+    words = philox4x32_10_numpy(np.uint64(offset) + np.arange(groups, dtype=np.uint64), int(seed)).reshape(-1)[:t_len]
+    ratio = decay / (decay + math.exp(seen / decay))
+    return (words.astype(np.float64) / 4294967296.0 < ratio).astype(np.int32)
+
+
+def check_teacher_flags(device):
+    """known-answer test of the device-side scheduled sampling: the flags are the documented function of the generator pair
+    and of the samples-seen counter; generator offset and counter advance on the stream; the flag rate follows the threshold."""
+    from eeg_gnn_ssl_amd import ops
+    st = torch.tensor([987654321, 5], dtype=torch.int64, device=device)
+    seen = torch.tensor([4000], dtype=torch.int64, device=device)
+    decay = 3000.0
+    f1 = ops.teacher_flags(st, seen, 96, decay, 12)
+    f2 = ops.teacher_flags(st, seen, 96, decay, 7)
+    assert f1.dtype == torch.int32 and f1.tolist() == expected_teacher_flags(987654321, 5, 4000, decay, 12).tolist()
+    assert f2.tolist() == expected_teacher_flags(987654321, 8, 4096, decay, 7).tolist()
+    assert st.tolist() == [987654321, 10] and seen.tolist() == [4192]
+    # rate: k / (k + exp(n / k)) at n = 0 is k / (k + 1) ~ 1 (always teacher-forced), far out it is ~ 0
+    seen0 = torch.zeros(1, dtype=torch.int64, device=device)
+    assert sum(ops.teacher_flags(st, seen0, 0, decay, 64).tolist()) >= 63
+    far = torch.tensor([60000], dtype=torch.int64, device=device)
+    assert sum(ops.teacher_flags(st, far, 0, decay, 64).tolist()) == 0
+    mid = torch.tensor([int(decay * np.log(decay))], dtype=torch.int64, device=device)       # ratio = 1/2
+    tot = sum(sum(ops.teacher_flags(st, mid, 0, decay, 64).tolist()) for _ in range(16))
+    assert abs(tot / 1024.0 - 0.5) < 3 * 0.5 / np.sqrt(1024.0) + 0.01, tot
+
+
+def check_ssl_device_curriculum(tag, adj3d, device, dropout=0.0):
+    """DCRNNModel_nextTimePred under curriculum learning with the teacher-forcing flags drawn ON THE DEVICE (batches_seen = a
+    device counter tensor): the flags the kernels read are re-derived from the generator pair and handed to the oracle ->
+    predictions and every gradient agree; the counter advanced by the increment."""
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred, ops, utils
+    c = cases.ssl_inputs(tag, adj3d)
+    cfg = c["cfg"]
+    args = _dropout_args(cfg, dropout)
+    args.use_curriculum_learning = True
+    args.cl_decay_steps = 50
+    model = DCRNNModel_nextTimePred(args, device=device)
+    load(model, c["params"], device)
+    model.train()
+    sup = [t.to(device) for t in c["sup"]]
+    x, y = c["x"].to(device), c["y"].to(device)
+    b, t_out, n, h = y.shape[0], y.shape[1], 19, cfg.rnn_units
+    assert ops.decoder_is_persistent(t_out, b, n, h, cfg.output_dim, 2 * cfg.max_diffusion_step + 1 if cfg.filter_type == "dual_random_walk"
+                                     else cfg.max_diffusion_step + 1, cfg.num_rnn_layers)
+    seen0 = 196                      # ratio = 50 / (50 + exp(3.92)) ~ 0.5
+    seen = torch.tensor([seen0], dtype=torch.int64, device=device)
+    model.batches_seen_increment = 24
+    model.decoder.set_dropout_seed(20240917, 3)
+    seeds = []
+    for rep in range(6):             # several draws: mixed flags must occur and each must match the oracle
+        seed, off = model.decoder.dropout_rng_state()
+        n_seen = int(seen.item())
+        flags = expected_teacher_flags(seed, off, n_seen, 50.0, t_out)
+        seeds.append(flags.tolist())
+        model.zero_grad()
+        pred = model(x, y, sup, batches_seen=seen)
+        assert int(seen.item()) == n_seen + 24
+        masks = None
+        if dropout > 0:
+            groups = t_out * b * n * h // 4
+            used = torch.tensor([seed, off + (t_out + 3) // 4], dtype=torch.int64, device=device)
+            masks = ops.dropout_mask(used, 4 * groups, dropout).view(t_out, b, n, h).cpu()
+            assert model.decoder.dropout_rng_state() == (seed, off + (t_out + 3) // 4 + groups)
+        else:
+            assert model.decoder.dropout_rng_state() == (seed, off + (t_out + 3) // 4)
+        loss = utils.compute_regression_loss(y_true=y, y_predicted=pred, standard_scaler=utils.StandardScaler(cases.SSL_MEAN, cases.SSL_STD),
+                                             loss_fn="MAE")
+        loss.backward()
+        uniq, po = {}, {}
+        for k, v in c["params"].items():
+            if id(v) not in uniq:
+                uniq[id(v)] = v.clone().requires_grad_(True)
+            po[k] = uniq[id(v)]
+        pro = orc.next_time_pred_forward(po, cfg, c["x"], c["y"], c["sup"], teacher_force_mask=[bool(v) for v in flags],
+                                         dropout_masks=masks)
+        lso = orc.regression_loss(c["y"], pro, cases.SSL_MEAN, cases.SSL_STD, loss_fn="MAE")
+        lso.backward()
+        assert_close(pred.detach().cpu().numpy(), pro.detach().numpy(), f"device curriculum ssl/{tag}/pred (flags {flags.tolist()})")
+        for k, q in model.named_parameters():
+            assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"device curriculum ssl/{tag}/d_{k}")
+    assert len({tuple(f) for f in seeds}) > 1 and any(0 < sum(f[:-1]) < t_out - 1 for f in seeds), seeds
+
+
+def check_device_step_adam(device):
+    """eeg_dcrnn_clip_adam_dev (step count and learning rate in device memory, the count advanced by the kernel) walks the same
+    parameters as eeg_dcrnn_clip_adam with the host's step / lr arguments, over several steps incl. a learning-rate change."""
+    from eeg_gnn_ssl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n = 5000
+    p0 = torch.randn(n, generator=g)
+    grads = [3.0 * torch.randn(n, generator=g) for _ in range(5)]
+    res = []
+    for dev_side in (False, True):
+        p, m, v = p0.clone().to(device), torch.zeros(n, device=device), torch.zeros(n, device=device)
+        ws, nrm = torch.zeros(64, device=device), torch.zeros(1, device=device)
+        step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        lr_dev = torch.full((1,), 1e-2, device=device)
+        norms = []
+        for k, g_ in enumerate(grads):
+            lr = 1e-2 if k < 3 else 2.5e-3
+            gd = g_.clone().to(device)
+            if dev_side:
+                lr_dev.fill_(lr)
+                ops.clip_adam_step_dev(p, gd, m, v, step_dev, lr_dev, (0.9, 0.999), 1e-8, 5e-4, 5.0, 0.5, ws, nrm)
+            else:
+                ops.clip_adam_step(p, gd, m, v, k + 1, lr, (0.9, 0.999), 1e-8, 5e-4, 5.0, 0.5, ws, nrm)
+            norms.append(float(nrm.item()))
+        if dev_side:
+            assert int(step_dev.item()) == len(grads)
+        res.append((p.cpu(), m.cpu(), v.cpu(), norms))
+    for a, b_ in zip(res[0][:3], res[1][:3]):
+        assert float((a - b_).abs().max()) <= 1e-7 * max(1.0, float(a.abs().max()))
+    assert res[0][3] == res[1][3]
+    # and against torch.optim.Adam + clip_grad_norm_ (the reference recipe, train.py:222-223,273-275)
+    q = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([q], lr=1e-2, weight_decay=5e-4)
+    for k, g_ in enumerate(grads):
+        for grp in opt.param_groups:
+            grp["lr"] = 1e-2 if k < 3 else 2.5e-3
+        q.grad = 0.5 * g_.clone()
+        torch.nn.utils.clip_grad_norm_([q], 5.0)
+        opt.step()
+    assert float((q.detach() - res[1][0]).abs().max()) < 2e-6
 
 
 def _dropout_args(cfg, p):

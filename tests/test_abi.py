@@ -39,7 +39,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(ctypes.CDLL(DEV_LIB), s)
     dll.eeg_dcrnn_is_device_build.restype = ctypes.c_int
     assert dll.eeg_dcrnn_is_device_build() == 1
-    assert dll.eeg_dcrnn_abi_version() == 3
+    assert dll.eeg_dcrnn_abi_version() == 4
     assert dll.eeg_dcrnn_supported(19, 64, 100, 3) == 1
     assert dll.eeg_dcrnn_supported(19, 48, 100, 3) == 0
     dll.eeg_dcrnn_last_error.restype = ctypes.c_char_p
@@ -59,10 +59,39 @@ def test_operators_are_registered_with_the_dispatcher():
     import eeg_gnn_ssl_amd  # noqa: F401  (registers the library)
     for name in ("hop_polys", "pack_cell", "diffusion_hops", "dconv", "dconv_bwd", "dcgru_layer", "dcgru_layer_bwd",
                  "dcgru_decoder", "dcgru_decoder_bwd", "cls_head", "cls_head_bwd", "rng_take_", "dropout_mask", "gather_last", "corr_graph", "fft_features",
-                 "bce_logits", "ce_logits", "masked_loss", "clip_adam_"):
+                 "bce_logits", "ce_logits", "masked_loss", "clip_adam_", "clip_adam_dev_", "teacher_flags_"):
         op = getattr(torch.ops.eeg_dcrnn, name)
         assert op.default._schema.name == f"eeg_dcrnn::{name}"
     assert torch.ops.eeg_dcrnn.clip_adam_.default._schema.is_mutable
+
+
+def test_a_library_of_another_abi_version_is_refused_in_both_modes(tmp_path, monkeypatch):
+    """strict=False (development A/B loads of older builds) tolerates MISSING entry points only: another ABI version means
+    other signatures behind the same names, i.e. shifted arguments"""
+    import pytest
+    from eeg_gnn_ssl_amd import _lib
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    for strict in (True, False):
+        with pytest.raises(ImportError, match="ABI version"):
+            _lib.EegDcrnnLib(LIB, strict=strict)
+
+
+def test_dropout_generator_state_is_created_with_the_module_and_leaves_the_global_generator_alone():
+    import torch
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, ops
+    import bench
+    torch.manual_seed(99)
+    before = torch.get_rng_state()
+    a, b = ops.make_rng_state("cpu", 0), ops.make_rng_state("cpu", 1)
+    assert torch.equal(before, torch.get_rng_state())                       # a dedicated generator: no global draw
+    assert a[0] != b[0] and a[1] == 0
+    torch.manual_seed(99)
+    assert torch.equal(ops.make_rng_state("cpu", 0), a)                     # torch.manual_seed governs the seed
+    args = bench.make_args("laplacian", dropout=0.5)
+    m = DCRNNModel_classification(args, 4)
+    assert "_dropout_rng" in dict(m.named_buffers()) and "_dropout_rng" not in m.state_dict()
+    m.set_dropout_seed(5, 9)
+    assert m.dropout_rng_state() == (5, 9)
 
 
 def test_product_has_no_cpu_path():

@@ -186,3 +186,78 @@ def test_uneven_evaluation_shards_gather(tmp_path):
     for r in range(3):
         got = torch.load(os.path.join(str(tmp_path), f"g{r}.pt"))
         assert torch.equal(got["prob"], want_prob) and torch.equal(got["soft"], want_soft) and torch.equal(got["lab"], want_lab), r
+
+
+# ---- SSL under curriculum learning with DEVICE-side teacher-forcing flags + the data-parallel SSL evaluation pass ------
+def _make_ssl64():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import numpy as np
+    import cases
+    import types
+    adj = np.load(os.path.join(ROOT, "tests", "golden", "adj_mx_3d.npy"))
+    args = types.SimpleNamespace(num_nodes=19, num_rnn_layers=2, rnn_units=64, input_dim=20, output_dim=20,
+                                 max_diffusion_step=1, dcgru_activation="tanh", filter_type="dual_random_walk", dropout=0.0,
+                                 cl_decay_steps=4, use_curriculum_learning=True)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(6, 3, 19, 20, generator=g)
+    y = torch.randn(6, 4, 19, 20, generator=g)
+    return args, x, y, cases.supports_for("dual_random_walk", adj, 6)
+
+
+SHARDS_SSL = [(0, 3), (3, 6)]          # even shards: the global sample counter is per-rank batch x world (train_step.py)
+
+
+def _worker_ssl64(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    import emu_support
+    emu_support.install_emulator()
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import TrainStep, evaluate_ssl
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args, x, y, sup = _make_ssl64()
+    torch.manual_seed(0)
+    model = DCRNNModel_nextTimePred(args).train()
+    step = TrainStep(model, task="ssl", lr=1e-2)
+    lo, hi = SHARDS_SSL[rank]
+    flags = []
+    for _ in range(3):
+        seed, off = model.decoder.dropout_rng_state()
+        flags.append((seed, off, int(step.samples_seen_dev.item())))
+        step.step(x[lo:hi], y[lo:hi], None, [s[lo:hi] for s in sup])
+    ev = evaluate_ssl(model, [(x[lo:hi], y[lo:hi], [s[lo:hi] for s in sup])], 0.3, 1.7)
+    torch.save({"param": step.fp.flat.clone(), "flags": flags, "device_curriculum": step.device_curriculum,
+                "seen_dev": int(step.samples_seen_dev.item()), "seen": step.samples_seen, "eval": ev},
+               os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_ssl_device_curriculum_and_evaluation(tmp_path):
+    """Curriculum learning with the flags drawn on the device (eeg_dcrnn_teacher_flags): both ranks draw the SAME flags (same
+    generator seed, same global sample counter, which advances by the GLOBAL batch), end with identical parameters, and
+    `evaluate_ssl` returns on every rank the batch-size-weighted masked MAE of the union of the shards."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_support
+    emu_support.install_emulator()
+    port = 30500 + (os.getpid() % 2000)
+    mp.spawn(_worker_ssl64, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"s{r}.pt") for r in range(2))
+    assert r0["device_curriculum"] is True and r1["device_curriculum"] is True
+    assert r0["flags"] == r1["flags"] and [f[2] for f in r0["flags"]] == [0, 6, 12]      # (seed, offset, samples seen) per step
+    assert r0["seen_dev"] == r1["seen_dev"] == r0["seen"] == r1["seen"] == 18
+    assert torch.equal(r0["param"], r1["param"])
+    assert r0["eval"] == r1["eval"]
+    # the union's loss from one process with the ranks' final parameters
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import FlatParameters, evaluate_ssl
+    args, x, y, sup = _make_ssl64()
+    model = DCRNNModel_nextTimePred(args)
+    fp = FlatParameters(model)
+    with torch.no_grad():
+        fp.flat.copy_(r0["param"])
+    want = evaluate_ssl(model, [(x[lo:hi], y[lo:hi], [s[lo:hi] for s in sup]) for lo, hi in SHARDS_SSL], 0.3, 1.7)
+    assert abs(want - r0["eval"]) < 1e-6 * max(1.0, abs(want))
+    emu_support.uninstall()

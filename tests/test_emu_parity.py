@@ -50,6 +50,24 @@ def test_ssl_model_training_dropout(tag, adj3d):
     ps.check_dropout_ssl_case(tag, adj3d, "cpu")
 
 
+def test_teacher_flags_known_answer():
+    ps.check_teacher_flags("cpu")
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.5])
+def test_ssl_model_device_curriculum(adj3d, dropout):
+    ps.check_ssl_device_curriculum("dual_default", adj3d, "cpu", dropout)
+
+
+def test_device_step_adam():
+    ps.check_device_step_adam("cpu")
+
+
+def test_device_flags_refused_outside_the_persistent_kernels(adj3d):
+    with pytest.raises(Exception, match="persistent decoder kernel"):
+        ps.check_decoder_vs_oracle("cpu", "laplacian", 8, 16, 2, 4, 2, adj3d, seed=1, ratio="device")
+
+
 def test_random_vs_oracle_h32_relu_varlen(adj3d):
     ps.check_vs_oracle_random("cpu", "dual_random_walk", 12, 32, 2, 4, 3, 4, adj3d, seed=3, lengths=[4, 2, 1], act="relu")
 
@@ -117,6 +135,7 @@ def test_decoder_vs_oracle(filt, dout, h, layers, t_out, b, ratio, act, adj3d):
     ("laplacian", 16, 2, 3, 2, 0.5, 19, 0),             # max_diffusion_step = 0: M = 1, no hop slots
     ("dual_random_walk", 20, 4, 2, 1, None, 5, 1),      # four layers (three uses of the shared cell), 5 nodes
     ("dual_random_walk", 60, 2, 2, 2, None, 19, 2),     # Dout = 60, M = 5: three leftover 16-byte pieces per hop slot -> 4 tail chunks of the quad pack
+    ("laplacian", 20, 3, 6, 2, "device", 19, 1),        # teacher-forcing flags read from DEVICE memory by the persistent kernels
 ])
 def test_persistent_decoder_edge_shapes(filt, dout, layers, t_out, b, ratio, n, order, adj3d):
     """the persistent decoder kernels (forward and BPTT, kernels_decoder.h) at the edges of their range"""
@@ -133,6 +152,10 @@ def test_grad_sink_equals_autograd_accumulation(adj3d):
 
 def test_hop_plane_handover_between_layers(adj3d):
     ps.check_plane_handover("cpu", adj3d)
+
+
+def test_ssl_evaluation_driver(adj3d):
+    ps.check_ssl_eval_driver("cpu", adj3d)
 
 
 def test_evaluation_driver(adj3d):

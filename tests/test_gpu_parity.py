@@ -496,6 +496,97 @@ def test_hip_graph_replay_equals_eager_steps():
     assert torch.equal(finals[0], finals[1])
 
 
+def test_whole_step_graph_equals_eager_steps():
+    """capture(include_update=True): zero_grad + forward + loss + backward + clip + Adam as ONE HIP graph (the step count and the
+    learning rate live on the device, `eeg_dcrnn_clip_adam_dev`).  Replays must walk the parameters of the same number of
+    eager steps bit for bit, incl. a learning-rate change between replays (train.py:224,329: the host rewrites lr per epoch)."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, classes = "classification", "laplacian", 4
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, 9, 6, classes, seed=3)
+    xd, yd, ld, supd = x.to(DEV), y.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup]
+    finals, losses = [], []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3)
+        if graphed:
+            snap = st.snapshot()
+            st.capture(xd, yd, ld, supd, include_update=True)      # (warm-ups and the upload replay applied real updates)
+            assert st.step_count == 3 and int(st.step_dev.item()) == 3
+            st.restore(snap)
+            assert st.step_count == 0 and int(st.step_dev.item()) == 0
+        ls = []
+        for k in range(5):
+            if k == 3:
+                st.set_epoch(3, 10)                                  # cosine schedule: lr changes, the graph reads lr_dev
+            ls.append(float((st.replay_step() if graphed else st.step(xd, yd, ld, supd)).item()))
+        torch.cuda.synchronize()
+        assert st.step_count == 5 and int(st.step_dev.item()) == 5
+        finals.append(st.fp.flat.detach().clone())
+        losses.append(ls)
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1])
+
+
+def test_curriculum_learning_replays_as_a_graph():
+    """model.py:194-200 under HIP-graph replay: the teacher-forcing flags are drawn by `eeg_dcrnn_teacher_flags` on the stream
+    (a node of the graph), so every replay draws fresh flags against the decayed threshold and the captured SSL step equals the
+    eager one bit for bit; the flags the replays used differ from step to step."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt = "ssl", "dual_random_walk"
+    g = torch.Generator().manual_seed(9)
+    b, t_in, t_out = 5, 6, 7
+    x = torch.randn(b, t_in, 19, 100, generator=g).to(DEV)
+    y = torch.randn(b, t_out, 19, 100, generator=g).to(DEV)
+    args = bench.make_args(filt, dropout=0.5)
+    args.use_curriculum_learning = True
+    args.cl_decay_steps = 12                   # ratio = 12 / (12 + exp(n / 12)): ~0.5 after ~30 samples
+    finals, losses, seen = [], [], []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        model = DCRNNModel_nextTimePred(args, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3)
+        model.decoder.set_dropout_seed(777, 0)
+        if graphed:
+            st.capture(x, y, None, None)       # supports built on the device inside the step
+            assert st.device_curriculum is True and st.samples_seen == 0 and int(st.samples_seen_dev.item()) == 0
+            model.decoder.set_dropout_seed(777, 0)
+        ls = []
+        for _ in range(8):
+            ls.append(float((st.replay_step() if graphed else st.step(x, y, None, None)).item()))
+        torch.cuda.synchronize()
+        finals.append(st.fp.flat.detach().clone())
+        losses.append(ls)
+        seen.append((st.samples_seen, int(st.samples_seen_dev.item()), model.decoder.dropout_rng_state()))
+    assert seen[0] == seen[1] and seen[0][0] == seen[0][1] == 8 * b
+    assert len(set(losses[1])) == 8
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1])
+
+
+def test_ssl_model_device_curriculum_vs_oracle(adj3d):
+    ps.check_teacher_flags(DEV)
+    for dropout in (0.0, 0.5):
+        ps.check_ssl_device_curriculum("dual_default", adj3d, DEV, dropout)
+
+
+def test_device_step_adam():
+    ps.check_device_step_adam(DEV)
+
+
+def test_device_flags_refused_outside_the_persistent_kernels(adj3d):
+    """32 units: the decoder runs per-step launches whose sequence the flags select on the host -> device flags are refused"""
+    from eeg_gnn_ssl_amd import ops
+    assert not ops.decoder_is_persistent(4, 2, 19, 32, 20, 3, 2)
+    assert ops.decoder_is_persistent(12, 512, 19, 64, 100, 5, 2) and ops.decoder_is_persistent(12, 8, 19, 64, 100, 7, 3)
+    with pytest.raises(Exception, match="persistent decoder kernel"):
+        ps.check_decoder_vs_oracle(DEV, "laplacian", 20, 32, 2, 4, 2, adj3d, seed=1, ratio="device")
+
+
 def test_two_slot_replay_equals_eager_steps_on_alternating_batches():
     """Streamed inputs without a device-side copy: the step captured on TWO input sets, replayed alternately while the
     next batch is written into the idle set, must walk the same parameters (bit for bit) as eager steps on the same
@@ -575,6 +666,45 @@ def test_world1_rccl_step_equals_plain_step():
     assert torch.equal(plain, reduced)
 
 
+def test_world1_rccl_all_reduce_captured_into_the_step_graph():
+    """Item "one launch per rank and step": with a process group the WHOLE step -- forward, loss, backward, the RCCL all-reduce of
+    the flat bucket, clip + Adam -- is captured as one HIP graph (RCCL collectives are capturable).  World size 1 over `nccl` on
+    the hardware at hand: replays equal the eager steps without a process group bit for bit."""
+    import torch.distributed as dist
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, classes = "detection", "laplacian", 1
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, 9, 6, classes, seed=5)
+    xd, yd, ld, supd = x.to(DEV), y.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup]
+
+    def run(whole):
+        torch.manual_seed(1)
+        model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV).train()
+        st = TrainStep(model, task=task, lr=1e-3, always_reduce=whole)
+        if whole:
+            snap = st.snapshot()
+            st.capture(xd, yd, ld, supd, include_update=True)
+            st.restore(snap)
+        for _ in range(3):
+            st.replay_step() if whole else st.step(xd, yd, ld, supd)
+        torch.cuda.synchronize()
+        return st.fp.flat.detach().clone()
+
+    plain = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() % 150))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        whole = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert torch.equal(plain, whole)
+
+
 @pytest.mark.parametrize("filt,dout,h,layers,t_out,b,ratio,act", [
     ("laplacian", 8, 16, 2, 5, 3, 0.5, "tanh"),            # teacher forcing on some steps
     ("dual_random_walk", 12, 32, 3, 4, 2, 0.6, "relu"),    # shared cell used by two layers + teacher forcing
@@ -605,6 +735,8 @@ def test_streamed_weight_bptt_kernel_large_batch(adj3d):
     ("dual_random_walk", 60, 2, 2, 2, None, 19, 2),     # Dout = 60, M = 5: three leftover 16-byte pieces per hop slot -> 4 tail chunks of the quad pack
     ("dual_random_walk", 100, 2, 2, 300, None, 19, 2),  # more clips than workgroups: the clip loop of a workgroup
     ("laplacian", 128, 2, 4, 2, 0.5, 19, 2),            # widest output the persistent kernels take (Dout = 128)
+    ("dual_random_walk", 100, 2, 12, 3, "device", 19, 2),   # teacher-forcing flags read from DEVICE memory (cfg5's decoder shape)
+    ("laplacian", 36, 3, 9, 2, "device", 20, 2),            # the same with three layers (shared cell), 20 nodes
 ])
 def test_persistent_decoder_edge_shapes(filt, dout, layers, t_out, b, ratio, n, order, adj3d):
     """the persistent decoder kernels (forward and BPTT, kernels_decoder.h) at the edges of their range"""
@@ -639,6 +771,10 @@ def test_training_trajectory_matches_reference(golden_train, adj3d):
 
 def test_ssl_training_trajectory_matches_reference(golden_train):
     ps.check_ssl_training_trajectory(DEV, golden_train)
+
+
+def test_ssl_evaluation_driver(adj3d):
+    ps.check_ssl_eval_driver(DEV, adj3d)
 
 
 def test_evaluation_driver(adj3d):
