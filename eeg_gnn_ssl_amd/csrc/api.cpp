@@ -750,6 +750,18 @@ int eeg_dcrnn_fft_features(const float* raw, int B, int N, int T, int W, const i
     if (W < 4 || W % 4 != 0 || W / 4 + 1 > 64) return fail("fft_features: window=%d unsupported (multiple of 4, <= 252)", W);
     if (feat_raw == nullptr && feat_std == nullptr) return fail("fft_features: no output requested");
     if (feat_std != nullptr && !(std_ != 0.f)) return fail("fft_features: std must be non-zero");
+    if (W == kFftWin) {                               // the reference's 200-sample steps: mixed-radix transform, 6 windows per wave
+        const long long n_windows = (long long)B * N * T;
+        const long long n_items = (n_windows + kFftPerWave - 1) / kFftPerWave;
+        long long blocks = (n_items + 3) / 4;
+        const long long cap = (long long)platform_num_cus() * 2;          // 2 workgroups of 4 waves per CU (187 registers: 2 waves per SIMD), persistent
+        if (blocks > cap) blocks = cap;
+        const size_t lds = 4 * (size_t)kFftWaveDoubles * sizeof(double);
+        EEG_SET_MAX_LDS(fft200_features_kernel, lds);
+        EEG_LAUNCH_P("fft_features", fft200_features_kernel, dim3((unsigned)blocks), dim3(256), lds, S_(stream), raw, N, T, n_windows,
+                     reinterpret_cast<const int*>(perm), log_scale, mean, 1.0f / std_, feat_raw, feat_std);
+        return check_launch("fft_features");
+    }
     int tchunk = T;                                   // ~8 waves per SIMD in total
     while (tchunk > 1 && (long long)B * N * ceil_div(T, tchunk) < 8192) tchunk = ceil_div(tchunk, 2);
     EEG_LAUNCH_P("fft_features", fft_features_kernel, dim3(B * N, ceil_div(T, tchunk)), dim3(64), (size_t)W * sizeof(double), S_(stream),

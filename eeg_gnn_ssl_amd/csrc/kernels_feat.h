@@ -57,4 +57,152 @@ __global__ __launch_bounds__(64) void fft_features_kernel(const float* __restric
     }
 }
 
+
+// ---- W = 200 (the reference's 200 Hz x 1-s steps, dataloader_detection.py:54-67): mixed-radix real transform -----------------
+// The direct DFT above does 2 x 200 x 100 multiply-adds per window (23 GFLOP fp64 for 256 one-minute clips = 5 x the HBM floor
+// of this kernel).  Here: z[n] = x[2n] + i x[2n+1] (n < 100), Z = DFT_100(z) as 10 x 10 Cooley-Tukey with every 10-point DFT done
+// in registers as a 2 x 5 prime-factor transform (no twiddles inside), then the real-input split
+//     2 X[k] = (Z[k] + conj Z[100-k]) - i e^{-2 pi i k / 200} (Z[k] - conj Z[100-k]),   k = 0..99,
+// all in fp64 (the log of a weak bin amplifies any error of the transform, see above): ~3 k fp64 operations per window instead of
+// 160 k.  Ten lanes own one window, six windows per wave (lanes 60..63 idle); a wave walks 6 CONSECUTIVE (b, t, node) windows, whose
+// outputs are one contiguous 2400-byte stretch of feat_std: the log amplitudes leave through a wave-private LDS tile as full
+// 16-byte pieces.  Wave-private LDS (11.3 KB), wave-level syncs only, no workgroup barrier.
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// forward 5-point DFT (kernel e^{-2 pi i n k / 5})
+__device__ __forceinline__ void dft5(const cplx (&x)[5], cplx (&X)[5]) {
+    constexpr double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;    // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;     // sin(2 pi / 5), sin(4 pi / 5)
+    const cplx s1 = cadd(x[1], x[4]), s2 = cadd(x[2], x[3]), d1 = csub(x[1], x[4]), d2 = csub(x[2], x[3]);
+    X[0] = {x[0].re + s1.re + s2.re, x[0].im + s1.im + s2.im};
+    const cplx a1 = {x[0].re + C1 * s1.re + C2 * s2.re, x[0].im + C1 * s1.im + C2 * s2.im};
+    const cplx a2 = {x[0].re + C2 * s1.re + C1 * s2.re, x[0].im + C2 * s1.im + C1 * s2.im};
+    const cplx b1 = {S1 * d1.re + S2 * d2.re, S1 * d1.im + S2 * d2.im};
+    const cplx b2 = {S2 * d1.re - S1 * d2.re, S2 * d1.im - S1 * d2.im};
+    X[1] = {a1.re + b1.im, a1.im - b1.re};        // a1 - i b1
+    X[4] = {a1.re - b1.im, a1.im + b1.re};        // a1 + i b1
+    X[2] = {a2.re + b2.im, a2.im - b2.re};
+    X[3] = {a2.re - b2.im, a2.im + b2.re};
+}
+// forward 10-point DFT as a 2 x 5 prime-factor transform: n = 5 n1 + 2 n2, k = 5 k1 + 6 k2 (mod 10) => W10^{nk} = (-1)^{n1 k1} W5^{n2 k2}
+__device__ __forceinline__ void dft10(const cplx (&x)[10], cplx (&X)[10]) {
+    cplx u[5], y0[5], y1[5];
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) u[n2] = x[(2 * n2) % 10];
+    dft5(u, y0);
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) u[n2] = x[(5 + 2 * n2) % 10];
+    dft5(u, y1);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) {
+        X[(6 * k2) % 10] = cadd(y0[k2], y1[k2]);
+        X[(5 + 6 * k2) % 10] = csub(y0[k2], y1[k2]);
+    }
+}
+
+constexpr int kFftWin = 200, kFftBins = 100, kFftPerWave = 6;
+constexpr int kFftRow = 11;                                              // transposed tile: 16-byte entries, row stride 11 (conflict-free)
+constexpr int kFftWaveDoubles = kFftPerWave * 10 * kFftRow * 2;          // 1320 doubles = 10.3 KB per wave (the Z and output tiles alias it)
+
+__global__ __launch_bounds__(256) void fft200_features_kernel(const float* __restrict__ raw, int N, int T, long long n_windows,
+                                                              const int* __restrict__ perm, const float* __restrict__ log_scale,
+                                                              float mean, float inv_std, float* __restrict__ feat_raw,
+                                                              float* __restrict__ feat_std) {
+    EEG_DYN_SMEM(sm);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    cplx* tile = reinterpret_cast<cplx*>(sm) + (size_t)wave * (kFftWaveDoubles / 2);
+    float* ftile = reinterpret_cast<float*>(tile);                       // [6][100] log amplitudes (aliases the tile, behind a wave sync)
+    const int w = lane / 10, q = lane - 10 * w;                          // window of the wave, position (n2 in stage 1, k1 in stage 2)
+    const bool active = w < kFftPerWave;
+    // twiddles of this lane: stage 1 -> 2: W100^{q k1}, k1 = 0..9; real-input split: W200^{q + 10 k2}, k2 = 0..9
+    cplx tw1[10], tw2[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        double sn, cs;
+        sincos(6.283185307179586476925286766559 * (double)(q * j) / 100.0, &sn, &cs);
+        tw1[j] = {cs, -sn};
+        sincos(6.283185307179586476925286766559 * (double)(q + 10 * j) / 200.0, &sn, &cs);
+        tw2[j] = {cs, sn};                                               // (cos, sin): the split uses both signs explicitly
+    }
+    const double log_floor = log(1e-8);                                  // computeFFT: amp == 0 -> 1e-8
+    const long long n_items = (n_windows + kFftPerWave - 1) / kFftPerWave;
+    for (long long item = (long long)blockIdx.x * 4 + wave; item < n_items; item += (long long)gridDim.x * 4) {
+        const long long w0 = item * kFftPerWave, wg = w0 + w;
+        const bool live = active && wg < n_windows;
+        cplx a[10], A[10];
+        if (live) {
+            const int nd = (int)(wg % N);
+            const long long bt = wg / N;
+            const int t = (int)(bt % T), b = (int)(bt / T);
+            const int src = perm != nullptr ? perm[b * N + nd] : nd;     // EEG_seq_reflect[:, pair] = EEG_seq[:, swapped pair]
+            const float* sig = raw + (((size_t)b * N + src) * T + t) * kFftWin;
+#pragma unroll
+            for (int n1 = 0; n1 < 10; ++n1) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(sig + 20 * n1 + 2 * q);        // z[10 n1 + q]
+                a[n1] = {(double)v[0], (double)v[1]};
+            }
+            dft10(a, A);                                                 // over n1 -> k1
+#pragma unroll
+            for (int k1 = 0; k1 < 10; ++k1) tile[(w * 10 + q) * kFftRow + k1] = cmul(A[k1], tw1[k1]);
+        }
+        EEG_WAVE_SYNC();
+        if (live) {
+#pragma unroll
+            for (int n2 = 0; n2 < 10; ++n2) a[n2] = tile[(w * 10 + n2) * kFftRow + q];
+            dft10(a, A);                                                 // over n2 -> k2: A[k2] = Z[q + 10 k2]
+        }
+        EEG_WAVE_SYNC();
+        if (live) {
+#pragma unroll
+            for (int k2 = 0; k2 < 10; ++k2) tile[w * 110 + q + 10 * k2] = A[k2];              // Z[k] at [w][k]
+        }
+        EEG_WAVE_SYNC();
+        float v[10];
+        if (live) {
+#pragma unroll
+            for (int k2 = 0; k2 < 10; ++k2) {
+                const int k = q + 10 * k2;
+                const cplx zp = tile[w * 110 + (k == 0 ? 0 : 100 - k)];
+                const double ar = A[k2].re + zp.re, ai = A[k2].im - zp.im;                    // Z[k] + conj Z[100-k]
+                const double br = A[k2].re - zp.re, bi = A[k2].im + zp.im;                    // Z[k] - conj Z[100-k]
+                const double xr = ar + (tw2[k2].re * bi - tw2[k2].im * br);
+                const double xi = ai - (tw2[k2].re * br + tw2[k2].im * bi);
+                const double pw = 0.25 * (xr * xr + xi * xi);
+                v[k2] = (float)(pw == 0.0 ? log_floor : 0.5 * log(pw));
+            }
+        }
+        EEG_WAVE_SYNC();                                                 // every partner read is done: the tile becomes the output tile
+        if (live) {
+#pragma unroll
+            for (int k2 = 0; k2 < 10; ++k2) ftile[w * kFftBins + q + 10 * k2] = v[k2];
+        }
+        EEG_WAVE_SYNC();
+        // 6 windows x 100 floats leave as 16-byte pieces: feat_std at the window's own (b, t, node) slot (6 windows = one 2400-byte
+        // stretch), feat_raw at the SOURCE node's slot (perm is a permutation: every slot is written once)
+        for (int c = lane; c < kFftPerWave * kFftBins / 4; c += 64) {
+            const int j = c / 25, pos = 4 * (c - 25 * j);
+            const long long wj = w0 + j;
+            if (wj >= n_windows) continue;
+            const f32x4 val = *reinterpret_cast<const f32x4*>(ftile + 4 * c);
+            const int nd = (int)(wj % N);
+            const long long bt = wj / N;
+            const int b = (int)(bt / T);
+            if (feat_raw != nullptr) {
+                const int src = perm != nullptr ? perm[b * N + nd] : nd;
+                *reinterpret_cast<f32x4*>(feat_raw + ((size_t)bt * N + src) * kFftBins + pos) = val;
+            }
+            if (feat_std != nullptr) {
+                const double ls = log_scale != nullptr ? (double)log_scale[b] : 0.0;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (float)((((double)val[e] + ls) - (double)mean) * (double)inv_std);
+                *reinterpret_cast<f32x4*>(feat_std + (size_t)wj * kFftBins + pos) = o;
+            }
+        }
+        EEG_WAVE_SYNC();                                                 // the output tile is free again
+    }
+}
+
 }  // namespace eeg

@@ -8,12 +8,13 @@
 
 namespace eeg {
 namespace {
-struct ProfRec { const char* name; hipEvent_t a, b; };
+struct ProfRec { const char* name; const char* sym; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open = nullptr;
 const char* g_open_name = nullptr;
+const char* g_open_sym = nullptr;
 const char* g_prefix = nullptr;
 std::vector<std::string*> g_names;
 hipEvent_t prof_event() {
@@ -24,8 +25,10 @@ hipEvent_t prof_event() {
 }
 }  // namespace
 void prof_set_prefix(const char* prefix) { g_prefix = prefix; }
-void prof_begin(const char* name, hipStream_t st) {
+bool prof_is_on() { return g_prof_on; }
+void prof_begin(const char* name, hipStream_t st, const char* sym) {
     if (!g_prof_on) return;
+    g_open_sym = sym;
     g_open = prof_event();
     if (g_prefix != nullptr) {                       // interned so that records can keep a plain pointer
         std::string full = std::string(g_prefix) + name;
@@ -42,12 +45,12 @@ void prof_end(hipStream_t st) {
     if (!g_prof_on || g_open == nullptr) return;
     hipEvent_t b = prof_event();
     (void)hipEventRecord(b, st);
-    g_recs.push_back({g_open_name, g_open, b});
+    g_recs.push_back({g_open_name, g_open_sym, g_open, b});
     g_open = nullptr;
 }
 void prof_enable(bool on) { g_prof_on = on; }
 size_t prof_report(char* buf, size_t cap) {
-    struct Agg { const char* name; int count; double ms; };
+    struct Agg { const char* name; const char* sym; int count; double ms; };
     std::vector<Agg> agg;
     for (auto& r : g_recs) {
         (void)hipEventSynchronize(r.b);
@@ -55,16 +58,25 @@ size_t prof_report(char* buf, size_t cap) {
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         bool found = false;
         for (auto& a : agg)
-            if (strcmp(a.name, r.name) == 0) { a.count++; a.ms += ms; found = true; break; }
-        if (!found) agg.push_back({r.name, 1, (double)ms});
+            if (strcmp(a.name, r.name) == 0 && a.sym == r.sym) { a.count++; a.ms += ms; found = true; break; }
+        if (!found) agg.push_back({r.name, r.sym, 1, (double)ms});
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
     g_recs.clear();
     std::string out;
-    char line[160];
+    char line[512];
     for (auto& a : agg) {
-        snprintf(line, sizeof(line), "%s %d %.6f\n", a.name, a.count, a.ms);
+        // kern_sym(): "const char *eeg::kern_sym() [K = &eeg::seq_fwd2_kernel<64, 3, 5, false>]" -> "seq_fwd2_kernel<64, 3, 5, false>"
+        std::string sym = a.sym != nullptr ? a.sym : "?";
+        const size_t k = sym.find("K = ");
+        if (k != std::string::npos) {
+            sym = sym.substr(k + 4);
+            if (!sym.empty() && sym[0] == '&') sym = sym.substr(1);
+            if (!sym.empty() && sym.back() == ']') sym.pop_back();
+            if (sym.rfind("eeg::", 0) == 0) sym = sym.substr(5);
+        }
+        snprintf(line, sizeof(line), "%s %d %.6f %s\n", a.name, a.count, a.ms, sym.c_str());
         out += line;
     }
     if (out.size() + 1 > cap) return out.size() + 1;

@@ -5,21 +5,28 @@
 #include "common.h"
 
 namespace eeg {
-void prof_begin(const char* name, hipStream_t st);
+// sym: the compiler's spelling of the launched kernel instantiation (kern_sym below), or nullptr
+void prof_begin(const char* name, hipStream_t st, const char* sym = nullptr);
+bool prof_is_on();
 void prof_end(hipStream_t st);
 void prof_set_prefix(const char* prefix);      // records made while set are named prefix+name
 void prof_enable(bool on);
-// "name count total_ms\n" per kernel name since the last report, into buf; returns the bytes needed (incl. NUL) if cap is too small, else 0
+// "name count total_ms symbol\n" per (kernel role, kernel symbol) since the last report, into buf; returns the bytes needed (incl. NUL) if cap is too small, else 0
 size_t prof_report(char* buf, size_t cap);
 struct ProfPrefix {                             // RAII: tag the launches of one API call (e.g. "dec_")
     explicit ProfPrefix(const char* p) { prof_set_prefix(p); }
     ~ProfPrefix() { prof_set_prefix(nullptr); }
 };
+
+// the instantiated kernel behind a launch, as the compiler spells it ("... [K = &eeg::seq_fwd2_kernel<64, 3, 5, false>]"): the report
+// carries it so that bench.py's per-kernel table is by SYMBOL, like a rocprofv3 kernel trace
+template <auto K>
+inline const char* kern_sym() { return __PRETTY_FUNCTION__; }
 }  // namespace eeg
 
 #define EEG_LAUNCH_P(name, kern, grid, block, smem, stream, ...) \
     do {                                                           \
-        eeg::prof_begin(name, stream);                             \
+        eeg::prof_begin(name, stream, eeg::prof_is_on() ? eeg::kern_sym<&kern>() : nullptr); \
         EEG_LAUNCH(kern, grid, block, smem, stream, __VA_ARGS__);  \
         eeg::prof_end(stream);                                     \
     } while (0)

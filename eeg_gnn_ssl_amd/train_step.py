@@ -56,9 +56,13 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, task: str = "detection", lr: float = 3e-4,
                  weight_decay: float = 5e-4, max_grad_norm: float = 5.0,
                  scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None,
-                 always_reduce: bool = False):
+                 always_reduce: bool = False, raw_window: Optional[int] = None, raw_mean: float = 0.0, raw_std: float = 1.0):
         """always_reduce: issue the gradient all-reduce whenever a process group exists, also at world size 1 (exercises
-        the RCCL path on a single GPU; a sum over one rank is the identity)."""
+        the RCCL path on a single GPU; a sum over one rank is the identity).
+        raw_window: the step takes RAW resampled signals (B, N, T*raw_window) instead of features and runs the reference's
+        DataLoader-side chain on the device in front of the model (dataloader_detection.py:57-71,346-354,384-393): log|FFT| of every
+        raw_window-sample step (`eeg_dcrnn_fft_features`) -> z-score with (raw_mean, raw_std) = the model input; with
+        supports=None the per-clip correlation graph is built from the UN-standardised features, as `_get_indiv_graphs` does."""
         assert task in ("detection", "classification", "ssl")
         self.model, self.task, self.max_grad_norm = model, task, max_grad_norm
         self.fp = FlatParameters(model)
@@ -82,6 +86,7 @@ class TrainStep:
         self.world = dist.get_world_size() if has_pg else 1
         self.reduce = has_pg and (self.world > 1 or always_reduce)
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
+        self.raw_window, self.raw_mean, self.raw_std = raw_window, float(raw_mean), float(raw_std)
         self._graphs = {}
         # curriculum learning (SSL, model.py:194-200): where the persistent decoder kernels apply, the teacher-forcing flags are
         # drawn on the device (`eeg_dcrnn_teacher_flags`) -- in eager steps and graph replays alike; elsewhere on the host
@@ -139,6 +144,10 @@ class TrainStep:
         """supports=None: build the per-clip correlation graph and its dual random-walk supports from
         the clips on the device (the DataLoader-side `_get_indiv_graphs` of the reference)."""
         self.fp.zero_grad()
+        if self.raw_window is not None:              # raw signals in: featurise on the device (x becomes the standardised log|FFT|)
+            feat_raw, x = ops.fft_features(x, window=self.raw_window, mean=self.raw_mean, std=self.raw_std)
+            if supports is None:
+                supports = ops.correlation_supports(feat_raw, top_k=3)
         if supports is None:
             supports = ops.correlation_supports(x, top_k=3)
         if self.task == "ssl":

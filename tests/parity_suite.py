@@ -635,13 +635,57 @@ def check_fft_features(device, golden_fft):
         assert np.abs(fr[b].cpu().numpy() - ref).max() <= 5e-6
         exp = ((ref[:, perm[b].numpy(), :] + float(ls[b])) - 0.5) / 2.0
         assert np.abs(fs[b].cpu().numpy() - exp).max() <= 5e-6
-    for (b, n, w, nwin) in ((1, 1, 4, 1), (2, 32, 252, 2), (3, 19, 200, 60), (70, 19, 8, 5)):   # smallest / widest window, long clip
+    # the same augmentation through the 200-sample kernel (mixed-radix transform, six windows per wave: 2 x 19 x 5 = 190 windows
+    # = 31 full groups + one of 4), feat_raw at the source channel's slot
+    rawb = torch.randn(2, 19, 5 * 200, generator=g) * 20.0
+    fr, fs = ops.fft_features(rawb.to(device), window=200, mean=0.5, std=2.0, perm=perm.to(device), log_scale=ls.to(device))
+    for b in range(2):
+        ref = orc.fft_features(rawb[b].numpy().astype(np.float64), window=200)         # (5, 19, 100)
+        assert np.abs(fr[b].cpu().numpy() - ref).max() <= 5e-6
+        exp = ((ref[:, perm[b].numpy(), :] + float(ls[b])) - 0.5) / 2.0
+        assert np.abs(fs[b].cpu().numpy() - exp).max() <= 5e-6
+    fr_only = torch.ops.eeg_dcrnn.fft_features(rawb.to(device), 200, 0.0, 1.0, False, None, None)[0]
+    assert torch.equal(fr_only, ops.fft_features(rawb.to(device), window=200, mean=0.0, std=1.0)[0])
+    for (b, n, w, nwin) in ((1, 1, 4, 1), (2, 32, 252, 2), (3, 19, 200, 60), (70, 19, 8, 5), (1, 1, 200, 1), (5, 3, 200, 7)):   # smallest / widest window, long clip
         rawb = torch.randn(b, n, w * nwin, generator=g) * 10.0
         fr, _ = ops.fft_features(rawb.to(device), window=w, mean=0.0, std=1.0)
         assert fr.shape == (b, nwin, n, w // 2)
         for i in (0, b - 1):
             ref = orc.fft_features(rawb[i].numpy().astype(np.float64), window=w)
             assert np.abs(fr[i].cpu().numpy() - ref).max() <= 5e-6, (b, n, w, nwin)
+
+
+def check_raw_input_chain(device, b=4, t_len=3):
+    """Raw signals in: TrainStep(raw_window=200) runs the reference's DataLoader-side chain on the device in front of the model
+    -- log|FFT| per 1-s step (data_utils.py:13-35), z-score (utils.py:393-428), per-clip correlation graph from the
+    UN-standardised features (dataloader_detection.py:258-307,346-354) -- and the detection step.  Against the oracle chain
+    (numpy FFT -> host graph builders -> oracle model) on the same signals: loss and every parameter gradient."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, utils
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    g = torch.Generator().manual_seed(31)
+    raw = 20.0 * torch.randn(b, 19, t_len * 200, generator=g)
+    y = (torch.rand(b, generator=g) > 0.5).float()
+    lengths = torch.full((b,), t_len, dtype=torch.int64)
+    mean, std = 5.53, 0.65
+    cfg = orc.DCRNNConfig(filter_type="dual_random_walk", num_classes=1)
+    params = orc.init_params(cfg, "classification", seed=2)
+    model = DCRNNModel_classification(make_args(cfg), 1, device=device)
+    load(model, params, device)
+    model.train()
+    st = TrainStep(model, task="detection", raw_window=200, raw_mean=mean, raw_std=std)
+    loss = st.forward_backward(raw.to(device), y.to(device), lengths.to(device), None)
+    feats = np.stack([orc.fft_features(raw[i].numpy().astype(np.float64), window=200) for i in range(b)])      # (B, T, N, 100)
+    x = torch.from_numpy(((feats - mean) / std).astype(np.float32))
+    s1, s2 = [], []
+    for i in range(b):
+        sp = utils.compute_supports(utils.correlation_graph(feats[i], top_k=3), "dual_random_walk")
+        s1.append(sp[0]); s2.append(sp[1])
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lo = orc.bce_with_logits(orc.classification_forward(po, cfg, x, lengths, [torch.stack(s1), torch.stack(s2)]), y)
+    lo.backward()
+    assert abs(float(loss.item()) - float(lo.item())) < 2e-5, (float(loss.item()), float(lo.item()))
+    for k, q in model.named_parameters():
+        assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"raw chain/d_{k}", tol=1e-4)
 
 
 def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_registration", "test_faketensor")):

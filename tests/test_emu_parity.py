@@ -162,6 +162,10 @@ def test_evaluation_driver(adj3d):
     ps.check_eval_driver("cpu", adj3d)
 
 
+def test_raw_signals_to_step_chain_vs_oracle():
+    ps.check_raw_input_chain("cpu", b=2, t_len=2)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features("cpu", golden_fft)
 

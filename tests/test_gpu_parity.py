@@ -183,12 +183,36 @@ def test_beyond_benchmark_sizes(filt, batch, t_len, adj3d):
     assert err < 1e-4, f"logits of clips {pick} differ from the oracle by {err:.2e}"
 
 
+def _device_supports_checked(x_host, x_dev, host_sup, top_k=3):
+    """The chain the benchmarked correlation-graph step runs: supports built ON THE DEVICE from the clips (eeg_dcrnn_corr_graph).
+    They must equal the host pipeline's (fp64 Gram) for every clip whose top-k choice is decided: a clip may differ only where
+    the oracle's own margin between the k-th and (k+1)-th strongest neighbour of some electrode is below 1e-6 (an fp32 Gram
+    cannot resolve that tie).  Returns the device supports and the number of such clips."""
+    from eeg_gnn_ssl_amd import ops
+    dev_sup = ops.correlation_supports(x_dev, top_k=top_k)
+    diff = torch.stack([(a.cpu() - b_).abs().amax(dim=(1, 2)) for a, b_ in zip(dev_sup, host_sup)]).amax(dim=0)
+    odd = torch.nonzero(diff > 1e-5).view(-1).tolist()
+    xn = x_host.numpy()
+    for i in odd:
+        clip = xn[i]
+        flat = np.transpose(clip, (1, 0, 2)).reshape(clip.shape[1], -1).astype(np.float64)
+        nrm = np.sqrt((flat * flat).sum(axis=1))
+        a = np.abs(flat @ flat.T / np.outer(nrm, nrm))
+        np.fill_diagonal(a, 0.0)
+        srt = -np.sort(-a, axis=1)
+        margin = (srt[:, top_k - 1] - srt[:, top_k]).min()
+        assert margin < 1e-6, f"clip {i}: device top-{top_k} graph differs from the host pipeline although the margin is {margin:.2e}"
+    return dev_sup, len(odd)
+
+
 @pytest.mark.parametrize("workload", ["cfg2", "cfg3", "cfg4"])
 def test_full_size_gradients_vs_oracle(workload, adj3d):
     """BASELINE cfg2 / cfg3 / cfg4 at FULL per-GPU size (B=256, T=60, ragged lengths; cfg3: one correlation graph per
     clip; cfg4: the 4-class model under cross-entropy): logits of every clip and every parameter gradient of the whole
     batch against the oracle run on the host on the same batch (fp32 tolerance 1e-4 of each tensor's largest entry,
-    the bar north_star states)."""
+    the bar north_star states).  cfg3 runs the chain of the benchmarked step: the per-clip graphs and supports are built on
+    the device from the clips (`supports=None` in TrainStep), checked against the host pipeline clip by clip, and fed to the
+    model; TrainStep.forward_backward(..., supports=None) must give the same gradients bit for bit."""
     import bench
     from oracle import dcrnn_oracle as orc
     task, filt, t_len, batch, classes = bench.WORKLOADS[workload]
@@ -196,18 +220,33 @@ def test_full_size_gradients_vs_oracle(workload, adj3d):
     lengths = torch.randint(t_len // 2, t_len + 1, (batch,), generator=torch.Generator().manual_seed(3))
     model = _full_size_model(filt, classes)
     from eeg_gnn_ssl_amd import ops
-    lg = model(x.to(DEV), lengths.to(DEV), [s.to(DEV) for s in sup])
+    xd = x.to(DEV)
+    if filt == "dual_random_walk":
+        sup_dev, n_ties = _device_supports_checked(x, xd, sup)
+        assert n_ties <= 2, n_ties
+        sup = [s.cpu() for s in sup_dev]                    # the oracle sees the graphs the model saw
+    else:
+        sup_dev = [s.to(DEV) for s in sup]
+    lg = model(xd, lengths.to(DEV), sup_dev)
     (ops.bce_with_logits(lg.view(-1), y.to(DEV)) if classes == 1 else ops.cross_entropy(lg, y.to(DEV))).backward()
     cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
-    po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items() if not k.endswith("_dropout_rng")}
     torch.set_num_threads(16)
     lo = orc.classification_forward(po, cfg, x, lengths, sup)
     (orc.bce_with_logits(lo, y) if classes == 1 else orc.cross_entropy(lo, y)).backward()
     assert (lg.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    grads = {}
     for k, p in model.named_parameters():
         ref = po[k].grad
         err = (p.grad.cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
         assert err < 1e-4, f"{k}: {err:.2e}"
+        grads[k] = p.grad.detach().clone()
+    if filt == "dual_random_walk":
+        from eeg_gnn_ssl_amd.train_step import TrainStep
+        st = TrainStep(model, task=task)
+        st.forward_backward(xd, y.to(DEV), lengths.to(DEV), None)
+        for k, p in model.named_parameters():
+            assert torch.equal(p.grad, grads[k]), k
 
 
 def test_ssl_full_size_gradients_vs_oracle():
@@ -779,6 +818,10 @@ def test_ssl_evaluation_driver(adj3d):
 
 def test_evaluation_driver(adj3d):
     ps.check_eval_driver(DEV, adj3d)
+
+
+def test_raw_signals_to_step_chain_vs_oracle():
+    ps.check_raw_input_chain(DEV, b=9, t_len=7)
 
 
 def test_fft_features(golden_fft):

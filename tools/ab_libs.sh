@@ -6,7 +6,7 @@ while [[ "${1:-}" == --* ]]; do case "$1" in --workload) WL=$2; shift 2;; --roun
 for r in $(seq 1 $R); do
   for t in "$@"; do
     args=""; [ "$t" != "-" ] && args="--lib $t"
-    python bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-stream-inputs $args 2>/dev/null | python -c "
+    python bench.py --workload $WL --steps 30 --warmup 10 --no-cpu-baseline --no-stream-inputs --secondary none $args 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if not l.startswith('{'): continue
