@@ -169,6 +169,21 @@ def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS,
     return w
 
 
+def synthetic_raw_signals(batch, t_len, seed):
+    """Synthetic resampled EEG (B, N, T*200), in microvolts: four AR(1) sources per clip (different spectra) mixed into the 19
+    electrodes with random weights + white sensor noise -- channels then differ in spectral SHAPE, so the correlation graph of
+    their log|FFT| features has decided top-3 neighbours (white noise alone gives |correlation| in 0.984..0.987 for every pair and
+    top-3 margins at fp32 rounding level: a graph of coin flips)."""
+    from scipy.signal import lfilter
+    g = torch.Generator().manual_seed(seed)
+    n_src, total = 4, t_len * RAW_WINDOW
+    e = torch.randn(batch, n_src, total, generator=g).numpy().astype(np.float64)
+    src = np.stack([lfilter([1.0], [1.0, -r], e[:, k], axis=-1) * np.sqrt(1.0 - r * r) for k, r in enumerate((0.5, 0.8, 0.95, -0.5))], axis=1)
+    mix = torch.randn(batch, N_NODES, n_src, generator=g).numpy().astype(np.float64)
+    noise = torch.randn(batch, N_NODES, total, generator=g).numpy()
+    return torch.from_numpy((20.0 * np.einsum("bnk,bkt->bnt", mix, src) + 5.0 * noise).astype(np.float32))
+
+
 def per_launch_work(filter_type, t_len, batch, layers=LAYERS):
     """Encoder roles: the algorithmic work of every launch of a step IN LAUNCH ORDER (forward roles bottom-up, backward roles
     top-down), so that a role whose layers run different kernel instantiations (e.g. `gemm_tn_x`: batch-major layer 0, planar
@@ -399,8 +414,8 @@ def measure(ctx, workload, steps, warmup, primary):
     model.train()
     raw_kw = {}
     if raw_in:
-        # synthetic resampled EEG: white noise of 20 uV -> |FFT| ~ 283, log ~ 5.5 +- 0.65: the scaler of the synthetic data set
-        raw_kw = dict(raw_window=RAW_WINDOW, raw_mean=5.53, raw_std=0.65)
+        # the scaler of the synthetic data set (synthetic_raw_signals): log|FFT| ~ 5.68 +- 0.87
+        raw_kw = dict(raw_window=RAW_WINDOW, raw_mean=5.68, raw_std=0.87)
     stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0, always_reduce=args.force_dist, **raw_kw)
     device_graph = filt == "dual_random_walk" and not args.host_supports
     # the host-side per-clip graph loop (numpy, 256-512 clips) is only needed to CHECK the device graphs: rank 0 of a
@@ -409,8 +424,7 @@ def measure(ctx, workload, steps, warmup, primary):
     if raw_in:
         if not device_graph:
             raise SystemExit("--workload raw builds its graphs on the device (no --host-supports)")
-        g = torch.Generator().manual_seed(123 + rank)
-        hx = 20.0 * torch.randn(batch, N_NODES, t_len * RAW_WINDOW, generator=g)          # (B, N, T*200) resampled signals
+        hx = synthetic_raw_signals(batch, t_len, seed=123 + rank)                          # (B, N, T*200) resampled signals
         hy = (hx[:, :, :10].mean(dim=(1, 2)) > 0).float()
         hlen = torch.full((batch,), t_len, dtype=torch.int64)
         hsup = None
@@ -443,11 +457,23 @@ def measure(ctx, workload, steps, warmup, primary):
             chk = ops.correlation_supports(fr, top_k=3)
         else:
             chk = ops.correlation_supports(x, top_k=3)
-        bad = int(sum((a - b_).abs().amax(dim=(1, 2)) > 1e-5 for a, b_ in zip(chk, supports)).clamp(max=1).sum().item())
-        graph_check = {"clips": batch, "clips_with_a_different_edge_set": bad,
-                       "note": "device supports vs the host pipeline (fp64 Gram); a top-3 near-tie may flip an edge"}
-        if bad > max(1, batch // 100):
-            raise SystemExit(f"device correlation-graph supports differ from the host pipeline on {bad} clips")
+        odd = torch.nonzero(sum((a - b_).abs().amax(dim=(1, 2)) > 1e-5 for a, b_ in zip(chk, supports)) > 0).view(-1).tolist()
+        # a clip may differ from the host pipeline (fp64 Gram) only where the host's own margin between the 3rd and the 4th
+        # strongest neighbour of some electrode is a rounding error of an fp32 Gram (|correlation| values ~1, 114 000 terms)
+        clips_np = host_feats.numpy() if raw_in else hx.numpy()
+        worst = 0.0
+        for i in odd:
+            flat = np.transpose(clips_np[i], (1, 0, 2)).reshape(N_NODES, -1).astype(np.float64)
+            nrm = np.sqrt((flat * flat).sum(axis=1))
+            a_ = np.abs(flat @ flat.T / np.outer(nrm, nrm))
+            np.fill_diagonal(a_, 0.0)
+            srt = -np.sort(-a_, axis=1)
+            worst = max(worst, float((srt[:, 2] - srt[:, 3]).min()))
+        graph_check = {"clips": batch, "clips_with_a_different_edge_set": len(odd), "largest_top3_margin_among_them": worst,
+                       "note": "device supports vs the host pipeline (fp64 Gram): edge sets may differ only where the host's margin "
+                               "between the 3rd and 4th strongest neighbour is below 2e-6 (an fp32 Gram cannot resolve it)"}
+        if worst > 2e-6:
+            raise SystemExit(f"device correlation-graph supports differ from the host pipeline on {len(odd)} clips (top-3 margin up to {worst:.2e})")
         supports = None
 
     log(f"{workload}: inputs on device, {warmup} warm-up steps")

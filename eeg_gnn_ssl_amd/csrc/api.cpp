@@ -304,7 +304,14 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
         const int want = ceil_div(g_tune[6] > 0 ? g_tune[6] : 4096, sB);   // dev knob 6 (512 .. 4096 measured alike)
         if (ny > want) ny = want;
         if (ny < 1) ny = 1;
-        EEG_LAUNCH_P("diffuse_adj", diffuse_adj_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, M, add, dX);
+        // round 5: Z walked in storage order (all hop slots of a node row together) where the hop count has an instantiation
+        if (g_tune[18] == 0 && M == 3) {
+            EEG_LAUNCH_P("diffuse_adj", (diffuse_adj_rows_kernel<19, 3>), dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, add, dX);
+        } else if (g_tune[18] == 0 && M == 5) {
+            EEG_LAUNCH_P("diffuse_adj", (diffuse_adj_rows_kernel<19, 5>), dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, add, dX);
+        } else {
+            EEG_LAUNCH_P("diffuse_adj", diffuse_adj_stream_kernel<19>, dim3(sB, ny), dim3(threads), 0, st, Z, P, p_batched, S, B, F, M, add, dX);
+        }
         return check_launch("diffuse_adj");
     }
     const int NR = round_up(N, 4);
@@ -357,7 +364,9 @@ struct BwdWs {
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
     if ((g_tune[2] & 2) != 0 || g_tune[1] != 0 || R < q_min_rows()) return TnqPlan{};
-    return tnq_plan(nseg, F, R, O, bt, g_tune[16] > 0 ? g_tune[16] / 2 : num_cus());    // dev knob 16: target workgroups of the whole-block TN GEMM
+    TnqPlan p = tnq_plan(nseg, F, R, O, bt, g_tune[16] > 0 ? g_tune[16] / 2 : num_cus());    // dev knob 16: target workgroups of the whole-block TN GEMM
+    p.no_xcd = g_tune[17] == 1 ? 1 : 0;                                                      // dev knob 17 = 1: plain workgroup order (A/B)
+    return p;
 }
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     BwdWs w;

@@ -215,6 +215,93 @@ __global__ __launch_bounds__(256, 3) void diffuse_adj_stream_kernel(const float*
     }
 }
 
+// ---- the same adjoint, walking Z in STORAGE ORDER (round 5) ------------------------------------------------------------------
+// A Z row (node q of sample s) holds the MM hop slots side by side (MM * F floats).  The kernel above consumes one hop plane at a
+// time, i.e. every load instruction of a wave takes F floats out of every MM * F (a third of a row at MM = 3) and returns to the same
+// DRAM pages MM times.  Here a thread owns the same 16-byte column but walks the rows of its sample once, top to bottom: the MM
+// slot pieces of node q are requested together, D nodes ahead of their use, and scattered into the N accumulators with the
+// wave-uniform coefficients P_m[q][n] (row q of P_m = column q of P_m^T).  Same arithmetic per output element, other sum order
+// inside an element only (hop-major -> node-major; fp32, ~1e-7 relative).
+template <int N, int MM>
+__global__ __launch_bounds__(256, 2) void diffuse_adj_rows_kernel(const float* __restrict__ Z,
+                                                                  const float* __restrict__ P, int p_batched,
+                                                                  int S, int B, int F,
+                                                                  const float* __restrict__ add,
+                                                                  float* __restrict__ dX) {
+    constexpr int D = MM <= 3 ? 3 : 2;                      // node rows in flight ahead of the one being consumed (registers)
+    const int F4 = F / 4, SPW = blockDim.x / F4;
+    const int tl = threadIdx.x / F4, c4 = threadIdx.x % F4;
+    const int sB = p_batched ? B : 1, g = p_batched ? blockIdx.x : 0;
+    const int T = S / sB;
+    const float* __restrict__ Pg = P + (size_t)g * (MM - 1) * N * N;
+    if (tl >= SPW) return;
+    const float4* Z4 = reinterpret_cast<const float4*>(Z);
+    const float4* A4 = reinterpret_cast<const float4*>(add);
+    float4* D4 = reinterpret_cast<float4*>(dX);
+    const unsigned zrow = (unsigned)(MM * F4);
+    for (int t = blockIdx.y * SPW + tl; t < T; t += gridDim.y * SPW) {
+        const unsigned s = (unsigned)t * sB + g;
+        const unsigned zl = s * N * zrow + c4, xl = s * N * F4 + c4;        // < 2^32 float4 (host-checked)
+        float4 acc[N];
+        if (add != nullptr) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = (A4 + n * F4)[xl];
+        } else {
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // D node rows in flight; the walk over the rows is a ROLLED loop in groups of D (fully unrolled, the compiler interleaves the
+        // multiply-adds of many rows and spills 200 registers), so the identity hop is a one-hot coefficient row like the others
+        float4 zb[D][MM];
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) zb[j][m] = (Z4 + j * zrow + m * F4)[zl];
+        auto consume = [&](int q, const float4 (&z)[MM]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const float e = n == q ? 1.f : 0.f;                          // hop 0 = the identity (wave-uniform select)
+                acc[n].x = fmaf(e, z[0].x, acc[n].x);
+                acc[n].y = fmaf(e, z[0].y, acc[n].y);
+                acc[n].z = fmaf(e, z[0].z, acc[n].z);
+                acc[n].w = fmaf(e, z[0].w, acc[n].w);
+            }
+#pragma unroll
+            for (int m1 = 0; m1 < MM - 1; ++m1) {
+                const float* __restrict__ Pm = Pg + m1 * N * N + q * N;      // row q of P_m
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    const float p = Pm[n];
+                    acc[n].x = fmaf(p, z[m1 + 1].x, acc[n].x);
+                    acc[n].y = fmaf(p, z[m1 + 1].y, acc[n].y);
+                    acc[n].z = fmaf(p, z[m1 + 1].z, acc[n].z);
+                    acc[n].w = fmaf(p, z[m1 + 1].w, acc[n].w);
+                }
+            }
+        };
+        constexpr int NG = N / D;                           // whole groups; the N % D rows behind them are already in flight
+#pragma unroll 1
+        for (int q0 = 0; q0 < NG * D; q0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float4 z[MM];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) z[m] = zb[j][m];
+                const int qn = q0 + j + D < N ? q0 + j + D : N - 1;         // (past the end: a valid row, never consumed)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) zb[j][m] = (Z4 + qn * zrow + m * F4)[zl];
+                EEG_SCHED_FENCE();
+                consume(q0 + j, z);
+                EEG_SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N - NG * D; ++j) consume(NG * D + j, zb[j]);
+#pragma unroll
+        for (int n = 0; n < N; ++n) (D4 + n * F4)[xl] = acc[n];
+    }
+}
+
 // ---- standalone adjoint: Z (S,N,M*F) -> dX (S,N,F) = Z_0 + sum_m P_m^T Z_m [+ add] -----------
 // LDS tile [NR][ZS], NR = round_up(N,4), ZS = lds_stride(M*FP): slot m holds Z_m (cols padded to FP).
 // Column chunk [c0, c0+Fc) of every F-wide slot per launch (wide rows).

@@ -288,7 +288,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg
     static_assert(!PLANAR || (!BT && KT % 2 == 0 && SA::has32 == 0), "planar blocks are whole 64-wide planes");
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), wk = w >> 1, wo = w & 1, li = lane & 15, kk = lane >> 4;
-    const int K = nseg * F, k0 = blockIdx.x * (32 * KT), split = blockIdx.y;
+    // flags 8: XCD-aware placement.  Workgroups go round-robin over the 8 XCDs by linear id, and every XCD has its own L2; the
+    // k-blocks of one row split read the SAME dY rows, so they are given linear ids congruent mod 8 (= one XCD, dispatched 8 ids
+    // apart = resident together): the second reader's dY lines stop at that L2 instead of crossing the fabric again (layer 0,
+    // K = 300 in two k-blocks: FETCH_SIZE counted dY twice).  The host sets it where gridDim.y % 8 == 0 and gridDim.x > 1.
+    int kblock = blockIdx.x, split = blockIdx.y;
+    if (flags & 8) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
+        split = xcd + 8 * (slot / (int)gridDim.x);
+        kblock = slot % (int)gridDim.x;
+    }
+    const int K = nseg * F, k0 = kblock * (32 * KT);
     const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
     const int Q = rend > rbeg ? ceil_div(rend - rbeg, RC) : 0;

@@ -40,6 +40,8 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // EEG_USE: the value is needed here (keeps accumulators of ablated code paths alive).  No instructions.
 #define EEG_PIN(v) asm volatile("" : "+v"(v))
 #define EEG_USE(v) asm volatile("" ::"v"(v))
+// the same for a wave-uniform (scalar-register) value: what is computed from it cannot be hoisted above this point
+#define EEG_PIN_S(v) asm volatile("" : "+s"(v))
 // gfx950 cross-lane register swaps (VOP1, no LDS): v_permlane32_swap_b32 exchanges lanes 32..63 of `a` with lanes 0..31 of `b`;
 // v_permlane16_swap_b32 exchanges the odd 16-lane rows of `a` with the even rows of `b` (a.row1 <-> b.row0, a.row3 <-> b.row2).
 // Inline asm: ROCm 7.2's __builtin_amdgcn_permlane{16,32}_swap returns the FIRST result twice (checked in the ISA), and the

@@ -1,5 +1,7 @@
 // Per-kernel timing with HIP events on the launch stream (prof.h; C ABI: include/eeg_dcrnn_prof.h).
 #include <cstdio>
+#include <cstdlib>
+#include <cxxabi.h>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -8,13 +10,13 @@
 
 namespace eeg {
 namespace {
-struct ProfRec { const char* name; const char* sym; hipEvent_t a, b; };
+struct ProfRec { const char* name; const void* kern; hipEvent_t a, b; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open = nullptr;
 const char* g_open_name = nullptr;
-const char* g_open_sym = nullptr;
+const void* g_open_kern = nullptr;
 const char* g_prefix = nullptr;
 std::vector<std::string*> g_names;
 hipEvent_t prof_event() {
@@ -26,9 +28,9 @@ hipEvent_t prof_event() {
 }  // namespace
 void prof_set_prefix(const char* prefix) { g_prefix = prefix; }
 bool prof_is_on() { return g_prof_on; }
-void prof_begin(const char* name, hipStream_t st, const char* sym) {
+void prof_begin(const char* name, hipStream_t st, const void* kern) {
     if (!g_prof_on) return;
-    g_open_sym = sym;
+    g_open_kern = kern;
     g_open = prof_event();
     if (g_prefix != nullptr) {                       // interned so that records can keep a plain pointer
         std::string full = std::string(g_prefix) + name;
@@ -45,12 +47,12 @@ void prof_end(hipStream_t st) {
     if (!g_prof_on || g_open == nullptr) return;
     hipEvent_t b = prof_event();
     (void)hipEventRecord(b, st);
-    g_recs.push_back({g_open_name, g_open_sym, g_open, b});
+    g_recs.push_back({g_open_name, g_open_kern, g_open, b});
     g_open = nullptr;
 }
 void prof_enable(bool on) { g_prof_on = on; }
 size_t prof_report(char* buf, size_t cap) {
-    struct Agg { const char* name; const char* sym; int count; double ms; };
+    struct Agg { const char* name; const void* kern; int count; double ms; };
     std::vector<Agg> agg;
     for (auto& r : g_recs) {
         (void)hipEventSynchronize(r.b);
@@ -58,8 +60,8 @@ size_t prof_report(char* buf, size_t cap) {
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         bool found = false;
         for (auto& a : agg)
-            if (strcmp(a.name, r.name) == 0 && a.sym == r.sym) { a.count++; a.ms += ms; found = true; break; }
-        if (!found) agg.push_back({r.name, r.sym, 1, (double)ms});
+            if (strcmp(a.name, r.name) == 0 && a.kern == r.kern) { a.count++; a.ms += ms; found = true; break; }
+        if (!found) agg.push_back({r.name, r.kern, 1, (double)ms});
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
@@ -67,13 +69,22 @@ size_t prof_report(char* buf, size_t cap) {
     std::string out;
     char line[512];
     for (auto& a : agg) {
-        // kern_sym(): "const char *eeg::kern_sym() [K = &eeg::seq_fwd2_kernel<64, 3, 5, false>]" -> "seq_fwd2_kernel<64, 3, 5, false>"
-        std::string sym = a.sym != nullptr ? a.sym : "?";
-        const size_t k = sym.find("K = ");
-        if (k != std::string::npos) {
-            sym = sym.substr(k + 4);
-            if (!sym.empty() && sym[0] == '&') sym = sym.substr(1);
-            if (!sym.empty() && sym.back() == ']') sym.pop_back();
+        // the kernel's symbol as a rocprofv3 kernel trace spells it ("void eeg::seq_fwd2_kernel<64, 3, 5, false>(eeg::SeqFwdArgs)")
+        // without the return type, the namespace and the argument list
+        std::string sym = "?";
+        const char* mangled = a.kern != nullptr ? hipKernelNameRefByPtr(a.kern, nullptr) : nullptr;
+        if (mangled != nullptr) {
+            int st = 0;
+            char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+            sym = (st == 0 && dem != nullptr) ? dem : mangled;
+            free(dem);
+            if (sym.rfind("void ", 0) == 0) sym = sym.substr(5);
+            int depth = 0;
+            for (size_t i = 0; i < sym.size(); ++i) {
+                depth += sym[i] == '<';
+                depth -= sym[i] == '>';
+                if (sym[i] == '(' && depth == 0) { sym = sym.substr(0, i); break; }
+            }
             if (sym.rfind("eeg::", 0) == 0) sym = sym.substr(5);
         }
         snprintf(line, sizeof(line), "%s %d %.6f %s\n", a.name, a.count, a.ms, sym.c_str());

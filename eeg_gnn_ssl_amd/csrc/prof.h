@@ -5,8 +5,8 @@
 #include "common.h"
 
 namespace eeg {
-// sym: the compiler's spelling of the launched kernel instantiation (kern_sym below), or nullptr
-void prof_begin(const char* name, hipStream_t st, const char* sym = nullptr);
+// kern: the host-side function of the launched kernel instantiation (resolved to its symbol in the report), or nullptr
+void prof_begin(const char* name, hipStream_t st, const void* kern = nullptr);
 bool prof_is_on();
 void prof_end(hipStream_t st);
 void prof_set_prefix(const char* prefix);      // records made while set are named prefix+name
@@ -18,15 +18,11 @@ struct ProfPrefix {                             // RAII: tag the launches of one
     ~ProfPrefix() { prof_set_prefix(nullptr); }
 };
 
-// the instantiated kernel behind a launch, as the compiler spells it ("... [K = &eeg::seq_fwd2_kernel<64, 3, 5, false>]"): the report
-// carries it so that bench.py's per-kernel table is by SYMBOL, like a rocprofv3 kernel trace
-template <auto K>
-inline const char* kern_sym() { return __PRETTY_FUNCTION__; }
 }  // namespace eeg
 
 #define EEG_LAUNCH_P(name, kern, grid, block, smem, stream, ...) \
     do {                                                           \
-        eeg::prof_begin(name, stream, eeg::prof_is_on() ? eeg::kern_sym<&kern>() : nullptr); \
+        eeg::prof_begin(name, stream, reinterpret_cast<const void*>(&kern));      \
         EEG_LAUNCH(kern, grid, block, smem, stream, __VA_ARGS__);  \
         eeg::prof_end(stream);                                     \
     } while (0)

@@ -251,7 +251,7 @@ def decoder_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, targets: Tensor
     w_proj = params[f"{prefix}.projection_layer.weight"]
     b_proj = params[f"{prefix}.projection_layer.bias"]
     hidden = [init_hidden[l] for l in range(cfg.num_rnn_layers)]
-    cur_in = torch.zeros(b, cfg.num_nodes * cfg.output_dim, dtype=targets.dtype)
+    cur_in = torch.zeros(b, cfg.num_nodes * cfg.output_dim, dtype=targets.dtype, device=targets.device)
     outs = []
     for t in range(t_len):
         x = cur_in
@@ -275,7 +275,7 @@ def decoder_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, targets: Tensor
 
 def last_relevant(output: Tensor, lengths: Tensor) -> Tensor:
     """utils.py:346-357 (batch_first=True): output (B,T,D) gathered at t = len-1 -> (B,D)."""
-    idx = (lengths.to(torch.int64) - 1).view(-1, 1, 1).expand(-1, 1, output.shape[2])
+    idx = (lengths.to(device=output.device, dtype=torch.int64) - 1).view(-1, 1, 1).expand(-1, 1, output.shape[2])
     return output.gather(1, idx).squeeze(1)
 
 
@@ -287,7 +287,7 @@ def classification_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, input_se
     model.py:267 as mask x 1/(1-p) factors (README.md:83 trains the 4-class model with --dropout 0.5); None = eval / p = 0."""
     b = input_seq.shape[0]
     x = input_seq.transpose(0, 1)
-    h0 = torch.zeros(cfg.num_rnn_layers, b, cfg.num_nodes * cfg.rnn_units, dtype=input_seq.dtype)
+    h0 = torch.zeros(cfg.num_rnn_layers, b, cfg.num_nodes * cfg.rnn_units, dtype=input_seq.dtype, device=input_seq.device)
     _, top = encoder_forward(params, cfg, x, h0, supports)
     last = last_relevant(top.transpose(0, 1), seq_lengths).view(b, cfg.num_nodes, cfg.rnn_units)
     if dropout_mask is not None:
@@ -304,7 +304,7 @@ def next_time_pred_forward(params: Dict[str, Tensor], cfg: DCRNNConfig, encoder_
     b, t_out, n, _ = decoder_inputs.shape
     enc_in = encoder_inputs.transpose(0, 1)
     dec_in = decoder_inputs.transpose(0, 1)
-    h0 = torch.zeros(cfg.num_rnn_layers, b, cfg.num_nodes * cfg.rnn_units, dtype=encoder_inputs.dtype)
+    h0 = torch.zeros(cfg.num_rnn_layers, b, cfg.num_nodes * cfg.rnn_units, dtype=encoder_inputs.dtype, device=encoder_inputs.device)
     enc_final, _ = encoder_forward(params, cfg, enc_in, h0, supports)
     out = decoder_forward(params, cfg, dec_in, enc_final, supports, teacher_force_mask, dropout_masks=dropout_masks)
     return out.reshape(t_out, b, n, -1).transpose(0, 1)

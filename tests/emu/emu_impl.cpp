@@ -5,7 +5,7 @@
 // the product's event-based kernel timer (csrc/prof.cpp) has nothing to time here
 #include "prof.h"
 namespace eeg {
-void prof_begin(const char*, hipStream_t, const char*) {}
+void prof_begin(const char*, hipStream_t, const void*) {}
 bool prof_is_on() { return false; }
 void prof_end(hipStream_t) {}
 void prof_set_prefix(const char*) {}

@@ -21,6 +21,7 @@ __device__ __forceinline__ void permlane16_swap(float& a, float& b) { emu::perml
 #define EEG_VM_WAIT(n) ((void)0)
 #define EEG_PIN(v) ((void)0)
 #define EEG_USE(v) ((void)0)
+#define EEG_PIN_S(v) ((void)0)
 __device__ __forceinline__ long long cycle_now() { return 0; }
 __device__ __forceinline__ long long realtime_now() { return 0; }
 
