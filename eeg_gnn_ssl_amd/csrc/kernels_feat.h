@@ -118,13 +118,22 @@ __global__ __launch_bounds__(256) void fft200_features_kernel(const float* __res
     const bool active = w < kFftPerWave;
     // twiddles of this lane: stage 1 -> 2: W100^{q k1}, k1 = 0..9; real-input split: W200^{q + 10 k2}, k2 = 0..9
     cplx tw1[10], tw2[10];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
+    {
+        // two sincos per lane; the other 18 twiddles by complex rotation (error ~10 eps; twenty library sincos calls were 3 000
+        // instructions = 5 us in front of every wave's first window)
         double sn, cs;
-        sincos(6.283185307179586476925286766559 * (double)(q * j) / 100.0, &sn, &cs);
-        tw1[j] = {cs, -sn};
-        sincos(6.283185307179586476925286766559 * (double)(q + 10 * j) / 200.0, &sn, &cs);
-        tw2[j] = {cs, sn};                                               // (cos, sin): the split uses both signs explicitly
+        sincos(6.283185307179586476925286766559 * (double)q / 100.0, &sn, &cs);
+        const cplx r1 = {cs, -sn};                                       // W100^q
+        sincos(6.283185307179586476925286766559 * (double)q / 200.0, &sn, &cs);
+        const cplx r2 = {cs, sn};                                        // (cos, sin) of 2 pi q / 200
+        const cplx s2 = {0.95105651629515357212, 0.30901699437494742410};   // (cos, sin) of 2 pi 10 / 200
+        tw1[0] = {1.0, 0.0};
+        tw2[0] = r2;
+#pragma unroll
+        for (int j = 1; j < 10; ++j) {
+            tw1[j] = cmul(tw1[j - 1], r1);
+            tw2[j] = cmul(tw2[j - 1], s2);                               // (cos, sin) of 2 pi (q + 10 j) / 200: the split uses both signs explicitly
+        }
     }
     const double log_floor = log(1e-8);                                  // computeFFT: amp == 0 -> 1e-8
     const long long n_items = (n_windows + kFftPerWave - 1) / kFftPerWave;
@@ -170,7 +179,13 @@ __global__ __launch_bounds__(256) void fft200_features_kernel(const float* __res
                 const double xr = ar + (tw2[k2].re * bi - tw2[k2].im * br);
                 const double xi = ai - (tw2[k2].re * br + tw2[k2].im * bi);
                 const double pw = 0.25 * (xr * xr + xi * xi);
-                v[k2] = (float)(pw == 0.0 ? log_floor : 0.5 * log(pw));
+                // log|X| = ln2/2 * (e + log2 m), |X|^2 = m 2^e with m in [0.5, 1): the exponent split is exact in fp64, the mantissa's
+                // log2 is one v_log_f32 (absolute error ~1e-7 on a value in (-1, 0]) and the two parts are combined in fp64 -- the fp64
+                // library log (~70 fp64 instructions per bin) was 60 % of this kernel's instructions
+                int ex;
+                const double mant = frexp(pw, &ex);
+                const double lg = 0.34657359027997264 * ((double)ex + (double)fast_log2((float)mant));
+                v[k2] = (float)(pw == 0.0 ? log_floor : lg);
             }
         }
         EEG_WAVE_SYNC();                                                 // every partner read is done: the tile becomes the output tile

@@ -108,6 +108,8 @@ namespace eeg {
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// v_log_f32 (log2; absolute error ~1e-7 for arguments in [0.5, 1), no denormal handling): the mantissa part of a split logarithm
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 // a*b + c with the product rounded first (what two separate framework kernels compute)
 __device__ __forceinline__ float unfused_mul_add(float a, float b, float c) {
 #pragma clang fp contract(off)

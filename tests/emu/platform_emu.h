@@ -59,6 +59,7 @@ namespace eeg {
 __device__ __forceinline__ float fast_exp(float x) { return expf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float fast_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return log2f(x); }
 __device__ __forceinline__ float unfused_mul_add(float a, float b, float c) { volatile float p = a * b; return p + c; }
 
 constexpr int kPlatformIsDevice = 0;
