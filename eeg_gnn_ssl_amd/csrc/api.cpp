@@ -364,9 +364,7 @@ struct BwdWs {
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
     if ((g_tune[2] & 2) != 0 || g_tune[1] != 0 || R < q_min_rows()) return TnqPlan{};
-    TnqPlan p = tnq_plan(nseg, F, R, O, bt, g_tune[16] > 0 ? g_tune[16] / 2 : num_cus());    // dev knob 16: target workgroups of the whole-block TN GEMM
-    p.no_xcd = g_tune[17] == 1 ? 1 : 0;                                                      // dev knob 17 = 1: plain workgroup order (A/B)
-    return p;
+    return tnq_plan(nseg, F, R, O, bt, g_tune[16] > 0 ? g_tune[16] / 2 : num_cus());    // dev knob 16: target workgroups of the whole-block TN GEMM
 }
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     BwdWs w;

@@ -71,9 +71,8 @@ int launch_tnq_one(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R
     constexpr int RC = 16;
     const size_t lds = 3 * (size_t)(RC * 32 * (KT + OT)) * sizeof(float);
     EEG_SET_MAX_LDS((gemm_tnq_kernel<KT, OT, RC, BT, PLANAR, false>), lds);
-    const int flags = (p.nkb > 1 && p.nsplit % 8 == 0 && !p.no_xcd) ? 8 : 0;      // k-blocks of a row split on one XCD (kernel comment)
     EEG_LAUNCH_P(tag, (gemm_tnq_kernel<KT, OT, RC, BT, PLANAR, false>), dim3(p.nkb, p.nsplit), dim3(256), lds, st, segs, nseg, F, R, dY, ldy,
-                 ycol0, O, partial, p.rps, btT, btB, btN, flags);
+                 ycol0, O, partial, p.rps, btT, btB, btN, 0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 template <int KT, bool BT, bool PLANAR>

@@ -18,7 +18,6 @@ struct TnqPlan {
     int ok;                 // 0: the shape is not covered (use gemm_tn_dma_kernel / gemm_tn_kernel)
     int KT, OT, planar;     // template instance
     int nkb, nsplit, rps;   // grid (k-blocks, row splits) and rows per split (multiple of 16)
-    int no_xcd;             // 1: plain (k-block, split) -> workgroup id order (dev A/B); default: the k-blocks of a split share an XCD
 };
 // bt: the A segments are batch-major.  Covered: O in {64, 128, 192}, R % 16 == 0, and either 64-wide planes (any count,
 // time-major) or O == 192 with any F % 4 == 0 (the x-part of a 64-unit cell)

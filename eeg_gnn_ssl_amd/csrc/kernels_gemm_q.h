@@ -288,16 +288,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg
     static_assert(!PLANAR || (!BT && KT % 2 == 0 && SA::has32 == 0), "planar blocks are whole 64-wide planes");
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), wk = w >> 1, wo = w & 1, li = lane & 15, kk = lane >> 4;
-    // flags 8: XCD-aware placement.  Workgroups go round-robin over the 8 XCDs by linear id, and every XCD has its own L2; the
-    // k-blocks of one row split read the SAME dY rows, so they are given linear ids congruent mod 8 (= one XCD, dispatched 8 ids
-    // apart = resident together): the second reader's dY lines stop at that L2 instead of crossing the fabric again (layer 0,
-    // K = 300 in two k-blocks: FETCH_SIZE counted dY twice).  The host sets it where gridDim.y % 8 == 0 and gridDim.x > 1.
-    int kblock = blockIdx.x, split = blockIdx.y;
-    if (flags & 8) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, slot = lin >> 3;
-        split = xcd + 8 * (slot / (int)gridDim.x);
-        kblock = slot % (int)gridDim.x;
-    }
+    // (Round 5 measured the XCD-aware placement of gemm_tn_dma_kernel here too -- the k-blocks of a row split given linear ids
+    //  congruent mod 8 so that the second reader of the dY rows hits that XCD's L2: FETCH_SIZE of the two-k-block layer-0 instance
+    //  stayed at 423 601 KB-units per launch and its time at 0.295 ms; with ~4 MB in flight per XCD the partner's lines are gone
+    //  before it asks.  Not kept: profiles/r05_c_pmc_traffic_cfg2_{default,plain_order}.json.)
+    const int kblock = blockIdx.x, split = blockIdx.y;
     const int K = nseg * F, k0 = kblock * (32 * KT);
     const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;

@@ -25,7 +25,7 @@ int eeg_dcrnn_set_seq_probe(int64_t* probe);
  * key 8: unused (round 1-3: k-steps per weight group of the layer-0 input part in the persistent decoder forward); key 3: the
  * streamed-weight BPTT kernel with two workgroups per CU (1 = wherever it exists, 2 = never; default: batches beyond
  * 1.5 clips per CU at M >= 4); keys 14 / 15: 8-wave TN GEMM from this dY width up / its workgroup target;
- * key 17 = 1: plain workgroup order in the whole-block TN GEMM (default: the k-blocks of a row split share an XCD); key 18 = 1: the round-4
+ * key 18 = 1: the round-4
  * adjoint diffusion (hop planes consumed one at a time) instead of the row-streaming one;
  * keys 5 / 6 / 7: target workgroup counts of the streaming diffusion (forward / adjoint) and the correlation-Gram launches.
  * Defaults (all 0) = the product configuration. */

@@ -766,6 +766,10 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
         (E.gather_last.default, (d(torch.randn(t_len, b, 5, generator=g)), d(torch.tensor([4, 1, 2])))),
         (E.clip_adam_.default, (d(torch.randn(64, generator=g)), d(torch.randn(64, generator=g)), d(torch.zeros(64)), d(torch.zeros(64)),
                                 1, 1e-3, 0.9, 0.999, 1e-8, 5e-4, 5.0, 1.0, d(torch.zeros(64)), d(torch.zeros(1)))),
+        (E.clip_adam_dev_.default, (d(torch.randn(64, generator=g)), d(torch.randn(64, generator=g)), d(torch.zeros(64)), d(torch.zeros(64)),
+                                    d(torch.zeros(1, dtype=torch.int32)), d(torch.full((1,), 1e-3)), 0.9, 0.999, 1e-8, 5e-4, 5.0, 1.0,
+                                    d(torch.zeros(64)), d(torch.zeros(1)))),
+        (E.teacher_flags_.default, (d(torch.tensor([99, 0], dtype=torch.int64)), d(torch.tensor([120], dtype=torch.int64)), 8, 50.0, 12)),
     ]
     # shapes where the fake implementations used to drift from the library: a 64-unit cell (quad packs bxq / bxtq exist from
     # 64 units on) and a transposed batch-major input at a width the zero-copy row map does not cover (Fin = 8: the library
