@@ -403,7 +403,8 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
 int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* planes, size_t x_stride, const float* Hprev,
                       const float* RHs, const float* dXW, const float* P, const float* hpl_in, const float* rpl_in,
                       size_t h_stride, float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate,
-                      float* dWg, float* dWc, hipStream_t st, BtMap bt = BtMap()) {
+                      float* dWg, float* dWc, hipStream_t st, BtMap bt = BtMap(), const float* bias_part = nullptr,
+                      float* dbg = nullptr, float* dbc = nullptr) {
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const int acc = accumulate ? 8 : 0;
     SegPtrs sx;
@@ -443,6 +444,9 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
         jobs.nblocks[j] = ceil_div(Ks[j] * Os[j], 64);
         nblocks += jobs.nblocks[j];
     }
+    // the cell's bias gradients (per-clip partials of the BPTT kernel -> dbg, dbc) as a fourth job of the same launch
+    jobs.bias_part = bias_part; jobs.bias_B = d->B; jobs.dbg = dbg; jobs.dbc = dbc;
+    if (bias_part != nullptr) nblocks += ceil_div(3 * H, 16);
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack3_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, acc, Fin, H, M, dWg, dWc);
     return check_launch("reduce_unpack");
 }
@@ -727,9 +731,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                  dXW, dh0, dbias, d->T, d->B, N, d->act, seq_probe_arg(st)};
     a.variant = g_tune[13] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 13 = 1: off)
     if (seq_bwd(H, M, a, st)) return 1;
-    EEG_LAUNCH_P("reduce_bias", reduce_bias_kernel, dim3(ceil_div(3 * H, 16)), dim3(256), 256 * sizeof(float), st, dbias, d->B, H, dbg, dbc);
-    if (check_launch("reduce_bias")) return 1;
-    // 2. weight gradients (hoisted, split-K with fixed-order reduction)
+    // 2. weight gradients (hoisted, split-K with fixed-order reduction); the bias sums ride in their reduction launch
     const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
     BtMap bt;
     if (d->x_batch_major) {
@@ -737,7 +739,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         bt.T = d->T; bt.B = d->B; bt.N = N;
     }
     if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
-                          ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, bt)) return 1;
+                          ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, bt, dbias, dbg, dbc)) return 1;
     // 3. gradient w.r.t. the layer input: Z = dXW @ Bx^T, dX = Z_0 + sum_m P_m^T Z_m
     if (dX != nullptr) {
         float* Z = ws + w.z;
@@ -761,7 +763,7 @@ int eeg_dcrnn_fft_features(const float* raw, int B, int N, int T, int W, const i
         const long long n_windows = (long long)B * N * T;
         const long long n_items = (n_windows + kFftPerWave - 1) / kFftPerWave;
         long long blocks = (n_items + 3) / 4;
-        const long long cap = (long long)platform_num_cus() * 2;          // 2 workgroups of 4 waves per CU (187 registers: 2 waves per SIMD), persistent
+        const long long cap = (long long)platform_num_cus() * kFftWgPerCu;  // workgroups of 4 waves per CU the kernel's registers allow, persistent
         if (blocks > cap) blocks = cap;
         const size_t lds = 4 * (size_t)kFftWaveDoubles * sizeof(double);
         EEG_SET_MAX_LDS(fft200_features_kernel, lds);

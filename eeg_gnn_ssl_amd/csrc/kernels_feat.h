@@ -102,11 +102,14 @@ __device__ __forceinline__ void dft10(const cplx (&x)[10], cplx (&X)[10]) {
     }
 }
 
-constexpr int kFftWin = 200, kFftBins = 100, kFftPerWave = 6;
+#ifndef EEG_FFT_MINW
+#define EEG_FFT_MINW 2          // waves per SIMD the kernel is compiled for (176 registers; 3 = 168 + 9 spilled: measured)
+#endif
+constexpr int kFftWin = 200, kFftBins = 100, kFftPerWave = 6, kFftWgPerCu = EEG_FFT_MINW;
 constexpr int kFftRow = 11;                                              // transposed tile: 16-byte entries, row stride 11 (conflict-free)
 constexpr int kFftWaveDoubles = kFftPerWave * 10 * kFftRow * 2;          // 1320 doubles = 10.3 KB per wave (the Z and output tiles alias it)
 
-__global__ __launch_bounds__(256) void fft200_features_kernel(const float* __restrict__ raw, int N, int T, long long n_windows,
+__global__ __launch_bounds__(256, EEG_FFT_MINW) void fft200_features_kernel(const float* __restrict__ raw, int N, int T, long long n_windows,
                                                               const int* __restrict__ perm, const float* __restrict__ log_scale,
                                                               float mean, float inv_std, float* __restrict__ feat_raw,
                                                               float* __restrict__ feat_std) {

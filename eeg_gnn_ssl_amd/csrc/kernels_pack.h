@@ -247,14 +247,41 @@ __global__ __launch_bounds__(256) void reduce_unpack_kernel(const float* __restr
                                                             float* __restrict__ dWg, float* __restrict__ dWc) {
     reduce_unpack_block(blockIdx.x, part, nsplit, K, O, kind_flags, Fin, H, M, dWg, dWc);
 }
+// column sums of per-sample bias-gradient partials [B][3H] -> dbg (2H), dbc (H); fixed order.
+// block = 256 threads = 16 columns x 16 row-slices; LDS combine in a fixed order (sm: 256 floats).
+__device__ __forceinline__ void reduce_bias_block(int blk, float* sm, const float* __restrict__ part, int B, int H,
+                                                  float* __restrict__ dbg, float* __restrict__ dbc) {
+    const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int j = blk * 16 + c;
+    float s = 0.f;
+    if (j < 3 * H)
+        for (int b = q; b < B; b += 16) s += part[(size_t)b * 3 * H + j];
+    sm[q * 16 + c] = s;
+    __syncthreads();
+    if (q == 0 && j < 3 * H) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += sm[i * 16 + c];
+        if (j < 2 * H) dbg[j] = t; else dbc[j - 2 * H] = t;
+    }
+}
 // The three weight-gradient GEMMs of one cell (x-part, h-gate, h-candidate: kinds 0, 1, 2) reduced by ONE launch:
 // blocks [0, nb0) serve job 0, [nb0, nb0 + nb1) job 1, the rest job 2.
-struct ReduceJobs { const float* part[3]; int nsplit[3]; int K[3]; int O[3]; int nblocks[3]; };
+// Round 5: the bias gradients of the cell (column sums of the BPTT kernel's per-clip partials [B][3H]) ride in the same launch as a
+// fourth job (blocks behind the three: one 5-us launch per layer and step less).
+struct ReduceJobs {
+    const float* part[3]; int nsplit[3]; int K[3]; int O[3]; int nblocks[3];
+    const float* bias_part; int bias_B; float* dbg; float* dbc;              // bias_part == nullptr: no bias job
+};
 __global__ __launch_bounds__(256) void reduce_unpack3_kernel(ReduceJobs jobs, int flags, int Fin, int H, int M,
                                                              float* __restrict__ dWg, float* __restrict__ dWc) {
     int b = blockIdx.x, j = 0;
     if (b >= jobs.nblocks[0]) { b -= jobs.nblocks[0]; j = 1; }
     if (j == 1 && b >= jobs.nblocks[1]) { b -= jobs.nblocks[1]; j = 2; }
+    if (j == 2 && b >= jobs.nblocks[2]) {            // the bias job (wave-uniform branch: whole blocks)
+        EEG_DYN_SMEM(sm);
+        reduce_bias_block(b - jobs.nblocks[2], sm, jobs.bias_part, jobs.bias_B, H, jobs.dbg, jobs.dbc);
+        return;
+    }
     reduce_unpack_block(b, jobs.part[j], jobs.nsplit[j], jobs.K[j], jobs.O[j], j | flags, Fin, H, M, dWg, dWc);
 }
 
@@ -323,25 +350,6 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nchun
     for (; i < nchunk; ++i) a0 += partial[(size_t)i * C + col];
     const float s = (a0 + a1) + (a2 + a3);
     if (col < split) out0[col] = s; else out1[col - split] = s;
-}
-
-// column sums of per-sample bias-gradient partials [B][3H] -> dbg (2H), dbc (H); fixed order.
-// block = 256 threads = 16 columns x 16 row-slices; LDS combine in a fixed order.
-__global__ void reduce_bias_kernel(const float* __restrict__ part, int B, int H,
-                                   float* __restrict__ dbg, float* __restrict__ dbc) {
-    EEG_DYN_SMEM(sm);                                 // [16][16]
-    const int c = threadIdx.x & 15, q = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + c;
-    float s = 0.f;
-    if (j < 3 * H)
-        for (int b = q; b < B; b += 16) s += part[(size_t)b * 3 * H + j];
-    sm[q * 16 + c] = s;
-    __syncthreads();
-    if (q == 0 && j < 3 * H) {
-        float t = 0.f;
-        for (int i = 0; i < 16; ++i) t += sm[i * 16 + c];
-        if (j < 2 * H) dbg[j] = t; else dbc[j - 2 * H] = t;
-    }
 }
 
 // Hop-polynomial matrices: P_0 = I (implicit), then for every support S, in order:

@@ -904,7 +904,7 @@ def check_teacher_flags(device):
     assert abs(tot / 1024.0 - 0.5) < 3 * 0.5 / np.sqrt(1024.0) + 0.01, tot
 
 
-def check_ssl_device_curriculum(tag, adj3d, device, dropout=0.0):
+def check_ssl_device_curriculum(tag, adj3d, device, dropout=0.0, reps=6):
     """DCRNNModel_nextTimePred under curriculum learning with the teacher-forcing flags drawn ON THE DEVICE (batches_seen = a
     device counter tensor): the flags the kernels read are re-derived from the generator pair and handed to the oracle ->
     predictions and every gradient agree; the counter advanced by the increment."""
@@ -927,7 +927,7 @@ def check_ssl_device_curriculum(tag, adj3d, device, dropout=0.0):
     model.batches_seen_increment = 24
     model.decoder.set_dropout_seed(20240917, 3)
     seeds = []
-    for rep in range(6):             # several draws: mixed flags must occur and each must match the oracle
+    for rep in range(reps):          # several draws: mixed flags must occur and each must match the oracle
         seed, off = model.decoder.dropout_rng_state()
         n_seen = int(seen.item())
         flags = expected_teacher_flags(seed, off, n_seen, 50.0, t_out)

@@ -17,7 +17,8 @@ import bench
 w = sys.argv[1]
 CLASSES = [("seq_fwd", "seq_fwd"), ("seq_bwd", "seq_bwd"), ("gemm_nn", "gemm_nn"), ("gemm_tn", "gemm_tn"),
            ("diffuse_fwd", "diffuse_fwd"), ("diffuse_adj", "diffuse_adj"), ("reduce_unpack", "reduce_unpack"),
-           ("corr_gram", "corr_gram")]
+           ("corr_gram", "corr_gram"), ("fft200_features", "fft_features"), ("dec_fwd_persist", "dec_fwd_persist"),
+           ("dec_bwd_persist", "dec_bwd_persist")]
 tot = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 cnt = {c: collections.defaultdict(int) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 variants = collections.defaultdict(lambda: collections.defaultdict(list))
