@@ -884,6 +884,10 @@ def main():
     ap.add_argument("--split-bf16-experiment", action="store_true", help="also run tools/micro/bf16x3_lab (a LAB kernel, not "
                     "the product path: the hoisted NN GEMM as a three-term bf16 split on the bf16 matrix pipe) and report its "
                     "time and error beside the true-fp32 kernel under `experimental_split_bf16`; `value` / `dtype` are untouched")
+    ap.add_argument("--split-bf16", action="store_true", help="also measure the primary workload once more with the OPT-IN three-term "
+                    "bf16 split of the hoisted NN GEMMs (ops.set_gemm_mode(1): x-part pre-activations and input gradient on "
+                    "v_mfma_f32_16x16x32_bf16, fp32 operands / results / accumulation, fp32-level error) and report it under "
+                    "`experimental_split_bf16` BESIDE the fp32 line: `value` / `dtype` stay the fp32-MFMA measurement")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning); loads "
                     "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
     ap.add_argument("--lib", default=None, help="development A/B runs only: load this build of the C ABI (e.g. a library built "
@@ -943,11 +947,33 @@ def main():
             sec_lines[w] = {"error": f"{type(e).__name__}: {e}"}
             ctx.log(f"{w}: secondary pass failed: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
+    # opt-in second line (never the headline): the same workload with the hoisted NN GEMMs as a three-term bf16 split
+    bf_line = None
+    if args.split_bf16:
+        from eeg_gnn_ssl_amd import ops as _ops
+        prev_mode = _ops.set_gemm_mode(1)
+        try:
+            bf_line = measure(ctx, args.workload, args.steps, args.warmup, primary=False)
+        finally:
+            _ops.set_gemm_mode(prev_mode)
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
         return
     out["secondary_workloads"] = sec_lines or None
+    if bf_line is not None:
+        r3 = bf_line["roofline"] or {}
+        out["experimental_split_bf16_step"] = {
+            "clips_per_s": bf_line["value"], "ms_per_step": bf_line["ms_per_step"], "ratio_to_fp32_value": round(bf_line["value"] / out["value"], 4),
+            "final_loss": bf_line["config"]["final_loss"], "final_loss_fp32": out["config"]["final_loss"],
+            "scope": "OPT-IN (ops.set_gemm_mode(1) / EEG_DCRNN_SPLIT_BF16=1), never the headline: the two hoisted NN GEMMs of every encoder "
+                     "layer (x-part pre-activations, input gradient) as a three-term bf16 split, 6 of 9 partial products on "
+                     "v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 operands and results; the whole `-m gpu` suite passes with "
+                     "the mode on (1e-4 vs the oracle); `value` / `dtype` above are the fp32-MFMA measurement",
+            "kernels": {k: {"ms_per_step": v["ms_per_step"], "launches_per_step": v["launches_per_step"]}
+                        for k, v in (r3.get("by_symbol") or {}).items() if "bf3" in k or "nnr" in k or "nn_dma" in k},
+            "nn_gemm_ms_per_step_fp32": round(sum(v["ms_per_step"] for k, v in ((out["roofline"] or {}).get("kernels") or {}).items() if k.startswith("gemm_nn")), 4),
+            "nn_gemm_ms_per_step_split": round(sum(v["ms_per_step"] for k, v in (r3.get("kernels") or {}).items() if k.startswith("gemm_nn")), 4)}
     if world == 1 and not args.no_cpu_baseline:
         ctx.log("aten gpu baseline (the oracle's op sequence on stock ATen kernels, same GPU, outside the timed region)")
         base_wl = "cfg3" if args.workload == "raw" else args.workload      # (the baselines time the model step on features)

@@ -22,7 +22,7 @@ class LayerDims(ctypes.Structure):
     """mirror of `eeg_layer_dims` (include/eeg_dcrnn.h)."""
     _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Fin", c_int32),
                 ("M", c_int32), ("act", c_int32), ("p_batched", c_int32), ("x_planes_ready", c_int32),
-                ("x_batch_major", c_int32), ("x_plane_stride", c_int64)]
+                ("x_batch_major", c_int32), ("x_plane_stride", c_int64), ("pack3", c_void_p)]
 
 
 class DecoderDims(ctypes.Structure):
@@ -50,6 +50,8 @@ _SIGNATURES = {
     "eeg_dcrnn_corr_graph": (c_int, [_FP, c_int, c_int, c_int, c_int, c_int, _FP, _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_pack_floats": (c_size_t, [c_int, c_int, c_int]),
     "eeg_dcrnn_pack_cell": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_pack3_halves": (c_size_t, [c_int, c_int, c_int]),
+    "eeg_dcrnn_pack_cell_bf16x3": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_diffuse_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_diffuse_adj": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_dconv_fwd_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -15,6 +15,7 @@
 #include "kernels_diffuse.h"
 #include "kernels_feat.h"
 #include "kernels_gemm.h"
+#include "kernels_gemm_bf.h"
 #include "kernels_graph.h"
 #include "kernels_head.h"
 #include "kernels_pack.h"
@@ -161,6 +162,26 @@ int gemm_nn(const SegPtrs& segs, int nseg, int F, int R, const float* Bp, int nc
         return run_nn_dma<5, 16>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
     if (pad4 < pad6 && nn_dma_ok(F, R, ldc)) return run_nn_kc<4>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
     return run_nn_kc<6>(segs, nseg, F, R, Bp, nct_total, bias, C, ldc, O, st, tag, bt);
+}
+
+// opt-in three-term bf16 split of an NN GEMM (kernels_gemm_bf.h).  Returns -1 when the shape has no instantiation (the caller
+// then takes the fp32 kernel), 0 ok, 1 error.
+template <int NTB>
+int run_nn_bf3(const SegPtrs& segs, int nseg, int F, int R, const unsigned short* Wp, int nct_total, const float* bias, float* C,
+               int ldc, int O, hipStream_t st, const char* tag, BtMap bt) {
+    const size_t lds = 2 * 3 * (size_t)NTB * 1024;
+    EEG_SET_MAX_LDS((gemm_nn_bf3_kernel<NTB>), lds);
+    EEG_LAUNCH_P(tag, (gemm_nn_bf3_kernel<NTB>), dim3(ceil_div(R, 128), nct_total / NTB), dim3(256), lds, st, segs, nseg, F, R, Wp, nct_total,
+                 bias, C, ldc, O, bt.T, bt.B, bt.N);
+    return check_launch("gemm_nn_bf3");
+}
+int gemm_nn_bf3(const SegPtrs& segs, int nseg, int F, int R, const unsigned short* Wp, int nct_total, const float* bias, float* C,
+                int ldc, int O, hipStream_t st, const char* tag, BtMap bt) {
+    if (F % 4 != 0 || ldc % 4 != 0 || O % 4 != 0 || (double)R * F >= 4.0e9) return -1;
+    if (nct_total % 12 == 0) return run_nn_bf3<12>(segs, nseg, F, R, Wp, nct_total, bias, C, ldc, O, st, tag, bt);
+    if (nct_total % 10 == 0) return run_nn_bf3<10>(segs, nseg, F, R, Wp, nct_total, bias, C, ldc, O, st, tag, bt);
+    if (nct_total % 8 == 0) return run_nn_bf3<8>(segs, nseg, F, R, Wp, nct_total, bias, C, ldc, O, st, tag, bt);
+    return -1;
 }
 
 template <int NCTW>
@@ -644,6 +665,13 @@ int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const
     EEG_LAUNCH_P("pack_cell", pack_cell_kernel, dim3(512), dim3(256), 0, S_(stream), Wg, bg, Wc, bc, pack, p);
     return check_launch("pack_cell");
 }
+size_t eeg_dcrnn_pack3_halves(int Fin, int H, int M) { return pack3_supported(Fin, H, M) ? make_pack3(Fin, H, M).total : 0; }
+int eeg_dcrnn_pack_cell_bf16x3(const float* Wg, const float* Wc, int Fin, int H, int M, uint16_t* pack3, void* stream) {
+    if (!pack3_supported(Fin, H, M)) return fail("pack_cell_bf16x3: rnn_units=%d, input_dim=%d, %d hop matrices: the bf16 split exists for 64 units", H, Fin, M);
+    if (Wg == nullptr || Wc == nullptr || pack3 == nullptr) return fail("pack_cell_bf16x3: null pointer");
+    EEG_LAUNCH_P("pack_cell", pack_cell_bf3_kernel, dim3(512), dim3(256), 0, S_(stream), Wg, Wc, Fin, H, M, pack3);
+    return check_launch("pack_cell_bf3");
+}
 
 int eeg_dcrnn_diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M,
                           float* planes, void* stream) {
@@ -700,7 +728,13 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * xs : nullptr);
     float* XW = ws;
-    if (gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt, p.has_bxq ? pack + p.bxq : nullptr)) return 1;
+    int rc3 = -1;
+    if (d->pack3 != nullptr && pack3_supported(Fin, H, M)) {          // opt-in: three-term bf16 split (include/eeg_dcrnn.h, eeg_layer_dims.pack3)
+        const Pack3 q = make_pack3(Fin, H, M);
+        rc3 = gemm_nn_bf3(segs, M, Fin, R, d->pack3 + q.xw, q.xw_nct, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt);
+        if (rc3 > 0) return 1;
+    }
+    if (rc3 < 0 && gemm_nn(segs, M, Fin, R, pack + p.bx, 3 * H / 16, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt, p.has_bxq ? pack + p.bxq : nullptr)) return 1;
     // 3. the recurrence
     if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
     SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, Hplanes, RHplanes,
@@ -745,7 +779,13 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         float* Z = ws + w.z;
         SegPtrs sd;
         for (int m = 0; m < kMaxM; ++m) sd.p[m] = m == 0 ? dXW : nullptr;
-        if (gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st, "gemm_nn_dx", BtMap(), p.has_bxtq ? pack + p.bxtq : nullptr)) return 1;
+        int rc3 = -1;
+        if (d->pack3 != nullptr && pack3_supported(Fin, H, M)) {      // opt-in: three-term bf16 split
+            const Pack3 q = make_pack3(Fin, H, M);
+            rc3 = gemm_nn_bf3(sd, 1, 3 * H, R, d->pack3 + q.dx, q.dx_nct, nullptr, Z, M * Fin, M * Fin, st, "gemm_nn_dx", BtMap());
+            if (rc3 > 0) return 1;
+        }
+        if (rc3 < 0 && gemm_nn(sd, 1, 3 * H, R, pack + p.bxt, round_up(M * Fin, 16) / 16, nullptr, Z, M * Fin, M * Fin, st, "gemm_nn_dx", BtMap(), p.has_bxtq ? pack + p.bxtq : nullptr)) return 1;
         if (diffuse_adj(Z, P, d->p_batched, S, d->B, N, Fin, M, dX, st)) return 1;
     }
     return 0;

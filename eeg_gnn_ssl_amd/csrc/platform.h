@@ -19,6 +19,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
+// bf16 matrix pipe (opt-in three-term split of the hoisted NN GEMMs, kernels_gemm_bf.h): a fragment of v_mfma_f32_16x16x32_bf16 is
+// 8 bf16 = 4 VGPRs per lane (A: row lane&15, k = 8*(lane>>4) + i; B: k = 8*(lane>>4) + i, column lane&15; D as the fp32 16x16 tile)
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// two fp32 -> packed bf16 (lo in bits 0..15), round to nearest even (gfx950 v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 // pins the instruction order at this point (keeps hand-placed LDS prefetches ahead of the MFMAs)
 #define EEG_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // A wave executes in lockstep and its LDS operations complete in order, so data a wave wrote to LDS

@@ -29,6 +29,41 @@ NS = "eeg_dcrnn"
 _libdef = torch.library.Library(NS, "DEF")
 
 
+# OPT-IN arithmetic of the two hoisted NN GEMMs of a DCGRU layer (x-part pre-activations, input gradient): 0 = the fp32 matrix pipe
+# (the default and the contract's arithmetic), 1 = three-term bf16 split (6 of 9 partial products on v_mfma_f32_16x16x32_bf16,
+# fp32 accumulation; include/eeg_dcrnn.h `eeg_layer_dims.pack3`).  Set it BEFORE building / capturing a step (`set_gemm_mode`, or
+# EEG_DCRNN_SPLIT_BF16=1 in the environment at import): a cell's weight pack then carries the bf16 term packs behind its fp32 part,
+# and forward and backward of a step must run under the same mode.
+import os as _os
+
+GEMM_MODE = 1 if _os.environ.get("EEG_DCRNN_SPLIT_BF16", "0") not in ("", "0") else 0
+
+
+def set_gemm_mode(mode: int) -> int:
+    """0 = fp32 MFMA (default), 1 = three-term bf16 split of the hoisted NN GEMMs (64 units; other sizes keep fp32). Returns the
+    previous mode."""
+    global GEMM_MODE
+    if mode not in (0, 1):
+        raise ValueError("gemm mode must be 0 (fp32 MFMA) or 1 (three-term bf16 split)")
+    prev, GEMM_MODE = GEMM_MODE, int(mode)
+    return prev
+
+
+def _pack3_halves(fin, h, m) -> int:
+    return int(_lib.get_lib().query("eeg_dcrnn_pack3_halves", int(fin), int(h), int(m))) if GEMM_MODE else 0
+
+
+def _pack_base_floats(fin, h, m) -> int:
+    """floats of the fp32 part of a cell's pack, rounded up so that what follows is 16-byte aligned"""
+    return (int(_lib.get_lib().query("eeg_dcrnn_pack_floats", int(fin), int(h), int(m))) + 3) // 4 * 4
+
+
+def _set_pack3(dims, pack, fin, h, m):
+    """point dims.pack3 at the bf16 term packs behind the fp32 part of `pack` (mode 1, supported cell sizes)"""
+    if _pack3_halves(fin, h, m) > 0:
+        dims.pack3 = pack.data_ptr() + 4 * _pack_base_floats(fin, h, m)
+
+
 def _p(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -138,15 +173,19 @@ def _pack_cell_impl(wg, bg, wc, bc, fin: int, h: int, m: int) -> torch.Tensor:
     if tuple(wg.shape) != (rows, 2 * h) or tuple(wc.shape) != (rows, h) or tuple(bg.shape) != (2 * h,) or tuple(bc.shape) != (h,):
         raise RuntimeError(f"cell parameter shapes {tuple(wg.shape)}, {tuple(bg.shape)}, {tuple(wc.shape)}, {tuple(bc.shape)} "
                            f"do not match input_dim={fin}, num_units={h}, num_matrices={m}")
-    pack = _new((lib.query("eeg_dcrnn_pack_floats", fin, h, m),), wg)
+    base = _pack_base_floats(fin, h, m)
+    halves = _pack3_halves(fin, h, m)
+    pack = _new((base + (halves + 1) // 2,), wg)
     lib.call("eeg_dcrnn_pack_cell", _p(tensors[0]), _p(tensors[1]), _p(tensors[2]), _p(tensors[3]), fin, h, m, _p(pack), _stream(pack))
+    if halves > 0:      # opt-in bf16 split: the three-term packs of the x-part weights ride behind the fp32 packs
+        lib.call("eeg_dcrnn_pack_cell_bf16x3", _p(tensors[0]), _p(tensors[2]), fin, h, m, ctypes.c_void_p(pack.data_ptr() + 4 * base), _stream(pack))
     return pack
 
 
 def _pack_floats(fin, h, m):
     """size of a cell's weight pack for shape inference: `eeg_dcrnn_pack_floats` is a pure host computation of the library
     (make_cell_pack, csrc/kernels_pack.h), so the fake implementations ask it instead of mirroring its layout"""
-    return int(_lib.get_lib().query("eeg_dcrnn_pack_floats", int(fin), int(h), int(m)))
+    return _pack_base_floats(fin, h, m) + (_pack3_halves(fin, h, m) + 1) // 2
 
 
 _define("pack_cell", "(Tensor wg, Tensor bg, Tensor wc, Tensor bc, int fin, int h, int m) -> Tensor", _pack_cell_impl,
@@ -315,6 +354,7 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
         _check(lib, h0, "initial_hidden_state")
     _check(lib, p, "P")
     pack = torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
+    _set_pack3(dims, pack, fin, h, m)
     s = t_len * b
     if ready:
         _check(lib, x_planes, "x_planes")
@@ -380,6 +420,7 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
             raise RuntimeError("dcgru_layer_bwd: x must be contiguous or the transposed view of a batch-major tensor")
         dims.x_batch_major = 1
     planes_ptr = x_planes.data_ptr() + 4 * b * n * fin if ready else planes.data_ptr()
+    _set_pack3(dims, pack, fin, h, m)
     state = b * n * h
     if d_hext is not None:
         d_hext = d_hext.contiguous()

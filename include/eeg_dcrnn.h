@@ -41,6 +41,12 @@ typedef struct eeg_layer_dims {
                                 map: no time-major copy is written (only where eeg_dcrnn_batch_major_ok() returns 2;
                                 pass the same X and planes to layer_bwd) */
     int64_t x_plane_stride;  /* floats between two hop planes of `planes`; 0 = T*B*N*Fin (contiguous) */
+    const uint16_t* pack3;   /* OPT-IN (NULL = off, the default and the contract's arithmetic): the cell's three-term bf16 weight packs
+                                of eeg_dcrnn_pack_cell_bf16x3.  When set, the two hoisted NN GEMMs of the layer -- the x-part
+                                pre-activations (layer_fwd) and the input gradient (layer_bwd) -- run as a three-term bf16 split
+                                (6 of the 9 partial products) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32 operands and
+                                results, error against an fp64 sum at the level of the fp32 matrix pipe's own (~2e-6 on values
+                                of a few units), 1.3-1.4 x its speed.  Everything else of the layer is unchanged. */
 } eeg_layer_dims;
 
 typedef struct eeg_decoder_dims {
@@ -99,6 +105,11 @@ size_t eeg_dcrnn_pack_floats(int Fin, int H, int M);
 /* Reference-layout parameters of one cell (cell.py:40-46,160-175) -> MFMA-fragment-ordered block. */
 int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const float* bc,
                         int Fin, int H, int M, float* pack, void* stream);
+
+/* Three-term bf16 packs (hi / mid / lo, round to nearest even) of the x-part weights of one cell for eeg_layer_dims.pack3:
+ * eeg_dcrnn_pack3_halves() 16-bit elements; available for rnn_units = 64 (else 0 / an error). */
+size_t eeg_dcrnn_pack3_halves(int Fin, int H, int M);
+int eeg_dcrnn_pack_cell_bf16x3(const float* Wg, const float* Wc, int Fin, int H, int M, uint16_t* pack3, void* stream);
 
 /* The HBM-bound diffusion step over all samples: planes[m-1][s] = P_m X_s  (cell.py:83-93 applied
  * to the input features of every time step at once).  Algorithmic bytes: 4*S*N*F*M. */

@@ -11,6 +11,13 @@ struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } const float
 #define EEG_SET_MAX_LDS(kern, bytes) ((void)0)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::mfma4(a, b, c); }
+using emu::bf16x8;
+using emu::u32x4;
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return emu::mfma_bf16(a, b, c); }
+__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {                 // round to nearest even, like v_cvt_pk_bf16_f32
+    auto rne = [](float x) { unsigned a; memcpy(&a, &x, 4); a += 0x7fffu + ((a >> 16) & 1u); return a >> 16; };
+    return rne(lo) | (rne(hi) << 16);
+}
 __device__ __forceinline__ void permlane32_swap(float& a, float& b) { emu::permlane_swap(a, b, 32); }
 __device__ __forceinline__ void permlane16_swap(float& a, float& b) { emu::permlane_swap(a, b, 16); }
 #define EEG_SCHED_FENCE() ((void)0)

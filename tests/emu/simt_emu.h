@@ -43,6 +43,8 @@ struct Fiber {
     f32x4 mc, md;
     bool sync_only = false;
     bool mfma4 = false;          // this rendezvous is a v_mfma_f32_4x4x1_16B_f32
+    bool mfma_bf = false;        // this rendezvous is a v_mfma_f32_16x16x32_bf16 of (bfa, bfb): 8 bf16 per lane and operand, as floats
+    float bfa[8] = {0}, bfb[8] = {0};
     int shfl_mask = -1;          // >= 0: this rendezvous is a __shfl_xor with that lane mask
     float shfl_val = 0.f;
     int swap_rows = 0;           // 16 / 32: this rendezvous is a v_permlane16_swap / v_permlane32_swap of (swap_a, swap_b)
@@ -80,6 +82,22 @@ inline f32x4 mfma4(float a, float b, f32x4 c) {
     cur->st = WAIT_WAVE;
     yield_to_sched();
     cur->mfma4 = false;
+    return cur->md;
+}
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+inline float bf16_bits_to_float(unsigned short h) { unsigned a = (unsigned)h << 16; float x; memcpy(&x, &a, 4); return x; }
+// v_mfma_f32_16x16x32_bf16: A[row = lane&15][k = 8*(lane>>4) + i], B[k = 8*(lane>>4) + i][col = lane&15], D[4*(lane>>4) + r][lane&15]
+inline f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    for (int i = 0; i < 8; ++i) {
+        cur->bfa[i] = bf16_bits_to_float((unsigned short)a[i]);
+        cur->bfb[i] = bf16_bits_to_float((unsigned short)b[i]);
+    }
+    cur->mc = c;
+    cur->mfma_bf = true;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    cur->mfma_bf = false;
     return cur->md;
 }
 // rendezvous of the 64 lanes of a wave: stands for the lockstep execution of real hardware where
@@ -217,6 +235,31 @@ static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
     }
     if (nswap != 0) {
         fprintf(stderr, "emu: wave mixes permlane swaps and mfma at one rendezvous\n");
+        abort();
+    }
+    unsigned nbf = 0;
+    for (unsigned l = 0; l < 64; ++l) nbf += f[w0 + l].mfma_bf;
+    if (nbf == 64) {
+        static float A[16][32], B[32][16];
+        for (unsigned l = 0; l < 64; ++l)
+            for (int i = 0; i < 8; ++i) {
+                A[l & 15][8 * (l >> 4) + i] = f[w0 + l].bfa[i];
+                B[8 * (l >> 4) + i][l & 15] = f[w0 + l].bfb[i];
+            }
+        for (unsigned l = 0; l < 64; ++l) {
+            Fiber& x = f[w0 + l];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * (l >> 4) + r, col = l & 15;
+                float acc = x.mc[r];
+                for (int k = 0; k < 32; ++k) acc = fmaf(A[row][k], B[k][col], acc);     // (products of bf16 pairs are exact in fp32)
+                x.md[r] = acc;
+            }
+            x.st = RUNNABLE;
+        }
+        return;
+    }
+    if (nbf != 0) {
+        fprintf(stderr, "emu: wave mixes bf16 and fp32 mfma at one rendezvous\n");
         abort();
     }
     unsigned n4 = 0;

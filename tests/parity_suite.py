@@ -688,6 +688,54 @@ def check_raw_input_chain(device, b=4, t_len=3):
         assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"raw chain/d_{k}", tol=1e-4)
 
 
+def check_split_bf16(device, adj3d, filt="laplacian", din=100, layers=2, t_len=3, b=3, seed=4):
+    """The OPT-IN three-term bf16 split of the hoisted NN GEMMs (ops.set_gemm_mode(1); include/eeg_dcrnn.h eeg_layer_dims.pack3):
+    logits and every parameter gradient of the classification model against the oracle at the suite's tolerance -- the split keeps
+    fp32-level accuracy -- and a result that differs from the fp32-MFMA path in the last bits (proof that the other kernels ran),
+    bit-identical between two runs; rnn_units != 64 keeps the fp32 kernels."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, ops
+    if ops.GEMM_MODE != 0:
+        import pytest
+        pytest.skip("the suite itself runs with EEG_DCRNN_SPLIT_BF16=1: this test compares the two modes")
+    g = torch.Generator().manual_seed(seed)
+    cfg = orc.DCRNNConfig(filter_type=filt, input_dim=din, rnn_units=64, num_rnn_layers=layers, num_classes=4)
+    params = orc.init_params(cfg, "classification", seed=seed)
+    sup = cases.supports_for(filt, adj3d, b)
+    x = torch.randn(b, t_len, 19, din, generator=g)
+    seq = torch.randint(max(1, t_len // 2), t_len + 1, (b,), generator=g)
+    y = torch.randint(0, 4, (b,), generator=g)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    lo = orc.classification_forward(po, cfg, x, seq, sup)
+    orc.cross_entropy(lo, y).backward()
+
+    def run():
+        model = DCRNNModel_classification(make_args(cfg), 4, device=device)
+        load(model, params, device)
+        model.train()
+        lg = model(x.to(device), seq.to(device), [s.to(device) for s in sup])
+        torch.nn.functional.cross_entropy(lg, y.to(device)).backward()
+        return lg.detach().cpu(), {k: q.grad.detach().cpu().clone() for k, q in model.named_parameters()}
+
+    assert ops.GEMM_MODE == 0
+    lg32, gr32 = run()
+    prev = ops.set_gemm_mode(1)
+    try:
+        assert ops._pack3_halves(din, 64, cfg.num_matrices) > 0 and ops._pack3_halves(din, 32, cfg.num_matrices) == 0
+        lg3, gr3 = run()
+        lg3b, gr3b = run()
+    finally:
+        ops.set_gemm_mode(prev)
+    assert_close(lg3.numpy(), lo.detach().numpy(), "split-bf16 logits vs oracle")
+    for k in gr3:
+        assert_close_scaled(gr3[k].numpy(), po[k].grad.numpy(), f"split-bf16 d_{k} vs oracle")
+        assert torch.equal(gr3[k], gr3b[k]), k
+    assert torch.equal(lg3, lg3b)
+    differs = any(not torch.equal(gr3[k], gr32[k]) for k in gr3)
+    assert differs, "the bf16 split produced bit-identical gradients to the fp32 path: it did not run"
+    worst = max(float((gr3[k] - gr32[k]).abs().max() / gr32[k].abs().max().clamp_min(1e-12)) for k in gr3)
+    assert worst < 2e-5, worst           # fp32-level agreement between the two arithmetic modes
+
+
 def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_registration", "test_faketensor")):
     """The operators are registered with the PyTorch dispatcher (north_star: "exposed as a torch.ops extension"):
     `torch.ops.eeg_dcrnn.*` called DIRECTLY (no module, no Python wrapper) against the oracle, and run through

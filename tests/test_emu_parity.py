@@ -50,6 +50,11 @@ def test_ssl_model_training_dropout(tag, adj3d):
     ps.check_dropout_ssl_case(tag, adj3d, "cpu")
 
 
+@pytest.mark.parametrize("filt,din,layers", [("laplacian", 100, 2), ("dual_random_walk", 36, 2)])
+def test_opt_in_split_bf16_gemms(filt, din, layers, adj3d):
+    ps.check_split_bf16("cpu", adj3d, filt=filt, din=din, layers=layers, t_len=2, b=2)
+
+
 def test_teacher_flags_known_answer():
     ps.check_teacher_flags("cpu")
 

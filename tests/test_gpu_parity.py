@@ -535,6 +535,15 @@ def test_hip_graph_replay_equals_eager_steps():
     assert torch.equal(finals[0], finals[1])
 
 
+@pytest.mark.parametrize("filt,din,t_len,b", [("laplacian", 100, 60, 256), ("dual_random_walk", 100, 60, 256), ("laplacian", 36, 5, 3),
+                                              ("dual_random_walk", 8, 4, 2)])
+def test_opt_in_split_bf16_gemms(filt, din, t_len, b, adj3d):
+    """the opt-in three-term bf16 split of the hoisted NN GEMMs at the benchmark shapes (cfg2 / cfg3: B = 256, T = 60) and at small
+    / narrow ones: fp32-level agreement with the oracle and with the fp32-MFMA path, deterministic, really another code path"""
+    torch.set_num_threads(16)
+    ps.check_split_bf16(DEV, adj3d, filt=filt, din=din, layers=2, t_len=t_len, b=b)
+
+
 def test_whole_step_graph_equals_eager_steps():
     """capture(include_update=True): zero_grad + forward + loss + backward + clip + Adam as ONE HIP graph (the step count and the
     learning rate live on the device, `eeg_dcrnn_clip_adam_dev`).  Replays must walk the parameters of the same number of

@@ -32,4 +32,4 @@ f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] 
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/gap_stats.py "$t" > gpurun_out/${TAG}_gap_stats.txt 2>&1 && head -3 gpurun_out/${TAG}_gap_stats.txt
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete
 echo "== SQ stalls"; timeout 900 bash tools/pmc_sq.sh cfg2 > gpurun_out/${TAG}_sq_stalls_cfg2.txt 2>&1; head -12 gpurun_out/${TAG}_sq_stalls_cfg2.txt
-rm -rf gpurun_out/pmc_cfg?_* gpurun_out/pmc_raw_* gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3 gpurun_out/prof_$TAG
+for d in gpurun_out/pmc_cfg?_FETCH_SIZE gpurun_out/pmc_cfg?_WRITE_SIZE gpurun_out/pmc_raw_FETCH_SIZE gpurun_out/pmc_raw_WRITE_SIZE gpurun_out/sq_1 gpurun_out/sq_2 gpurun_out/sq_3 gpurun_out/prof_$TAG; do rm -rf "$d"; done   # (the directories; the *.log files stay)

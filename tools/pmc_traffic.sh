@@ -9,6 +9,7 @@ cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc_${W}_$c" -o pmc -- \
       python "$OLDPWD/bench.py" --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-graph --no-stream-inputs --secondary none "$@" > "$OLDPWD/gpurun_out/pmc_${W}_$c.log" 2>&1 )
+  tail -3 "gpurun_out/pmc_${W}_$c.log" | cut -c1-400
 done
 python - "$W" <<'PY'
 import csv, glob, collections, json, os, sys
