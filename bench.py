@@ -966,6 +966,11 @@ def main():
         out["experimental_split_bf16_step"] = {
             "clips_per_s": bf_line["value"], "ms_per_step": bf_line["ms_per_step"], "ratio_to_fp32_value": round(bf_line["value"] / out["value"], 4),
             "final_loss": bf_line["config"]["final_loss"], "final_loss_fp32": out["config"]["final_loss"],
+            # the bf16 kernels draw more power: the clock the part holds right behind the split-mode steps is lower than behind the
+            # fp32 steps, which slows every OTHER kernel of the step -- why the step gains less than the NN GEMMs do
+            "shader_clock_mhz_under_load": bf_line["shader_clock_mhz_under_load"], "shader_clock_mhz_under_load_fp32": out["shader_clock_mhz_under_load"],
+            "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in (r3.get("kernels") or {}).items() if v["ms_per_step"] >= 0.02},
+            "kernel_ms_per_step_fp32": {k: v["ms_per_step"] for k, v in ((out["roofline"] or {}).get("kernels") or {}).items() if v["ms_per_step"] >= 0.02},
             "scope": "OPT-IN (ops.set_gemm_mode(1) / EEG_DCRNN_SPLIT_BF16=1), never the headline: the two hoisted NN GEMMs of every encoder "
                      "layer (x-part pre-activations, input gradient) as a three-term bf16 split, 6 of 9 partial products on "
                      "v_mfma_f32_16x16x32_bf16 with fp32 accumulation; fp32 operands and results; the whole `-m gpu` suite passes with "

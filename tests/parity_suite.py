@@ -697,14 +697,30 @@ def check_split_bf16(device, adj3d, filt="laplacian", din=100, layers=2, t_len=3
     if ops.GEMM_MODE != 0:
         import pytest
         pytest.skip("the suite itself runs with EEG_DCRNN_SPLIT_BF16=1: this test compares the two modes")
-    g = torch.Generator().manual_seed(seed)
     cfg = orc.DCRNNConfig(filter_type=filt, input_dim=din, rnn_units=64, num_rnn_layers=layers, num_classes=4)
-    params = orc.init_params(cfg, "classification", seed=seed)
     sup = cases.supports_for(filt, adj3d, b)
-    x = torch.randn(b, t_len, 19, din, generator=g)
-    seq = torch.randint(max(1, t_len // 2), t_len + 1, (b,), generator=g)
-    y = torch.randint(0, 4, (b,), generator=g)
-    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    while True:
+        g = torch.Generator().manual_seed(seed)
+        params = orc.init_params(cfg, "classification", seed=seed)
+        x = torch.randn(b, t_len, 19, din, generator=g)
+        seq = torch.randint(max(1, t_len // 2), t_len + 1, (b,), generator=g)
+        y = torch.randint(0, 4, (b,), generator=g)
+        po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        # the head is fc(relu(h)) followed by a max over nodes: an input of the ReLU within rounding distance of 0 at a maximising node
+        # (or two nodes tied for the maximum) has two valid sub-gradients, and which one an implementation takes is decided by its
+        # summation order ("ReLU kink").  Such a draw says nothing about the GEMMs: take the next seed.
+        with torch.no_grad():
+            h0 = torch.zeros(layers, b, 19 * 64)
+            _, top = orc.encoder_forward(params, cfg, x.transpose(0, 1), h0, sup)
+            last = orc.last_relevant(top.transpose(0, 1), seq).view(b, 19, 64)
+            nl = torch.relu(last) @ params["fc.weight"].t() + params["fc.bias"]
+            srt = nl.sort(dim=1, descending=True).values
+            arg = nl.argmax(dim=1)                                              # (B, C) maximising nodes
+            zmin = last.abs().gather(1, arg.unsqueeze(-1).expand(-1, -1, 64)).min().item()
+            tie = (srt[:, 0] - srt[:, 1]).min().item() if srt.shape[1] > 1 else 1.0
+        if zmin > 1e-5 and tie > 1e-4:
+            break
+        seed += 1
     lo = orc.classification_forward(po, cfg, x, seq, sup)
     orc.cross_entropy(lo, y).backward()
 
