@@ -84,7 +84,9 @@ def run(seconds=None, cases=None, seed=0, dev="cuda", small=False):
                 p.update(b=rng.choice([257, 300, 385, 520]), t_len=rng.choice([1, 2, 3]), layers=rng.choice([1, 2]), din=rng.choice([4, 20]))
         else:
             p = dict(filt=filt, dout=rng.choice([4, 8, 12, 16, 20, 28, 40, 60, 100]), h=h, layers=rng.choice([1, 2, 3, 4]),
-                     t_out=rng.choice([1, 2, 3, 6]), b=rng.choice([1, 2, 4]), seed=case_seed, ratio=rng.choice([None, None, 0.5]),
+                     t_out=rng.choice([1, 2, 3, 6]), b=rng.choice([1, 2, 4]), seed=case_seed,
+                     # teacher forcing: none / host coin flips / round 5: the flags as a DEVICE tensor (refused loudly outside the persistent kernels)
+                     ratio=rng.choice([None, None, 0.5, "device"]),
                      act=rng.choice(["tanh", "relu"]), n=n, order=k)
             if small:
                 p.update(dout=rng.choice([4, 8, 20]), layers=rng.choice([1, 2]), t_out=rng.choice([1, 2]), b=rng.choice([1, 2]))
