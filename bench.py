@@ -887,7 +887,9 @@ def main():
     ap.add_argument("--split-bf16", action="store_true", help="also measure the primary workload once more with the OPT-IN three-term "
                     "bf16 split of the hoisted NN GEMMs (ops.set_gemm_mode(1): x-part pre-activations and input gradient on "
                     "v_mfma_f32_16x16x32_bf16, fp32 operands / results / accumulation, fp32-level error) and report it under "
-                    "`experimental_split_bf16` BESIDE the fp32 line: `value` / `dtype` stay the fp32-MFMA measurement")
+                    "`experimental_split_bf16_step` BESIDE the fp32 line: `value` / `dtype` stay the fp32-MFMA measurement (the default "
+                    "single-GPU cfg2 line carries it anyway, behind the secondary workloads)")
+    ap.add_argument("--no-split-bf16", action="store_true", help="leave the experimental split-bf16 pass out of the default single-GPU line")
     ap.add_argument("--tune", action="append", default=[], help="development knob key=value (eeg_dcrnn_set_tuning); loads "
                     "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
     ap.add_argument("--lib", default=None, help="development A/B runs only: load this build of the C ABI (e.g. a library built "
@@ -948,12 +950,20 @@ def main():
             ctx.log(f"{w}: secondary pass failed: {type(e).__name__}: {e}")
             torch.cuda.synchronize()
     # opt-in second line (never the headline): the same workload with the hoisted NN GEMMs as a three-term bf16 split
-    bf_line = None
-    if args.split_bf16:
+    # (part of the default single-GPU line, behind everything else: it cannot touch `value` or the secondary workloads)
+    bf_line, bf_error = None, None
+    default_line = world == 1 and args.workload == "cfg2" and not args.batch and not args.tune and not args.lib and args.secondary is None
+    if args.split_bf16 or (default_line and not args.no_split_bf16):
         from eeg_gnn_ssl_amd import ops as _ops
         prev_mode = _ops.set_gemm_mode(1)
         try:
             bf_line = measure(ctx, args.workload, args.steps, args.warmup, primary=False)
+        except BaseException as e:                               # noqa: BLE001 -- the experimental pass never takes the headline line down
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            bf_error = f"{type(e).__name__}: {e}"
+            ctx.log(f"split-bf16 pass failed: {bf_error}")
+            torch.cuda.synchronize()
         finally:
             _ops.set_gemm_mode(prev_mode)
     if rank != 0:
@@ -961,6 +971,8 @@ def main():
             dist.destroy_process_group()
         return
     out["secondary_workloads"] = sec_lines or None
+    if bf_error is not None:
+        out["experimental_split_bf16_step"] = {"error": bf_error}
     if bf_line is not None:
         r3 = bf_line["roofline"] or {}
         out["experimental_split_bf16_step"] = {
