@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256) void corr_gram_kernel(const float* __restrict_
             a0[q] = (has0 && f < D) ? v0 : z;
             a1[q] = (has1 && f < D) ? v1 : z;
         }
+        // Round 5 (a race found by the margin-aware graph check of bench.py: 1-2 % of the calls returned ONE clip with a wrong Gram):
+        // the fragment reads above must have RETURNED before the DMA below may overwrite the buffer.  A wave-level sync orders
+        // instruction issue, not completion: under LDS contention (16 waves per CU) this wave's queued ds_reads could still be
+        // waiting when the next step's data -- L2-hot, through the texture path -- landed in the buffer.
+        EEG_LDS_WAIT();
         EEG_WAVE_SYNC();
         if (t + dt < T) stage(t + dt);                      // next step of this wave: flies during the MFMAs below
 #pragma unroll

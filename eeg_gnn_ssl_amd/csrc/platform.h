@@ -46,6 +46,9 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
 // memory another wave of its workgroup wrote in the same launch), so waiting for the LDS counter is sufficient; the
 // compiler still tracks the outstanding loads and waits where their registers are first used.
 #define EEG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// This wave's LDS reads have RETURNED (their data is in registers): what an LDS-DMA into the buffer they read must wait for -- the
+// DMA's write reaches LDS through the texture path and is not ordered behind the wave's own queued ds_reads.
+#define EEG_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // counted wait on the vector-memory queue (it retires in order), alone or in front of a raw workgroup barrier
 #define EEG_VM_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
 #define EEG_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")

@@ -24,6 +24,7 @@ __device__ __forceinline__ void permlane16_swap(float& a, float& b) { emu::perml
 #define EEG_WAVE_SYNC() emu::wave_sync()
 #define EEG_SETPRIO(p) ((void)0)
 #define EEG_LDS_BARRIER() __syncthreads()
+#define EEG_LDS_WAIT() ((void)0)
 #define EEG_VM_WAIT_BARRIER(n) __syncthreads()
 #define EEG_VM_WAIT(n) ((void)0)
 #define EEG_PIN(v) ((void)0)

@@ -806,6 +806,34 @@ def test_correlation_graph_supports(golden):
     ps.check_correlation_supports(DEV, golden)
 
 
+def test_correlation_graph_and_featurisation_are_run_to_run_deterministic():
+    """300 repeats of eeg_dcrnn_corr_graph on the cfg3 batch, with unrelated GEMM traffic in front of every third call to vary the
+    timing, must return bit-identical supports (round 5: the barrier-free Gram kernel issued the LDS-DMA of its next time step before
+    the fragment reads of the current one had RETURNED -- 1-2 % of the calls came back with one clip's Gram wrong; found by the
+    margin check of bench.py's device-graph comparison, fixed with an lgkmcnt wait in front of the DMA).  The featurisation kernel
+    (wave-private LDS tiles, wave-level syncs only) gets the same treatment."""
+    import bench
+    from eeg_gnn_ssl_amd import ops
+    x, _, _, _ = bench.synthetic_batch("detection", "dual_random_walk", 60, 256, 1, seed=123, host_supports=False)
+    xd = x.to(DEV)
+    raw = bench.synthetic_raw_signals(32, 20, seed=3).to(DEV)
+    ref = ref_f = None
+    for it in range(300):
+        if it % 3 == 1:
+            torch.randn(2048, 2048, device=DEV) @ torch.randn(2048, 2048, device=DEV)
+        s1, s2 = ops.correlation_supports(xd, top_k=3)
+        cur = torch.stack([s1, s2])
+        if ref is None:
+            ref = cur.clone()
+        assert torch.equal(cur, ref), f"corr_graph: repeat {it} differs from the first run"
+        if it % 10 == 0:
+            fr, fs = ops.fft_features(raw, window=200, mean=5.0, std=1.0)
+            curf = torch.stack([fr, fs])
+            if ref_f is None:
+                ref_f = curf.clone()
+            assert torch.equal(curf, ref_f), f"fft_features: repeat {it} differs from the first run"
+
+
 def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink(DEV, adj3d)
 
