@@ -834,6 +834,48 @@ def test_correlation_graph_and_featurisation_are_run_to_run_deterministic():
             assert torch.equal(curf, ref_f), f"fft_features: repeat {it} differs from the first run"
 
 
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "cfg4", "cfg5", "raw"])
+def test_captured_step_replays_bit_identically_100_times(workload):
+    """Every full-size workload of bench.py, captured as ONE graph (featurisation / correlation graphs included where the workload
+    has them), replayed 100 times on unchanged parameters with unrelated GEMM traffic in front of every third replay: the loss
+    and the whole flat gradient bucket must be bit-identical to the first replay.  A single-shot parity test cannot see a race
+    that fires in 1-2 % of the launches (the round-5 correlation-Gram hazard did exactly that)."""
+    import bench
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    task, filt, t_len, batch, classes = bench.WORKLOADS[workload]
+    torch.manual_seed(123)
+    if task == "ssl":
+        model = DCRNNModel_nextTimePred(bench.make_args(filt), device=DEV).to(DEV)
+    else:
+        model = DCRNNModel_classification(bench.make_args(filt), classes, device=DEV).to(DEV)
+    model.train()
+    kw = dict(raw_window=bench.RAW_WINDOW, raw_mean=5.68, raw_std=0.87) if workload == "raw" else {}
+    stepper = TrainStep(model, task=task, lr=3e-4, weight_decay=5e-4, max_grad_norm=5.0, **kw)
+    if workload == "raw":
+        x = bench.synthetic_raw_signals(batch, t_len, seed=123)
+        y = (x[:, :, :10].mean(dim=(1, 2)) > 0).float()
+        lengths, sup = torch.full((batch,), t_len, dtype=torch.int64), None
+    else:
+        x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123, host_supports=False)
+    x, y, lengths = x.to(DEV), y.to(DEV), lengths.to(DEV)
+    sup = [t.to(DEV) for t in sup] if sup is not None else None
+    graph = stepper.capture(x, y, lengths, sup)
+    loss = stepper._graphs[0][1]
+    noise = torch.randn(2048, 2048, device=DEV)
+    ref_loss = ref_grad = None
+    for it in range(100):
+        if it % 3 == 1:
+            noise @ noise
+        graph.replay()
+        if ref_grad is None:
+            ref_loss, ref_grad = loss.clone(), stepper.fp.flat_grad.clone()
+            assert torch.isfinite(ref_grad).all() and float(ref_grad.abs().max()) > 0
+            continue
+        assert torch.equal(loss, ref_loss), f"{workload}: loss of replay {it} differs from the first replay"
+        assert torch.equal(stepper.fp.flat_grad, ref_grad), f"{workload}: gradients of replay {it} differ from the first replay"
+
+
 def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink(DEV, adj3d)
 
