@@ -21,7 +21,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));     // 8 bf16 = 4 VGPR
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // round-to-nearest-even fp32 -> bf16 (as the upper 16 bits), two at a time
-__device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
+__device__ __forceinline__ unsigned lab_pk_bf16(float lo, float hi) {
     unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));      // gfx950: two fp32 -> packed bf16, round to nearest even
     return r;
@@ -34,11 +34,11 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& h, bf16x8& m
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float a = x[2 * i], b = x[2 * i + 1];
-        const unsigned ph = pk_bf16(a, b);
+        const unsigned ph = lab_pk_bf16(a, b);
         const float ra = a - bf16_lo(ph), rb = b - bf16_hi(ph);
-        const unsigned pm = pk_bf16(ra, rb);
+        const unsigned pm = lab_pk_bf16(ra, rb);
         const float sa = ra - bf16_lo(pm), sb = rb - bf16_hi(pm);
-        H[i] = ph; M[i] = pm; L[i] = pk_bf16(sa, sb);
+        H[i] = ph; M[i] = pm; L[i] = lab_pk_bf16(sa, sb);
     }
     h = __builtin_bit_cast(bf16x8, H); m = __builtin_bit_cast(bf16x8, M); l = __builtin_bit_cast(bf16x8, L);
 }
