@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-REPEATS = 24
+REPEATS = 200
 
 
 def _args(n, h, din, k, filt, layers, act="tanh", dropout=0.0):
