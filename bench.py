@@ -30,6 +30,11 @@ if __name__ == "__main__" and int(os.environ.get("WORLD_SIZE", "1")) == 1:
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
 
+if __name__ == "__main__":
+    # multi-process GPU work on this image needs dmabuf IPC (RCCL / tensor sharing across processes fail with `hipIpcGetMemHandle:
+    # invalid argument` in legacy mode); the driver's environment exports it already -- a bare shell may not
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
