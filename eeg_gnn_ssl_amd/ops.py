@@ -96,10 +96,36 @@ _impls = {}       # operator name -> device implementation (read by tests/emu_su
 #                   implementations through the emulator build of the kernel sources)
 
 
+def _tensor_device(args):
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if a.is_cuda:
+                return a.device
+        elif isinstance(a, (list, tuple)):
+            d = _tensor_device(a)
+            if d is not None:
+                return d
+    return None
+
+
+def _device_guarded(impl):
+    """Python-registered operators get no DeviceGuard from the dispatcher: a call on tensors of cuda:1 while cuda:0 is the current
+    device would allocate and launch on the wrong GPU.  (One process per GPU -- the layout this package is built for -- never takes
+    the slow branch: one integer comparison per call.)"""
+    def run(*args, **kwargs):
+        dev = _tensor_device(args) or _tensor_device(tuple(kwargs.values()))
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return impl(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return impl(*args, **kwargs)
+    run.__name__ = getattr(impl, "__name__", "impl")
+    return run
+
+
 def _define(name: str, schema: str, impl, fake):
     """schema + device implementation (CUDA key = HIP) + fake implementation."""
     _libdef.define(f"{name}{schema}")
-    _libdef.impl(name, impl, "CUDA")
+    _libdef.impl(name, _device_guarded(impl), "CUDA")
     _impls[name] = impl
     torch.library.register_fake(f"{NS}::{name}", fake, lib=_libdef)
 

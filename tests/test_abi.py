@@ -94,6 +94,32 @@ def test_dropout_generator_state_is_created_with_the_module_and_leaves_the_globa
     assert m.dropout_rng_state() == (5, 9)
 
 
+def test_operators_switch_to_the_device_of_their_tensors(monkeypatch):
+    """Python-registered operators get no DeviceGuard from the dispatcher; ops._device_guarded supplies it: same device -> the
+    implementation runs as it is (one comparison), another device -> inside torch.cuda.device(that device)."""
+    import contextlib
+    import torch
+    from eeg_gnn_ssl_amd import ops
+    entered = []
+
+    @contextlib.contextmanager
+    def fake_device(d):
+        entered.append(d)
+        yield
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+    calls = []
+    run = ops._device_guarded(lambda *a, **k: calls.append((a, k)) or "out")
+    monkeypatch.setattr(ops, "_tensor_device", lambda args: torch.device("cuda", 1) if args else None)
+    assert run(1, 2, x=3) == "out" and entered == [torch.device("cuda", 1)] and calls == [((1, 2), {"x": 3})]
+    monkeypatch.setattr(ops, "_tensor_device", lambda args: torch.device("cuda", 0) if args else None)
+    assert run(5) == "out" and len(entered) == 1          # same device: no switch
+    monkeypatch.undo()
+    # the device is found in nested tensor lists too; CPU tensors name none
+    assert ops._tensor_device((1, [torch.zeros(1)], "s")) is None
+
+
 def test_product_has_no_cpu_path():
     """Without a GPU the product ops must refuse CPU tensors loudly (no silent fallback)."""
     import pytest
