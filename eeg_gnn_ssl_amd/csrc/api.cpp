@@ -646,6 +646,7 @@ int eeg_dcrnn_hop_polys(const float* const* supports, int n_supports, int n_grap
     if (n_supports < 1 || n_supports > 4) return fail("hop_polys: n_supports=%d unsupported (1..4)", n_supports);
     if (N < 1 || N > kMaxNodes) return fail("hop_polys: num_nodes=%d unsupported", N);
     if (K < 0) return fail("hop_polys: max_diffusion_step=%d unsupported (>= 0)", K);
+    if (n_graphs < 1) return fail("hop_polys: no graphs (n_graphs=%d)", n_graphs);
     if (K == 0) return 0;                            // cell.py:80-81: no hop matrices beyond the identity, P_out is empty
     if (n_supports * K + 1 > kMaxM) return fail("hop_polys: %d supports x K=%d exceeds %d hop matrices", n_supports, K, kMaxM);
     SupPtrs sp;
@@ -660,7 +661,8 @@ size_t eeg_dcrnn_pack_floats(int Fin, int H, int M) { return make_cell_pack(Fin,
 int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const float* bc, int Fin, int H, int M,
                         float* pack, void* stream) {
     if (!h_supported(H)) return fail("pack_cell: rnn_units=%d unsupported", H);
-    if (Fin % 4 != 0) return fail("pack_cell: input dim %d must be a multiple of 4", Fin);
+    if (Fin < 4 || Fin % 4 != 0) return fail("pack_cell: input dim %d must be a positive multiple of 4", Fin);
+    if (!m_supported(M)) return fail("pack_cell: num hop matrices M=%d unsupported (1,2,3,4,5,7)", M);
     CellPack p = make_cell_pack(Fin, H, M);
     EEG_LAUNCH_P("pack_cell", pack_cell_kernel, dim3(512), dim3(256), 0, S_(stream), Wg, bg, Wc, bc, pack, p);
     return check_launch("pack_cell");
@@ -675,16 +677,22 @@ int eeg_dcrnn_pack_cell_bf16x3(const float* Wg, const float* Wc, int Fin, int H,
 
 int eeg_dcrnn_diffuse_fwd(const float* X, const float* P, int p_batched, int S, int B, int N, int F, int M,
                           float* planes, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("diffuse_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F < 4 || F % 4 != 0 || M < 1 || M > kMaxM) return fail("diffuse_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (S < 1 || B < 1) return fail("diffuse_fwd: empty input (S=%d, B=%d)", S, B);
     return diffuse_fwd(X, P, p_batched, S, B, N, F, M, planes, S_(stream));
 }
 int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int N, int F, int M,
                           float* dX, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("diffuse_adj: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F < 4 || F % 4 != 0 || M < 1 || M > kMaxM) return fail("diffuse_adj: bad dims N=%d F=%d M=%d", N, F, M);
+    if (S < 1 || B < 1) return fail("diffuse_adj: empty input (S=%d, B=%d)", S, B);
     return diffuse_adj(Z, P, p_batched, S, B, N, F, M, dX, S_(stream));
 }
 
-size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return (size_t)d->T * d->B * d->N * 3 * d->H; }
+// Size queries never fail and never fault: dims the compute entry would refuse (empty batch / sequence, zero widths) size to 0.
+static bool layer_dims_positive(const eeg_layer_dims* d) {
+    return d != nullptr && d->T >= 1 && d->B >= 1 && d->N >= 1 && d->H >= 1 && d->Fin >= 1 && d->M >= 1;
+}
+size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return layer_dims_positive(d) ? (size_t)d->T * d->B * d->N * 3 * d->H : 0; }
 
 int eeg_dcrnn_batch_major_ok(const eeg_layer_dims* d) {
     if (!diffuse_streams(d->p_batched, d->T * d->B, d->B, d->N, d->Fin)) return 0;
@@ -743,7 +751,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     return seq_fwd(H, M, a, st);
 }
 
-size_t eeg_dcrnn_layer_bwd_ws_floats(const eeg_layer_dims* d, int need_dx) { return bwd_ws(d, need_dx).total; }
+size_t eeg_dcrnn_layer_bwd_ws_floats(const eeg_layer_dims* d, int need_dx) { return layer_dims_positive(d) ? bwd_ws(d, need_dx).total : 0; }
 
 int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P, const float* pack,
                         const float* planes, const float* Hext, const float* Rs, const float* Us, const float* Cs,
@@ -752,6 +760,7 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                         const int64_t* lengths, float* dX, float* dh0, float* dWg, float* dbg, float* dWc,
                         float* dbc, float* ws, void* stream) {
     if (check_dims(d->N, d->H, d->Fin, d->M)) return 1;
+    if (d->T < 1 || d->B < 1) return fail("layer_bwd: empty sequence/batch (T=%d, B=%d)", d->T, d->B);
     hipStream_t st = S_(stream);
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const size_t state = (size_t)d->B * N * H;
@@ -825,7 +834,7 @@ static int corr_nsplit(int B, int T) {
     if (ns > cap) ns = cap;
     return ns < 1 ? 1 : ns;
 }
-size_t eeg_dcrnn_corr_graph_ws_floats(int B, int T) { return (size_t)B * corr_nsplit(B, T) * kGramFloats; }
+size_t eeg_dcrnn_corr_graph_ws_floats(int B, int T) { return (B >= 1 && T >= 1) ? (size_t)B * corr_nsplit(B, T) * kGramFloats : 0; }
 int eeg_dcrnn_corr_graph(const float* X, int B, int T, int N, int D, int top_k, float* adj, float* S1, float* S2,
                          float* ws, void* stream) {
     if (N < 1 || N > kMaxNodes) return fail("corr_graph: num_nodes=%d unsupported (1..%d)", N, kMaxNodes);
@@ -858,9 +867,12 @@ int eeg_dcrnn_corr_graph(const float* X, int B, int T, int N, int D, int top_k, 
 }
 
 /* ---- decoder ---------------------------------------------------------------------------------- */
-size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d) { return dec_layout(d).saved_total; }
-size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d) { return (size_t)d->B * d->N * 3 * d->H; }
-size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d) { return dec_layout(d).bwd_total; }
+static bool dec_dims_positive(const eeg_decoder_dims* d) {
+    return d != nullptr && d->T >= 1 && d->B >= 1 && d->N >= 1 && d->H >= 1 && d->Dout >= 1 && d->M >= 1 && d->L >= 1;
+}
+size_t eeg_dcrnn_decoder_saved_floats(const eeg_decoder_dims* d) { return dec_dims_positive(d) ? dec_layout(d).saved_total : 0; }
+size_t eeg_dcrnn_decoder_fwd_ws_floats(const eeg_decoder_dims* d) { return dec_dims_positive(d) ? (size_t)d->B * d->N * 3 * d->H : 0; }
+size_t eeg_dcrnn_decoder_bwd_ws_floats(const eeg_decoder_dims* d) { return dec_dims_positive(d) ? dec_layout(d).bwd_total : 0; }
 
 // the persistent decoder kernels (kernels_decoder.h) cover this shape: forward and backward always pair up over the shared `saved`
 // layout (64 units, <= 20 nodes, <= 4 layers, horizon <= 64, Dout <= 128 with Dout/4 divisible by 4 or 5 = the weight-group
@@ -1094,6 +1106,7 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
 }
 
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH, float* last, void* stream) {
+    if (T < 1 || B < 1 || NH < 1) return fail("gather_last: empty input (T=%d, B=%d, N*H=%d)", T, B, NH);
     EEG_LAUNCH_P("gather_last", gather_last_kernel, dim3(ceil_div(B * NH, 256)), dim3(256), 0, S_(stream), Htop,
                reinterpret_cast<const long long*>(lengths), T, B, NH, last);
     return check_launch("gather_last");
@@ -1141,6 +1154,7 @@ int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits,
     if (check_dropout_p("cls_head_bwd", dropout_p)) return 1;
     const DropCfg drop = make_drop_cfg(dropout_p);
     if (drop.on && rng_used == nullptr) return fail("cls_head_bwd: dropout_p > 0 needs the rng_used pair of the forward call");
+    if (B < 1 || N < 1 || H < 1 || C < 1) return fail("cls_head_bwd: empty input (B=%d, N=%d, H=%d, C=%d)", B, N, H, C);
     const unsigned long long* used = reinterpret_cast<const unsigned long long*>(rng_used);
     EEG_LAUNCH_P("cls_head_bwd_dz", cls_head_bwd_dz_kernel, dim3(ceil_div(B * N * H, 256)), dim3(256), 0, S_(stream), z, W, dlogits, arg, B, N, H, C, drop, used, dz);
     if (check_launch("cls_head_bwd_dz")) return 1;
@@ -1149,11 +1163,13 @@ int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits,
 }
 
 size_t eeg_dcrnn_dconv_fwd_ws_floats(int B, int N, int F, int M, int O) {
+    if (B < 1 || N < 1 || F < 1 || M < 1 || O < 1) return 0;
     return (size_t)(M - 1) * B * N * F + (size_t)F * M * O;
 }
 int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M,
                         const float* W, const float* bias, int O, float* out, float* ws, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("dconv_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F < 4 || F % 4 != 0 || M < 1 || M > kMaxM) return fail("dconv_fwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (B < 1) return fail("dconv_fwd: empty batch (B=%d)", B);
     if (O % 16 != 0) return fail("dconv_fwd: output_dim=%d must be a multiple of 16", O);
     hipStream_t st = S_(stream);
     float* planes = ws;
@@ -1166,6 +1182,7 @@ int eeg_dcrnn_dconv_fwd(const float* X, const float* P, int p_batched, int B, in
     return gemm_nn(segs, M, F, B * N, pack, O / 16, bias, out, O, O, st);
 }
 size_t eeg_dcrnn_dconv_bwd_ws_floats(int B, int N, int F, int M, int O) {
+    if (B < 1 || N < 1 || F < 1 || M < 1 || O < 1) return 0;
     const int R = B * N;
     int rps;
     const int nsplit = tn_split(M, F, R, O, &rps);
@@ -1174,7 +1191,8 @@ size_t eeg_dcrnn_dconv_bwd_ws_floats(int B, int N, int F, int M, int O) {
 }
 int eeg_dcrnn_dconv_bwd(const float* X, const float* P, int p_batched, int B, int N, int F, int M, const float* W, int O,
                         const float* dOut, float* dX, float* dW, float* dbias, float* ws, void* stream) {
-    if (N < 1 || N > kMaxNodes || F % 4 != 0 || M < 1 || M > kMaxM) return fail("dconv_bwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (N < 1 || N > kMaxNodes || F < 4 || F % 4 != 0 || M < 1 || M > kMaxM) return fail("dconv_bwd: bad dims N=%d F=%d M=%d", N, F, M);
+    if (B < 1) return fail("dconv_bwd: empty batch (B=%d)", B);
     if (O % 16 != 0 || O > 192) return fail("dconv_bwd: output_dim=%d must be a multiple of 16 (<= 192)", O);
     hipStream_t st = S_(stream);
     const int R = B * N;
@@ -1243,6 +1261,7 @@ static int clip_adam_launch(float* params, float* grads, float* exp_avg, float* 
                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, float* ws,
                             float* norm_out, int32_t* step_dev, const float* lr_dev, void* stream) {
     const int nparts = 64;
+    if (n < 1) return fail("clip_adam: empty parameter buffer");
     EEG_LAUNCH_P("grad_sqnorm", sqnorm_partial_kernel, dim3(nparts), dim3(256), 256 * sizeof(float), S_(stream), grads, n, ws, reinterpret_cast<int*>(step_dev));
     if (check_launch("grad_sqnorm")) return 1;
     // torch.optim.Adam forms `1 - beta ** step` and its square root as Python (fp64) scalars

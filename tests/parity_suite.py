@@ -655,6 +655,68 @@ def check_fft_features(device, golden_fft):
             assert np.abs(fr[i].cpu().numpy() - ref).max() <= 5e-6, (b, n, w, nwin)
 
 
+def check_empty_inputs(device):
+    """Empty batches / sequences: the reference raises RuntimeError (model.py:253-255,321-324: its `reshape(..., -1)` of a tensor
+    without elements is ambiguous -- probed on the genuine reference: B = 0 and T = 0 alike, both models); so does this package,
+    from the module level down to the C ABI ("empty sequence/batch", "empty input"), never a launch with a zero-sized grid."""
+    import pytest
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, DCRNNModel_nextTimePred, ops
+    cfg = orc.DCRNNConfig(filter_type="laplacian", input_dim=8, output_dim=8)
+    cls = DCRNNModel_classification(make_args(cfg), 1, device=device).to(device)
+    ssl = DCRNNModel_nextTimePred(make_args(cfg), device=device).to(device)
+    n = cfg.num_nodes
+    for b, t_len in ((0, 4), (2, 0)):
+        x = torch.zeros(b, t_len, n, 8, device=device)
+        sup = [torch.zeros(b, n, n, device=device)]
+        with pytest.raises(RuntimeError):
+            cls(x, torch.full((b,), max(t_len, 1), dtype=torch.int64, device=device), sup)
+        with pytest.raises(RuntimeError):
+            ssl(x, torch.zeros(b, 3, n, 8, device=device), sup)
+    with pytest.raises(RuntimeError):                          # no decoder steps
+        ssl(torch.zeros(2, 4, n, 8, device=device), torch.zeros(2, 0, n, 8, device=device), [torch.zeros(2, n, n, device=device)])
+    # operator level: the C ABI refuses, the message names the cause
+    with pytest.raises(RuntimeError, match="empty"):
+        ops.fft_features(torch.zeros(0, n, 400, device=device), window=200)
+    with pytest.raises(RuntimeError):
+        ops.correlation_supports(torch.zeros(0, 4, n, 8, device=device), top_k=3)
+    h, m = 64, 3
+    wg, bg = torch.zeros((8 + h) * m, 2 * h, device=device), torch.zeros(2 * h, device=device)
+    wc, bc = torch.zeros((8 + h) * m, h, device=device), torch.zeros(h, device=device)
+    pz = torch.zeros(m - 1, n, n, device=device)
+    with pytest.raises(RuntimeError, match="empty"):
+        torch.ops.eeg_dcrnn.dcgru_layer(torch.zeros(0, 2, n, 8, device=device), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, False, False)
+    # every other operator with a zero-sized operand: a RuntimeError from the C ABI's own checks, never a fault and never a launch
+    # with an empty grid (the size queries these paths call first used to divide by the batch size: tests/test_abi.py)
+    o = torch.ops.eeg_dcrnn
+    z = lambda *shape: torch.zeros(*shape, device=device)                      # noqa: E731
+    i64 = lambda *shape: torch.zeros(*shape, dtype=torch.int64, device=device)  # noqa: E731
+    p4 = pz.unsqueeze(0)
+    refused = {
+        "hop_polys": lambda: o.hop_polys([z(0, n, n)], 2, 0),
+        "diffusion_hops": lambda: o.diffusion_hops(z(0, n, 8), p4, 0, 0),
+        "dconv": lambda: o.dconv(z(0, n, 8), p4, 0, z(8 * m, 64), z(64)),
+        "dconv_bwd": lambda: o.dconv_bwd(z(0, n, 64), z(0, n, 8), p4, 0, z(8 * m, 64), True),
+        "gather_last B=0": lambda: o.gather_last(z(4, 0, n * h), i64(0)),
+        "gather_last T=0": lambda: o.gather_last(z(0, 2, n * h), i64(2) + 1),
+        "cls_head": lambda: o.cls_head(z(0, n, h), z(1, h), z(1), 0.0, None),
+        "cls_head_bwd": lambda: o.cls_head_bwd(z(0, n, h), z(1, h), z(0, 1), torch.zeros(0, 1, dtype=torch.int32, device=device), 0.0, None, z(1, h), z(1)),
+        "bce_logits": lambda: o.bce_logits(z(0), z(0)),
+        "ce_logits": lambda: o.ce_logits(z(0, 4), i64(0)),
+        "masked_loss": lambda: o.masked_loss(z(0, 3, n, 8), z(0, 3, n, 8), False, 0.0, 1.0, 0.0, 1),
+        "pack_cell": lambda: o.pack_cell(z(h * m, 2 * h), bg, z(h * m, h), bc, 0, h, m),
+        "corr_graph T=0": lambda: o.corr_graph(z(2, 0, n, 8), 3),
+        "dcgru_layer B=0": lambda: o.dcgru_layer(z(3, 0, n, 8), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, True, False),
+        "teacher_flags": lambda: o.teacher_flags_(i64(2), i64(1), 1, 3000.0, 0),
+        "clip_adam": lambda: ops.clip_adam_step_dev(z(0), z(0), z(0), z(0), torch.zeros(1, dtype=torch.int32, device=device), z(1),
+                                                    (0.9, 0.999), 1e-8, 0.0, 5.0, 1.0, z(64), z(1)),
+    }
+    for name, call in refused.items():
+        with pytest.raises(RuntimeError):
+            call()
+            pytest.fail(f"{name}: accepted an empty operand")
+    assert o.dropout_mask(i64(2), 0, 0.5).numel() == 0                          # (an empty mask is a valid answer)
+
+
 def check_raw_input_chain(device, b=4, t_len=3):
     """Raw signals in: TrainStep(raw_window=200) runs the reference's DataLoader-side chain on the device in front of the model
     -- log|FFT| per 1-s step (data_utils.py:13-35), z-score (utils.py:393-428), per-clip correlation graph from the

@@ -120,6 +120,53 @@ def test_operators_switch_to_the_device_of_their_tensors(monkeypatch):
     assert ops._tensor_device((1, [torch.zeros(1)], "s")) is None
 
 
+def test_size_queries_never_fault_on_degenerate_dims():
+    """Every host-only size / capability query of the C ABI with zero batch, zero steps, zero widths: must return (0 = "nothing
+    to allocate" / "not covered"), never fault -- round 5 found `eeg_dcrnn_corr_graph_ws_floats(0, T)` and five more dividing by
+    the batch size (SIGFPE in the host process).  Runs in a subprocess: a fault would otherwise take the test session down."""
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import ctypes, itertools, sys
+        sys.path.insert(0, %r)
+        from eeg_gnn_ssl_amd import _lib
+        lib = _lib.get_lib()
+        n = 0
+        for b, t in itertools.product((0, 1, 256), (0, 1, 60)):
+            v = lib.query("eeg_dcrnn_corr_graph_ws_floats", b, t); n += 1
+            assert (v == 0) == (b == 0 or t == 0), (b, t, v)
+        layer = [(0, 0, 0, 0, 0, 0), (60, 0, 19, 64, 100, 3), (0, 256, 19, 64, 100, 3), (60, 256, 0, 64, 100, 3), (60, 256, 19, 0, 100, 3),
+                 (60, 256, 19, 64, 0, 3), (60, 256, 19, 64, 100, 0)]
+        for dims in layer:
+            d = _lib.LayerDims()
+            for f, v in zip(("T", "B", "N", "H", "Fin", "M"), dims): setattr(d, f, v)
+            assert lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(d)) == 0
+            assert lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(d), 1) == 0
+            lib.query("eeg_dcrnn_batch_major_ok", ctypes.byref(d)); n += 3
+        dec = [(0, 0, 0, 0, 0, 0, 0), (12, 0, 19, 64, 100, 5, 2), (0, 512, 19, 64, 100, 5, 2), (12, 512, 0, 64, 100, 5, 2), (12, 512, 19, 0, 100, 5, 2),
+               (12, 512, 19, 64, 0, 5, 2), (12, 512, 19, 64, 100, 0, 2), (12, 512, 19, 64, 100, 5, 0)]
+        for dims in dec:
+            d = _lib.DecoderDims()
+            for f, v in zip(("T", "B", "N", "H", "Dout", "M", "L"), dims): setattr(d, f, v)
+            for fn in ("eeg_dcrnn_decoder_saved_floats", "eeg_dcrnn_decoder_fwd_ws_floats", "eeg_dcrnn_decoder_bwd_ws_floats", "eeg_dcrnn_decoder_is_persistent"):
+                assert lib.query(fn, ctypes.byref(d)) == 0, (fn, dims); n += 1
+        for dims in [(0, 19, 100, 3, 64), (4, 0, 100, 3, 64), (4, 19, 0, 3, 64), (4, 19, 100, 0, 64), (4, 19, 100, 3, 0)]:
+            assert lib.query("eeg_dcrnn_dconv_fwd_ws_floats", *dims) == 0 and lib.query("eeg_dcrnn_dconv_bwd_ws_floats", *dims) == 0; n += 2
+        for dims in [(0, 0, 0), (100, 64, 0), (0, 64, 3), (100, 0, 3)]:
+            lib.query("eeg_dcrnn_pack_floats", *dims); lib.query("eeg_dcrnn_pack3_halves", *dims); n += 2
+        for dims in [(0, 0, 0, 0), (19, 64, 100, 0), (19, 0, 100, 3), (0, 64, 100, 3), (19, 64, 0, 3)]:
+            assert lib.query("eeg_dcrnn_supported", *dims) == 0; n += 1
+        # and the sizes of a real shape are not zero
+        d = _lib.LayerDims()
+        for f, v in zip(("T", "B", "N", "H", "Fin", "M"), (60, 256, 19, 64, 100, 3)): setattr(d, f, v)
+        assert lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(d), 1) > 0
+        print("queries:", n)
+    """ % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"rc={r.returncode} (negative = signal)\n{r.stdout[-500:]}\n{r.stderr[-1500:]}"
+    assert "queries:" in r.stdout
+
+
 def test_product_has_no_cpu_path():
     """Without a GPU the product ops must refuse CPU tensors loudly (no silent fallback)."""
     import pytest

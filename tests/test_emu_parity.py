@@ -55,6 +55,10 @@ def test_opt_in_split_bf16_gemms(filt, din, layers, adj3d):
     ps.check_split_bf16("cpu", adj3d, filt=filt, din=din, layers=layers, t_len=2, b=2)
 
 
+def test_empty_inputs_raise_like_the_reference():
+    ps.check_empty_inputs("cpu")
+
+
 def test_teacher_flags_known_answer():
     ps.check_teacher_flags("cpu")
 

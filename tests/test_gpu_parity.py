@@ -876,6 +876,10 @@ def test_captured_step_replays_bit_identically_100_times(workload):
         assert torch.equal(stepper.fp.flat_grad, ref_grad), f"{workload}: gradients of replay {it} differ from the first replay"
 
 
+def test_empty_inputs_raise_like_the_reference():
+    ps.check_empty_inputs(DEV)
+
+
 def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink(DEV, adj3d)
 
