@@ -5,6 +5,9 @@
  * contiguous fp32 (int64 for lengths) unless stated; `stream` is a hipStream_t passed as void*.
  * All functions enqueue work on `stream` and return without synchronising; they never allocate.
  * Return value: 0 on success, non-zero on error (see eeg_dcrnn_last_error()).
+ * Empty operands (zero clips, zero steps, zero widths) are an error of every compute entry, raised before anything is launched --
+ * the reference raises on them too (model.py:253-255: its reshape(..., -1) of a tensor without elements); the host-only size /
+ * capability queries (size_t eeg_dcrnn_*_floats, eeg_dcrnn_supported, *_ok, *_is_persistent) never fail and return 0 for such dims.
  *
  * The reference has no FFI of its own (pure Python); each entry point below states
  * the reference code it replaces.  The ctypes binding that a maintainer of the reference would
