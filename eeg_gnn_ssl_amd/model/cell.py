@@ -92,6 +92,10 @@ class DCGRUCell(nn.Module):
         if len(supports) != self._num_supports:
             raise RuntimeError(f"filter_type={self._filter_type!r} expects {self._num_supports} support(s), "
                                f"got {len(supports)}")
+        n = self._num_nodes
+        for i, s in enumerate(supports):
+            if s.dim() not in (2, 3) or s.shape[-1] != n or s.shape[-2] != n:
+                raise RuntimeError(f"supports[{i}] has shape {tuple(s.shape)}, expected ({n}, {n}) or (B, {n}, {n})")
 
     def run_sequence(self, x, h0, p, p_batched, lengths=None, x_off=0, x_planes=None, want_hsel=True):
         """x (T + x_off, B, N, Din) -> ops.LayerOut (hext (T+1,B,N*H), hsel (B,N*H), hpl); used by the encoder /

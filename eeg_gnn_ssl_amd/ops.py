@@ -84,6 +84,19 @@ def _check(lib, t: torch.Tensor, name: str, dtype=torch.float32):
         raise RuntimeError(f"{name}: tensor must be contiguous")
 
 
+def _check_polys(p: torch.Tensor, p_batched: int, b: int, n: int, m: int, what: str = "P"):
+    """hop-polynomial tensor of `ops.hop_polys`: (G, M-1, N, N) with G = B (per-clip graphs) or 1 (shared) -- the kernels index it
+    with exactly these extents, so a tensor built for another node count / batch / hop count is refused here, not read out of bounds"""
+    want = (b if p_batched else 1, m - 1, n, n)
+    if m > 1 and tuple(p.shape) != want:
+        raise RuntimeError(f"{what} has shape {tuple(p.shape)}, expected {want} (graphs, hop matrices - 1, num_nodes, num_nodes)")
+
+
+def _check_lengths(lengths: torch.Tensor, b: int):
+    if lengths.numel() != b:
+        raise RuntimeError(f"seq_lengths has {lengths.numel()} entries for a batch of {b}")
+
+
 def _new(shape, like: torch.Tensor, dtype=torch.float32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -223,7 +236,12 @@ def _diffusion_hops_impl(x, p, p_batched: int, batch: int) -> torch.Tensor:
     _check(lib, x, "x")
     _check(lib, p, "P")
     s, n, f = x.shape
+    if p.dim() != 4:
+        raise RuntimeError(f"P has shape {tuple(p.shape)}, expected (graphs, hop matrices - 1, num_nodes, num_nodes)")
     m = p.shape[1] + 1
+    _check_polys(p, p_batched, batch, n, m)
+    if batch < 1 or s % max(batch, 1) != 0:
+        raise RuntimeError(f"diffusion_hops: {s} samples are not a multiple of the batch {batch}")
     out = _new((m - 1, s, n, f), x)
     lib.call("eeg_dcrnn_diffuse_fwd", _p(x), _p(p), p_batched, s, batch, n, f, m, _p(out), _stream(x))
     return out
@@ -243,9 +261,14 @@ def _dconv_impl(x, p, p_batched: int, weight, biases) -> torch.Tensor:
     for t, nm in ((x, "inputs_and_state"), (p, "P"), (w, "weight"), (bvec, "biases")):
         _check(lib, t, nm)
     b, n, f = x.shape
+    if p.dim() != 4:
+        raise RuntimeError(f"P has shape {tuple(p.shape)}, expected (graphs, hop matrices - 1, num_nodes, num_nodes)")
     m, o = p.shape[1] + 1, w.shape[1]
+    _check_polys(p, p_batched, b, n, m)
     if w.shape[0] != f * m:
         raise RuntimeError(f"weight has {w.shape[0]} rows, expected (input_dim+hid_dim)*num_matrices = {f * m}")
+    if bvec.numel() != o:
+        raise RuntimeError(f"biases has {bvec.numel()} entries, expected output_dim = {o}")
     out = _new((b, n, o), x)
     ws = _new((lib.query("eeg_dcrnn_dconv_fwd_ws_floats", b, n, f, m, o),), x)
     lib.call("eeg_dcrnn_dconv_fwd", _p(x), _p(p), p_batched, b, n, f, m, _p(w), _p(bvec), o, _p(out), _p(ws), _stream(x))
@@ -259,6 +282,9 @@ def _dconv_bwd_impl(dout, x, p, p_batched: int, weight, need_dx: bool):
         _check(lib, t, nm)
     b, n, f = x.shape
     m, o = p.shape[1] + 1, w.shape[1]
+    _check_polys(p, p_batched, b, n, m)
+    if w.shape[0] != f * m or tuple(dout.shape) != (b, n, o):
+        raise RuntimeError(f"dconv_bwd: weight {tuple(w.shape)} / grad_output {tuple(dout.shape)} do not match inputs {tuple(x.shape)} with {m} hop matrices")
     dx = _new((b, n, f), x) if need_dx else _new((0,), x)
     dw, db = _new((f * m, o), x), _new((o,), x)
     ws = _new((lib.query("eeg_dcrnn_dconv_bwd_ws_floats", b, n, f, m, o),), x)
@@ -348,9 +374,16 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     state, slot t+1 = h_t), hsel (B, N*H) = h at t = lengths-1 (T-1 without lengths) and the tensors the backward
     needs: [xtm, pack, planes, rs, us, cs, rhs, hpl, rhpl] (numel-0 placeholders where nothing is kept)."""
     lib = _lib.get_lib()
+    if x.dim() != 4 or x.shape[2] != n:
+        raise RuntimeError(f"inputs have shape {tuple(x.shape)}, expected (T, B, num_nodes={n}, input_dim)")
     t_len, b, fin = x.shape[0] - x_off, x.shape[1], x.shape[3]
     if not lib.query("eeg_dcrnn_supported", n, h, fin, m):
         raise RuntimeError("eeg_gnn_ssl_amd: " + lib.last_error())
+    _check_polys(p, p_batched, b, n, m)
+    if lengths is not None:
+        _check_lengths(lengths, b)
+    if h0 is not None and h0.numel() != b * n * h:
+        raise RuntimeError(f"initial_hidden_state has shape {tuple(h0.shape)}, expected ({b}, {n * h})")
     ready = x_planes is not None
     dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, ready)
     empty = _new((0,), p)
@@ -584,6 +617,12 @@ def _dcgru_decoder_impl(targets, h0, p, p_batched: int, wg0, bg0, wc0, bc0, wg1,
         _check(lib, t, nm)
     if tuple(wp.shape) != (dout, h) or tuple(bp.shape) != (dout,):
         raise RuntimeError(f"projection_layer shapes {tuple(wp.shape)}, {tuple(bp.shape)} do not match ({dout}, {h})")
+    if tuple(h0.shape) != (n_layers, b, n * h):
+        raise RuntimeError(f"initial_hidden_state has shape {tuple(h0.shape)}, expected ({n_layers}, {b}, {n * h})")
+    _check_polys(p, p_batched, b, n, m)
+    if targets is not None and targets.numel() != t_len * b * n * dout:
+        raise RuntimeError(f"decoder inputs have shape {tuple(targets.shape)}, expected ({t_len}, {b}, {n}*{dout}) "
+                           f"(T, B, num_nodes * output_dim)")
     tf_ptr, tf_keep, tf_dev = _teacher_arg(lib, teacher, teacher_dev, t_len)
     use_tf = tf_ptr is not None
     if use_tf:
@@ -766,6 +805,7 @@ def _gather_last_impl(htop, lengths):
     htop = htop.contiguous()
     _check(lib, htop, "output")
     t_len, b, d = htop.shape
+    _check_lengths(lengths, b)
     lengths = lengths.to(device=htop.device, dtype=torch.int64).contiguous()
     out = _new((b, d), htop)
     lib.call("eeg_dcrnn_gather_last", _p(htop), _p(lengths), t_len, b, d, _p(out), _stream(htop))

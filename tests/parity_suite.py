@@ -682,7 +682,7 @@ def check_empty_inputs(device):
     h, m = 64, 3
     wg, bg = torch.zeros((8 + h) * m, 2 * h, device=device), torch.zeros(2 * h, device=device)
     wc, bc = torch.zeros((8 + h) * m, h, device=device), torch.zeros(h, device=device)
-    pz = torch.zeros(m - 1, n, n, device=device)
+    pz = torch.zeros(1, m - 1, n, n, device=device)
     with pytest.raises(RuntimeError, match="empty"):
         torch.ops.eeg_dcrnn.dcgru_layer(torch.zeros(0, 2, n, 8, device=device), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, False, False)
     # every other operator with a zero-sized operand: a RuntimeError from the C ABI's own checks, never a fault and never a launch
@@ -690,7 +690,7 @@ def check_empty_inputs(device):
     o = torch.ops.eeg_dcrnn
     z = lambda *shape: torch.zeros(*shape, device=device)                      # noqa: E731
     i64 = lambda *shape: torch.zeros(*shape, dtype=torch.int64, device=device)  # noqa: E731
-    p4 = pz.unsqueeze(0)
+    p4 = pz
     refused = {
         "hop_polys": lambda: o.hop_polys([z(0, n, n)], 2, 0),
         "diffusion_hops": lambda: o.diffusion_hops(z(0, n, 8), p4, 0, 0),
@@ -715,6 +715,78 @@ def check_empty_inputs(device):
             call()
             pytest.fail(f"{name}: accepted an empty operand")
     assert o.dropout_mask(i64(2), 0, 0.5).numel() == 0                          # (an empty mask is a valid answer)
+
+
+def check_malformed_inputs(device):
+    """Operands whose extents do not fit each other are refused by the host layer BEFORE a kernel indexes them (the kernels take
+    extents from the dims struct, not from the tensors): lengths of another batch size, supports / hop polynomials of another node
+    count or batch, a decoder state of another layer count.  Found by probing at the end of round 5: `seq_lengths` with one
+    entry for two clips and supports of 18 nodes for a 19-node model were read out of bounds.  Lenient where the reference is
+    (integer / float lengths of any dtype, (B,1) lengths, float64 supports, flattened node x feature inputs, shared (N,N) supports)."""
+    import pytest
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, DCRNNModel_nextTimePred, ops
+    cfg = orc.DCRNNConfig(filter_type="dual_random_walk", input_dim=8, output_dim=8)
+    torch.manual_seed(0)
+    cls = DCRNNModel_classification(make_args(cfg), 1, device=device).to(device)
+    ssl = DCRNNModel_nextTimePred(make_args(cfg), device=device).to(device)
+    b, t_len, n = 2, 3, cfg.num_nodes
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, t_len, n, 8, generator=g).to(device)
+    lens = torch.full((b,), t_len, dtype=torch.int64, device=device)
+    sup = [torch.rand(b, n, n, generator=g).to(device) for _ in range(2)]
+    good = cls(x, lens, sup).detach()
+    for what, call in {
+        "lengths as int32": lambda: cls(x, lens.int(), sup),
+        "lengths as float": lambda: cls(x, lens.float(), sup),
+        "lengths (B,1)": lambda: cls(x, lens.view(b, 1), sup),
+        "float64 supports": lambda: cls(x, lens, [s.double() for s in sup]),
+        "flattened node x feature inputs": lambda: cls(x.reshape(b, t_len, n * 8), lens, sup),
+        "non-contiguous inputs": lambda: cls(torch.stack([x, x], dim=-1)[..., 0], lens, sup),
+    }.items():
+        assert torch.equal(call().detach(), good), what
+    shared = cls(x, lens, [sup[0][0], sup[1][0]]).detach()                     # (N,N) supports = the same graph for every clip
+    assert torch.allclose(shared[0], good[0], atol=1e-6)
+    o = torch.ops.eeg_dcrnn
+    z = lambda *shape: torch.zeros(*shape, device=device)                       # noqa: E731
+    h, m = cfg.rnn_units, 5
+    p_ok, _ = ops.hop_polys(sup, 2, b)
+    wg, bg, wc, bc = z((8 + h) * m, 2 * h), z(2 * h), z((8 + h) * m, h), z(h)
+    layer = lambda xx, pp, ll=None, h0=None: o.dcgru_layer(xx, 0, h0, pp, 1, wg, bg, wc, bc, ll, None, n, h, m, 0, False, True)   # noqa: E731
+    layer(x.transpose(0, 1).contiguous(), p_ok)                                 # (the well-formed call goes through)
+    refused = {
+        "lengths of another batch size": lambda: cls(x, lens[:1], sup),
+        "supports of another batch size": lambda: cls(x, lens, [torch.rand(3, n, n).to(device)] * 2),
+        "supports with a batch of 1": lambda: cls(x, lens, [s[:1] for s in sup]),
+        "one batched and one (1,N,N) support": lambda: cls(x, lens, [sup[0], sup[1][:1]]),
+        "supports of 18 nodes": lambda: cls(x, lens, [torch.rand(b, 18, 18).to(device)] * 2),
+        "too few supports": lambda: cls(x, lens, sup[:1]),
+        "too many supports": lambda: cls(x, lens, sup + sup[:1]),
+        "inputs of 18 nodes": lambda: cls(torch.randn(b, t_len, 18, 8).to(device), lens, sup),
+        "inputs of another width": lambda: cls(torch.randn(b, t_len, n, 12).to(device), lens, sup),
+        "float64 inputs": lambda: cls(x.double(), lens, sup),
+        "targets of another batch": lambda: ssl(x, torch.randn(3, 2, n, 8).to(device), sup),
+        "targets of 18 nodes": lambda: ssl(x, torch.randn(b, 2, 18, 8).to(device), sup),
+        "layer: P of another node count": lambda: layer(x.transpose(0, 1).contiguous(), z(b, m - 1, 18, 18)),
+        "layer: P of another batch": lambda: layer(x.transpose(0, 1).contiguous(), z(3, m - 1, n, n)),
+        "layer: P of another hop count": lambda: layer(x.transpose(0, 1).contiguous(), z(b, 2, n, n)),
+        "layer: inputs of 18 nodes": lambda: layer(z(t_len, b, 18, 8), p_ok),
+        "layer: short lengths": lambda: layer(x.transpose(0, 1).contiguous(), p_ok, lens[:1]),
+        "layer: h0 of another batch": lambda: layer(x.transpose(0, 1).contiguous(), p_ok, None, z(3, n * h)),
+        "gather_last: short lengths": lambda: o.gather_last(z(t_len, b, n * h), lens[:1]),
+        "dconv: P of another node count": lambda: o.dconv(z(b, n, 8), z(b, m - 1, 18, 18), 1, z(8 * m, 64), z(64)),
+        "dconv: weight rows": lambda: o.dconv(z(b, n, 8), p_ok, 1, z(8 * 3, 64), z(64)),
+        "diffusion_hops: P of another batch": lambda: o.diffusion_hops(z(b, n, 8), z(3, m - 1, n, n), 1, b),
+    }
+    for what, call in refused.items():
+        with pytest.raises(RuntimeError):
+            call()
+            pytest.fail(f"{what}: accepted")
+    # a decoder state of another layer count / batch
+    dec = ssl.decoder
+    with pytest.raises(RuntimeError):
+        dec(z(2, b, n, 8), z(3, b, n * h), sup)
+    with pytest.raises(RuntimeError):
+        dec(z(2, b, n, 8), z(2, 3, n * h), sup)
 
 
 def check_raw_input_chain(device, b=4, t_len=3):

@@ -59,6 +59,10 @@ def test_empty_inputs_raise_like_the_reference():
     ps.check_empty_inputs("cpu")
 
 
+def test_operands_that_do_not_fit_each_other_are_refused_before_launch():
+    ps.check_malformed_inputs("cpu")
+
+
 def test_teacher_flags_known_answer():
     ps.check_teacher_flags("cpu")
 

@@ -880,6 +880,10 @@ def test_empty_inputs_raise_like_the_reference():
     ps.check_empty_inputs(DEV)
 
 
+def test_operands_that_do_not_fit_each_other_are_refused_before_launch():
+    ps.check_malformed_inputs(DEV)
+
+
 def test_grad_sink_equals_autograd_accumulation(adj3d):
     ps.check_grad_sink(DEV, adj3d)
 
