@@ -15,6 +15,14 @@
 
 namespace eeg {
 
+// source channel of node nd under the reflection augmentation; an entry outside 0..N-1 (not a permutation: caller error) falls back to
+// the node itself instead of addressing another clip's signals / features
+__device__ __forceinline__ int perm_source(const int* __restrict__ perm, int b, int N, int nd) {
+    if (perm == nullptr) return nd;
+    const int s = perm[b * N + nd];
+    return (unsigned)s < (unsigned)N ? s : nd;
+}
+
 __global__ __launch_bounds__(64) void fft_features_kernel(const float* __restrict__ raw, int N, int T, int W, int tchunk,
                                                           const int* __restrict__ perm, const float* __restrict__ log_scale,
                                                           float mean, float inv_std, float* __restrict__ feat_raw,
@@ -22,7 +30,7 @@ __global__ __launch_bounds__(64) void fft_features_kernel(const float* __restric
     EEG_DYN_SMEM(sm);
     double* xs = reinterpret_cast<double*>(sm);          // [W]
     const int lane = threadIdx.x, b = blockIdx.x / N, nd = blockIdx.x % N, H2 = W / 2;
-    const int src = perm != nullptr ? perm[b * N + nd] : nd;            // EEG_seq_reflect[:, pair] = EEG_seq[:, swapped pair]
+    const int src = perm_source(perm, b, N, nd);            // EEG_seq_reflect[:, pair] = EEG_seq[:, swapped pair]
     const double ls = log_scale != nullptr ? (double)log_scale[b] : 0.0;
     const float* sig = raw + ((size_t)b * N + src) * (size_t)T * W;
     const bool active = lane <= W / 4;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256, EEG_FFT_MINW) void fft200_features_kernel(cons
             const int nd = (int)(wg % N);
             const long long bt = wg / N;
             const int t = (int)(bt % T), b = (int)(bt / T);
-            const int src = perm != nullptr ? perm[b * N + nd] : nd;     // EEG_seq_reflect[:, pair] = EEG_seq[:, swapped pair]
+            const int src = perm_source(perm, b, N, nd);     // EEG_seq_reflect[:, pair] = EEG_seq[:, swapped pair]
             const float* sig = raw + (((size_t)b * N + src) * T + t) * kFftWin;
 #pragma unroll
             for (int n1 = 0; n1 < 10; ++n1) {
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256, EEG_FFT_MINW) void fft200_features_kernel(cons
             const long long bt = wj / N;
             const int b = (int)(bt / T);
             if (feat_raw != nullptr) {
-                const int src = perm != nullptr ? perm[b * N + nd] : nd;
+                const int src = perm_source(perm, b, N, nd);
                 *reinterpret_cast<f32x4*>(feat_raw + ((size_t)bt * N + src) * kFftBins + pos) = val;
             }
             if (feat_std != nullptr) {

@@ -39,8 +39,12 @@ __global__ void ce_logits_kernel(const float* __restrict__ x, const long long* _
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(r[c] - mx);
         const float lse = mx + logf(se);
-        const int t = (int)y[i];
-        acc += lse - r[t];
+        // a label outside 0..C-1 (torch: a device-side assert that ends the process) makes the LOSS NaN instead of reading logits out
+        // of bounds; the gradient of that clip is the softmax alone
+        const long long tl = y[i];
+        const bool t_ok = tl >= 0 && tl < (long long)C;
+        const int t = t_ok ? (int)tl : -1;
+        acc += lse - (t_ok ? r[t] : __builtin_nanf(""));
         for (int c = 0; c < C; ++c) dx[(size_t)i * C + c] = (expf(r[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
     }
     sm[threadIdx.x] = acc;

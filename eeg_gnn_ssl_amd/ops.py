@@ -724,8 +724,12 @@ def _cls_head_impl(z, w, bias, dropout_p: float, rng_used):
     z, w, bias = z.contiguous(), w.detach().contiguous(), bias.detach().contiguous()
     for t, nm in ((z, "last_out"), (w, "fc.weight"), (bias, "fc.bias")):
         _check(lib, t, nm)
+    if z.dim() != 3:
+        raise RuntimeError(f"cls_head: last_out has shape {tuple(z.shape)}, expected (B, num_nodes, rnn_units)")
     b, n, h = z.shape
     c = w.shape[0]
+    if tuple(w.shape) != (c, h) or bias.numel() != c:
+        raise RuntimeError(f"cls_head: fc.weight {tuple(w.shape)} / fc.bias {tuple(bias.shape)} do not match rnn_units={h}")
     drop = dropout_p > 0
     if drop:
         if rng_used is None:
@@ -752,6 +756,11 @@ def _cls_head_bwd_impl(z, w, dlogits, arg, dropout_p: float, rng_used, dw, db):
     lib = _lib.get_lib()
     z, w, dlogits = z.contiguous(), w.detach().contiguous(), dlogits.contiguous()
     b, n, h = z.shape
+    c = w.shape[0]
+    if tuple(w.shape) != (c, h) or tuple(dlogits.shape) != (b, c) or tuple(arg.shape) != (b, c) or arg.dtype != torch.int32 \
+            or tuple(dw.shape) != (c, h) or db.numel() != c:
+        raise RuntimeError(f"cls_head_bwd: operands do not fit: z {tuple(z.shape)}, w {tuple(w.shape)}, dlogits {tuple(dlogits.shape)}, "
+                           f"arg {tuple(arg.shape)} {arg.dtype}, dw {tuple(dw.shape)}, db {tuple(db.shape)}")
     dz = torch.empty_like(z)
     lib.call("eeg_dcrnn_cls_head_bwd", _p(z), _p(w), _p(dlogits), _p(arg), b, n, h, w.shape[0], float(dropout_p),
              _p(rng_used) if dropout_p > 0 else None, _p(dz), _p(dw), _p(db), _stream(z))
@@ -844,7 +853,11 @@ def _fft_features_impl(raw, window: int, mean: float, std: float, standardise: b
     feat_raw = _new((b, t_len, n, window // 2), raw)
     feat_std = torch.empty_like(feat_raw) if standardise else _new((0,), raw)
     if perm is not None:
+        if perm.numel() != b * n:
+            raise RuntimeError(f"fft_features: perm has shape {tuple(perm.shape)}, expected ({b}, {n}) source channels")
         perm = perm.to(device=raw.device, dtype=torch.int32).contiguous()
+    if log_scale is not None and log_scale.numel() != b:
+        raise RuntimeError(f"fft_features: log_scale has {log_scale.numel()} entries for {b} clips")
     if log_scale is not None:
         log_scale = log_scale.to(device=raw.device, dtype=torch.float32).contiguous()
     lib.call("eeg_dcrnn_fft_features", _p(raw), b, n, t_len, window, _p(perm), _p(log_scale), float(mean), float(std),
@@ -870,6 +883,8 @@ def _bce_logits_impl(logits, y):
     yy = y.to(torch.float32).contiguous().view(-1)
     _check(lib, x, "logits")
     _check(lib, yy, "targets")
+    if yy.numel() != x.numel():
+        raise RuntimeError(f"bce_logits: {yy.numel()} targets for {x.numel()} logits")
     loss, dx = _new((1,), x), torch.empty_like(x)
     lib.call("eeg_dcrnn_bce_logits", _p(x), _p(yy), x.numel(), _p(loss), _p(dx), _stream(x))
     return loss[0], dx.view(logits.shape)
@@ -881,6 +896,8 @@ def _ce_logits_impl(logits, y):
     yy = y.to(torch.int64).contiguous()
     _check(lib, x, "logits")
     _check(lib, yy, "targets", torch.int64)
+    if x.dim() != 2 or yy.numel() != x.shape[0]:
+        raise RuntimeError(f"ce_logits: logits {tuple(x.shape)} need shape (B, C) and {yy.numel()} targets B entries")
     loss, dx = _new((1,), x), torch.empty_like(x)
     lib.call("eeg_dcrnn_ce_logits", _p(x), _p(yy), x.shape[0], x.shape[1], _p(loss), _p(dx), _stream(x))
     return loss[0], dx

@@ -781,6 +781,33 @@ def check_malformed_inputs(device):
         with pytest.raises(RuntimeError):
             call()
             pytest.fail(f"{what}: accepted")
+    # index operands with values outside their range never address other memory: a class label outside 0..C-1 gives a NaN loss
+    # (torch: a device-side assert that ends the process) with the softmax as that clip's gradient; a reflection "permutation"
+    # entry outside 0..N-1 falls back to the node itself
+    lg = torch.randn(3, 4, generator=g).to(device)
+    loss, dl = o.ce_logits(lg, torch.tensor([1, 7, -3], device=device))
+    assert torch.isnan(loss) and torch.isfinite(dl).all()
+    assert torch.allclose(dl[1:], torch.softmax(lg[1:], dim=1) / 3, atol=1e-6)
+    raw = torch.randn(2, n, 400, generator=g).to(device)
+    ident = torch.arange(n, dtype=torch.int32).repeat(2, 1).to(device)
+    bad = ident.clone()
+    bad[0, 3], bad[1, 7] = 99, -5
+    f_id = ops.fft_features(raw, window=200, mean=0.0, std=1.0, perm=ident)
+    f_bad = ops.fft_features(raw, window=200, mean=0.0, std=1.0, perm=bad)
+    assert torch.equal(f_id[0], f_bad[0]) and torch.equal(f_id[1], f_bad[1])
+    for what, call in {
+        "bce: fewer targets than logits": lambda: o.bce_logits(z(4), z(3)),
+        "ce: fewer targets than rows": lambda: o.ce_logits(z(4, 4), torch.zeros(3, dtype=torch.int64, device=device)),
+        "ce: 1-D logits": lambda: o.ce_logits(z(4), torch.zeros(4, dtype=torch.int64, device=device)),
+        "fft_features: perm of another shape": lambda: ops.fft_features(raw, window=200, perm=ident[:1]),
+        "fft_features: log_scale of another batch": lambda: ops.fft_features(raw, window=200, mean=0.0, std=1.0, log_scale=z(3)),
+        "cls_head: fc.weight of another width": lambda: o.cls_head(z(b, n, h), z(1, 32), z(1), 0.0, None),
+        "cls_head_bwd: arg of another shape": lambda: o.cls_head_bwd(z(b, n, h), z(1, h), z(b, 1), torch.zeros(b, 2, dtype=torch.int32, device=device),
+                                                                     0.0, None, z(1, h), z(1)),
+    }.items():
+        with pytest.raises(RuntimeError):
+            call()
+            pytest.fail(f"{what}: accepted")
     # a decoder state of another layer count / batch
     dec = ssl.decoder
     with pytest.raises(RuntimeError):
