@@ -304,8 +304,18 @@ def predict(model, batches, task: str = "detection"):
         logits = model(x, seq_lengths, supports)
         probs.append(torch.sigmoid(logits.view(-1)) if task == "detection" else torch.softmax(logits, dim=1))
         labels.append(y.view(-1))
-    prob, lab = torch.cat(probs), torch.cat(labels)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if probs:
+        prob, lab = torch.cat(probs), torch.cat(labels)
+    elif multi:
+        # a rank whose shard of the evaluation set is empty still takes part in the gather (the others are waiting in it)
+        dev = next(model.parameters()).device
+        prob = torch.empty((0,) if task == "detection" else (0, model.fc.out_features), device=dev)
+        lab = torch.empty((0,), dtype=torch.float32 if task == "detection" else torch.int64, device=dev)
+    else:
+        model.train(was_training)
+        raise ValueError("predict: no batches")
+    if multi:
         prob, lab = _all_gather_uneven(prob), _all_gather_uneven(lab)
     model.train(was_training)
     return prob.cpu().numpy(), lab.cpu().numpy()
@@ -336,11 +346,17 @@ def evaluate_ssl(model, batches, scaler_mean: Optional[float] = None, scaler_std
         if return_predictions:
             preds.append(pred)
             truths.append(y)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if tot is None:
-        raise ValueError("evaluate_ssl: no batches")
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if not multi:
+            model.train(was_training)
+            raise ValueError("evaluate_ssl: no batches")
+        tot = torch.zeros(2, dtype=torch.float64, device=next(model.parameters()).device)    # an empty shard still joins the all-reduce
+    if multi:
         dist.all_reduce(tot)
     model.train(was_training)
+    if float(tot[1].item()) == 0.0:
+        raise ValueError("evaluate_ssl: no batches on any rank")
     eval_loss = float((tot[0] / tot[1]).item())
     if return_predictions:
         return eval_loss, torch.cat(preds).cpu().numpy(), torch.cat(truths).cpu().numpy()

@@ -261,3 +261,55 @@ def test_two_ranks_ssl_device_curriculum_and_evaluation(tmp_path):
     want = evaluate_ssl(model, [(x[lo:hi], y[lo:hi], [s[lo:hi] for s in sup]) for lo, hi in SHARDS_SSL], 0.3, 1.7)
     assert abs(want - r0["eval"]) < 1e-6 * max(1.0, abs(want))
     emu_support.uninstall()
+
+
+# ---- a rank WITHOUT evaluation batches still takes part in the collectives of predict / evaluate_ssl -------------------------
+def _worker_empty_shard(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(1)
+    import types
+    import emu_support
+    emu_support.install_emulator()
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, DCRNNModel_nextTimePred
+    from eeg_gnn_ssl_amd.train_step import evaluate_ssl, predict
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = types.SimpleNamespace(num_nodes=19, num_rnn_layers=1, rnn_units=16, input_dim=4, output_dim=4, max_diffusion_step=1,
+                                 dcgru_activation="tanh", filter_type="laplacian", dropout=0.0, cl_decay_steps=3000,
+                                 use_curriculum_learning=False)
+    g = torch.Generator().manual_seed(5)
+    x, sup = torch.randn(3, 2, 19, 4, generator=g), [torch.rand(3, 19, 19, generator=g)]
+    lens = torch.full((3,), 2, dtype=torch.int64)
+    torch.manual_seed(0)
+    det, cls, ssl = DCRNNModel_classification(args, 1), DCRNNModel_classification(args, 4), DCRNNModel_nextTimePred(args)
+    y_ssl = torch.randn(3, 2, 19, 4, generator=g)
+    mine = rank == 0                                        # rank 1 has no batches at all
+    p1, l1 = predict(det, [(x, torch.tensor([0.0, 1.0, 1.0]), lens, sup)] if mine else [], "detection")
+    p4, l4 = predict(cls, [(x, torch.tensor([0, 3, 2]), lens, sup)] if mine else [], "classification")
+    ev = evaluate_ssl(ssl, [(x, y_ssl, sup)] if mine else [])
+    torch.save({"p1": p1, "l1": l1, "p4": p4, "l4": l4, "ev": ev}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_evaluation_batches_joins_the_collectives(tmp_path):
+    """Uneven evaluation shards can leave a rank with NO batch (fewer batches than ranks): it must still enter the gathers of
+    `predict` and the all-reduce of `evaluate_ssl` -- the other ranks are waiting there -- and every rank returns the union."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_support
+    emu_support.install_emulator()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_empty_shard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"e{r}.pt", weights_only=False) for r in range(2))
+    for k in ("p1", "l1", "p4", "l4"):
+        assert r0[k].shape == r1[k].shape and (r0[k] == r1[k]).all(), k
+    assert r0["p1"].shape == (3,) and r0["p4"].shape == (3, 4) and r0["l4"].tolist() == [0, 3, 2]
+    assert r0["ev"] == r1["ev"] and r0["ev"] > 0
+    emu_support.uninstall()
+    # one process, no process group: an empty iterator is an error with a message
+    import pytest
+    from eeg_gnn_ssl_amd.train_step import evaluate_ssl, predict
+    with pytest.raises(ValueError, match="no batches"):
+        predict(torch.nn.Linear(1, 1), [])
+    with pytest.raises(ValueError, match="no batches"):
+        evaluate_ssl(torch.nn.Linear(1, 1), [])
