@@ -212,6 +212,19 @@ def per_launch_work(filter_type, t_len, batch, layers=LAYERS):
     return out
 
 
+def merge_paired_roles(work, launch_work, roles):
+    """Round 5: the library launches the two h-part weight-gradient GEMMs of a cell (roles `gemm_tn_hg`, `gemm_tn_hc`) as ONE paired
+    kernel where their plans agree (role `gemm_tn_h`, `dec_gemm_tn_h` inside the decoder operator): the work tables follow the
+    roles the recorder actually reports -- the pair is priced with the sum of the two problems, nothing is counted twice."""
+    for pre in ("", "dec_"):
+        pair, a, b = pre + "gemm_tn_h", pre + "gemm_tn_hg", pre + "gemm_tn_hc"
+        if pair in roles and a not in roles and b not in roles and a in work and b in work:
+            work[pair] = work.pop(a) + work.pop(b)
+            if a in launch_work and b in launch_work:
+                launch_work[pair] = [x + y for x, y in zip(launch_work.pop(a), launch_work.pop(b))]
+    return work, launch_work
+
+
 def short_symbol(sym):
     """the recorder's kernel spelling without blanks and without the trailing default `false` template flags"""
     sym = sym.replace(" ", "")
@@ -659,6 +672,7 @@ def measure(ctx, workload, steps, warmup, primary):
     clips_per_s = batch * world / (elapsed / steps)
     work = algorithmic_work(filt, t_len, batch, task, layers, raw=raw_in)
     launch_work = per_launch_work(filt, t_len, batch, layers)
+    merge_paired_roles(work, launch_work, prof)
 
     def rate(w, ms, hbm):
         """(bound, achieved, peak, unit, frac[, frac_of_achievable]) of `w` algorithmic bytes / FLOPs in `ms`"""

@@ -443,7 +443,6 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sh;
     for (int m = 0; m < kMaxM; ++m) sh.p[m] = m == 0 ? Hprev : (m < M ? hpl + (size_t)(m - 1) * hs : nullptr);
-    if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st, "gemm_tn_hg", BtMap(), &w.qg)) return 1;
     //   h-part of the candidate: hops(r*h_{t-1})^T dC
     const float* rpl = rpl_in;
     size_t rs = h_stride;
@@ -454,7 +453,19 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     }
     SegPtrs sr;
     for (int m = 0; m < kMaxM; ++m) sr.p[m] = m == 0 ? RHs : (m < M ? rpl + (size_t)(m - 1) * rs : nullptr);
-    if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st, "gemm_tn_hc", BtMap(), &w.qc)) return 1;
+    // Round 5: where the whole-block TN kernel covers both h-part problems with the same plan (same K, row splits and dY rows; only
+    // the column count differs: 2H vs H) they go out as ONE launch whose workgroups alternate between the two -- the 64-column
+    // problem waits for its operands (0.61 of the MFMA peak alone), the 128-column one for the matrix pipe (0.77): side by side on
+    // the two workgroup slots of a CU they take 0.366 instead of 0.390 ms per cfg2 step (role `gemm_tn_h`; dev knob 19 = 1: one by one)
+    int pair = -1;
+    if (g_tune[19] == 0) {
+        pair = launch_tnq_pair(w.qg, w.qc, sh, sr, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, 2 * H, H, part_c, st, "gemm_tn_h");
+        if (pair > 0) return fail("gemm_tnq_pair: launch failed");
+    }
+    if (pair < 0) {
+        if (gemm_tn(sh, M, H, R, dXW, 3 * H, 0, 2 * H, part_g, w.nsplit_hg, w.rps_hg, st, "gemm_tn_hg", BtMap(), &w.qg)) return 1;
+        if (gemm_tn(sr, M, H, R, dXW, 3 * H, 2 * H, H, part_c, w.nsplit_hc, w.rps_hc, st, "gemm_tn_hc", BtMap(), &w.qc)) return 1;
+    }
     //   one fixed-order reduction of the three sets of split-K partials into the reference's gradient layout
     ReduceJobs jobs;
     const int Ks[3] = {M * Fin, M * H, M * H}, Os[3] = {3 * H, 2 * H, H}, ns[3] = {w.nsplit_x, w.nsplit_hg, w.nsplit_hc};

@@ -88,6 +88,27 @@ int launch_tnq_ot(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R,
 }
 }  // namespace
 
+// hg (OT = 4) and hc (OT = 2) of one cell in one launch; both plans must agree in everything but OT (-1: not covered)
+int launch_tnq_pair(const TnqPlan& pg, const TnqPlan& pc, const SegPtrs& sg, const SegPtrs& sc, int nseg, int F, int R, const float* dY, int ldy,
+                    int ycol_g, int Og, float* part_g, int ycol_c, int Oc, float* part_c, hipStream_t st, const char* tag) {
+    if (!pg.ok || !pc.ok || pg.OT != 4 || pc.OT != 2 || pg.KT != pc.KT || pg.planar != pc.planar || pg.nkb != pc.nkb || pg.nsplit != pc.nsplit ||
+        pg.rps != pc.rps) return -1;
+    constexpr int RC = 16;
+    TnqJob ja{sg, ycol_g, Og, part_g}, jb{sc, ycol_c, Oc, part_c};
+#define EEG_PAIR(KT, PL)                                                                                                         \
+    {                                                                                                                            \
+        const size_t lds = 3 * (size_t)(RC * 32 * (KT + 4)) * sizeof(float);                                                     \
+        EEG_SET_MAX_LDS((gemm_tnq_pair_kernel<KT, RC, PL>), lds);                                                                \
+        EEG_LAUNCH_P(tag, (gemm_tnq_pair_kernel<KT, RC, PL>), dim3(pg.nkb, 2 * pg.nsplit), dim3(256), lds, st, ja, jb, nseg, F, R, dY, ldy, \
+                     pg.rps, 0);                                                                                                 \
+        return hipGetLastError() == hipSuccess ? 0 : 2;                                                                          \
+    }
+    if (pg.planar && pg.KT == 6) EEG_PAIR(6, true)
+    if (!pg.planar && pg.KT == 5) EEG_PAIR(5, false)
+#undef EEG_PAIR
+    return -1;
+}
+
 int launch_tnq(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
                float* partial, int btT, int btB, int btN, hipStream_t st, const char* tag) {
 #define EEG_TNQ(KT, BT, PL) launch_tnq_ot<KT, BT, PL>(p, segs, nseg, F, R, dY, ldy, ycol0, O, partial, btT, btB, btN, st, tag)

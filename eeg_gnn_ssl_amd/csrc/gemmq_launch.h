@@ -25,4 +25,8 @@ TnqPlan tnq_plan(int nseg, int F, int R, int O, bool bt, int num_cus);
 int launch_tnq(const TnqPlan& p, const SegPtrs& segs, int nseg, int F, int R, const float* dY, int ldy, int ycol0, int O,
                float* partial, int btT, int btB, int btN, hipStream_t st, const char* tag);
 
+// hg + hc of one cell in one launch (kernels_gemm_q.h gemm_tnq_pair_kernel); -1 = the pair is not covered (launch them one by one)
+int launch_tnq_pair(const TnqPlan& pg, const TnqPlan& pc, const SegPtrs& sg, const SegPtrs& sc, int nseg, int F, int R, const float* dY, int ldy,
+                    int ycol_g, int Og, float* part_g, int ycol_c, int Oc, float* part_c, hipStream_t st, const char* tag);
+
 }  // namespace eeg

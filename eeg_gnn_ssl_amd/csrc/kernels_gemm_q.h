@@ -274,10 +274,10 @@ __device__ __forceinline__ void tnq_image_pos(int pos, int& row, int& wv, int& u
 // PLANAR: F == 64 and KT in {2, 4, 6} (a k-block = KT / 2 whole planes), not BT.  Requires Ov == 32 * OT (whole column block).
 // TAIL = false: R % RC == 0 and rows_per_split % RC == 0 (no partial chunk anywhere): the clamp / zero-fill paths are compiled out.
 template <int KT, int OT, int RC, bool BT, bool PLANAR, bool TAIL>
-__global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg, int F, int R,
-                                                         const float* __restrict__ dY, int ldy, int ycol0, int Ov,
-                                                         float* __restrict__ partial, int rows_per_split,
-                                                         int btT, int btB, int btN, int flags) {
+__device__ __forceinline__ void gemm_tnq_body(const SegPtrs& segs, int nseg, int F, int R,
+                                              const float* __restrict__ dY, int ldy, int ycol0, int Ov,
+                                              float* __restrict__ partial, int rows_per_split,
+                                              int btT, int btB, int btN, int flags, const int kblock, const int split) {
     using SA = TnqSlice<KT>;
     using SY = TnqSlice<OT>;
     constexpr int NS = 3, KS = RC / 4;
@@ -292,7 +292,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg
     //  congruent mod 8 so that the second reader of the dY rows hits that XCD's L2: FETCH_SIZE of the two-k-block layer-0 instance
     //  stayed at 423 601 KB-units per launch and its time at 0.295 ms; with ~4 MB in flight per XCD the partner's lines are gone
     //  before it asks.  Not kept: profiles/r05_c_pmc_traffic_cfg2_{default,plain_order}.json.)
-    const int kblock = blockIdx.x, split = blockIdx.y;
     const int K = nseg * F, k0 = kblock * (32 * KT);
     const int rbeg = split * rows_per_split;
     const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
@@ -546,6 +545,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg
             }
         }
     }
+}
+
+template <int KT, int OT, int RC, bool BT, bool PLANAR, bool TAIL>
+__global__ __launch_bounds__(256, 2) void gemm_tnq_kernel(SegPtrs segs, int nseg, int F, int R,
+                                                         const float* __restrict__ dY, int ldy, int ycol0, int Ov,
+                                                         float* __restrict__ partial, int rows_per_split,
+                                                         int btT, int btB, int btN, int flags) {
+    gemm_tnq_body<KT, OT, RC, BT, PLANAR, TAIL>(segs, nseg, F, R, dY, ldy, ycol0, Ov, partial, rows_per_split, btT, btB, btN, flags,
+                                                (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Round 5: the two h-part weight-gradient GEMMs of a cell -- hops(h)^T [dR|dU] (128 columns, MFMA-bound) and
+// hops(r*h)^T dC (64 columns, waits for its operands) -- as ONE launch of 2 * nsplit workgroups per k-block: the two problems
+// share K, the row splits and the dY rows; the jobs alternate over the two workgroup slots of a CU.
+struct TnqJob {
+    SegPtrs segs;
+    int ycol0, Ov;
+    float* partial;
+};
+template <int KT, int RC, bool PLANAR>
+__global__ __launch_bounds__(256, 2) void gemm_tnq_pair_kernel(TnqJob ja, TnqJob jb, int nseg, int F, int R,
+                                                              const float* __restrict__ dY, int ldy, int rows_per_split, int flags) {
+    const int y = (int)blockIdx.y, split = y >> 1;
+    const int which = (y & 1) ^ ((y >> 8) & 1);      // WG y lands on CU y % 256, slot y / 256: one job of each kind per CU
+    if (which == 0)
+        gemm_tnq_body<KT, 4, RC, false, PLANAR, false>(ja.segs, nseg, F, R, dY, ldy, ja.ycol0, ja.Ov, ja.partial, rows_per_split, 0, 0, 0, flags,
+                                                       (int)blockIdx.x, split);
+    else
+        gemm_tnq_body<KT, 2, RC, false, PLANAR, false>(jb.segs, nseg, F, R, dY, ldy, jb.ycol0, jb.Ov, jb.partial, rows_per_split, 0, 0, 0, flags,
+                                                       (int)blockIdx.x, split);
 }
 
 }  // namespace eeg

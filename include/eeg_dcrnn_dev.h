@@ -27,6 +27,7 @@ int eeg_dcrnn_set_seq_probe(int64_t* probe);
  * 1.5 clips per CU at M >= 4); keys 14 / 15: 8-wave TN GEMM from this dY width up / its workgroup target;
  * key 18 = 1: the round-4
  * adjoint diffusion (hop planes consumed one at a time) instead of the row-streaming one;
+ * key 19 = 1: the two h-part weight-gradient GEMMs of a cell as two launches instead of the paired one;
  * keys 5 / 6 / 7: target workgroup counts of the streaming diffusion (forward / adjoint) and the correlation-Gram launches.
  * Defaults (all 0) = the product configuration. */
 int eeg_dcrnn_set_tuning(int key, int value);

@@ -195,6 +195,7 @@ def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3
     assert_close(lg.detach().cpu().numpy(), lo.detach().numpy(), "logits vs oracle")
     for k, p in model.named_parameters():
         assert_close_scaled(p.grad.cpu().numpy(), po[k].grad.numpy(), f"d_{k} vs oracle", tol=5e-5)
+    return {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
 
 
 def check_shape_sweep(device, n, h, filt, k, din=8, layers=2, t_len=3, b=2, classes=4, seed=0):

@@ -59,3 +59,19 @@ def test_synthetic_raw_signals_have_structure():
     # channels of a clip are correlated through the shared sources (white noise alone would give |r| ~ 0.04 at this length)
     r = np.corrcoef(x[0].numpy())
     assert np.abs(r[np.triu_indices(bench.N_NODES, 1)]).max() > 0.5
+
+
+def test_paired_h_part_role_is_priced_with_the_sum_of_its_two_problems():
+    """the library reports ONE role (`gemm_tn_h`) where it launches the two h-part weight-gradient GEMMs of a cell as a pair:
+    the work tables follow the roles of the report, totals unchanged, nothing counted twice; a report with the two separate
+    roles (dev knob 19, shapes outside the whole-block kernel) leaves the tables alone"""
+    work = bench.algorithmic_work("dual_random_walk", 60, 512, task="ssl")
+    lw = bench.per_launch_work("dual_random_walk", 60, 512)
+    total = sum(work.values())
+    hg, hc, dhg, dhc = work["gemm_tn_hg"], work["gemm_tn_hc"], work["dec_gemm_tn_hg"], work["dec_gemm_tn_hc"]
+    w2, l2 = bench.merge_paired_roles(dict(work), {k: list(v) for k, v in lw.items()}, {"gemm_tn_h": {}, "dec_gemm_tn_h": {}, "gemm_tn_x": {}})
+    assert "gemm_tn_hg" not in w2 and "gemm_tn_hc" not in w2 and w2["gemm_tn_h"] == hg + hc and w2["dec_gemm_tn_h"] == dhg + dhc
+    assert abs(sum(w2.values()) - total) < 1e-3 * total
+    assert l2["gemm_tn_h"] == [a + b for a, b in zip(lw["gemm_tn_hg"], lw["gemm_tn_hc"])] and "gemm_tn_hg" not in l2
+    w3, l3 = bench.merge_paired_roles(dict(work), {k: list(v) for k, v in lw.items()}, {"gemm_tn_hg": {}, "gemm_tn_hc": {}})
+    assert w3 == work and l3 == lw

@@ -125,6 +125,26 @@ def test_streamed_weight_bptt_kernel(emulator, adj3d, filt, k, lengths, act):
         emulator.call("eeg_dcrnn_set_tuning", 3, 0)
 
 
+@pytest.mark.parametrize("filt,k", [("laplacian", 2), ("dual_random_walk", 2)])
+def test_round3_hoisted_gemms_and_the_paired_h_part_launch(emulator, adj3d, filt, k):
+    """The whole-block GEMMs of kernels_gemm_q.h take over from 256 rows per CU on (the GPU suite's full-size cases); dev knob 2
+    lowers that to one row per CU so that the emulator runs them too: gemm_nnr_kernel, gemm_tnq_kernel (planar at M = 3, per-lane
+    pointers at M = 5) and -- round 5 -- gemm_tnq_pair_kernel, the two h-part weight-gradient GEMMs of a cell in one launch
+    (knob 19 = 1: one by one; both must match the oracle, and each other bit for bit: same partial sums, same reduction)."""
+    grads = {}
+    for one_by_one in (0, 1):
+        emulator.call("eeg_dcrnn_set_tuning", 2, 4)
+        emulator.call("eeg_dcrnn_set_tuning", 19, one_by_one)
+        try:
+            grads[one_by_one] = ps.check_vs_oracle_random("cpu", filt, 8, 64, 2, 4, 4, 4, adj3d, seed=7, k=k)
+        finally:
+            emulator.call("eeg_dcrnn_set_tuning", 2, 0)
+            emulator.call("eeg_dcrnn_set_tuning", 19, 0)
+    if grads[0] is not None:
+        for name in grads[0]:
+            assert (grads[0][name] == grads[1][name]).all(), name
+
+
 def test_training_tail_kernels():
     ps.check_training_tail("cpu")
 
