@@ -59,8 +59,8 @@ def _repeat(run, what):
 #  M = 7 and M = 2 / 1: generic hop counts;  16 / 32 units: the narrow instantiations;  n = 8 / 16 / 20 / 32: empty / full second node tile;
 #  B = 300 / 520: resident workgroups walking more clips than CUs;  din = 20: non-planar x-part;  3 layers: x_planes_ready chains
 CLS_CASES = [
-    (19, 64, 100, 2, "laplacian", 2, 1, 256, 12),
-    (19, 64, 100, 2, "dual_random_walk", 2, 1, 256, 12),
+    (19, 64, 100, 2, "laplacian", 2, 1, 256, 16),            # 77 824 rows: from 65 536 on the whole-block GEMMs of kernels_gemm_q.h
+    (19, 64, 100, 2, "dual_random_walk", 2, 1, 256, 16),     # (gemm_nnr, gemm_tnq and the paired h-part launch) take over
     (19, 64, 100, 2, "dual_random_walk", 2, 4, 520, 6),
     (19, 64, 20, 3, "dual_random_walk", 1, 1, 256, 8),
     (19, 64, 100, 1, "random_walk", 2, 4, 300, 8),
