@@ -15,14 +15,15 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip.so")
 DEV_LIB_PATH = os.path.join(_HERE, "libeeg_dcrnn_hip_dev.so")     # `make dev`: tools/ and `bench.py --tune` only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class LayerDims(ctypes.Structure):
     """mirror of `eeg_layer_dims` (include/eeg_dcrnn.h)."""
     _fields_ = [("T", c_int32), ("B", c_int32), ("N", c_int32), ("H", c_int32), ("Fin", c_int32),
                 ("M", c_int32), ("act", c_int32), ("p_batched", c_int32), ("x_planes_ready", c_int32),
-                ("x_batch_major", c_int32), ("x_plane_stride", c_int64), ("pack3", c_void_p)]
+                ("x_batch_major", c_int32), ("x_plane_stride", c_int64), ("pack3", c_void_p), ("spectral", c_void_p),
+                ("spack", c_void_p)]
 
 
 class DecoderDims(ctypes.Structure):
@@ -58,6 +59,12 @@ _SIGNATURES = {
     "eeg_dcrnn_dconv_fwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, _FP, _FP, c_int, _FP, _FP, c_void_p]),
     "eeg_dcrnn_dconv_bwd_ws_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "eeg_dcrnn_dconv_bwd": (c_int, [_FP, _FP, c_int, c_int, c_int, c_int, c_int, _FP, c_int, _FP, _FP, _FP, _FP, _FP, c_void_p]),
+    "eeg_dcrnn_spectral_basis_floats": (c_size_t, [c_int]),
+    "eeg_dcrnn_spectral_basis": (c_int, [_FP, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_spectral_pack_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "eeg_dcrnn_pack_cell_spectral": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_spectral_ok": (c_int, [POINTER(LayerDims), c_int]),
+    "eeg_dcrnn_spectral_rows": (c_size_t, [c_size_t]),
     "eeg_dcrnn_layer_fwd_ws_floats": (c_size_t, [POINTER(LayerDims)]),
     "eeg_dcrnn_batch_major_ok": (c_int, [POINTER(LayerDims)]),
     "eeg_dcrnn_layer_fwd": (c_int, [POINTER(LayerDims)] + [_FP] * 14 + [c_void_p]),

@@ -19,6 +19,8 @@
 #include "kernels_graph.h"
 #include "kernels_head.h"
 #include "kernels_pack.h"
+#include "spec_common.h"
+#include "spec_launch.h"
 #include "kernels_tail.h"
 #include "prof.h"
 #include "seq_launch.h"
@@ -381,6 +383,9 @@ struct BwdWs {
     size_t dxw, dbias, hplanes, rhplanes, partial, part_g, part_c, z, total;   // partial = x-part region; part_g / part_c follow it
     int nsplit_x, rps_x, nsplit_hg, rps_hg, nsplit_hc, rps_hc;
     TnqPlan qx, qg, qc;        // round-3 TN kernel where it covers the shape (ok = 1): its split plan replaces tn_split's
+    // spectral form (d->spectral): dyh = U^T dXW (N, Sp, 3H); partial = the grouped TN's [N*spg][Fin][3H]; z = dXh (N, Sp, Fin)
+    size_t dyh;
+    TngPlan gx;
 };
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
@@ -390,11 +395,15 @@ TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
 BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     BwdWs w;
     const size_t R = (size_t)d->T * d->B * d->N;
+    const bool spec = d->spectral != nullptr;
+    const size_t Rp = (size_t)d->N * spec_rows(d->T * d->B);
     size_t o = 0;
     w.dxw = o;      o += R * 3 * d->H;
     w.dbias = o;    o += round_up(d->B * 3 * d->H, 64);
     w.hplanes = o;  o += (size_t)(d->M - 1) * R * d->H;
     w.rhplanes = o; o += (size_t)(d->M - 1) * R * d->H;
+    w.dyh = o;      o += spec ? Rp * 3 * d->H : 0;
+    w.gx = spec ? tng_plan(d->Fin, spec_rows(d->T * d->B), d->N, num_cus()) : TngPlan{};
     w.nsplit_x = tn_split(d->M, d->Fin, (int)R, 3 * d->H, &w.rps_x);
     w.nsplit_hg = tn_split(d->M, d->H, (int)R, 2 * d->H, &w.rps_hg);
     w.nsplit_hc = tn_split(d->M, d->H, (int)R, d->H, &w.rps_hc);
@@ -405,12 +414,13 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     if (w.qg.ok) { w.nsplit_hg = w.qg.nsplit; w.rps_hg = w.qg.rps; }
     if (w.qc.ok) { w.nsplit_hc = w.qc.nsplit; w.rps_hc = w.qc.rps; }
     size_t px = (size_t)w.nsplit_x * d->M * d->Fin * 3 * d->H;
+    if (spec) px = (size_t)d->N * w.gx.spg * d->Fin * 3 * d->H;
     size_t pg = (size_t)w.nsplit_hg * d->M * d->H * 2 * d->H;
     size_t pc = (size_t)w.nsplit_hc * d->M * d->H * d->H;
     w.partial = o;  o += (px + 63) / 64 * 64;      // one region per GEMM: the three are reduced by one launch
     w.part_g = o;   o += (pg + 63) / 64 * 64;
     w.part_c = o;   o += (pc + 63) / 64 * 64;
-    w.z = o;        o += need_dx ? R * d->M * d->Fin : 0;
+    w.z = o;        o += need_dx ? (spec ? Rp * d->Fin : R * d->M * d->Fin) : 0;
     w.total = o;
     return w;
 }
@@ -425,14 +435,18 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
                       const float* RHs, const float* dXW, const float* P, const float* hpl_in, const float* rpl_in,
                       size_t h_stride, float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate,
                       float* dWg, float* dWc, hipStream_t st, BtMap bt = BtMap(), const float* bias_part = nullptr,
-                      float* dbg = nullptr, float* dbc = nullptr) {
+                      float* dbg = nullptr, float* dbc = nullptr, const float* dYh = nullptr) {
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const int acc = accumulate ? 8 : 0;
+    const bool spec = dYh != nullptr;                 // spectral x-part: `planes` = Xh (N, Sp, Fin), dYh = U^T dXW (N, Sp, 3H)
     SegPtrs sx;
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
     float* part_g = part + (w.part_g - w.partial);
     float* part_c = part + (w.part_c - w.partial);
-    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt, &w.qx)) return 1;
+    if (spec) {
+        if (launch_tng(w.gx, planes, Fin, spec_rows(S), N, dYh, part, st, "gemm_tn_x")) return fail("gemm_tng: launch failed");
+        if (check_launch("gemm_tng")) return 1;
+    } else if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt, &w.qx)) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
     size_t hs = h_stride;
@@ -473,12 +487,18 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     int nblocks = 0;
     for (int j = 0; j < 3; ++j) {
         jobs.part[j] = parts[j]; jobs.nsplit[j] = ns[j]; jobs.K[j] = Ks[j]; jobs.O[j] = Os[j];
-        jobs.nblocks[j] = ceil_div(Ks[j] * Os[j], 64);
+        jobs.nblocks[j] = (spec && j == 0) ? 0 : ceil_div(Ks[j] * Os[j], 64);
         nblocks += jobs.nblocks[j];
     }
     // the cell's bias gradients (per-clip partials of the BPTT kernel -> dbg, dbc) as a fourth job of the same launch
     jobs.bias_part = bias_part; jobs.bias_B = d->B; jobs.dbg = dbg; jobs.dbc = dbc;
     if (bias_part != nullptr) nblocks += ceil_div(3 * H, 16);
+    if (spec) {                                       // x-part: dW_m = sum_i T_m(lam_i) dWt_i, folded in the same launch
+        SpecFoldJob sj{part, d->spectral, N, w.gx.spg, ceil_div(Fin * 3 * H, 64)};
+        nblocks += sj.nblocks;
+        EEG_LAUNCH_P("reduce_unpack", reduce_unpack3s_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, sj, acc, Fin, H, M, dWg, dWc);
+        return check_launch("reduce_unpack");
+    }
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack3_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, acc, Fin, H, M, dWg, dWc);
     return check_launch("reduce_unpack");
 }
@@ -583,7 +603,7 @@ int copy_floats(float* dst, const float* src, size_t n, hipStream_t st) {
 extern "C" {
 
 const char* eeg_dcrnn_last_error(void) { return g_err; }
-int eeg_dcrnn_abi_version(void) { return 4; }
+int eeg_dcrnn_abi_version(void) { return 5; }
 int eeg_dcrnn_is_device_build(void) { return kPlatformIsDevice; }
 #if defined(EEG_DEV)
 int eeg_dcrnn_set_tuning(int key, int value) {
@@ -703,7 +723,36 @@ int eeg_dcrnn_diffuse_adj(const float* Z, const float* P, int p_batched, int S, 
 static bool layer_dims_positive(const eeg_layer_dims* d) {
     return d != nullptr && d->T >= 1 && d->B >= 1 && d->N >= 1 && d->H >= 1 && d->Fin >= 1 && d->M >= 1;
 }
-size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) { return layer_dims_positive(d) ? (size_t)d->T * d->B * d->N * 3 * d->H : 0; }
+size_t eeg_dcrnn_layer_fwd_ws_floats(const eeg_layer_dims* d) {
+    if (!layer_dims_positive(d)) return 0;
+    const size_t xw = (size_t)d->T * d->B * d->N * 3 * d->H;
+    return d->spectral != nullptr ? xw + (size_t)d->N * spec_rows(d->T * d->B) * 3 * d->H : xw;   // + Yh (N, Sp, 3H)
+}
+
+size_t eeg_dcrnn_spectral_basis_floats(int N) { return (N >= 1 && N <= kMaxNodes) ? (size_t)spec_basis_floats(N) : 0; }
+size_t eeg_dcrnn_spectral_rows(size_t S) { return (S + 15) / 16 * 16; }
+int eeg_dcrnn_spectral_basis(const float* support, int N, float* basis, void* stream) {
+    if (N < 2 || N > kMaxNodes) return fail("spectral_basis: num_nodes=%d unsupported (2..%d)", N, kMaxNodes);
+    if (support == nullptr || basis == nullptr) return fail("spectral_basis: null pointer");
+    if (launch_spec_basis(support, N, basis, S_(stream))) return fail("spectral_basis: launch failed");
+    return check_launch("spectral_basis");
+}
+size_t eeg_dcrnn_spectral_pack_floats(int Fin, int H, int M, int N) {
+    return (Fin >= 4 && Fin % 4 == 0 && H == 64 && M >= 1 && M <= kMaxM && N >= 1 && N <= kMaxNodes) ? spec_pack_floats(Fin, H, M, N) : 0;
+}
+int eeg_dcrnn_pack_cell_spectral(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N, float* spack,
+                                 void* stream) {
+    if (eeg_dcrnn_spectral_pack_floats(Fin, H, M, N) == 0)
+        return fail("pack_cell_spectral: input_dim=%d rnn_units=%d hop matrices=%d nodes=%d: the spectral form exists for 64 units", Fin, H, M, N);
+    if (Wg == nullptr || Wc == nullptr || basis == nullptr || spack == nullptr) return fail("pack_cell_spectral: null pointer");
+    if (launch_spec_pack(Wg, Wc, basis, Fin, H, M, N, spack, S_(stream))) return fail("pack_cell_spectral: launch failed");
+    return check_launch("pack_cell_spectral");
+}
+int eeg_dcrnn_spectral_ok(const eeg_layer_dims* d, int need_dx) {
+    if (!layer_dims_positive(d) || d->p_batched || d->x_planes_ready) return 0;
+    if (check_dims(d->N, d->H, d->Fin, d->M)) return 0;
+    return spec_supported(d->T, d->B, d->N, d->H, d->Fin, d->M, need_dx) ? 1 : 0;
+}
 
 int eeg_dcrnn_batch_major_ok(const eeg_layer_dims* d) {
     if (!diffuse_streams(d->p_batched, d->T * d->B, d->B, d->N, d->Fin)) return 0;
@@ -734,10 +783,26 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     BtMap bt;
     if (d->x_batch_major) {
         if (Xtm != nullptr || d->x_planes_ready) return fail("layer_fwd: x_batch_major excludes Xtm and x_planes_ready");
-        if (eeg_dcrnn_batch_major_ok(d) != 2) return fail("layer_fwd: x_batch_major is not available for this shape (eeg_dcrnn_batch_major_ok)");
+        if (d->spectral == nullptr && eeg_dcrnn_batch_major_ok(d) != 2) return fail("layer_fwd: x_batch_major is not available for this shape (eeg_dcrnn_batch_major_ok)");
         bt.T = d->T; bt.B = d->B; bt.N = d->N;
     }
-    if (d->x_planes_ready) {
+    float* XW = ws;
+    int rc3 = -1;
+    if (d->spectral != nullptr) {
+        // spectral form of 1. + 2. (shared symmetric support): Xh = U^T X (node-major, kept in `planes` for the backward),
+        // Yh_i = Xh_i Wt_i (grouped GEMM, K = Fin), XW = U Yh + bias.  A batch-major X is read in its storage order: the rows of Xh /
+        // Yh are then batch-major too and the second mix restores the time-major order the recurrence wants.
+        if (!eeg_dcrnn_spectral_ok(d, 0)) return fail("layer_fwd: the spectral form does not cover this shape (eeg_dcrnn_spectral_ok)");
+        if (Xtm != nullptr || d->spack == nullptr) return fail("layer_fwd: spectral excludes Xtm and needs spack");
+        const SpecPack sp = make_spec_pack(Fin, H, M, d->N);
+        const int Sp = spec_rows(S);
+        float* Yh = ws + (size_t)R * 3 * H;
+        if (launch_spec_mix(1, X, d->spectral, nullptr, d->N, d->T, d->B, Fin, 0, planes, st, "spec_mix_x")) return fail("spec_mix: launch failed");
+        if (launch_nng(planes, Fin, Sp, d->N, d->spack + sp.sxq, sp.sxq_stride, sp.nct_x, Yh, num_cus(), st, "gemm_nn_xw")) return fail("gemm_nng: launch failed");
+        if (launch_spec_mix(0, Yh, d->spectral, pack + p.bias, d->N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, XW, st, "spec_mix_y")) return fail("spec_mix: launch failed");
+        if (check_launch("layer_fwd (spectral x-part)")) return 1;
+        rc3 = 0;
+    } else if (d->x_planes_ready) {
         if (Xtm != nullptr) return fail("layer_fwd: x_planes_ready excludes a batch-major input");
     } else {
         if (diffuse_fwd(X, P, d->p_batched, S, d->B, d->N, Fin, M, planes, st, xs, d->x_batch_major ? 2 : (Xtm != nullptr ? 1 : 0), Xtm)) return 1;
@@ -746,9 +811,7 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     // 2. hoisted x-part GEMM: XW = [X | planes] @ Bx + [bg|bc]
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * xs : nullptr);
-    float* XW = ws;
-    int rc3 = -1;
-    if (d->pack3 != nullptr && pack3_supported(Fin, H, M)) {          // opt-in: three-term bf16 split (include/eeg_dcrnn.h, eeg_layer_dims.pack3)
+    if (rc3 < 0 && d->pack3 != nullptr && pack3_supported(Fin, H, M)) {          // opt-in: three-term bf16 split (include/eeg_dcrnn.h, eeg_layer_dims.pack3)
         const Pack3 q = make_pack3(Fin, H, M);
         rc3 = gemm_nn_bf3(segs, M, Fin, R, d->pack3 + q.xw, q.xw_nct, pack + p.bias, XW, 3 * H, 3 * H, st, "gemm_nn_xw", bt);
         if (rc3 > 0) return 1;
@@ -789,8 +852,26 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
     const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
     BtMap bt;
     if (d->x_batch_major) {
-        if (eeg_dcrnn_batch_major_ok(d) != 2) return fail("layer_bwd: x_batch_major is not available for this shape");
+        if (d->spectral == nullptr && eeg_dcrnn_batch_major_ok(d) != 2) return fail("layer_bwd: x_batch_major is not available for this shape");
         bt.T = d->T; bt.B = d->B; bt.N = N;
+    }
+    if (d->spectral != nullptr) {
+        // spectral form: dYh = U^T dXW (node-major, rows in the order of Xh), dWt_i = Xh_i^T dYh_i folded into dW_m by the
+        // reduction, dX = U [dYh_i Wt_i^T]_i
+        if (!eeg_dcrnn_spectral_ok(d, dX != nullptr)) return fail("layer_bwd: the spectral form does not cover this shape (eeg_dcrnn_spectral_ok)");
+        if (d->spack == nullptr) return fail("layer_bwd: spectral needs spack");
+        const SpecPack sp = make_spec_pack(Fin, H, M, N);
+        const int Sp = spec_rows(S);
+        float* dYh = ws + w.dyh;
+        if (launch_spec_mix(1, dXW, d->spectral, nullptr, N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, dYh, st, "spec_mix_dy")) return fail("spec_mix: launch failed");
+        if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
+                              ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, BtMap(), dbias, dbg, dbc, dYh)) return 1;
+        if (dX != nullptr) {
+            float* dXh = ws + w.z;
+            if (launch_nng(dYh, 3 * H, Sp, N, d->spack + sp.sxtq, sp.sxtq_stride, sp.nct_t, dXh, num_cus(), st, "gemm_nn_dx")) return fail("gemm_nng: launch failed");
+            if (launch_spec_mix(0, dXh, d->spectral, nullptr, N, d->T, d->B, Fin, d->x_batch_major ? 1 : 0, dX, st, "spec_mix_dx")) return fail("spec_mix: launch failed");
+        }
+        return check_launch("layer_bwd (spectral x-part)");
     }
     if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
                           ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, bt, dbias, dbg, dbc)) return 1;

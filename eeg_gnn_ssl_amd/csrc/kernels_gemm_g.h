@@ -1,0 +1,160 @@
+// Grouped hoisted GEMMs of the spectral form (kernels_spectral.h): one plain GEMM per graph frequency i, all in ONE launch.
+//
+//  gemm_nng_kernel: C[i*Sp + r][:] = A[i*Sp + r][0:F) * W_i for the G row groups of Sp rows (Sp % 16 == 0) of a node-major
+//  (G, Sp, F) tensor -- gemm_nnr_kernel (kernels_gemm_q.h: persistent balanced row ranges, LDS ring filled by
+//  buffer_load ... lds, ds_read_b128 fragments against quad-ordered weights streamed from L2 into registers, transposed MFMA
+//  issue) with the right-hand side selected per 128-row tile.  Differences:
+//   * one A segment (nseg = 1); a tile never straddles a group: the tile walk of a workgroup's row range is cut at the group
+//     boundaries (tiles of 1..8 row tiles), and three cursors walk it -- the DMA cursor three chunks ahead, the weight cursor
+//     one chunk ahead, the MFMA cursor;
+//   * every row tile is whole (Sp % 16 == 0) and every column block is whole (nct == 4 * NJ): no guards on the stores;
+//   * NJ column tiles per wave: 3 (192 columns: the pre-activations [r|u|c] of a 64-unit cell) or 1 (64 columns: dX of a layer
+//     above the first); no bias (it is added by the node mix that follows).
+//  K order: the F / 16 whole chunks, then one tail chunk with the (F / 4) % 4 left-over pieces (zero weights behind them; the
+//  lanes of the padding pieces fetch columns 0..3 of their row: finite values times zero).
+// Reference semantics: model/cell.py:98-117 in the eigenbasis of the support.
+#pragma once
+#include "kernels_gemm_q.h"
+
+namespace eeg {
+
+template <int NJ, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __restrict__ A, int F, int Sp, int G,
+                                                         const float* __restrict__ Wq, unsigned w_group_stride,
+                                                         float* __restrict__ C, int ldc) {
+    constexpr int NS = 4, ST = 128 * 16, NCT = 4 * NJ;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
+    const NnqOrder ko = make_nnq_order(1, F);
+    const int nch = ko.nch;
+    const int RTg = Sp / 16, RT = RTg * G, Rtot = RT * 16;
+    const int Gd = gridDim.x, bid = blockIdx.x;
+    const int rt0 = (int)((long long)bid * RT / Gd), rt1 = (int)((long long)(bid + 1) * RT / Gd);
+    if (rt1 <= rt0) return;
+    // tile walk: a tile starts at `cur` and ends at the next of {cur + 8, rt1, group boundary}
+    auto tile_len = [&](int cur) __attribute__((always_inline)) -> int {
+        int len = rt1 - cur;
+        if (len > 8) len = 8;
+        const int to_boundary = RTg - cur % RTg;
+        return len < to_boundary ? len : to_boundary;
+    };
+    int ntile = 0;
+    for (int cur = rt0; cur < rt1; cur += tile_len(cur)) ++ntile;
+    const int Q = ntile * nch;
+
+    // ---- DMA side (activations) ------------------------------------------------------------------------------------------
+    const wbuf_t ra = make_wbuf(A);
+    const int a_piece = (lane & 3) ^ nnq_gsw(lg);
+    // tail chunk: piece pp is valid for pp < ko.b (columns 16a + 4pp ..), else columns 0..3 (their weights are zero)
+    const int t_adj = a_piece < ko.b ? 4 * (ko.a * 16) : -16 * a_piece;       // bytes, relative to the main-chunk lane offset
+    int d_cur = rt0, d_c = 0, d_stage = 0;
+    unsigned a_voff[2];
+    auto tile_rows = [&](int cur) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = cur * 16 + 16 * (w + 4 * i) + (lane >> 2);
+            if (r >= Rtot) r = Rtot - 1;
+            a_voff[i] = ((unsigned)r * F + 4 * a_piece) * 4u;
+        }
+    };
+    tile_rows(d_cur);
+    auto issue_a = [&]() __attribute__((always_inline)) {
+        float* base = sm + d_stage * ST;
+        if (d_c < ko.nmain) {
+            wbuf_dma16(ra, base + w * 256, a_voff[0], (unsigned)d_c * 64u);
+            wbuf_dma16(ra, base + (w + 4) * 256, a_voff[1], (unsigned)d_c * 64u);
+        } else {
+            wbuf_dma16(ra, base + w * 256, a_voff[0] + (unsigned)t_adj, 0u);
+            wbuf_dma16(ra, base + (w + 4) * 256, a_voff[1] + (unsigned)t_adj, 0u);
+        }
+        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+        if (++d_c == nch) {
+            d_c = 0;
+            d_cur += tile_len(d_cur);
+            if (d_cur < rt1) tile_rows(d_cur);
+        }
+    };
+
+    // ---- compute side ----------------------------------------------------------------------------------------------------
+    const wbuf_t rb = make_wbuf(Wq + (size_t)(NJ * w) * 256);
+    const unsigned b_voff = (unsigned)lane * 4u;                             // floats
+    const int c_col = 16 * NJ * w + 4 * lg;
+    const wbuf_t rc = make_wbuf(C);
+    const int a_lds = lr * 16 + 4 * (lg ^ nnq_gsw((lr >> 2) & 3));
+    f32x4 acc[8][NJ], oa[8], ob[NJ], obn[NJ];
+    int b_cur = rt0, b_c = 0;                                                // weight cursor: (tile start, chunk) requested next
+    auto load_b = [&](f32x4 (&dst)[NJ]) __attribute__((always_inline)) {
+        const unsigned so = (unsigned)(b_cur / RTg) * w_group_stride + (unsigned)(b_c * NCT) * 256u;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) dst[j] = wbuf_ld4(rb, b_voff + 256 * j, so);
+        if (++b_c == nch) { b_c = 0; b_cur += tile_len(b_cur); }
+    };
+    load_b(ob);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < Q) issue_a();
+    __syncthreads();                                                         // the prologue DMAs of all waves
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oa[i] = *reinterpret_cast<const f32x4*>(sm + a_lds + i * 256);
+    int r_stage = 1, m_c = 0, m_cur = rt0, nrt = tile_len(rt0);
+    for (int q = 0; q < Q; ++q) {
+        const bool more = q + 1 < Q, dma = q + NS - 1 < Q;
+        if (more) EEG_LDS_BARRIER();                                         // chunk q+1 landed in every wave
+        if (more) load_b(obn);
+        if (dma) issue_a();                                                  // chunk q+3 into the stage of chunk q-1
+        EEG_SCHED_FENCE();
+        const float* st = sm + r_stage * ST;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < nrt) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(ob[j][s], oa[i][s], acc[i][j]);   // transposed issue
+            }
+            oa[i] = *reinterpret_cast<const f32x4*>(st + a_lds + i * 256);  // refilled in place from chunk q+1
+        }
+        EEG_SCHED_FENCE();
+        if (more) {
+            if (dma) EEG_VM_WAIT(2); else EEG_VM_WAIT(0);                    // (see gemm_nnr_kernel: the queue discipline)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) ob[j] = obn[j];
+        }
+        r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+        if (++m_c == nch) {                                                  // the tile of chunk q is complete
+            const int row0 = m_cur * 16;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (i < nrt) wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+            EEG_SCHED_FENCE();                                               // (a store's data registers must not be rewritten right behind it)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            m_c = 0;
+            m_cur += nrt;
+            nrt = m_cur < rt1 ? tile_len(m_cur) : 0;
+        }
+    }
+}
+
+// Grouped weight-gradient GEMM: gemm_tnq_body (kernels_gemm_q.h) with the row range of a workgroup taken from ONE group:
+// split y = i * spg + ls covers rows [i*Sp + ls*rps, min(i*Sp + (ls+1)*rps, (i+1)*Sp)) and writes partial[y][K][Ov].
+template <int KT, int OT, int RC, bool PLANAR>
+__global__ __launch_bounds__(256, 2) void gemm_tnq_grouped_kernel(SegPtrs segs, int F, int Sp, int G, int spg,
+                                                                 const float* __restrict__ dY, int ldy, int Ov,
+                                                                 float* __restrict__ partial, int rows_per_split) {
+    const int y = (int)blockIdx.y, i = y / spg, ls = y - i * spg;
+    const int rbeg = i * Sp + ls * rows_per_split;
+    int rend = rbeg + rows_per_split;
+    if (rend > (i + 1) * Sp) rend = (i + 1) * Sp;
+    gemm_tnq_rows<KT, OT, RC, false, PLANAR, false>(segs, 1, F, Sp * G, dY, ldy, 0, Ov, partial, 0, 0, 0, 0, (int)blockIdx.x, y, rbeg, rend);
+}
+
+}  // namespace eeg

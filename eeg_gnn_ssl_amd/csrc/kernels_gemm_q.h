@@ -273,11 +273,13 @@ __device__ __forceinline__ void tnq_image_pos(int pos, int& row, int& wv, int& u
 // BT: the A segments are batch-major (btB clips x btT steps x btN nodes, see gemm_nn_dma_kernel); dY is always time-major.
 // PLANAR: F == 64 and KT in {2, 4, 6} (a k-block = KT / 2 whole planes), not BT.  Requires Ov == 32 * OT (whole column block).
 // TAIL = false: R % RC == 0 and rows_per_split % RC == 0 (no partial chunk anywhere): the clamp / zero-fill paths are compiled out.
+// gemm_tnq_rows: the rows [rbeg, rend) of the operands (rend - rbeg a multiple of RC unless TAIL) -> partial slot `split`.
 template <int KT, int OT, int RC, bool BT, bool PLANAR, bool TAIL>
-__device__ __forceinline__ void gemm_tnq_body(const SegPtrs& segs, int nseg, int F, int R,
+__device__ __forceinline__ void gemm_tnq_rows(const SegPtrs& segs, int nseg, int F, int R,
                                               const float* __restrict__ dY, int ldy, int ycol0, int Ov,
-                                              float* __restrict__ partial, int rows_per_split,
-                                              int btT, int btB, int btN, int flags, const int kblock, const int split) {
+                                              float* __restrict__ partial,
+                                              int btT, int btB, int btN, int flags, const int kblock, const int split,
+                                              const int rbeg, const int rend) {
     using SA = TnqSlice<KT>;
     using SY = TnqSlice<OT>;
     constexpr int NS = 3, KS = RC / 4;
@@ -293,8 +295,6 @@ __device__ __forceinline__ void gemm_tnq_body(const SegPtrs& segs, int nseg, int
     //  stayed at 423 601 KB-units per launch and its time at 0.295 ms; with ~4 MB in flight per XCD the partner's lines are gone
     //  before it asks.  Not kept: profiles/r05_c_pmc_traffic_cfg2_{default,plain_order}.json.)
     const int K = nseg * F, k0 = kblock * (32 * KT);
-    const int rbeg = split * rows_per_split;
-    const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
     const int Q = rend > rbeg ? ceil_div(rend - rbeg, RC) : 0;
 
     // ---- DMA side ------------------------------------------------------------------------------------------------------
@@ -545,6 +545,17 @@ __device__ __forceinline__ void gemm_tnq_body(const SegPtrs& segs, int nseg, int
             }
         }
     }
+}
+
+// row split `split` of rows_per_split rows (the last one ends at R)
+template <int KT, int OT, int RC, bool BT, bool PLANAR, bool TAIL>
+__device__ __forceinline__ void gemm_tnq_body(const SegPtrs& segs, int nseg, int F, int R,
+                                              const float* __restrict__ dY, int ldy, int ycol0, int Ov,
+                                              float* __restrict__ partial, int rows_per_split,
+                                              int btT, int btB, int btN, int flags, const int kblock, const int split) {
+    const int rbeg = split * rows_per_split;
+    const int rend = (rbeg + rows_per_split < R) ? rbeg + rows_per_split : R;
+    gemm_tnq_rows<KT, OT, RC, BT, PLANAR, TAIL>(segs, nseg, F, R, dY, ldy, ycol0, Ov, partial, btT, btB, btN, flags, kblock, split, rbeg, rend);
 }
 
 template <int KT, int OT, int RC, bool BT, bool PLANAR, bool TAIL>

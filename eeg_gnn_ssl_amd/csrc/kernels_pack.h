@@ -12,6 +12,7 @@
 #pragma once
 #include "common.h"
 #include "nnq_order.h"
+#include "spec_common.h"
 
 namespace eeg {
 
@@ -278,6 +279,26 @@ __global__ __launch_bounds__(256) void reduce_unpack3_kernel(ReduceJobs jobs, in
     if (b >= jobs.nblocks[0]) { b -= jobs.nblocks[0]; j = 1; }
     if (j == 1 && b >= jobs.nblocks[1]) { b -= jobs.nblocks[1]; j = 2; }
     if (j == 2 && b >= jobs.nblocks[2]) {            // the bias job (wave-uniform branch: whole blocks)
+        EEG_DYN_SMEM(sm);
+        reduce_bias_block(b - jobs.nblocks[2], sm, jobs.bias_part, jobs.bias_B, H, jobs.dbg, jobs.dbc);
+        return;
+    }
+    reduce_unpack_block(b, jobs.part[j], jobs.nsplit[j], jobs.K[j], jobs.O[j], j | flags, Fin, H, M, dWg, dWc);
+}
+
+// The same launch with the x-part job replaced by the spectral fold (kernels_spectral.h): blocks [0, sj.nblocks) fold the grouped
+// TN GEMM's per-frequency partials into the x-rows of dWg / dWc, the rest serve jobs 1, 2 and the bias job (jobs.nblocks[0] = 0).
+__global__ __launch_bounds__(256) void reduce_unpack3s_kernel(ReduceJobs jobs, SpecFoldJob sj, int flags, int Fin, int H, int M,
+                                                              float* __restrict__ dWg, float* __restrict__ dWc) {
+    int b = blockIdx.x;
+    if (b < sj.nblocks) {
+        spec_fold_block(b, sj, (flags & 8) != 0 ? 1 : 0, Fin, H, M, dWg, dWc);
+        return;
+    }
+    b -= sj.nblocks;
+    int j = 1;
+    if (b >= jobs.nblocks[1]) { b -= jobs.nblocks[1]; j = 2; }
+    if (j == 2 && b >= jobs.nblocks[2]) {
         EEG_DYN_SMEM(sm);
         reduce_bias_block(b - jobs.nblocks[2], sm, jobs.bias_part, jobs.bias_B, H, jobs.dbg, jobs.dbc);
         return;

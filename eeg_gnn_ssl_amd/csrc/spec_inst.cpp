@@ -1,0 +1,117 @@
+// Instantiations + launch logic of the spectral form of the hoisted x-part, in their own translation unit.
+#include "kernels_gemm_g.h"
+#include "kernels_spectral.h"
+#include "spec_launch.h"
+#include "prof.h"
+
+namespace eeg {
+
+bool spec_supported(int T, int B, int N, int H, int Fin, int M, int need_dx) {
+    if (T < 1 || B < 1 || N < 2 || N > kMaxNodes || H != 64 || Fin < 4 || Fin % 4 != 0 || M < 2 || M > kMaxM) return false;
+    if (need_dx && Fin != 64) return false;
+    if (Fin / 4 > 256 || make_nnq_order(1, Fin).ntail > 1) return false;
+    const double rows = (double)N * spec_rows(T * B);
+    // 2 GB buffer descriptors on every operand (platform.h make_wbuf) and 32-bit float4 indices in the mixes
+    return rows * (Fin > 192 ? Fin : 192) * 4.0 < 2147483648.0;
+}
+
+size_t spec_pack_floats(int Fin, int H, int M, int N) { return make_spec_pack(Fin, H, M, N).total; }
+
+int launch_spec_basis(const float* S, int N, float* basis, hipStream_t st) {
+    EEG_SET_MAX_LDS(spectral_basis_kernel, kSpecBasisLds);
+    EEG_LAUNCH_P("spec_basis", spectral_basis_kernel, dim3(1), dim3(256), kSpecBasisLds, st, S, N, basis);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_spec_pack(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N, float* spack, hipStream_t st) {
+    const SpecPack p = make_spec_pack(Fin, H, M, N);
+    EEG_LAUNCH_P("pack_cell", pack_spectral_kernel, dim3(1024), dim3(256), 0, st, Wg, Wc, basis, spack, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bt,
+                    float* out, hipStream_t st, const char* tag) {
+    const int S = T * B, Sp = spec_rows(S), F4 = F / 4;
+    if (N == 19 && F4 <= 128) {
+        int threads = 256;
+        while (threads > 64 && (threads / 2) >= F4 && (threads / 2) / F4 >= Sp) threads /= 2;
+        const int SPW = threads / F4;
+        int nb = ceil_div(to_nodes ? Sp : S, SPW);
+        if (nb > 1024) nb = 1024;                          // ~4 workgroups per CU, each walking consecutive passes (cf. diffuse_fwd)
+        if (to_nodes) EEG_LAUNCH_P(tag, spec_mix_in_kernel<19>, dim3(nb), dim3(threads), 0, st, in, basis, S, Sp, F, bt, T, B, out);
+        else EEG_LAUNCH_P(tag, spec_mix_out_kernel<19>, dim3(nb), dim3(threads), 0, st, in, basis, bias, S, Sp, F, bt, T, B, out);
+    } else {
+        const size_t total = (size_t)(to_nodes ? Sp : S) * N * F4;
+        int nb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        EEG_LAUNCH_P(tag, spec_mix_generic_kernel, dim3(nb), dim3(256), (size_t)N * N * sizeof(float), st, in, basis, bias, N, S, Sp, F, bt,
+                     T, B, to_nodes, out);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wstride, int nct, float* C, int num_cus, hipStream_t st,
+               const char* tag) {
+    const size_t lds = (size_t)4 * 128 * 16 * sizeof(float);
+    const int RT = (Sp / 16) * G;
+    int Gw = 2 * (num_cus > 0 ? num_cus : 256);
+    if (Gw > ceil_div(RT, 8)) Gw = ceil_div(RT, 8);
+    if (Gw < 1) Gw = 1;
+    if (nct == 12) {
+        EEG_SET_MAX_LDS((gemm_nng_kernel<3, 2>), lds);
+        EEG_LAUNCH_P(tag, (gemm_nng_kernel<3, 2>), dim3(Gw), dim3(256), lds, st, A, F, Sp, G, Wq, (unsigned)wstride, C, 16 * nct);
+    } else if (nct == 4) {
+        EEG_SET_MAX_LDS((gemm_nng_kernel<1, 2>), lds);
+        EEG_LAUNCH_P(tag, (gemm_nng_kernel<1, 2>), dim3(Gw), dim3(256), lds, st, A, F, Sp, G, Wq, (unsigned)wstride, C, 16 * nct);
+    } else {
+        return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+TngPlan tng_plan(int F, int Sp, int G, int num_cus) {
+    TngPlan p{};
+    if (F < 4 || F % 4 != 0 || Sp < 16 || Sp % 16 != 0 || G < 1) return p;
+    if (F == 64) {
+        p.planar = 1; p.KT = 2; p.nkb = 1;
+    } else {                                               // per-lane source pointers, k-blocks of 4 or 5 tiles per wave slice: least padded K
+        int best = 5, bcost = 1 << 30, bnkb = 1;
+        for (int kt = 5; kt >= 4; --kt) {
+            const int nkb = ceil_div(F, 32 * kt), cost = nkb * 32 * kt;
+            if (cost < bcost) { best = kt; bcost = cost; bnkb = nkb; }
+        }
+        p.KT = best; p.nkb = bnkb;
+    }
+    const int target = 2 * (num_cus > 0 ? num_cus : 256);
+    int spg = target / (G * p.nkb);
+    if (spg < 1) spg = 1;
+    int rps = round_up(ceil_div(Sp, spg), 16);
+    if (rps < 64) rps = 64;
+    if (rps > Sp) rps = Sp;
+    p.rps = rps;
+    p.spg = ceil_div(Sp, rps);
+    p.ok = 1;
+    return p;
+}
+
+namespace {
+template <int KT, bool PLANAR>
+int launch_tng_one(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag) {
+    constexpr int RC = 16, OT = 6;
+    const size_t lds = 3 * (size_t)(RC * 32 * (KT + OT)) * sizeof(float);
+    SegPtrs segs;
+    for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? A : nullptr;
+    EEG_SET_MAX_LDS((gemm_tnq_grouped_kernel<KT, OT, RC, PLANAR>), lds);
+    EEG_LAUNCH_P(tag, (gemm_tnq_grouped_kernel<KT, OT, RC, PLANAR>), dim3(p.nkb, G * p.spg), dim3(256), lds, st, segs, F, Sp, G, p.spg, dY, 192,
+                 192, partial, p.rps);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+}  // namespace
+
+int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag) {
+    if (!p.ok) return 1;
+    if (p.planar) return launch_tng_one<2, true>(p, A, F, Sp, G, dY, partial, st, tag);
+    if (p.KT == 4) return launch_tng_one<4, false>(p, A, F, Sp, G, dY, partial, st, tag);
+    return launch_tng_one<5, false>(p, A, F, Sp, G, dY, partial, st, tag);
+}
+
+}  // namespace eeg

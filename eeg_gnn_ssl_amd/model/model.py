@@ -83,6 +83,9 @@ class DCRNNEncoder(nn.Module):
         t_len, b = inputs.shape[0], inputs.shape[1]
         self.encoding_cells[0]._check_supports(supports)
         p, p_batched = ops.hop_polys(supports, self.max_diffusion_step, b)
+        # one symmetric support shared by all clips (given as an (N,N) tensor: the scaled Laplacian of the distance graph): the
+        # hoisted x-part of every layer runs in its eigenbasis (K = Fin instead of M * Fin); else None = the general path
+        basis = ops.shared_spectral_basis(supports, self.max_diffusion_step)
         cur, x_off, planes = inputs.reshape(t_len, b, self.num_nodes, -1), 0, None
         finals, top_sel, out = [], None, None
         for layer, cell in enumerate(self.encoding_cells):
@@ -91,7 +94,7 @@ class DCRNNEncoder(nn.Module):
             # layers >= 1 read the `hext` of the layer below (slots 1..T) and take its hop planes as their own
             # (a layer's final state is only copied out when somebody reads it: `finals`, or the top state at len-1)
             out = cell.run_sequence(cur, h0, p, p_batched, lengths if is_top else None, x_off, planes,
-                                    want_hsel=want_finals or (is_top and lengths is not None))
+                                    want_hsel=want_finals or (is_top and lengths is not None), basis=basis)
             if is_top and lengths is not None:
                 top_sel = out.hsel
                 finals.append(out.hext[t_len] if want_finals else None)

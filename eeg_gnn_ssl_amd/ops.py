@@ -59,9 +59,16 @@ def _pack_base_floats(fin, h, m) -> int:
 
 
 def _set_pack3(dims, pack, fin, h, m):
-    """point dims.pack3 at the bf16 term packs behind the fp32 part of `pack` (mode 1, supported cell sizes)"""
-    if _pack3_halves(fin, h, m) > 0:
-        dims.pack3 = pack.data_ptr() + 4 * _pack_base_floats(fin, h, m)
+    """point dims.pack3 at the bf16 term packs behind the fp32 part of `pack` -- decided by what THIS pack tensor carries (it was
+    built under the mode of its forward call), not by the mode at the time of the call: a backward that runs after `set_gemm_mode`
+    changed keeps the arithmetic of its forward and never addresses past the end of a pack built without the term packs."""
+    base = _pack_base_floats(fin, h, m)
+    halves = int(_lib.get_lib().query("eeg_dcrnn_pack3_halves", int(fin), int(h), int(m)))
+    if halves > 0 and pack.numel() >= base + (halves + 1) // 2:
+        dims.pack3 = pack.data_ptr() + 4 * base
+    elif pack.numel() != base:
+        raise RuntimeError(f"weight pack has {pack.numel()} floats, expected {base} (fp32) or {base + (halves + 1) // 2} (with the "
+                           f"bf16 term packs) for input_dim={fin}, num_units={h}, num_matrices={m}")
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -231,6 +238,61 @@ _define("pack_cell", "(Tensor wg, Tensor bg, Tensor wc, Tensor bc, int fin, int 
         lambda wg, bg, wc, bc, fin, h, m: wg.new_empty((_pack_floats(fin, h, m),)))
 
 
+# ---- spectral form of the hoisted x-part for ONE shared symmetric support (include/eeg_dcrnn.h: eeg_layer_dims.spectral) ----------
+# 1 (default): layers whose supports are given as ONE 2-D (N,N) tensor -- i.e. declared shared by the batch -- and turn out
+# symmetric run their hoisted x-part in the eigenbasis of the support (K = Fin instead of M*Fin); 0: always the general path.
+SPECTRAL_MODE = 0 if _os.environ.get("EEG_DCRNN_SPECTRAL", "1") in ("", "0") else 1
+SPECTRAL_TOL = 2e-6          # largest |S - U diag(lam) U^T| (relative to max |S|) for which a support counts as symmetric
+
+
+def set_spectral_mode(mode: int) -> int:
+    """0 = general path everywhere, 1 = spectral form for shared symmetric supports (default).  Returns the previous mode."""
+    global SPECTRAL_MODE
+    prev, SPECTRAL_MODE = SPECTRAL_MODE, 1 if mode else 0
+    return prev
+
+
+def _spectral_basis_impl(support) -> torch.Tensor:
+    lib = _lib.get_lib()
+    sup = support.to(torch.float32).contiguous()
+    _check(lib, sup, "support")
+    if sup.dim() != 2 or sup.shape[0] != sup.shape[1]:
+        raise RuntimeError(f"spectral_basis: support has shape {tuple(sup.shape)}, expected (num_nodes, num_nodes)")
+    n = sup.shape[0]
+    out = _new((lib.query("eeg_dcrnn_spectral_basis_floats", n),), sup)
+    lib.call("eeg_dcrnn_spectral_basis", _p(sup), n, _p(out), _stream(sup))
+    return out
+
+
+def _spectral_basis_floats(n):
+    return int(_lib.get_lib().query("eeg_dcrnn_spectral_basis_floats", int(n)))
+
+
+_define("spectral_basis", "(Tensor support) -> Tensor", _spectral_basis_impl,
+        lambda support: support.new_empty((_spectral_basis_floats(support.shape[0]),), dtype=torch.float32))
+
+
+def _pack_cell_spectral_impl(wg, wc, basis, fin: int, h: int, m: int, n: int) -> torch.Tensor:
+    lib = _lib.get_lib()
+    wg, wc = wg.detach(), wc.detach()
+    for t, nm in ((wg, "dconv_gate.weight"), (wc, "dconv_candidate.weight"), (basis, "basis")):
+        _check(lib, t, nm)
+    rows = (fin + h) * m
+    if tuple(wg.shape) != (rows, 2 * h) or tuple(wc.shape) != (rows, h) or basis.numel() != _spectral_basis_floats(n):
+        raise RuntimeError(f"pack_cell_spectral: operands {tuple(wg.shape)}, {tuple(wc.shape)}, basis {tuple(basis.shape)} do not match "
+                           f"input_dim={fin}, num_units={h}, num_matrices={m}, num_nodes={n}")
+    size = lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)
+    if size == 0:
+        raise RuntimeError(f"pack_cell_spectral: the spectral form exists for 64 units (got num_units={h}, input_dim={fin})")
+    out = _new((size,), wg)
+    lib.call("eeg_dcrnn_pack_cell_spectral", _p(wg), _p(wc), _p(basis), fin, h, m, n, _p(out), _stream(out))
+    return out
+
+
+_define("pack_cell_spectral", "(Tensor wg, Tensor wc, Tensor basis, int fin, int h, int m, int n) -> Tensor", _pack_cell_spectral_impl,
+        lambda wg, wc, basis, fin, h, m, n: wg.new_empty((int(_lib.get_lib().query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)),)))
+
+
 def _diffusion_hops_impl(x, p, p_batched: int, batch: int) -> torch.Tensor:
     lib = _lib.get_lib()
     _check(lib, x, "x")
@@ -368,11 +430,13 @@ def _layer_dims(t_len, b, n, h, fin, m, act, p_batched, planes_ready):
 
 
 def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, lengths, x_planes, n: int, h: int, m: int,
-                      act: int, save: bool, want_hsel: bool):
+                      act: int, save: bool, want_hsel: bool, basis=None):
     """x: (T + x_off, B, N, Fin) — x_off = 1 when x is the `hext` of the layer below (its slot 0 is that layer's
     initial state), whose `hpl` output is then passed as x_planes.  Returns hext (T+1, B, N*H) (slot 0 = initial
     state, slot t+1 = h_t), hsel (B, N*H) = h at t = lengths-1 (T-1 without lengths) and the tensors the backward
-    needs: [xtm, pack, planes, rs, us, cs, rhs, hpl, rhpl] (numel-0 placeholders where nothing is kept)."""
+    needs: [xtm, pack, planes, rs, us, cs, rhs, hpl, rhpl, spack] (numel-0 placeholders where nothing is kept).
+    basis (`spectral_basis` of the ONE symmetric support all clips share; p_batched must be 0): the hoisted x-part runs in the
+    eigenbasis of the support; `planes` is then the node-major transformed input (N, Sp, Fin) and spack the per-frequency packs."""
     lib = _lib.get_lib()
     if x.dim() != 4 or x.shape[2] != n:
         raise RuntimeError(f"inputs have shape {tuple(x.shape)}, expected (T, B, num_nodes={n}, input_dim)")
@@ -385,14 +449,20 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     if h0 is not None and h0.numel() != b * n * h:
         raise RuntimeError(f"initial_hidden_state has shape {tuple(h0.shape)}, expected ({b}, {n * h})")
     ready = x_planes is not None
+    spec = basis is not None
     dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, ready)
+    if spec:
+        _check(lib, basis, "basis")
+        if ready or p_batched or basis.numel() != _spectral_basis_floats(n) or not lib.query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), 0):
+            raise RuntimeError("dcgru_layer: the spectral form needs one shared support (p_batched = 0), no handed-over hop planes and "
+                               "a shape eeg_dcrnn_spectral_ok accepts")
     empty = _new((0,), p)
     # a transposed view of a contiguous batch-major (B,T,N,Fin) tensor (what model.py:253 produces) is consumed
     # as it is: the diffusion kernel emits the time-major copy as a by-product
     xsrc, xtm = None, None
     bm = 0
     if not x.is_contiguous() and x_off == 0 and not ready and x.transpose(0, 1).is_contiguous():
-        bm = lib.query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims))
+        bm = 2 if spec else lib.query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims))   # (the spectral node mix reads any row order)
     if bm:
         xsrc = x.transpose(0, 1)
         _check(lib, xsrc, "inputs")
@@ -415,7 +485,13 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     pack = torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
     _set_pack3(dims, pack, fin, h, m)
     s = t_len * b
-    if ready:
+    spack = empty
+    if spec:
+        spack = torch.ops.eeg_dcrnn.pack_cell_spectral(wg, wc, basis, fin, h, m, n)
+        dims.spectral, dims.spack = basis.data_ptr(), spack.data_ptr()
+        planes = _new((n, lib.query("eeg_dcrnn_spectral_rows", s), fin), x)
+        planes_ptr = planes.data_ptr()
+    elif ready:
         _check(lib, x_planes, "x_planes")
         if tuple(x_planes.shape) != (m - 1, t_len + 1, b, n, fin):
             raise RuntimeError(f"x_planes has shape {tuple(x_planes.shape)}, expected {(m - 1, t_len + 1, b, n, fin)}")
@@ -442,10 +518,10 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
         hsel = _new((0,), x)           # nobody reads the final state of this layer (a lower layer of the classification model)
     if not save:
         return hext, hsel, []
-    return hext, hsel, [xtm if xtm is not None else empty, pack, planes, rs, us, cs, rhs, hpl, rhpl]
+    return hext, hsel, [xtm if xtm is not None else empty, pack, planes, rs, us, cs, rhs, hpl, rhpl, spack]
 
 
-def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel):
+def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel, basis=None):
     t_len, b, fin = x.shape[0] - x_off, x.shape[1], x.shape[3]
     ne = lambda *shape: x.new_empty(shape)   # noqa: E731
     hext, hsel = ne(t_len + 1, b, n * h), (ne(b, n * h) if (want_hsel or lengths is not None) else ne(0))
@@ -455,18 +531,24 @@ def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_pla
     # tensor at a layer without handed-over planes where the kernels read it through a row map: exactly when the library's host-side
     # predicate eeg_dcrnn_batch_major_ok says 2 (1: the diffusion kernel emits the time-major copy, 0: torch copies; both keep xtm)
     zero_copy = False
+    spec = basis is not None
     if not x.is_contiguous() and x_off == 0 and x_planes is None and x.transpose(0, 1).is_contiguous():
         dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, False)
-        zero_copy = _lib.get_lib().query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)) == 2
+        zero_copy = spec or _lib.get_lib().query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)) == 2
     xtm = ne(t_len, b, n, fin) if (not x.is_contiguous() and not zero_copy) else ne(0)
     planes = ne(0) if x_planes is not None else ne(m - 1, t_len * b, n, fin)
+    spack = ne(0)
+    if spec:
+        lib = _lib.get_lib()
+        planes = ne(n, int(lib.query("eeg_dcrnn_spectral_rows", t_len * b)), fin)
+        spack = ne(int(lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)))
     return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + \
-        [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)]
+        [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)] + [spack]
 
 
 def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack, planes, x_planes, hext, rs, us, cs, rhs,
                           hpl, rhpl, lengths, has_h0: bool, n: int, h: int, m: int, act: int, need_dx: bool, need_dh0: bool,
-                          dwg, dbg, dwc, dbc):
+                          dwg, dbg, dwc, dbc, basis=None, spack=None):
     """BPTT + all parameter gradients of one layer.  d_hext (T+1,B,N*H) w.r.t. hext (slot 0 is ignored), d_hsel
     (B,N*H) w.r.t. hsel.  dwg/dbg/dwc/dbc are overwritten.  Returns (dx (T + x_off, B, N, Fin) with the step
     gradients in slots x_off.., dh0 (B,N*H)) — numel-0 tensors where not requested."""
@@ -480,6 +562,11 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
         dims.x_batch_major = 1
     planes_ptr = x_planes.data_ptr() + 4 * b * n * fin if ready else planes.data_ptr()
     _set_pack3(dims, pack, fin, h, m)
+    if basis is not None:                 # the forward ran the spectral form: `planes` is its node-major transformed input
+        if spack is None or ready or not lib.query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), 1 if need_dx else 0):
+            raise RuntimeError("dcgru_layer_bwd: the spectral form does not cover this call (input gradient of a layer whose "
+                               "input width is not 64?)")
+        dims.spectral, dims.spack = basis.data_ptr(), spack.data_ptr()
     state = b * n * h
     if d_hext is not None:
         d_hext = d_hext.contiguous()
@@ -506,7 +593,7 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
 
 
 def _dcgru_layer_bwd_fake(d_hext, d_hsel, x, x_off, p, p_batched, pack, planes, x_planes, hext, rs, us, cs, rhs, hpl, rhpl,
-                          lengths, has_h0, n, h, m, act, need_dx, need_dh0, dwg, dbg, dwc, dbc):
+                          lengths, has_h0, n, h, m, act, need_dx, need_dh0, dwg, dbg, dwc, dbc, basis=None, spack=None):
     t_len, b, fin = hext.shape[0] - 1, hext.shape[1], x.shape[3]
     return (hext.new_empty((t_len + x_off, b, n, fin) if need_dx else (0,)),
             hext.new_empty((b, n * h) if (need_dh0 and has_h0) else (0,)))
@@ -514,32 +601,35 @@ def _dcgru_layer_bwd_fake(d_hext, d_hsel, x, x_off, p, p_batched, pack, planes, 
 
 _define("dcgru_layer",
         "(Tensor x, int x_off, Tensor? h0, Tensor P, int p_batched, Tensor wg, Tensor bg, Tensor wc, Tensor bc, Tensor? lengths, "
-        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel) -> (Tensor hext, Tensor hsel, Tensor[] saved)",
+        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel, Tensor? basis=None) -> "
+        "(Tensor hext, Tensor hsel, Tensor[] saved)",
         _dcgru_layer_impl, _dcgru_layer_fake)
 _define("dcgru_layer_bwd",
         "(Tensor? d_hext, Tensor? d_hsel, Tensor x, int x_off, Tensor P, int p_batched, Tensor pack, Tensor planes, Tensor? x_planes, "
         "Tensor hext, Tensor rs, Tensor us, Tensor cs, Tensor rhs, Tensor hpl, Tensor rhpl, Tensor? lengths, bool has_h0, int n, int h, "
-        "int m, int act, bool need_dx, bool need_dh0, Tensor(a!) dwg, Tensor(b!) dbg, Tensor(c!) dwc, Tensor(d!) dbc) -> (Tensor, Tensor)",
+        "int m, int act, bool need_dx, bool need_dh0, Tensor(a!) dwg, Tensor(b!) dbg, Tensor(c!) dwc, Tensor(d!) dbc, "
+        "Tensor? basis=None, Tensor? spack=None) -> (Tensor, Tensor)",
         _dcgru_layer_bwd_impl, _dcgru_layer_bwd_fake)
 
 
 def _dcgru_layer_setup(ctx, inputs, output):
-    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel) = inputs
+    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel) = inputs[:17]
+    basis = inputs[17] if len(inputs) > 17 else None
     hext, _, saved = output
     ctx.set_materialize_grads(False)
-    ctx.saved_ok = bool(save) and len(saved) == 9
+    ctx.saved_ok = bool(save) and len(saved) == 10
     ctx.meta = (x_off, p_batched, n, h, m, act, h0 is not None)
     ctx.params = (wg, bg, wc, bc)
     if ctx.saved_ok:
         xtm = saved[0]
         lens = None if lengths is None else lengths.to(device=x.device, dtype=torch.int64).contiguous()
-        ctx.save_for_backward(xtm if xtm.numel() else x, p, x_planes, lens, hext, *saved[1:])
+        ctx.save_for_backward(xtm if xtm.numel() else x, p, x_planes, lens, basis, hext, *saved[1:])
 
 
 def _dcgru_layer_backward(ctx, d_hext, d_hsel, d_saved):
     if not ctx.saved_ok:
         raise RuntimeError("eeg_dcrnn::dcgru_layer was run with save=False: nothing was kept for the backward pass")
-    xk, p, x_planes, lens, hext, pack, planes, rs, us, cs, rhs, hpl, rhpl = ctx.saved_tensors
+    xk, p, x_planes, lens, basis, hext, pack, planes, rs, us, cs, rhs, hpl, rhpl, spack = ctx.saved_tensors
     x_off, p_batched, n, h, m, act, has_h0 = ctx.meta
     need_dx, need_dh0 = ctx.needs_input_grad[0], has_h0 and ctx.needs_input_grad[2]
     fin = xk.shape[3]
@@ -548,9 +638,11 @@ def _dcgru_layer_backward(ctx, d_hext, d_hsel, d_saved):
     sunk = [GradSink.take(q) for q in ctx.params]           # written in place -> nothing for autograd to add
     bufs = [t if t is not None else _new(sh, hext) for t, sh in zip(sunk, shapes)]
     dx, dh0 = torch.ops.eeg_dcrnn.dcgru_layer_bwd(d_hext, d_hsel, xk, x_off, p, p_batched, pack, planes, x_planes, hext,
-                                                  rs, us, cs, rhs, hpl, rhpl, lens, has_h0, n, h, m, act, need_dx, need_dh0, *bufs)
+                                                  rs, us, cs, rhs, hpl, rhpl, lens, has_h0, n, h, m, act, need_dx, need_dh0, *bufs,
+                                                  basis, spack if basis is not None else None)
     ret = [None if t is not None else g for t, g in zip(sunk, bufs)]
-    return (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None, None)
+    return (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None, None,
+            None)
 
 
 torch.library.register_autograd(f"{NS}::dcgru_layer", _dcgru_layer_backward, setup_context=_dcgru_layer_setup, lib=_libdef)
@@ -1066,18 +1158,60 @@ class LayerOut:
 
 
 def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None, x_planes=None,
-                   want_hsel=True) -> LayerOut:
+                   want_hsel=True, basis=None) -> LayerOut:
     """One DCGRU layer over x (T + x_off, B, N, Fin).  x_off = 1 / x_planes: x is the `hext` of the layer below and
     x_planes its `hpl` (the layer then skips its own diffusion pass).  want_hsel=False: the caller does not read the layer's
-    final state (hsel comes back empty; saves one copy per step)."""
+    final state (hsel comes back empty; saves one copy per step).  basis (`shared_spectral_basis`): the hoisted x-part of the
+    layer runs in the eigenbasis of the shared symmetric support where the kernels cover the shape (else the general path)."""
     act = ACT_CODES.get(activation, 1)
     save = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, h0, wg, bg, wc, bc))
+    if basis is not None:
+        need_dx = 1 if (save and x.requires_grad) else 0
+        dims = _layer_dims(x.shape[0] - x_off, x.shape[1], n, h, x.shape[3], m, act, int(p_batched), False)
+        if p_batched or not _lib.get_lib().query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), need_dx):
+            basis = None
+        else:
+            x_planes = None                # the spectral layer transforms its own input: no hop-plane hand-over
     if x_planes is not None:
         global hop_plane_handovers
         hop_plane_handovers += 1
     hext, hsel, saved = torch.ops.eeg_dcrnn.dcgru_layer(x, int(x_off), h0, p, int(p_batched), wg, bg, wc, bc, lengths, x_planes,
-                                                        n, h, m, act, save, bool(want_hsel))
+                                                        n, h, m, act, save, bool(want_hsel), basis)
     return LayerOut(hext, hsel, saved[7].detach() if save else None)
+
+
+# (data_ptr, version, device, shape) of a support tensor -> (weakref to it, basis or None): the eigenbasis is a pure function of the
+# support, the distance graph is one constant tensor for a whole run, and its residual has to be READ once (a device-to-host
+# synchronisation) to know that the support is symmetric -- neither belongs into a training step.
+_basis_cache = {}
+
+
+def shared_spectral_basis(supports, max_diffusion_step: int):
+    """The eigenbasis block of the support when the spectral form applies: exactly ONE support, given as a 2-D (N,N) tensor
+    (= declared shared by all clips; batched supports always take the general path), at least one diffusion step, and
+    |S - U diag(lam) U^T| at rounding level (S symmetric: filter_type "laplacian" on an undirected graph).  Else None.
+    The first call for a support synchronises once to read the residual; under stream capture an unseen support gets None."""
+    if not SPECTRAL_MODE or max_diffusion_step < 1 or len(supports) != 1:
+        return None
+    sup = supports[0]
+    if sup.dim() != 2 or sup.shape[0] != sup.shape[1] or sup.shape[0] < 2 or sup.shape[0] > 32:
+        return None
+    import weakref
+    key = (sup.data_ptr(), sup._version, str(sup.device), tuple(sup.shape), sup.dtype)
+    hit = _basis_cache.get(key)
+    if hit is not None and hit[0]() is sup:
+        return hit[1]
+    if sup.is_cuda and torch.cuda.is_current_stream_capturing():
+        return None
+    if len(_basis_cache) > 64:
+        for k in [k for k, v in _basis_cache.items() if v[0]() is None]:
+            del _basis_cache[k]
+    basis = torch.ops.eeg_dcrnn.spectral_basis(sup)
+    n = sup.shape[0]
+    info = basis[n * n + 256:n * n + 259].tolist()        # residual, off-diagonal left, max |S|  (one synchronisation per support)
+    ok = info[0] <= SPECTRAL_TOL * max(info[2], 1e-30) and info[1] <= 1e-9 * max(info[2], 1e-30)
+    _basis_cache[key] = (weakref.ref(sup), basis if ok else None)
+    return basis if ok else None
 
 
 def dcgru_layer(x, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None):

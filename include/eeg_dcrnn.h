@@ -50,6 +50,17 @@ typedef struct eeg_layer_dims {
                                 (6 of the 9 partial products) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32 operands and
                                 results, error against an fp64 sum at the level of the fp32 matrix pipe's own (~2e-6 on values
                                 of a few units), 1.3-1.4 x its speed.  Everything else of the layer is unchanged. */
+    const float* spectral;   /* NULL = off.  Else: the eeg_dcrnn_spectral_basis block of the ONE symmetric support all clips share
+                                (p_batched = 0; the scaled Laplacian of the distance graph, filter_type "laplacian") and `spack` the
+                                cell's per-frequency weight packs (eeg_dcrnn_pack_cell_spectral).  The hoisted x-part of the layer
+                                then runs in the eigenbasis of the support: all hop matrices are Chebyshev polynomials of one
+                                symmetric S = U diag(lam) U^T (cell.py:83-93), so sum_m P_m X W_m = U [ (U^T X)_i Wt_i ]_i with
+                                Wt_i = sum_m T_m(lam_i) W_m -- the GEMMs contract over Fin instead of M*Fin, framed by two HBM-bound
+                                node mixes; backward likewise.  Exact up to re-association (~1e-6); the recurrence is unchanged.
+                                Only where eeg_dcrnn_spectral_ok() says so.  `planes` of layer_fwd / layer_bwd is then the
+                                node-major transformed input Xh (N, eeg_dcrnn_spectral_rows(T*B), Fin) (written by layer_fwd, read
+                                by layer_bwd) and x_planes_ready must be 0. */
+    const float* spack;
 } eeg_layer_dims;
 
 typedef struct eeg_decoder_dims {
@@ -113,6 +124,23 @@ int eeg_dcrnn_pack_cell(const float* Wg, const float* bg, const float* Wc, const
  * eeg_dcrnn_pack3_halves() 16-bit elements; available for rnn_units = 64 (else 0 / an error). */
 size_t eeg_dcrnn_pack3_halves(int Fin, int H, int M);
 int eeg_dcrnn_pack_cell_bf16x3(const float* Wg, const float* Wc, int Fin, int H, int M, uint16_t* pack3, void* stream);
+
+/* Spectral form of the hoisted x-part for a shared symmetric support (eeg_layer_dims.spectral).
+ *   eeg_dcrnn_spectral_basis: support (N,N) -> basis block of eeg_dcrnn_spectral_basis_floats(N) floats:
+ *       U (N*N; column i = eigenvector i) | T_m(lam_i) as [8][32] | info[32]: info[0] = max |S - U diag(lam) U^T| (it contains the
+ *       asymmetry of S: a caller reads it ONCE per support and keeps the general path when it is not at rounding level),
+ *       info[1] = largest off-diagonal left by the Jacobi sweeps, info[2] = max |S|.  One workgroup, fp64, ~50 us: once per
+ *       support, not per step.
+ *   eeg_dcrnn_pack_cell_spectral: the cell's x-part weights (reference layout) -> per-frequency packs Wt_i, Wt_i^T.
+ *   eeg_dcrnn_spectral_ok: 1 if layer_fwd / layer_bwd (with or without an input gradient) take d->spectral for this shape
+ *       (64 units, Fin % 4 == 0; need_dx: Fin == 64), else 0.  eeg_dcrnn_spectral_rows(S) = rows per frequency (S rounded up to 16). */
+size_t eeg_dcrnn_spectral_basis_floats(int N);
+int eeg_dcrnn_spectral_basis(const float* support, int N, float* basis, void* stream);
+size_t eeg_dcrnn_spectral_pack_floats(int Fin, int H, int M, int N);
+int eeg_dcrnn_pack_cell_spectral(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N,
+                                 float* spack, void* stream);
+int eeg_dcrnn_spectral_ok(const eeg_layer_dims* d, int need_dx);
+size_t eeg_dcrnn_spectral_rows(size_t S);
 
 /* The HBM-bound diffusion step over all samples: planes[m-1][s] = P_m X_s  (cell.py:83-93 applied
  * to the input features of every time step at once).  Algorithmic bytes: 4*S*N*F*M. */

@@ -40,6 +40,7 @@ def build(force=False):
     units = [("api", os.path.join(CSRC, "api.cpp"), []),
              ("emu_impl", os.path.join(HERE, "emu_impl.cpp"), [])]
     units.append(("gemmq", os.path.join(CSRC, "gemmq_inst.cpp"), []))
+    units.append(("spec", os.path.join(CSRC, "spec_inst.cpp"), []))
     units.append(("dec", os.path.join(CSRC, "dec_inst.cpp"), []))
     units.append(("decb", os.path.join(CSRC, "decb_inst.cpp"), []))
     units.append(("seqs", os.path.join(CSRC, "seqs_inst.cpp"), []))

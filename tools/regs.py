@@ -12,6 +12,8 @@ unit = sys.argv[1] if len(sys.argv) > 1 else "api"
 filt = sys.argv[2:]
 if unit == "api":
     src, extra = "api.cpp", []
+elif unit in ("spec", "gemmq"):
+    src, extra = unit + "_inst.cpp", []
 elif unit in ("dec", "decb", "seqs"):
     src, extra = unit + "_inst.cpp", ["-fno-slp-vectorize"]
 else:
