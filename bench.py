@@ -118,7 +118,15 @@ def synthetic_batch(task, filter_type, t_len, batch, classes, seed, host_support
     return x, y, lengths, supports
 
 
-def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS, raw=False):
+HBM_ROLES = ("corr_gram", "fft_features")
+
+
+def is_hbm_role(name):
+    """roles priced in bytes against the HBM roof (everything else: FLOPs against the fp32-MFMA roof)"""
+    return "diffuse" in name or "spec_mix" in name or name in HBM_ROLES
+
+
+def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS, raw=False, spectral=False):
     """Per-step algorithmic FLOPs / bytes of every profiled kernel role.  Roles = the names the
     library's event recorder uses; at the benchmark shapes each role is ONE kernel symbol per layer
     (reported by the library's recorder with every launch), so `roofline.kernels` carries the symbols and `roofline.by_symbol`
@@ -141,6 +149,17 @@ def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS,
         w["gemm_tn_x"] += 2.0 * r * (m * fin) * 3 * h
         w["gemm_tn_hg"] += 2.0 * r * (m * h) * 2 * h
         w["gemm_tn_hc"] += 2.0 * r * (m * h) * h
+        if spectral:
+            # spectral form of the hoisted x-part (shared symmetric support; csrc/spec_common.h): the GEMMs contract over Fin, not
+            # M * Fin (EXECUTED FLOPs), framed by HBM-bound node mixes (bytes = every operand read once + every result written once)
+            w["gemm_nn_xw"] += 2.0 * r * fin * 3 * h - 2.0 * r * (m * fin) * 3 * h
+            w["gemm_tn_x"] += 2.0 * r * fin * 3 * h - 2.0 * r * (m * fin) * 3 * h
+            for k_, wd in (("spec_mix_x", fin), ("spec_mix_y", 3 * h), ("spec_mix_dy", 3 * h)):
+                w[k_] = w.get(k_, 0.0) + 2 * 4.0 * r * wd
+            if l > 0:
+                w["gemm_nn_dx"] += 2.0 * r * 3 * h * fin
+                w["spec_mix_dx"] = w.get("spec_mix_dx", 0.0) + 2 * 4.0 * r * fin
+            continue
         # layer 0 only (the layers above take their input planes from the recurrent kernel below): SURVEY.md §8(d)'s
         # bytes = read X once, write M-1 planes
         if l == 0:
@@ -189,7 +208,7 @@ def synthetic_raw_signals(batch, t_len, seed):
     return torch.from_numpy((20.0 * np.einsum("bnk,bkt->bnt", mix, src) + 5.0 * noise).astype(np.float32))
 
 
-def per_launch_work(filter_type, t_len, batch, layers=LAYERS):
+def per_launch_work(filter_type, t_len, batch, layers=LAYERS, spectral=False):
     """Encoder roles: the algorithmic work of every launch of a step IN LAUNCH ORDER (forward roles bottom-up, backward roles
     top-down), so that a role whose layers run different kernel instantiations (e.g. `gemm_tn_x`: batch-major layer 0, planar
     above) can be priced per SYMBOL.  Sums equal algorithmic_work()."""
@@ -207,6 +226,12 @@ def per_launch_work(filter_type, t_len, batch, layers=LAYERS):
            "gemm_tn_hc": [2.0 * r * (m * h) * h for _ in fins],
            "gemm_nn_dx": [2.0 * r * 3 * h * (m * fin) for fin in fins[1:]],
            "diffuse_adj": [4.0 * s * n * fin * (m + 1) for fin in fins[1:]]}
+    if spectral:
+        fwd = {"seq_fwd": fwd["seq_fwd"], "gemm_nn_xw": [2.0 * r * fin * 3 * h for fin in fins],
+               "spec_mix_x": [8.0 * r * fin for fin in fins], "spec_mix_y": [8.0 * r * 3 * h for _ in fins]}
+        bwd.update({"gemm_tn_x": [2.0 * r * fin * 3 * h for fin in fins], "gemm_nn_dx": [2.0 * r * 3 * h * fin for fin in fins[1:]],
+                    "spec_mix_dy": [8.0 * r * 3 * h for _ in fins], "spec_mix_dx": [8.0 * r * fin for fin in fins[1:]]})
+        bwd.pop("diffuse_adj")
     out = dict(fwd)
     out.update({k: v[::-1] for k, v in bwd.items()})
     return out
@@ -670,8 +695,9 @@ def measure(ctx, workload, steps, warmup, primary):
 
     ms_per_step = elapsed / steps * 1e3
     clips_per_s = batch * world / (elapsed / steps)
-    work = algorithmic_work(filt, t_len, batch, task, layers, raw=raw_in)
-    launch_work = per_launch_work(filt, t_len, batch, layers)
+    spectral = any(k.startswith("spec_mix") for k in prof)      # the encoder ran the spectral form of its hoisted x-part
+    work = algorithmic_work(filt, t_len, batch, task, layers, raw=raw_in, spectral=spectral)
+    launch_work = per_launch_work(filt, t_len, batch, layers, spectral=spectral)
     merge_paired_roles(work, launch_work, prof)
 
     def rate(w, ms, hbm):
@@ -691,7 +717,7 @@ def measure(ctx, workload, steps, warmup, primary):
                "avg_launch_ms": round(per_step_ms / (cnt / steps), 4)}
         syms = pr["symbols"]
         ent["symbol"] = " + ".join(syms)
-        hbm = "diffuse" in name or name in ("corr_gram", "fft_features")
+        hbm = is_hbm_role(name)
         priced = name in work and work[name] > 0 and per_step_ms > 0
         if priced:
             ent.update(rate(work[name], per_step_ms, hbm))
@@ -748,7 +774,7 @@ def measure(ctx, workload, steps, warmup, primary):
         by_class = {k: {"ms_per_step": round(v["ms_per_step"], 4),
                         "frac": round(v["work"] / (v["ms_per_step"] * 1e-3) / (PEAK_HBM_GBS * 1e9 if v["bound"] == "hbm" else PEAK_MFMA_F32_TFLOPS * 1e12), 4)}
                     for k, v in classes_ms.items()}
-        flops = sum(v for k, v in work.items() if "diffuse" not in k and k not in ("corr_gram", "fft_features") and not k.endswith("_persist"))
+        flops = sum(v for k, v in work.items() if not is_hbm_role(k) and not k.endswith("_persist"))
         # frac_at_held_clock: the fraction of the cycles the chip actually ran.  For the two-wave recurrent kernels the clock is
         # sampled INSIDE the kernel (eeg_dcrnn_prof_clock_samples), for the others by the MFMA-burn probe behind the timed steps.
         # In steady state both read 2.37-2.42 GHz (the peak is a 2.4 GHz figure); a process that has just started runs its first

@@ -33,6 +33,10 @@ class _FusedDropout:
 
     def _init_dropout_rng(self, stream_id: int):
         self.register_buffer("_dropout_rng", ops.make_rng_state("cpu", stream_id), persistent=False)
+        # a wrapper that broadcasts buffers (torch DistributedDataParallel, broadcast_buffers=True) must leave the generator state
+        # alone: rank 0's state on every rank would mean identical masks / teacher-forcing flags everywhere, and a collective
+        # inside a forward that may be under graph capture.  (The seed already mixes the rank in: ops.make_rng_state.)
+        self._ddp_params_and_buffers_to_ignore = ["_dropout_rng"]
 
     def _drop_p(self) -> float:
         return float(self.dropout.p) if self.training else 0.0
@@ -217,6 +221,7 @@ class DCRNNModel_nextTimePred(nn.Module):
         self.use_curriculum_learning = bool(args.use_curriculum_learning)
         # device-side scheduled sampling (see forward): what one forward adds to a `batches_seen` counter tensor
         self.batches_seen_increment = 0
+        self._ddp_params_and_buffers_to_ignore = ["decoder._dropout_rng"]     # (see _FusedDropout._init_dropout_rng)
         self.encoder = DCRNNEncoder(input_dim=args.input_dim, max_diffusion_step=args.max_diffusion_step,
                                     hid_dim=args.rnn_units, num_nodes=args.num_nodes,
                                     num_rnn_layers=args.num_rnn_layers,

@@ -485,7 +485,7 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     pack = torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
     _set_pack3(dims, pack, fin, h, m)
     s = t_len * b
-    spack = empty
+    spack = _new((0,), p)            # (its own placeholder: outputs must not alias)
     if spec:
         spack = torch.ops.eeg_dcrnn.pack_cell_spectral(wg, wc, basis, fin, h, m, n)
         dims.spectral, dims.spack = basis.data_ptr(), spack.data_ptr()
@@ -601,20 +601,19 @@ def _dcgru_layer_bwd_fake(d_hext, d_hsel, x, x_off, p, p_batched, pack, planes, 
 
 _define("dcgru_layer",
         "(Tensor x, int x_off, Tensor? h0, Tensor P, int p_batched, Tensor wg, Tensor bg, Tensor wc, Tensor bc, Tensor? lengths, "
-        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel, Tensor? basis=None) -> "
+        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel, Tensor? basis) -> "
         "(Tensor hext, Tensor hsel, Tensor[] saved)",
         _dcgru_layer_impl, _dcgru_layer_fake)
 _define("dcgru_layer_bwd",
         "(Tensor? d_hext, Tensor? d_hsel, Tensor x, int x_off, Tensor P, int p_batched, Tensor pack, Tensor planes, Tensor? x_planes, "
         "Tensor hext, Tensor rs, Tensor us, Tensor cs, Tensor rhs, Tensor hpl, Tensor rhpl, Tensor? lengths, bool has_h0, int n, int h, "
         "int m, int act, bool need_dx, bool need_dh0, Tensor(a!) dwg, Tensor(b!) dbg, Tensor(c!) dwc, Tensor(d!) dbc, "
-        "Tensor? basis=None, Tensor? spack=None) -> (Tensor, Tensor)",
+        "Tensor? basis, Tensor? spack) -> (Tensor, Tensor)",
         _dcgru_layer_bwd_impl, _dcgru_layer_bwd_fake)
 
 
 def _dcgru_layer_setup(ctx, inputs, output):
-    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel) = inputs[:17]
-    basis = inputs[17] if len(inputs) > 17 else None
+    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel, basis) = inputs
     hext, _, saved = output
     ctx.set_materialize_grads(False)
     ctx.saved_ok = bool(save) and len(saved) == 10
@@ -675,7 +674,10 @@ def make_rng_state(device, stream_id: int = 0) -> torch.Tensor:
     (the classification head and the decoder use different ones), drawn from a DEDICATED generator: the global CPU generator
     is not advanced.  Every forward call that drops advances the offset ON THE DEVICE (a replayed HIP graph keeps drawing
     fresh masks)."""
-    g = torch.Generator().manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * int(stream_id)) % (1 << 63))
+    rank = 0
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        rank = torch.distributed.get_rank()           # same-seed ranks draw different masks (as their data shards differ)
+    g = torch.Generator().manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * int(stream_id) + 0xD1B54A32D192ED03 * rank) % (1 << 63))
     seed = int(torch.randint(0, 2 ** 62, (1,), generator=g).item())
     return torch.tensor([seed, 0], dtype=torch.int64, device=device)
 
@@ -1086,8 +1088,10 @@ _define("teacher_flags_", "(Tensor(a!) rng_state, Tensor(b!) samples_seen, int i
 # =============================================================================================
 # Python conveniences used by model/, utils.py and train_step.py
 # =============================================================================================
-# diagnostics: how often a layer took its input hop planes from the recurrent kernel of the layer below
+# diagnostics: how often a layer took its input hop planes from the recurrent kernel of the layer below / ran its hoisted x-part
+# in the eigenbasis of a shared symmetric support
 hop_plane_handovers = 0
+spectral_layer_calls = 0
 
 
 def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: int) -> Tuple[torch.Tensor, int]:
@@ -1100,6 +1104,35 @@ def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: 
         raise RuntimeError("hop_polys: empty supports list")
     flag = 1 if any(s.dim() == 3 for s in sups) else 0
     return torch.ops.eeg_dcrnn.hop_polys(sups, int(max_diffusion_step), int(batch)), flag
+
+
+# id of a batched supports tensor -> (weakref, its 2-D form or None)
+_shared_cache = {}
+
+
+def collapse_shared_supports(supports):
+    """[S (B,N,N)] whose B clips all carry the SAME graph -> [S[0] (N,N)]: the 2-D form declares the graph shared, which is what
+    lets the encoder run the spectral form (`shared_spectral_basis`).  The reference's trainers always pass batched supports, even
+    for the one distance graph, so `TrainStep` asks here.  Anything else (several supports, per-clip graphs, already
+    2-D, spectral mode off) is returned unchanged.  The comparison reads one flag back from the device -- once per supports
+    tensor (cached on its identity and version); under stream capture an unseen tensor is returned unchanged."""
+    if not SPECTRAL_MODE or supports is None or len(supports) != 1 or not torch.is_tensor(supports[0]) or supports[0].dim() != 3:
+        return supports
+    import weakref
+    sup = supports[0]
+    key = (sup.data_ptr(), sup._version, str(sup.device), tuple(sup.shape), sup.dtype)
+    hit = _shared_cache.get(key)
+    if hit is not None and hit[0]() is sup:
+        return supports if hit[1] is None else [hit[1]]
+    if sup.is_cuda and torch.cuda.is_current_stream_capturing():
+        return supports
+    if len(_shared_cache) > 64:
+        for k in [k for k, v in _shared_cache.items() if v[0]() is None]:
+            del _shared_cache[k]
+    same = sup.shape[0] >= 1 and bool((sup == sup[0:1]).all().item())
+    flat = sup[0].to(torch.float32).clone() if same else None
+    _shared_cache[key] = (weakref.ref(sup), flat)
+    return supports if flat is None else [flat]
 
 
 def fft_features(raw: torch.Tensor, window: int = 200, mean: Optional[float] = None, std: Optional[float] = None,
@@ -1172,6 +1205,8 @@ def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activati
             basis = None
         else:
             x_planes = None                # the spectral layer transforms its own input: no hop-plane hand-over
+            global spectral_layer_calls
+            spectral_layer_calls += 1
     if x_planes is not None:
         global hop_plane_handovers
         hop_plane_handovers += 1

@@ -56,8 +56,14 @@ class TrainStep:
     def __init__(self, model: torch.nn.Module, task: str = "detection", lr: float = 3e-4,
                  weight_decay: float = 5e-4, max_grad_norm: float = 5.0,
                  scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None,
-                 always_reduce: bool = False, raw_window: Optional[int] = None, raw_mean: float = 0.0, raw_std: float = 1.0):
-        """always_reduce: issue the gradient all-reduce whenever a process group exists, also at world size 1 (exercises
+                 always_reduce: bool = False, raw_window: Optional[int] = None, raw_mean: float = 0.0, raw_std: float = 1.0,
+                 shared_graph: bool = True):
+        """shared_graph: batched supports whose clips all carry one and the same graph (the reference's trainers pass the distance
+        graph that way) are handed to the model in their 2-D form, which lets the encoder run its hoisted GEMMs in the
+        eigenbasis of that graph (`ops.collapse_shared_supports`: one comparison + one flag read per supports TENSOR, cached; a
+        captured step keeps the decision of its capture -- refill a captured supports buffer with per-clip graphs only after
+        re-capturing, or pass shared_graph=False).
+        always_reduce: issue the gradient all-reduce whenever a process group exists, also at world size 1 (exercises
         the RCCL path on a single GPU; a sum over one rank is the identity).
         raw_window: the step takes RAW resampled signals (B, N, T*raw_window) instead of features and runs the reference's
         DataLoader-side chain on the device in front of the model (dataloader_detection.py:57-71,346-354,384-393): log|FFT| of every
@@ -87,10 +93,39 @@ class TrainStep:
         self.reduce = has_pg and (self.world > 1 or always_reduce)
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
         self.raw_window, self.raw_mean, self.raw_std = raw_window, float(raw_mean), float(raw_std)
+        self.shared_graph = bool(shared_graph)
         self._graphs = {}
         # curriculum learning (SSL, model.py:194-200): where the persistent decoder kernels apply, the teacher-forcing flags are
         # drawn on the device (`eeg_dcrnn_teacher_flags`) -- in eager steps and graph replays alike; elsewhere on the host
         self.device_curriculum = None     # decided at the first batch (needs the shapes)
+
+    # `step_count` / `samples_seen`: host mirrors of the device-resident counters the kernels read (Adam's bias correction uses
+    # step_dev, the scheduled-sampling threshold samples_seen_dev); assigning to them (a resumed or restarted run) rewrites the
+    # device tensors too -- outside any captured graph, like `lr`.
+    @property
+    def step_count(self):
+        return self._step_count
+
+    @step_count.setter
+    def step_count(self, value):
+        self._step_count = int(value)
+        if hasattr(self, "step_dev"):
+            self.step_dev.fill_(self._step_count)
+
+    @property
+    def samples_seen(self):
+        return self._samples_seen
+
+    @samples_seen.setter
+    def samples_seen(self, value):
+        self._samples_seen = int(value)
+        if hasattr(self, "samples_seen_dev"):
+            self.samples_seen_dev.fill_(self._samples_seen)
+
+    def _advance(self, steps: int = 0, samples: int = 0):
+        """the kernels of a step advanced the device counters themselves: move the host mirrors only"""
+        self._step_count += int(steps)
+        self._samples_seen += int(samples)
 
     @property
     def lr(self):
@@ -150,6 +185,8 @@ class TrainStep:
                 supports = ops.correlation_supports(feat_raw, top_k=3)
         if supports is None:
             supports = ops.correlation_supports(x, top_k=3)
+        elif self.shared_graph:
+            supports = ops.collapse_shared_supports(supports)
         if self.task == "ssl":
             if self._use_device_curriculum(y):
                 self.model.batches_seen_increment = x.shape[0] * self.world
@@ -207,8 +244,7 @@ class TrainStep:
         # hipGraphUpload); it recomputes the gradients of the captured batch (and, with include_update, applies one more update)
         graph.replay()
         if include_update:
-            self.step_count += warmup + 1
-            self.samples_seen += (warmup + 1) * x.shape[0] * self.world
+            self._advance(warmup + 1, (warmup + 1) * x.shape[0] * self.world)
         elif keep is not None:
             self.restore(keep, counters_only=True)        # the warm-up draws advanced the device-side sample counter
         self._graphs[slot] = (graph, loss, (x, y, seq_lengths, supports), include_update)
@@ -235,9 +271,9 @@ class TrainStep:
         """One optimisation step on the captured tensors of `slot`: graph replay + all-reduce + clip/Adam."""
         graph, loss, inputs, whole = self._graphs[slot]
         graph.replay()
-        self.samples_seen += inputs[0].shape[0] * self.world
+        self._advance(0, inputs[0].shape[0] * self.world)
         if whole:
-            self.step_count += 1
+            self._advance(1)
         else:
             self.reduce_and_update()
         return loss
@@ -247,7 +283,7 @@ class TrainStep:
         if self.reduce:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)        # RCCL over xGMI: one flat bucket
         if count:
-            self.step_count += 1
+            self._advance(1)
         # mean over ranks (grad_scale), clip_grad_norm_(max_norm) and Adam in one pass over the buffers; the kernel advances
         # the device-resident step count itself
         ops.clip_adam_step_dev(self.fp.flat, g, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr_dev, self.betas,
@@ -256,7 +292,7 @@ class TrainStep:
 
     def step(self, x, y, seq_lengths, supports):
         loss = self.forward_backward(x, y, seq_lengths, supports)
-        self.samples_seen += x.shape[0] * self.world
+        self._advance(0, x.shape[0] * self.world)
         self.reduce_and_update()
         return loss
 

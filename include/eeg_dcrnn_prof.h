@@ -16,7 +16,10 @@ extern "C" {
 
 /* enable(1) starts recording an event pair around every kernel launch; enable(0) stops. */
 int eeg_dcrnn_prof_enable(int on);
-/* Synchronises on the recorded events and writes "name launches total_ms" lines into buf (clears the records). */
+/* Synchronises on the recorded events and writes one line per (kernel role, kernel symbol) into buf and clears the records:
+ *     "role launches total_ms symbol\n"     -- FOUR fields; `symbol` is the demangled kernel name of the launches (it contains
+ * blanks: split with a field limit of 3) and a role whose launches ran different instantiations yields several lines (sum them
+ * for a per-role figure).  Returns the bytes needed (incl. NUL) when cap is too small, else 0. */
 int eeg_dcrnn_prof_report(char* buf, size_t cap);
 /* Enqueues a kernel on `stream` that keeps every SIMD of the chip streaming fp32 MFMAs for 200 us of the chip-wide 100 MHz counter
  * (s_memrealtime) and ADDS, per workgroup, {shader-clock cycles (s_memtime), 100 MHz ticks} of the second 100 us to out2 (device,

@@ -198,6 +198,114 @@ def check_vs_oracle_random(device, filt, din, h, layers, t_len, b, classes, adj3
     return {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
 
 
+def shared_laplacian(n, adj3d, g):
+    """one symmetric scaled Laplacian (N,N): the distance graph for the 19-electrode montage, else of a random undirected graph"""
+    if n == 19:
+        return cases.supports_for("laplacian", adj3d, 1)[0][0].clone()
+    a = torch.rand(n, n, generator=g).numpy().astype(np.float32)
+    np.fill_diagonal(a, 1.0)
+    return orc.compute_supports(a, "laplacian")[0]
+
+
+def check_spectral_form(device, adj3d, din=100, layers=2, t_len=3, b=4, classes=1, k=2, n=19, seed=0, lengths=None, act="tanh"):
+    """The spectral form of the hoisted x-part (csrc/spec_common.h): a model fed the ONE symmetric support in its shared (N,N) form
+    runs every layer in the eigenbasis of that support -- logits and all parameter gradients against the oracle (which diffuses hop
+    by hop on the batched form, cell.py:83-93) and against the general path of the same library (batched form of the same graph)."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, ops
+    g = torch.Generator().manual_seed(seed)
+    cfg = orc.DCRNNConfig(filter_type="laplacian", input_dim=din, rnn_units=64, num_rnn_layers=layers, num_classes=classes,
+                          max_diffusion_step=k, num_nodes=n, dcgru_activation=act)
+    params = orc.init_params(cfg, "classification", seed=seed)
+    for name in params:
+        if name.endswith("biases"):
+            params[name] = 0.1 * torch.randn(params[name].shape, generator=g)
+    s2 = shared_laplacian(n, adj3d, g)
+    supb = [s2.unsqueeze(0).repeat(b, 1, 1)]
+    x = torch.randn(b, t_len, n, din, generator=g)
+    seq = torch.tensor(lengths if lengths is not None else [t_len] * b, dtype=torch.int64)
+    y = (torch.rand(b, generator=g) > 0.5).float() if classes == 1 else torch.randint(0, classes, (b,), generator=g)
+    po = {name: v.clone().requires_grad_(True) for name, v in params.items()}
+    lo = orc.classification_forward(po, cfg, x, seq, supb)
+    (orc.bce_with_logits(lo, y) if classes == 1 else orc.cross_entropy(lo, y)).backward()
+    model = DCRNNModel_classification(make_args(cfg), classes, device=device)
+    load(model, params, device)
+    xd, sd, yd = x.to(device), seq.to(device), y.to(device)
+    loss_of = lambda lg: (torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), yd) if classes == 1   # noqa: E731
+                          else torch.nn.functional.cross_entropy(lg, yd))
+    shared = [s2.to(device)]
+    assert ops.shared_spectral_basis(shared, k) is not None, "the scaled Laplacian of an undirected graph is symmetric"
+    before = ops.spectral_layer_calls
+    lg = model(xd, sd, shared)
+    assert ops.spectral_layer_calls == before + layers, "every layer of the encoder takes the spectral form"
+    loss_of(lg).backward()
+    assert_close(lg.detach().cpu().numpy(), lo.detach().numpy(), "spectral logits vs oracle")
+    spec = {}
+    for name, p in model.named_parameters():
+        assert_close_scaled(p.grad.cpu().numpy(), po[name].grad.numpy(), f"spectral d_{name} vs oracle", tol=5e-5)
+        spec[name] = p.grad.detach().clone()
+    model.zero_grad(set_to_none=True)
+    lg2 = model(xd, sd, [t.to(device) for t in supb])       # batched form: the general path
+    assert ops.spectral_layer_calls == before + layers
+    loss_of(lg2).backward()
+    assert_close(lg.detach().cpu().numpy(), lg2.detach().cpu().numpy(), "spectral vs general logits")
+    for name, p in model.named_parameters():
+        assert_close_scaled(spec[name].cpu().numpy(), p.grad.cpu().numpy(), f"spectral vs general d_{name}", tol=5e-5)
+    # the same model with the mode switched off takes the general path on the shared form too, bit-equal to ... itself
+    prev = ops.set_spectral_mode(0)
+    try:
+        model.zero_grad(set_to_none=True)
+        lg3 = model(xd, sd, shared)
+        assert ops.spectral_layer_calls == before + layers
+    finally:
+        ops.set_spectral_mode(prev)
+    assert_close(lg3.detach().cpu().numpy(), lo.detach().numpy(), "general path on the shared form vs oracle")
+
+
+def check_spectral_basis(device, adj3d):
+    """`eeg_dcrnn_spectral_basis`: U orthonormal, U diag(lam) U^T = S, the Chebyshev table T_m(lam); a non-symmetric support is
+    reported through the residual and the Python layer keeps the general path for it; batched / several / per-clip supports too."""
+    from eeg_gnn_ssl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for n in (19, 2, 7, 20, 32):
+        s2 = shared_laplacian(n, adj3d, g).to(device)
+        blk = torch.ops.eeg_dcrnn.spectral_basis(s2).cpu().double()
+        u, tc, info = blk[:n * n].view(n, n), blk[n * n:n * n + 256].view(8, 32), blk[n * n + 256:]
+        lam = tc[1, :n]
+        assert (u.T @ u - torch.eye(n, dtype=torch.float64)).abs().max() < 5e-7
+        assert (u @ torch.diag(lam) @ u.T - s2.cpu().double()).abs().max() < 1e-6
+        ref = torch.linalg.eigvalsh(s2.cpu().double())
+        assert (torch.sort(lam).values - ref).abs().max() < 5e-7
+        assert (tc[0, :n] - 1).abs().max() == 0 and (tc[2, :n] - (2 * lam * lam - 1)).abs().max() < 5e-7
+        assert (tc[3, :n] - (4 * lam ** 3 - 3 * lam)).abs().max() < 1e-6 and (n == 32 or tc[:, n:].abs().max() == 0)
+        assert info[0] < 1e-6 and info[1] < 1e-12 and abs(info[2] - s2.abs().max().item()) < 1e-6
+        assert ops.shared_spectral_basis([s2], 2) is not None
+        assert ops.shared_spectral_basis([s2], 2) is ops.shared_spectral_basis([s2], 2), "cached per support tensor"
+        assert ops.shared_spectral_basis([s2], 0) is None
+    rw = cases.supports_for("random_walk", adj3d, 1)[0][0].to(device) if hasattr(cases, "supports_for") else None
+    skew = shared_laplacian(19, adj3d, g).to(device)
+    skew[3, 5] += 1e-3                                       # a support that is not symmetric: residual far above rounding
+    assert torch.ops.eeg_dcrnn.spectral_basis(skew)[19 * 19 + 256].item() > 1e-4
+    assert ops.shared_spectral_basis([skew], 2) is None
+    if rw is not None and (rw - rw.T).abs().max() > 1e-4:
+        assert ops.shared_spectral_basis([rw], 2) is None
+    s2 = shared_laplacian(19, adj3d, g).to(device)
+    assert ops.shared_spectral_basis([s2.unsqueeze(0).repeat(3, 1, 1)], 2) is None, "batched supports are per-clip by declaration"
+    assert ops.shared_spectral_basis([s2, s2], 2) is None
+    # batched copies of one graph collapse to the shared form (once per tensor); per-clip graphs do not
+    same = s2.unsqueeze(0).repeat(4, 1, 1)
+    col = ops.collapse_shared_supports([same])
+    assert col[0].dim() == 2 and torch.equal(col[0], s2) and ops.collapse_shared_supports([same])[0] is col[0]
+    diff = same.clone()
+    diff[2, 0, 1] += 0.5
+    assert ops.collapse_shared_supports([diff])[0] is diff
+    assert ops.collapse_shared_supports([same, same])[0] is same and ops.collapse_shared_supports(None) is None
+    prev = ops.set_spectral_mode(0)
+    try:
+        assert ops.collapse_shared_supports([same.clone()])[0].dim() == 3 and ops.shared_spectral_basis([s2], 2) is None
+    finally:
+        ops.set_spectral_mode(prev)
+
+
 def check_shape_sweep(device, n, h, filt, k, din=8, layers=2, t_len=3, b=2, classes=4, seed=0):
     """Model-level parity vs the oracle away from the 19-electrode defaults: other node counts (second MFMA
     node tile empty / partial / full), hidden sizes and hop counts.  Random graph of n nodes."""
@@ -685,7 +793,7 @@ def check_empty_inputs(device):
     wc, bc = torch.zeros((8 + h) * m, h, device=device), torch.zeros(h, device=device)
     pz = torch.zeros(1, m - 1, n, n, device=device)
     with pytest.raises(RuntimeError, match="empty"):
-        torch.ops.eeg_dcrnn.dcgru_layer(torch.zeros(0, 2, n, 8, device=device), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, False, False)
+        torch.ops.eeg_dcrnn.dcgru_layer(torch.zeros(0, 2, n, 8, device=device), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, False, False, None)
     # every other operator with a zero-sized operand: a RuntimeError from the C ABI's own checks, never a fault and never a launch
     # with an empty grid (the size queries these paths call first used to divide by the batch size: tests/test_abi.py)
     o = torch.ops.eeg_dcrnn
@@ -706,7 +814,7 @@ def check_empty_inputs(device):
         "masked_loss": lambda: o.masked_loss(z(0, 3, n, 8), z(0, 3, n, 8), False, 0.0, 1.0, 0.0, 1),
         "pack_cell": lambda: o.pack_cell(z(h * m, 2 * h), bg, z(h * m, h), bc, 0, h, m),
         "corr_graph T=0": lambda: o.corr_graph(z(2, 0, n, 8), 3),
-        "dcgru_layer B=0": lambda: o.dcgru_layer(z(3, 0, n, 8), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, True, False),
+        "dcgru_layer B=0": lambda: o.dcgru_layer(z(3, 0, n, 8), 0, None, pz, 0, wg, bg, wc, bc, None, None, n, h, m, 0, True, False, None),
         "teacher_flags": lambda: o.teacher_flags_(i64(2), i64(1), 1, 3000.0, 0),
         "clip_adam": lambda: ops.clip_adam_step_dev(z(0), z(0), z(0), z(0), torch.zeros(1, dtype=torch.int32, device=device), z(1),
                                                     (0.9, 0.999), 1e-8, 0.0, 5.0, 1.0, z(64), z(1)),
@@ -752,7 +860,7 @@ def check_malformed_inputs(device):
     h, m = cfg.rnn_units, 5
     p_ok, _ = ops.hop_polys(sup, 2, b)
     wg, bg, wc, bc = z((8 + h) * m, 2 * h), z(2 * h), z((8 + h) * m, h), z(h)
-    layer = lambda xx, pp, ll=None, h0=None: o.dcgru_layer(xx, 0, h0, pp, 1, wg, bg, wc, bc, ll, None, n, h, m, 0, False, True)   # noqa: E731
+    layer = lambda xx, pp, ll=None, h0=None: o.dcgru_layer(xx, 0, h0, pp, 1, wg, bg, wc, bc, ll, None, n, h, m, 0, False, True, None)   # noqa: E731
     layer(x.transpose(0, 1).contiguous(), p_ok)                                 # (the well-formed call goes through)
     refused = {
         "lengths of another batch size": lambda: cls(x, lens[:1], sup),
@@ -947,8 +1055,8 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
     assert tuple(P.shape) == (b, 2 * k, n, n)
     leaf = [d(t).clone().requires_grad_(True) for t in (x, h0, wg, bg, wc, bc)]
     xd, h0d, wgd, bgd, wcd, bcd = leaf
-    hext, hsel, saved = E.dcgru_layer(xd, 0, h0d, P, 1, wgd, bgd, wcd, bcd, None, None, n, h, 2 * k + 1, 0, True, True)
-    assert tuple(hext.shape) == (t_len + 1, b, n * h) and len(saved) == 9
+    hext, hsel, saved = E.dcgru_layer(xd, 0, h0d, P, 1, wgd, bgd, wcd, bcd, None, None, n, h, 2 * k + 1, 0, True, True, None)
+    assert tuple(hext.shape) == (t_len + 1, b, n * h) and len(saved) == 10
     assert_close(hext[1:].detach().cpu().numpy(), top.detach().numpy(), "torch.ops dcgru_layer hseq")
     assert_close(hsel.detach().cpu().numpy(), top[-1].detach().numpy(), "torch.ops dcgru_layer hsel")
     assert_close(hext[0].detach().cpu().numpy(), h0.numpy(), "hext slot 0 = initial state", tol=1e-7)
@@ -961,8 +1069,8 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
     w2 = [d(t) for t in (0.1 * torch.randn((h + h) * 5, 2 * h, generator=g), torch.zeros(2 * h),
                          0.1 * torch.randn((h + h) * 5, h, generator=g), torch.zeros(h))]
     xin = hext.detach().view(t_len + 1, b, n, h)
-    a1 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, saved[7].detach(), n, h, 5, 0, False, True)[0]
-    a2 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, None, n, h, 5, 0, False, True)[0]
+    a1 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, saved[7].detach(), n, h, 5, 0, False, True, None)[0]
+    a2 = E.dcgru_layer(xin, 1, None, P, 1, *w2, None, None, n, h, 5, 0, False, True, None)[0]
     assert_close(a1.cpu().numpy(), a2.cpu().numpy(), "x_planes hand-over", tol=1e-6)
     # opcheck: schema + aliasing annotations, autograd registration, fake (meta) implementations
     nog = [t.detach() for t in leaf]
@@ -971,7 +1079,7 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
         (E.pack_cell.default, (nog[2], nog[3], nog[4], nog[5], din, h, 5)),
         (E.diffusion_hops.default, (nog[0].reshape(t_len * b, n, din), P, 1, b)),
         (E.dcgru_layer.default, (xd.detach().requires_grad_(True), 0, h0d.detach().requires_grad_(True), P, 1,
-                                 *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True, True)),
+                                 *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True, True, None)),
         (E.dconv.default, (torch.randn(b, n, din + h, generator=g).to(device).requires_grad_(True), P, 1,
                            nog[2].clone().requires_grad_(True), nog[3].clone().requires_grad_(True))),
         (E.cls_head.default, (torch.randn(b, n, h, generator=g).to(device).requires_grad_(True),
@@ -1005,7 +1113,7 @@ def check_torch_ops(device, adj3d, opcheck_utils=("test_schema", "test_autograd_
                                           d(0.1 * torch.randn(rows64, 64, generator=g)), d(torch.zeros(64)), 100, 64, 3)))
     x_bm = d(torch.randn(b, t_len, n, din, generator=g))
     samples.append((E.dcgru_layer.default, (x_bm.transpose(0, 1).requires_grad_(True), 0, None, P, 1,
-                                            *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True, False)))
+                                            *[t.detach().requires_grad_(True) for t in (wgd, bgd, wcd, bcd)], None, None, n, h, 5, 0, True, False, None)))
     for op, args in samples:
         res = torch.library.opcheck(op, args, test_utils=list(opcheck_utils), raise_exception=True)
         assert all(v == "SUCCESS" for v in res.values()), (str(op), res)

@@ -39,7 +39,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(ctypes.CDLL(DEV_LIB), s)
     dll.eeg_dcrnn_is_device_build.restype = ctypes.c_int
     assert dll.eeg_dcrnn_is_device_build() == 1
-    assert dll.eeg_dcrnn_abi_version() == 4
+    assert dll.eeg_dcrnn_abi_version() == 5
     assert dll.eeg_dcrnn_supported(19, 64, 100, 3) == 1
     assert dll.eeg_dcrnn_supported(19, 48, 100, 3) == 0
     dll.eeg_dcrnn_last_error.restype = ctypes.c_char_p
@@ -58,7 +58,7 @@ def test_operators_are_registered_with_the_dispatcher():
     import torch
     import eeg_gnn_ssl_amd  # noqa: F401  (registers the library)
     for name in ("hop_polys", "pack_cell", "diffusion_hops", "dconv", "dconv_bwd", "dcgru_layer", "dcgru_layer_bwd",
-                 "dcgru_decoder", "dcgru_decoder_bwd", "cls_head", "cls_head_bwd", "rng_take_", "dropout_mask", "gather_last", "corr_graph", "fft_features",
+                 "dcgru_decoder", "dcgru_decoder_bwd", "spectral_basis", "pack_cell_spectral", "cls_head", "cls_head_bwd", "rng_take_", "dropout_mask", "gather_last", "corr_graph", "fft_features",
                  "bce_logits", "ce_logits", "masked_loss", "clip_adam_", "clip_adam_dev_", "teacher_flags_"):
         op = getattr(torch.ops.eeg_dcrnn, name)
         assert op.default._schema.name == f"eeg_dcrnn::{name}"

@@ -55,6 +55,21 @@ def test_opt_in_split_bf16_gemms(filt, din, layers, adj3d):
     ps.check_split_bf16("cpu", adj3d, filt=filt, din=din, layers=layers, t_len=2, b=2)
 
 
+SPECTRAL_CASES = [dict(din=100, layers=2, t_len=3, b=4, classes=1),
+                  dict(din=8, layers=2, t_len=5, b=7, classes=4, k=3, seed=3, lengths=[5, 4, 3, 2, 1, 5, 5]),
+                  dict(din=36, layers=3, t_len=2, b=3, classes=1, k=1, seed=5, n=20, act="relu"),
+                  dict(din=12, layers=2, t_len=2, b=40, classes=1, seed=6, n=7)]
+
+
+@pytest.mark.parametrize("case", SPECTRAL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k in ("din", "layers", "n", "b", "k")))
+def test_spectral_form_of_the_hoisted_x_part(case, adj3d):
+    ps.check_spectral_form("cpu", adj3d, **case)
+
+
+def test_spectral_basis_and_shared_support_detection(adj3d):
+    ps.check_spectral_basis("cpu", adj3d)
+
+
 def test_empty_inputs_raise_like_the_reference():
     ps.check_empty_inputs("cpu")
 

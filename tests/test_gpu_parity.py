@@ -249,6 +249,63 @@ def test_full_size_gradients_vs_oracle(workload, adj3d):
             assert torch.equal(p.grad, grads[k]), k
 
 
+SPECTRAL_CASES = [dict(din=100, layers=2, t_len=3, b=4, classes=1),
+                  dict(din=8, layers=2, t_len=5, b=7, classes=4, k=3, seed=3, lengths=[5, 4, 3, 2, 1, 5, 5]),
+                  dict(din=36, layers=3, t_len=2, b=3, classes=1, k=1, seed=5, n=20, act="relu"),
+                  dict(din=12, layers=2, t_len=2, b=40, classes=1, seed=6, n=7),
+                  dict(din=100, layers=2, t_len=12, b=300, classes=1, seed=8),          # more row tiles than workgroups, S % 128 != 0
+                  dict(din=64, layers=3, t_len=7, b=33, classes=4, seed=9, n=32)]       # S = 231: pad rows in every frequency
+
+
+@pytest.mark.parametrize("case", SPECTRAL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k in ("din", "layers", "n", "b", "k")))
+def test_spectral_form_of_the_hoisted_x_part(case, adj3d):
+    ps.check_spectral_form(DEV, adj3d, **case)
+
+
+def test_spectral_basis_and_shared_support_detection(adj3d):
+    ps.check_spectral_basis(DEV, adj3d)
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg4"])
+def test_full_size_gradients_vs_oracle_spectral_form(workload, adj3d):
+    """BASELINE cfg2 / cfg4 at FULL per-GPU size with the distance graph handed over in its shared (N,N) form: both layers run
+    their hoisted x-part in the eigenbasis of the scaled Laplacian (grouped K = Fin GEMMs framed by node mixes) -- logits and every
+    parameter gradient against the oracle (which diffuses hop by hop, cell.py:83-93) within 1e-4 of each tensor's largest entry,
+    and within 2e-5 of the general path of the same library on the batched form of the same graph."""
+    import bench
+    from oracle import dcrnn_oracle as orc
+    from eeg_gnn_ssl_amd import ops
+    task, filt, t_len, batch, classes = bench.WORKLOADS[workload]
+    x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=79)
+    lengths = torch.randint(t_len // 2, t_len + 1, (batch,), generator=torch.Generator().manual_seed(4))
+    model = _full_size_model(filt, classes)
+    xd, ld, yd = x.to(DEV), lengths.to(DEV), y.to(DEV)
+    shared = ops.collapse_shared_supports([sup[0].to(DEV)])
+    assert shared[0].dim() == 2
+    before = ops.spectral_layer_calls
+    lg = model(xd, ld, shared)
+    assert ops.spectral_layer_calls == before + 2
+    (ops.bce_with_logits(lg.view(-1), yd) if classes == 1 else ops.cross_entropy(lg, yd)).backward()
+    spec = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    lg2 = model(xd, ld, [sup[0].to(DEV)])                   # batched form: the general path
+    assert ops.spectral_layer_calls == before + 2
+    (ops.bce_with_logits(lg2.view(-1), yd) if classes == 1 else ops.cross_entropy(lg2, yd)).backward()
+    assert (lg - lg2).abs().max().item() < 2e-5
+    for k, p in model.named_parameters():
+        assert (spec[k] - p.grad).abs().max().item() <= 2e-5 * max(p.grad.abs().max().item(), 1e-12), k
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=classes)
+    po = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items() if not k.endswith("_dropout_rng")}
+    torch.set_num_threads(16)
+    lo = orc.classification_forward(po, cfg, x, lengths, sup)
+    (orc.bce_with_logits(lo, y) if classes == 1 else orc.cross_entropy(lo, y)).backward()
+    assert (lg.detach().cpu() - lo.detach()).abs().max().item() < 1e-4
+    for k in spec:
+        ref = po[k].grad
+        err = (spec[k].cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+        assert err < 1e-4, f"{k}: {err:.2e}"
+
+
 def test_ssl_full_size_gradients_vs_oracle():
     """BASELINE cfg5 at FULL per-GPU size (B=512; 60-s encoder, 12-s decoder, dual random walk, 100 features,
     64 units): predictions, masked-RMSE loss and every parameter gradient against the oracle on the same batch."""

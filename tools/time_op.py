@@ -20,7 +20,11 @@ torch.cuda.synchronize()
 lib.query("eeg_dcrnn_prof_enable", 0)
 buf = ctypes.create_string_buffer(1 << 16)
 lib.call("eeg_dcrnn_prof_report", buf, len(buf))
+agg = {}                                          # report lines are "role count total_ms symbol" (one per role AND kernel symbol; symbols contain blanks)
 for line in buf.value.decode().strip().splitlines():
-    name, cnt, ms = line.split()
-    print(f"{name:16s} {float(ms) / int(cnt) * 1e3:9.1f} us / launch")
+    name, cnt, ms = line.split(None, 3)[:3]
+    c, m = agg.get(name, (0, 0.0))
+    agg[name] = (c + int(cnt), m + float(ms))
+for name, (cnt, ms) in agg.items():
+    print(f"{name:16s} {ms / cnt * 1e3:9.1f} us / launch")
 print("raw signals", raw.numel() * 4 / 1e6, "MB; features", fr.numel() * 4 / 1e6, "MB")
