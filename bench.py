@@ -154,7 +154,9 @@ def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS,
             # M * Fin (EXECUTED FLOPs), framed by HBM-bound node mixes (bytes = every operand read once + every result written once)
             w["gemm_nn_xw"] += 2.0 * r * fin * 3 * h - 2.0 * r * (m * fin) * 3 * h
             w["gemm_tn_x"] += 2.0 * r * fin * 3 * h - 2.0 * r * (m * fin) * 3 * h
-            for k_, wd in (("spec_mix_x", fin), ("spec_mix_y", 3 * h), ("spec_mix_dy", 3 * h)):
+            w["gemm_tn_hg"] += 2.0 * r * h * 2 * h - 2.0 * r * (m * h) * 2 * h
+            w["gemm_tn_hc"] += 2.0 * r * h * h - 2.0 * r * (m * h) * h
+            for k_, wd in (("spec_mix_x", fin), ("spec_mix_y", 3 * h), ("spec_mix_dy", 3 * h), ("spec_mix_h", 2 * h)):
                 w[k_] = w.get(k_, 0.0) + 2 * 4.0 * r * wd
             if l > 0:
                 w["gemm_nn_dx"] += 2.0 * r * 3 * h * fin
@@ -230,6 +232,8 @@ def per_launch_work(filter_type, t_len, batch, layers=LAYERS, spectral=False):
         fwd = {"seq_fwd": fwd["seq_fwd"], "gemm_nn_xw": [2.0 * r * fin * 3 * h for fin in fins],
                "spec_mix_x": [8.0 * r * fin for fin in fins], "spec_mix_y": [8.0 * r * 3 * h for _ in fins]}
         bwd.update({"gemm_tn_x": [2.0 * r * fin * 3 * h for fin in fins], "gemm_nn_dx": [2.0 * r * 3 * h * fin for fin in fins[1:]],
+                    "gemm_tn_hg": [2.0 * r * h * 2 * h for _ in fins], "gemm_tn_hc": [2.0 * r * h * h for _ in fins],
+                    "spec_mix_h": [8.0 * r * h for _ in fins for _ in (0, 1)],
                     "spec_mix_dy": [8.0 * r * 3 * h for _ in fins], "spec_mix_dx": [8.0 * r * fin for fin in fins[1:]]})
         bwd.pop("diffuse_adj")
     out = dict(fwd)

@@ -383,9 +383,10 @@ struct BwdWs {
     size_t dxw, dbias, hplanes, rhplanes, partial, part_g, part_c, z, total;   // partial = x-part region; part_g / part_c follow it
     int nsplit_x, rps_x, nsplit_hg, rps_hg, nsplit_hc, rps_hc;
     TnqPlan qx, qg, qc;        // round-3 TN kernel where it covers the shape (ok = 1): its split plan replaces tn_split's
-    // spectral form (d->spectral): dyh = U^T dXW (N, Sp, 3H); partial = the grouped TN's [N*spg][Fin][3H]; z = dXh (N, Sp, Fin)
+    // spectral form (d->spectral): dyh = U^T dXW (N, Sp, 3H); hplanes / rhplanes = U^T h_{t-1}, U^T (r*h_{t-1}) (N, Sp, H); partial /
+    // part_g / part_c = the grouped TNs' [N*spg][K][O]; z = dXh (N, Sp, Fin)
     size_t dyh;
-    TngPlan gx;
+    TngPlan gx, gh;
 };
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
@@ -400,10 +401,11 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     size_t o = 0;
     w.dxw = o;      o += R * 3 * d->H;
     w.dbias = o;    o += round_up(d->B * 3 * d->H, 64);
-    w.hplanes = o;  o += (size_t)(d->M - 1) * R * d->H;
-    w.rhplanes = o; o += (size_t)(d->M - 1) * R * d->H;
+    w.hplanes = o;  o += spec ? Rp * d->H : (size_t)(d->M - 1) * R * d->H;
+    w.rhplanes = o; o += spec ? Rp * d->H : (size_t)(d->M - 1) * R * d->H;
     w.dyh = o;      o += spec ? Rp * 3 * d->H : 0;
     w.gx = spec ? tng_plan(d->Fin, spec_rows(d->T * d->B), d->N, num_cus()) : TngPlan{};
+    w.gh = spec ? tng_plan(d->H, spec_rows(d->T * d->B), d->N, num_cus()) : TngPlan{};
     w.nsplit_x = tn_split(d->M, d->Fin, (int)R, 3 * d->H, &w.rps_x);
     w.nsplit_hg = tn_split(d->M, d->H, (int)R, 2 * d->H, &w.rps_hg);
     w.nsplit_hc = tn_split(d->M, d->H, (int)R, d->H, &w.rps_hc);
@@ -414,9 +416,13 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     if (w.qg.ok) { w.nsplit_hg = w.qg.nsplit; w.rps_hg = w.qg.rps; }
     if (w.qc.ok) { w.nsplit_hc = w.qc.nsplit; w.rps_hc = w.qc.rps; }
     size_t px = (size_t)w.nsplit_x * d->M * d->Fin * 3 * d->H;
-    if (spec) px = (size_t)d->N * w.gx.spg * d->Fin * 3 * d->H;
     size_t pg = (size_t)w.nsplit_hg * d->M * d->H * 2 * d->H;
     size_t pc = (size_t)w.nsplit_hc * d->M * d->H * d->H;
+    if (spec) {
+        px = (size_t)d->N * w.gx.spg * d->Fin * 3 * d->H;
+        pg = (size_t)d->N * w.gh.spg * d->H * 2 * d->H;
+        pc = (size_t)d->N * w.gh.spg * d->H * d->H;
+    }
     w.partial = o;  o += (px + 63) / 64 * 64;      // one region per GEMM: the three are reduced by one launch
     w.part_g = o;   o += (pg + 63) / 64 * 64;
     w.part_c = o;   o += (pc + 63) / 64 * 64;
@@ -435,18 +441,14 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
                       const float* RHs, const float* dXW, const float* P, const float* hpl_in, const float* rpl_in,
                       size_t h_stride, float* hpl_ws, float* rpl_ws, float* part, const BwdWs& w, bool accumulate,
                       float* dWg, float* dWc, hipStream_t st, BtMap bt = BtMap(), const float* bias_part = nullptr,
-                      float* dbg = nullptr, float* dbc = nullptr, const float* dYh = nullptr) {
+                      float* dbg = nullptr, float* dbc = nullptr) {
     const int S = d->T * d->B, R = S * d->N, H = d->H, M = d->M, Fin = d->Fin, N = d->N;
     const int acc = accumulate ? 8 : 0;
-    const bool spec = dYh != nullptr;                 // spectral x-part: `planes` = Xh (N, Sp, Fin), dYh = U^T dXW (N, Sp, 3H)
     SegPtrs sx;
     for (int m = 0; m < kMaxM; ++m) sx.p[m] = m == 0 ? X : (m < M ? planes + (size_t)(m - 1) * x_stride : nullptr);
     float* part_g = part + (w.part_g - w.partial);
     float* part_c = part + (w.part_c - w.partial);
-    if (spec) {
-        if (launch_tng(w.gx, planes, Fin, spec_rows(S), N, dYh, part, st, "gemm_tn_x")) return fail("gemm_tng: launch failed");
-        if (check_launch("gemm_tng")) return 1;
-    } else if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt, &w.qx)) return 1;
+    if (gemm_tn(sx, M, Fin, R, dXW, 3 * H, 0, 3 * H, part, w.nsplit_x, w.rps_x, st, "gemm_tn_x", bt, &w.qx)) return 1;
     //   h-part of the gate: hops(h_{t-1})^T [dR|dU]
     const float* hpl = hpl_in;
     size_t hs = h_stride;
@@ -487,20 +489,41 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
     int nblocks = 0;
     for (int j = 0; j < 3; ++j) {
         jobs.part[j] = parts[j]; jobs.nsplit[j] = ns[j]; jobs.K[j] = Ks[j]; jobs.O[j] = Os[j];
-        jobs.nblocks[j] = (spec && j == 0) ? 0 : ceil_div(Ks[j] * Os[j], 64);
+        jobs.nblocks[j] = ceil_div(Ks[j] * Os[j], 64);
         nblocks += jobs.nblocks[j];
     }
     // the cell's bias gradients (per-clip partials of the BPTT kernel -> dbg, dbc) as a fourth job of the same launch
     jobs.bias_part = bias_part; jobs.bias_B = d->B; jobs.dbg = dbg; jobs.dbc = dbc;
     if (bias_part != nullptr) nblocks += ceil_div(3 * H, 16);
-    if (spec) {                                       // x-part: dW_m = sum_i T_m(lam_i) dWt_i, folded in the same launch
-        SpecFoldJob sj{part, d->spectral, N, w.gx.spg, ceil_div(Fin * 3 * H, 64)};
-        nblocks += sj.nblocks;
-        EEG_LAUNCH_P("reduce_unpack", reduce_unpack3s_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, sj, acc, Fin, H, M, dWg, dWc);
-        return check_launch("reduce_unpack");
-    }
     EEG_LAUNCH_P("reduce_unpack", reduce_unpack3_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, acc, Fin, H, M, dWg, dWc);
     return check_launch("reduce_unpack");
+}
+
+// The same weight gradients in the eigenbasis of a shared symmetric support (spec_common.h): every hoisted contraction runs per
+// graph frequency i over K = Fin (x-part) / K = H (h-parts) instead of M * Fin / M * H, and the fold dW_m = sum_i T_m(lam_i) dWt_i
+// rides in the reduction launch.  Xh = U^T X (N, Sp, Fin) kept by the forward; dYh = U^T dXW (N, Sp, 3H); hh / rhh (N, Sp, H) are
+// filled here with U^T h_{t-1} and U^T (r*h_{t-1}) (node mixes of Hext[0:T] and RHs, rows in the order `map` of Xh / dYh).
+int cell_weight_grads_spectral(const eeg_layer_dims* d, const float* Xh, const float* Hprev, const float* RHs, const float* dYh,
+                               float* hh, float* rhh, float* part, const BwdWs& w, int map, float* dWg, float* dWc, hipStream_t st,
+                               const float* bias_part, float* dbg, float* dbc) {
+    const int S = d->T * d->B, H = d->H, M = d->M, Fin = d->Fin, N = d->N, Sp = spec_rows(S);
+    float* part_g = part + (w.part_g - w.partial);
+    float* part_c = part + (w.part_c - w.partial);
+    if (launch_tng(w.gx, Xh, Fin, Sp, N, dYh, part, st, "gemm_tn_x")) return fail("gemm_tng: launch failed");
+    if (launch_spec_mix(1, Hprev, d->spectral, nullptr, N, d->T, d->B, H, map, hh, st, "spec_mix_h")) return fail("spec_mix: launch failed");
+    if (launch_spec_mix(1, RHs, d->spectral, nullptr, N, d->T, d->B, H, map, rhh, st, "spec_mix_h")) return fail("spec_mix: launch failed");
+    if (launch_tng_pair(w.gh, hh, rhh, Sp, N, dYh, part_g, part_c, st, "gemm_tn_h")) return fail("gemm_tng_pair: launch failed");
+    ReduceJobs jobs{};
+    SpecFoldJobs sj{};
+    sj.basis = d->spectral; sj.N = N;
+    sj.j[0] = SpecFoldJob{part, w.gx.spg, Fin, 3 * H, ceil_div(Fin * 3 * H, 64)};
+    sj.j[1] = SpecFoldJob{part_g, w.gh.spg, H, 2 * H, ceil_div(H * 2 * H, 64)};
+    sj.j[2] = SpecFoldJob{part_c, w.gh.spg, H, H, ceil_div(H * H, 64)};
+    int nblocks = sj.j[0].nblocks + sj.j[1].nblocks + sj.j[2].nblocks;
+    jobs.bias_part = bias_part; jobs.bias_B = d->B; jobs.dbg = dbg; jobs.dbc = dbc;
+    if (bias_part != nullptr) nblocks += ceil_div(3 * H, 16);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack3s_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, sj, 0, Fin, H, M, dWg, dWc);
+    return check_launch("reduce_unpack (spectral)");
 }
 
 // out0[c] (c < split) / out1[c - split] = sum_r A[r][c]: two fixed-order stages.
@@ -864,8 +887,8 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         const int Sp = spec_rows(S);
         float* dYh = ws + w.dyh;
         if (launch_spec_mix(1, dXW, d->spectral, nullptr, N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, dYh, st, "spec_mix_dy")) return fail("spec_mix: launch failed");
-        if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
-                              ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, BtMap(), dbias, dbg, dbc, dYh)) return 1;
+        if (cell_weight_grads_spectral(d, planes, Hext, RHs, dYh, ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w,
+                                       d->x_batch_major ? 1 : 0, dWg, dWc, st, dbias, dbg, dbc)) return 1;
         if (dX != nullptr) {
             float* dXh = ws + w.z;
             if (launch_nng(dYh, 3 * H, Sp, N, d->spack + sp.sxtq, sp.sxtq_stride, sp.nct_t, dXh, num_cus(), st, "gemm_nn_dx")) return fail("gemm_nng: launch failed");

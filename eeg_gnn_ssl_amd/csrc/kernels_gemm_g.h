@@ -145,16 +145,32 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
 }
 
 // Grouped weight-gradient GEMM: gemm_tnq_body (kernels_gemm_q.h) with the row range of a workgroup taken from ONE group:
-// split y = i * spg + ls covers rows [i*Sp + ls*rps, min(i*Sp + (ls+1)*rps, (i+1)*Sp)) and writes partial[y][K][Ov].
+// split y = i * spg + ls covers rows [i*Sp + ls*rps, min(i*Sp + (ls+1)*rps, (i+1)*Sp)) and writes partial[y][K][Ov] =
+// A_i^T dY_i[:, ycol0 : ycol0 + Ov].
 template <int KT, int OT, int RC, bool PLANAR>
 __global__ __launch_bounds__(256, 2) void gemm_tnq_grouped_kernel(SegPtrs segs, int F, int Sp, int G, int spg,
-                                                                 const float* __restrict__ dY, int ldy, int Ov,
+                                                                 const float* __restrict__ dY, int ldy, int ycol0, int Ov,
                                                                  float* __restrict__ partial, int rows_per_split) {
     const int y = (int)blockIdx.y, i = y / spg, ls = y - i * spg;
     const int rbeg = i * Sp + ls * rows_per_split;
     int rend = rbeg + rows_per_split;
     if (rend > (i + 1) * Sp) rend = (i + 1) * Sp;
-    gemm_tnq_rows<KT, OT, RC, false, PLANAR, false>(segs, 1, F, Sp * G, dY, ldy, 0, Ov, partial, 0, 0, 0, 0, (int)blockIdx.x, y, rbeg, rend);
+    gemm_tnq_rows<KT, OT, RC, false, PLANAR, false>(segs, 1, F, Sp * G, dY, ldy, ycol0, Ov, partial, 0, 0, 0, 0, (int)blockIdx.x, y, rbeg, rend);
+}
+// The two h-part problems of a cell in the eigenbasis -- (U^T h)_i^T dYh_i[:, 0:2H] and (U^T (r*h))_i^T dYh_i[:, 2H:3H] -- as ONE launch
+// whose workgroups alternate between the two over the workgroup slots of a CU (cf. gemm_tnq_pair_kernel).
+template <int KT, int RC, bool PLANAR>
+__global__ __launch_bounds__(256, 2) void gemm_tnq_grouped_pair_kernel(TnqJob ja, TnqJob jb, int F, int Sp, int G, int spg,
+                                                                      const float* __restrict__ dY, int ldy, int rows_per_split) {
+    const int yy = (int)blockIdx.y, y = yy >> 1, i = y / spg, ls = y - i * spg;
+    const int which = (yy & 1) ^ ((yy >> 8) & 1);
+    const int rbeg = i * Sp + ls * rows_per_split;
+    int rend = rbeg + rows_per_split;
+    if (rend > (i + 1) * Sp) rend = (i + 1) * Sp;
+    if (which == 0)
+        gemm_tnq_rows<KT, 4, RC, false, PLANAR, false>(ja.segs, 1, F, Sp * G, dY, ldy, ja.ycol0, ja.Ov, ja.partial, 0, 0, 0, 0, (int)blockIdx.x, y, rbeg, rend);
+    else
+        gemm_tnq_rows<KT, 2, RC, false, PLANAR, false>(jb.segs, 1, F, Sp * G, dY, ldy, jb.ycol0, jb.Ov, jb.partial, 0, 0, 0, 0, (int)blockIdx.x, y, rbeg, rend);
 }
 
 }  // namespace eeg

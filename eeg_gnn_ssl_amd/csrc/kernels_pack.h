@@ -286,24 +286,31 @@ __global__ __launch_bounds__(256) void reduce_unpack3_kernel(ReduceJobs jobs, in
     reduce_unpack_block(b, jobs.part[j], jobs.nsplit[j], jobs.K[j], jobs.O[j], j | flags, Fin, H, M, dWg, dWc);
 }
 
-// The same launch with the x-part job replaced by the spectral fold (kernels_spectral.h): blocks [0, sj.nblocks) fold the grouped
-// TN GEMM's per-frequency partials into the x-rows of dWg / dWc, the rest serve jobs 1, 2 and the bias job (jobs.nblocks[0] = 0).
-__global__ __launch_bounds__(256) void reduce_unpack3s_kernel(ReduceJobs jobs, SpecFoldJob sj, int flags, int Fin, int H, int M,
+// The same launch for the spectral form (spec_common.h): jobs of kind 0..2 present in `sj` are folds of grouped TN partials
+// (blocks first, in kind order); the h-part jobs NOT present there are the plain reductions of `jobs` (1, 2); the bias job last.
+__global__ __launch_bounds__(256) void reduce_unpack3s_kernel(ReduceJobs jobs, SpecFoldJobs sj, int flags, int Fin, int H, int M,
                                                               float* __restrict__ dWg, float* __restrict__ dWc) {
     int b = blockIdx.x;
-    if (b < sj.nblocks) {
-        spec_fold_block(b, sj, (flags & 8) != 0 ? 1 : 0, Fin, H, M, dWg, dWc);
-        return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (sj.j[k].part == nullptr) continue;
+        if (b < sj.j[k].nblocks) {
+            spec_fold_block(b, sj.j[k], k, sj.basis, sj.N, (flags & 8) != 0 ? 1 : 0, Fin, H, M, dWg, dWc);
+            return;
+        }
+        b -= sj.j[k].nblocks;
     }
-    b -= sj.nblocks;
-    int j = 1;
-    if (b >= jobs.nblocks[1]) { b -= jobs.nblocks[1]; j = 2; }
-    if (j == 2 && b >= jobs.nblocks[2]) {
-        EEG_DYN_SMEM(sm);
-        reduce_bias_block(b - jobs.nblocks[2], sm, jobs.bias_part, jobs.bias_B, H, jobs.dbg, jobs.dbc);
-        return;
+#pragma unroll
+    for (int j = 1; j < 3; ++j) {
+        if (sj.j[j].part != nullptr) continue;
+        if (b < jobs.nblocks[j]) {
+            reduce_unpack_block(b, jobs.part[j], jobs.nsplit[j], jobs.K[j], jobs.O[j], j | flags, Fin, H, M, dWg, dWc);
+            return;
+        }
+        b -= jobs.nblocks[j];
     }
-    reduce_unpack_block(b, jobs.part[j], jobs.nsplit[j], jobs.K[j], jobs.O[j], j | flags, Fin, H, M, dWg, dWc);
+    EEG_DYN_SMEM(sm);
+    reduce_bias_block(b, sm, jobs.bias_part, jobs.bias_B, H, jobs.dbg, jobs.dbc);
 }
 
 // Column sums of a dense (R x C) matrix in two fixed-order stages (projection bias gradient):

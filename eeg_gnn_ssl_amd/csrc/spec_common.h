@@ -52,29 +52,36 @@ __host__ __device__ inline SpecPack make_spec_pack(int Fin, int H, int M, int N)
     return p;
 }
 // ---- weight-gradient fold ------------------------------------------------------------------------------------------------------------
-// partial [N * spg][Fin][3H]: split (i, ls) = row split ls of frequency i (fixed-order split-K partials of the grouped TN GEMM).
-// dW x-rows (f*M + m, o) = sum_i T_m(lam_i) * sum_ls partial[i*spg + ls][f][o].  Block = 16 split groups x 16 float4 columns like
+// partial [N * spg][K][O]: split (i, ls) = row split ls of frequency i (fixed-order split-K partials of a grouped TN GEMM).
+//   kind 0 (x-part,  K = Fin, O = 3H): dW rows f*M + m       (columns < 2H -> dWg, the rest -> dWc)
+//   kind 1 (h-gate,  K = H,   O = 2H): dWg rows (Fin + f)*M + m
+//   kind 2 (h-cand,  K = H,   O = H ): dWc rows (Fin + f)*M + m
+// value = sum_i T_m(lam_i) * sum_ls partial[i*spg + ls][f][o].  Block = 16 split groups x 16 float4 columns like
 // reduce_unpack_block (kernels_pack.h): group g walks the splits g, g+16, ... in order with M accumulators, the 16 group sums are
 // added in group order.  LDS: [16][16] float4 per hop slot, one slot at a time.
 struct SpecFoldJob {
-    const float* part;      // nullptr: no spectral job
+    const float* part;      // nullptr: no job
+    int spg, K, O, nblocks;
+};
+struct SpecFoldJobs {
+    SpecFoldJob j[3];       // kinds 0, 1, 2
     const float* basis;
-    int N, spg, nblocks;
+    int N;
 };
 template <int MM>
-__device__ __forceinline__ void spec_fold_block_m(int block, const SpecFoldJob& jb, int acc_flag, int Fin, int H, int M,
-                                                   float* __restrict__ dWg, float* __restrict__ dWc) {
+__device__ __forceinline__ void spec_fold_block_m(int block, const SpecFoldJob& jb, int kind, const float* __restrict__ basis, int N,
+                                                   int acc_flag, int Fin, int H, int M, float* __restrict__ dWg, float* __restrict__ dWc) {
     EEG_DYN_SMEM(sm);
     float4 (*red)[16] = reinterpret_cast<float4 (*)[16]>(sm);
-    const int O = 3 * H;
-    const size_t total = (size_t)Fin * O;
+    const int O = jb.O;
+    const size_t total = (size_t)jb.K * O;
     const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
     const size_t idx4 = ((size_t)block * 16 + q) * 4;
-    const float* tc = jb.basis + jb.N * jb.N;
+    const float* tc = basis + N * N;
     float4 a[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) a[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nsplit = jb.N * jb.spg;
+    const int nsplit = N * jb.spg;
     if (idx4 < total) {
         for (int sp = g; sp < nsplit; sp += 16) {
             const float4 v = *reinterpret_cast<const float4*>(jb.part + (size_t)sp * total + idx4);
@@ -107,16 +114,19 @@ __device__ __forceinline__ void spec_fold_block_m(int block, const SpecFoldJob& 
             for (int e = 0; e < 4; ++e) {
                 const size_t idx = idx4 + e;
                 const int f = (int)(idx / O), o = (int)(idx % O);
-                float* dst = o < 2 * H ? &dWg[((size_t)f * M + m) * (2 * H) + o] : &dWc[((size_t)f * M + m) * H + (o - 2 * H)];
+                float* dst;
+                if (kind == 0) dst = o < 2 * H ? &dWg[((size_t)f * M + m) * (2 * H) + o] : &dWc[((size_t)f * M + m) * H + (o - 2 * H)];
+                else if (kind == 1) dst = &dWg[((size_t)(Fin + f) * M + m) * (2 * H) + o];
+                else dst = &dWc[((size_t)(Fin + f) * M + m) * H + o];
                 *dst = acc_flag ? *dst + sv[e] : sv[e];
             }
         }
     }
 }
-__device__ __forceinline__ void spec_fold_block(int block, const SpecFoldJob& jb, int acc_flag, int Fin, int H, int M,
-                                                float* __restrict__ dWg, float* __restrict__ dWc) {
-    if (M <= 4) spec_fold_block_m<4>(block, jb, acc_flag, Fin, H, M, dWg, dWc);
-    else spec_fold_block_m<kMaxM>(block, jb, acc_flag, Fin, H, M, dWg, dWc);
+__device__ __forceinline__ void spec_fold_block(int block, const SpecFoldJob& jb, int kind, const float* __restrict__ basis, int N,
+                                                int acc_flag, int Fin, int H, int M, float* __restrict__ dWg, float* __restrict__ dWc) {
+    if (M <= 4) spec_fold_block_m<4>(block, jb, kind, basis, N, acc_flag, Fin, H, M, dWg, dWc);
+    else spec_fold_block_m<kMaxM>(block, jb, kind, basis, N, acc_flag, Fin, H, M, dWg, dWc);
 }
 
 }  // namespace eeg

@@ -102,10 +102,25 @@ int launch_tng_one(const TngPlan& p, const float* A, int F, int Sp, int G, const
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? A : nullptr;
     EEG_SET_MAX_LDS((gemm_tnq_grouped_kernel<KT, OT, RC, PLANAR>), lds);
     EEG_LAUNCH_P(tag, (gemm_tnq_grouped_kernel<KT, OT, RC, PLANAR>), dim3(p.nkb, G * p.spg), dim3(256), lds, st, segs, F, Sp, G, p.spg, dY, 192,
-                 192, partial, p.rps);
+                 0, 192, partial, p.rps);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 }  // namespace
+
+int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp, int G, const float* dY, float* part_g, float* part_c,
+                    hipStream_t st, const char* tag) {
+    if (!p.ok || !p.planar || p.KT != 2 || p.nkb != 1) return 1;
+    constexpr int RC = 16, KT = 2;
+    const size_t lds = 3 * (size_t)(RC * 32 * (KT + 4)) * sizeof(float);
+    TnqJob ja, jb;
+    for (int m = 0; m < kMaxM; ++m) { ja.segs.p[m] = m == 0 ? Ah : nullptr; jb.segs.p[m] = m == 0 ? Arh : nullptr; }
+    ja.ycol0 = 0; ja.Ov = 128; ja.partial = part_g;
+    jb.ycol0 = 128; jb.Ov = 64; jb.partial = part_c;
+    EEG_SET_MAX_LDS((gemm_tnq_grouped_pair_kernel<KT, RC, true>), lds);
+    EEG_LAUNCH_P(tag, (gemm_tnq_grouped_pair_kernel<KT, RC, true>), dim3(1, 2 * G * p.spg), dim3(256), lds, st, ja, jb, 64, Sp, G, p.spg, dY, 192,
+                 p.rps);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag) {
     if (!p.ok) return 1;

@@ -26,5 +26,8 @@ int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wst
 struct TngPlan { int ok, KT, planar, nkb, spg, rps; };
 TngPlan tng_plan(int F, int Sp, int G, int num_cus);
 int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag);
+// h-part pair (F = 64): part_g [G*spg][64][128] = Ah^T dY[:, 0:128], part_c [G*spg][64][64] = Arh^T dY[:, 128:192]; one launch
+int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp, int G, const float* dY, float* part_g, float* part_c,
+                    hipStream_t st, const char* tag);
 
 }  // namespace eeg

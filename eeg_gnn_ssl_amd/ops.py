@@ -502,12 +502,14 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     hext = _new((t_len + 1, b, n * h), x)
     if save:
         rs, us, cs, rhs = (_new((t_len, b, n * h), x) for _ in range(4))
-        hpl, rhpl = (_new((m - 1, t_len + 1, b, n, h), x) for _ in range(2))
+        # (spectral form: the backward contracts U^T h, not the hop rows P_m h -- the recurrent kernel keeps no by-product planes)
+        hpl, rhpl = (_new((0,) if spec else (m - 1, t_len + 1, b, n, h), x) for _ in range(2))
     else:
         rs = us = cs = rhs = hpl = rhpl = None
     ws = _new((lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)),), x)
     lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(xsrc if xsrc is not None else xk), _p(xtm) if (xsrc is not None and bm != 2) else None,
-             _p(h0), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
+             _p(h0), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), None if spec else _p(hpl),
+             None if spec else _p(rhpl), _p(ws), _stream(x))
     if lengths is not None:
         lengths = lengths.to(device=x.device, dtype=torch.int64).contiguous()
         hsel = _new((b, n * h), x)
@@ -543,7 +545,7 @@ def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_pla
         planes = ne(n, int(lib.query("eeg_dcrnn_spectral_rows", t_len * b)), fin)
         spack = ne(int(lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)))
     return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + \
-        [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)] + [spack]
+        [(ne(0) if spec else ne(m - 1, t_len + 1, b, n, h)) for _ in range(2)] + [spack]
 
 
 def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack, planes, x_planes, hext, rs, us, cs, rhs,
@@ -587,7 +589,7 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
     dh0 = _new((b, n * h), hext) if (need_dh0 and has_h0) else _new((0,), hext)
     ws = _new((lib.query("eeg_dcrnn_layer_bwd_ws_floats", ctypes.byref(dims), 1 if need_dx else 0),), hext)
     lib.call("eeg_dcrnn_layer_bwd", ctypes.byref(dims), xk_ptr, _p(p), _p(pack), planes_ptr, _p(hext), _p(rs),
-             _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), d_hseq_ptr, _p(d_at_end), _p(d_at_len), _p(lengths), dx_ptr,
+             _p(us), _p(cs), _p(rhs), _p(_none_if_empty(hpl)), _p(_none_if_empty(rhpl)), d_hseq_ptr, _p(d_at_end), _p(d_at_len), _p(lengths), dx_ptr,
              _p(dh0) if dh0.numel() else None, _p(dwg), _p(dbg), _p(dwc), _p(dbc), _p(ws), _stream(hext))
     return dx, dh0
 
@@ -1212,7 +1214,7 @@ def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activati
         hop_plane_handovers += 1
     hext, hsel, saved = torch.ops.eeg_dcrnn.dcgru_layer(x, int(x_off), h0, p, int(p_batched), wg, bg, wc, bc, lengths, x_planes,
                                                         n, h, m, act, save, bool(want_hsel), basis)
-    return LayerOut(hext, hsel, saved[7].detach() if save else None)
+    return LayerOut(hext, hsel, saved[7].detach() if (save and saved[7].numel()) else None)
 
 
 # (data_ptr, version, device, shape) of a support tensor -> (weakref to it, basis or None): the eigenbasis is a pure function of the
