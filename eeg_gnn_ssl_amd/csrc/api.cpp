@@ -870,6 +870,10 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                  reinterpret_cast<const long long*>(lengths), P, d->p_batched, pack + p.b1, pack + p.b2,
                  dXW, dh0, dbias, d->T, d->B, N, d->act, seq_probe_arg(st)};
     a.variant = g_tune[13] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 13 = 1: off)
+    int dyh_done = 0;                             // spectral form: the two-wave BPTT kernel writes dYh = U^T dXW itself (dev knob 21 = 1: separate pass)
+    if (d->spectral != nullptr && g_tune[21] == 0) {
+        a.spec_U = d->spectral; a.dYh = ws + w.dyh; a.spec_Sp = spec_rows(S); a.spec_bt = d->x_batch_major ? 1 : 0; a.spec_done = &dyh_done;
+    }
     if (seq_bwd(H, M, a, st)) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction); the bias sums ride in their reduction launch
     const size_t xs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)R * Fin;
@@ -886,7 +890,9 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         const SpecPack sp = make_spec_pack(Fin, H, M, N);
         const int Sp = spec_rows(S);
         float* dYh = ws + w.dyh;
-        if (launch_spec_mix(1, dXW, d->spectral, nullptr, N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, dYh, st, "spec_mix_dy")) return fail("spec_mix: launch failed");
+        if (dyh_done) {
+            if (launch_spec_zero_pad(dYh, N, S, 3 * H, st)) return fail("spec_zero_pad: launch failed");
+        } else if (launch_spec_mix(1, dXW, d->spectral, nullptr, N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, dYh, st, "spec_mix_dy")) return fail("spec_mix: launch failed");
         if (cell_weight_grads_spectral(d, planes, Hext, RHs, dYh, ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w,
                                        d->x_batch_major ? 1 : 0, dWg, dWc, st, dbias, dbg, dbc)) return 1;
         if (dX != nullptr) {

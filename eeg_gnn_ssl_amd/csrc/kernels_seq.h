@@ -241,6 +241,50 @@ __device__ __forceinline__ void mfma_tile_quads(const float* __restrict__ X, int
     }
 }
 
+// Spectral form (spec_common.h): U^T applied to NG 16-column tiles that live in swizzled LDS node-row tiles, results straight to the
+// NODE-major global tensor (N, Sp, ld): out[i][row][gcol[g] + col] = sum_n U[n][i] tile_g[n][src_col[g] + col].  Issued transposed
+// like every node mix here (features as A operand): frequencies 0..15 come out of one 16x16x4 chain per tile (lane (lr, lg): four
+// consecutive columns of frequency lr), frequencies 16..19 of a 4x4x1 chain (A operand = U[n][16 + (lane & 3)], B operand = the
+// same feature value; rem4_reduce leaves ONE element per lane: frequency 16 + lg, column lr).  uf / u4: this lane's U fragments
+// (load_spec_frags), zero for nodes / frequencies >= N.  The NG chains are independent (no lone-accumulator stalls).
+template <int NKS>
+__device__ __forceinline__ void load_spec_frags(const float* __restrict__ U, int N, int lane, float (&uf)[NKS], float (&u4)[NKS]) {
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int n = 4 * ks + lg, i4 = 16 + (lane & 3);
+        uf[ks] = (n < N && lr < N) ? U[n * N + lr] : 0.f;
+        u4[ks] = (n < N && i4 < N) ? U[n * N + i4] : 0.f;
+    }
+}
+template <int NKS, int NG>
+__device__ __forceinline__ void spec_mix_tiles_out(const float* const (&tile)[NG], const int (&stride)[NG], const int (&src_col)[NG],
+                                                   const int (&gcol)[NG], const float (&uf)[NKS], const float (&u4)[NKS], int lr, int lg,
+                                                   wbuf_t out, unsigned voff0, unsigned voff1, unsigned soff, bool valid0, bool valid1) {
+    float a[NG][NKS];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) a[g][ks] = tile[g][lds_sw(4 * ks + lg, src_col[g] + lr, stride[g])];
+    f32x4 acc[NG], rem[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = rem[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = mfma16(a[g][ks], uf[ks], acc[g]);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) rem[g] = mfma4(u4[ks], a[g][ks], rem[g]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float r1 = rem4_reduce(rem[g]);
+        if (valid0) wbuf_st4(out, voff0 + (unsigned)gcol[g], soff, acc[g]);
+        if (valid1) wbuf_st1(out, voff1 + (unsigned)gcol[g], soff, r1);
+    }
+}
+
 // Optional in-kernel phase timer (development aid, eeg_dcrnn_set_seq_probe): lane 0 of every wave
 // accumulates shader-clock cycles per phase.  COMPILE-TIME switch: a run-time "probe != nullptr"
 // branch directly behind an MFMA chain lets the compiler sink the first VALU read of the MFMA
@@ -1055,14 +1099,18 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 //   window 0 (after barrier 3 of step t+1)  A: g = dh_part + DP, dC, dU, P^T dC, P^T dU; takes hr1, r    B: sums dR(t+1)
 //   window 1 (after barrier 1)               A: GEMM1, dR, P^T dR       B: coefficients(t-1) -> LDS, requests operands(t-2); GEMM2 dU half; sums dC, dU
 //   window 2 (after barrier 2)               A: -                       B: GEMM2 dR half; DP = result + external gradient(t-1)
-template <int H, int M, int NKS, bool PROBE = false>
+// SPEC (spectral form of the hoisted x-part, spec_common.h): the step's [dR|dU|dC] leaves as dYh = U^T dXW in the NODE-major layout
+// (N, Sp, 3H) the grouped weight-gradient / input-gradient GEMMs read (row of (t, b): b*T + t when spec_bt, else t*B + b), instead
+// of dXW -- role A mixes its column tile of dC, dU, dR with U^T in window 2, where it has nothing else to do (15 + 15 MFMAs beside
+// role B's dR half), from the slot-0 columns it wrote itself.  A separate HBM pass over dXW (read 3H, write 3H per node row) is gone.
+template <int H, int M, int NKS, bool PROBE = false, bool SPEC = false>
 __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     const float* __restrict__ Hseq, const float* __restrict__ h0, const float* __restrict__ Rs,
     const float* __restrict__ Us, const float* __restrict__ Cs, const float* __restrict__ dHseq,
     const float* __restrict__ d_at_end, const float* __restrict__ d_at_len, const long long* __restrict__ lengths,
     const float* __restrict__ P, int p_batched, const float* __restrict__ b1p, const float* __restrict__ b2p,
     float* __restrict__ dXW, float* __restrict__ dh0, float* __restrict__ dbias_part, int T, int B, int N, int act,
-    long long* probe) {
+    long long* probe, const float* __restrict__ spec_U = nullptr, float* __restrict__ dYh = nullptr, int spec_Sp = 0, int spec_bt = 0) {
     using G = SeqGeom<H, M>;
     static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
     constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, NCT = G::NCT, ROWS = 32, DPS = 20;
@@ -1235,6 +1283,10 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     EEG_SETPRIO(3);                                                 // windows 0 and 1: the chain issues first
     float pf[poly_slots<M, NKS>()][NKS];
     load_poly_frags<M, NKS, true>(Pl, pf, lr, lg);
+    float uf[NKS], u4[NKS];                                         // SPEC: this lane's fragments of U
+    if constexpr (SPEC) load_spec_frags<NKS>(spec_U, N, lane, uf, u4);
+    const wbuf_t bY = make_wbuf(SPEC ? dYh : dXW);
+    const unsigned oy0 = (unsigned)lr * (unsigned)spec_Sp * (3 * H) + col, oy1 = (unsigned)node1 * (unsigned)spec_Sp * (3 * H) + col1;
     const int oxw0 = node[0] * (3 * H) + col, oxw1 = node1 * (3 * H) + col1;
     const int lc1 = lds_sw(node1, col1, KAP), lg1 = lds_sw(node1, col1, KGP), lu1 = lds_sw(node1, H + col1, KGP);
     const size_t boff = (size_t)b * N * H;
@@ -1258,7 +1310,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             const f32x4 dC = g * ld4(CF + 0 * 256), du_ = g * ld4(CF + 1 * 256);
             st4(EC + lds_sw(lr, col, KAP), dC);                     // zeros on padding nodes
             st4(EG + lds_sw(lr, H + col, KGP), du_);
-            if (valid[0]) {
+            if (!SPEC && valid[0]) {
                 wbuf_st4(bX, oxw0 + 2 * H, sx, dC);
                 wbuf_st4(bX, oxw0 + H, sx, du_);
             }
@@ -1271,7 +1323,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             const float dC1 = g1 * k1[0], du1 = g1 * k1[1];
             EC[lc1] = dC1;
             EG[lu1] = du1;
-            if (valid1) {
+            if (!SPEC && valid1) {
                 wbuf_st1(bX, oxw1 + 2 * H, sx, dC1);
                 wbuf_st1(bX, oxw1 + H, sx, du1);
             }
@@ -1295,11 +1347,11 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             const f32x4 dR = drh * hr1;
             dhn += drh * rg;
             st4(EG + lds_sw(lr, col, KGP), dR);
-            if (valid[0]) wbuf_st4(bX, oxw0, sx, dR);
+            if (!SPEC && valid[0]) wbuf_st4(bX, oxw0, sx, dR);
             const float drh1 = acc[0][1][0], dR1 = drh1 * hr1_1;
             dhn1 += drh1 * rg1;
             EG[lg1] = dR1;
-            if (valid1) wbuf_st1(bX, oxw1, sx, dR1);
+            if (!SPEC && valid1) wbuf_st1(bX, oxw1, sx, dR1);
         }
         pp.mark(3);
         EEG_WAVE_SYNC();
@@ -1307,6 +1359,14 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
         EEG_LDS_BARRIER();                                          // (2) P_m^T dR complete
         pp.mark(4);
         EEG_SETPRIO(0);                                             // window 2 belongs to role B's half GEMM
+        if constexpr (SPEC) {
+            // dYh = U^T [dR | dU | dC] of this column tile, from the slot-0 columns this wave wrote itself (complete for all nodes)
+            const float* const tl[3] = {EG, EG, EC};
+            const int strd[3] = {KGP, KGP, KAP}, scol[3] = {ct * 16, H + ct * 16, ct * 16}, gcol[3] = {0, H, 2 * H};
+            const unsigned row = spec_bt ? (unsigned)b * (unsigned)T + (unsigned)t : (unsigned)t * (unsigned)B + (unsigned)b;
+            EEG_WAVE_SYNC();
+            spec_mix_tiles_out<NKS, 3>(tl, strd, scol, gcol, uf, u4, lr, lg, bY, oy0, oy1, row * (3 * H), valid[0], valid1);
+        }
         EEG_LDS_BARRIER();                                          // (3) role B's GEMM2 is in DP
         EEG_SETPRIO(3);
         pp.mark(6);

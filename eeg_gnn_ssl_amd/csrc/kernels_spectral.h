@@ -209,6 +209,15 @@ __global__ __launch_bounds__(256) void spec_mix_out_kernel(const float* __restri
     }
 }
 
+// rows [S, Sp) of every frequency of a node-major (N, Sp, F) tensor <- 0 (a producer that writes the S real rows only)
+__global__ void spec_zero_pad_kernel(float* __restrict__ Xh, int N, int S, int Sp, int F) {
+    const int per = (Sp - S) * F, total = N * per;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int i = e / per, r = e - i * per;
+        Xh[((size_t)i * Sp + S) * F + r] = 0.f;
+    }
+}
+
 // The same two mixes for any node count (rolled loops, coefficients from LDS): montages other than the 19-electrode one.
 __global__ __launch_bounds__(256) void spec_mix_generic_kernel(const float* __restrict__ in, const float* __restrict__ basis,
                                                               const float* __restrict__ bias, int N, int S, int Sp, int F, int map,

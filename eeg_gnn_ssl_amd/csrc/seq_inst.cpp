@@ -83,15 +83,25 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
                     EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, true>), lds2);
                     EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us,
                                  a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
+                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe, nullptr, nullptr, 0, 0);
                     return hipGetLastError() == hipSuccess ? 0 : 2;
                 }
             }
 #endif
+            if constexpr (M >= 2) {
+                if (a.dYh != nullptr && a.spec_U != nullptr && a.spec_done != nullptr && (double)a.N * a.spec_Sp * 3 * H * sizeof(float) < 2147483648.0) {
+                    EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, false, true>), lds2);
+                    EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, false, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq,
+                                 a.h0, a.Rs, a.Us, a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
+                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe, a.spec_U, a.dYh, a.spec_Sp, a.spec_bt);
+                    *a.spec_done = 1;
+                    return hipGetLastError() == hipSuccess ? 0 : 2;
+                }
+            }
             EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS>), lds2);
             EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                          a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe);
+                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe, nullptr, nullptr, 0, 0);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }

@@ -27,6 +27,12 @@ struct SeqBwdArgs {
     int T, B, N, act;
     long long* probe;
     int variant = 0;        // 1: two waves per SIMD (seq_bwd2_kernel) or two workgroups per CU (seq_bwd_stream_kernel) where they apply
+    // spectral form (spec_common.h): where the two-wave kernel runs it writes dYh = U^T dXW (node-major (N, spec_Sp, 3H); row of
+    // (t, b) = b*T + t when spec_bt, else t*B + b) INSTEAD of dXW and sets *spec_done = 1; elsewhere dXW is written as usual
+    const float* spec_U = nullptr;
+    float* dYh = nullptr;
+    int spec_Sp = 0, spec_bt = 0;
+    int* spec_done = nullptr;
 };
 
 // return 0 ok, 1 unsupported M for this H, 2 launch error

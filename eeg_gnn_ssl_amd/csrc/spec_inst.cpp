@@ -49,6 +49,13 @@ int launch_spec_mix(int to_nodes, const float* in, const float* basis, const flo
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+int launch_spec_zero_pad(float* Xh, int N, int S, int F, hipStream_t st) {
+    const int Sp = spec_rows(S);
+    if (Sp == S) return 0;
+    EEG_LAUNCH_P("zero", spec_zero_pad_kernel, dim3(ceil_div(N * (Sp - S) * F, 256)), dim3(256), 0, st, Xh, N, S, Sp, F);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wstride, int nct, float* C, int num_cus, hipStream_t st,
                const char* tag) {
     const size_t lds = (size_t)4 * 128 * 16 * sizeof(float);

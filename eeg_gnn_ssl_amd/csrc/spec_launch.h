@@ -18,6 +18,9 @@ int launch_spec_pack(const float* Wg, const float* Wc, const float* basis, int F
 int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bt,
                     float* out, hipStream_t st, const char* tag);
 
+// pad rows [S, Sp) of every frequency of a node-major (N, Sp, F) tensor <- 0 (no launch when Sp == S)
+int launch_spec_zero_pad(float* Xh, int N, int S, int F, hipStream_t st);
+
 // grouped NN: C (N*Sp, 16*nct) = A (N*Sp, F) * W_i;  Wq = block 0 of the per-frequency quad packs, wstride floats apart
 int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wstride, int nct, float* C, int num_cus,
                hipStream_t st, const char* tag);
