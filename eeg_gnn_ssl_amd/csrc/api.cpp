@@ -353,6 +353,14 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
     return 0;
 }
 
+// the two-wave recurrent kernels exist in a SPEC instantiation (spectral form: seq_launch.h) for exactly these calls -- mirrors the
+// selection inside seq_inst.cpp (64 units, at most 20 nodes, 2 or 3 hop matrices, two-wave variant on, 2 GB buffer descriptors)
+bool seq2_spec_ok(int H, int M, int N, int T, int B, int variant, int Sp, int SpE) {
+    if (H != 64 || N > 20 || M < 2 || M > 3 || variant != 1 || phase_probe_armed()) return false;
+    return (double)T * B * N * 3 * H * sizeof(float) < 2147483648.0 && (double)N * Sp * 3 * H * sizeof(float) < 2147483648.0 &&
+           (double)N * SpE * H * sizeof(float) < 2147483648.0;
+}
+
 int seq_fwd(int H, int M, const SeqFwdArgs& a, hipStream_t st) {
     int rc = H == 16 ? launch_seq_fwd_h16(M, a, st) : H == 32 ? launch_seq_fwd_h32(M, a, st) : launch_seq_fwd_h64(M, a, st);
     if (rc == 1) return fail("seq_fwd: no kernel for H=%d M=%d", H, M);
@@ -501,18 +509,17 @@ int cell_weight_grads(const eeg_layer_dims* d, const float* X, const float* plan
 
 // The same weight gradients in the eigenbasis of a shared symmetric support (spec_common.h): every hoisted contraction runs per
 // graph frequency i over K = Fin (x-part) / K = H (h-parts) instead of M * Fin / M * H, and the fold dW_m = sum_i T_m(lam_i) dWt_i
-// rides in the reduction launch.  Xh = U^T X (N, Sp, Fin) kept by the forward; dYh = U^T dXW (N, Sp, 3H); hh / rhh (N, Sp, H) are
-// filled here with U^T h_{t-1} and U^T (r*h_{t-1}) (node mixes of Hext[0:T] and RHs, rows in the order `map` of Xh / dYh).
-int cell_weight_grads_spectral(const eeg_layer_dims* d, const float* Xh, const float* Hprev, const float* RHs, const float* dYh,
-                               float* hh, float* rhh, float* part, const BwdWs& w, int map, float* dWg, float* dWc, hipStream_t st,
+// rides in the reduction launch.  Xh = U^T X (N, Sp, Fin; groups x_gs floats apart), dYh = U^T dXW (N, Sp, 3H), hh = U^T h_{t-1}
+// (groups hh_gs floats apart, 0 = contiguous), rhh = U^T (r*h_{t-1}) (N, Sp, H); all rows time-major.
+size_t xs_spec(const eeg_layer_dims* d) { return d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : 0; }
+int cell_weight_grads_spectral(const eeg_layer_dims* d, const float* Xh, size_t x_gs, const float* hh, size_t hh_gs, const float* rhh,
+                               const float* dYh, float* part, const BwdWs& w, float* dWg, float* dWc, hipStream_t st,
                                const float* bias_part, float* dbg, float* dbc) {
     const int S = d->T * d->B, H = d->H, M = d->M, Fin = d->Fin, N = d->N, Sp = spec_rows(S);
     float* part_g = part + (w.part_g - w.partial);
     float* part_c = part + (w.part_c - w.partial);
-    if (launch_tng(w.gx, Xh, Fin, Sp, N, dYh, part, st, "gemm_tn_x")) return fail("gemm_tng: launch failed");
-    if (launch_spec_mix(1, Hprev, d->spectral, nullptr, N, d->T, d->B, H, map, hh, st, "spec_mix_h")) return fail("spec_mix: launch failed");
-    if (launch_spec_mix(1, RHs, d->spectral, nullptr, N, d->T, d->B, H, map, rhh, st, "spec_mix_h")) return fail("spec_mix: launch failed");
-    if (launch_tng_pair(w.gh, hh, rhh, Sp, N, dYh, part_g, part_c, st, "gemm_tn_h")) return fail("gemm_tng_pair: launch failed");
+    if (launch_tng(w.gx, Xh, Fin, Sp, N, dYh, part, st, "gemm_tn_x", x_gs)) return fail("gemm_tng: launch failed");
+    if (launch_tng_pair(w.gh, hh, rhh, Sp, N, dYh, part_g, part_c, st, "gemm_tn_h", hh_gs)) return fail("gemm_tng_pair: launch failed");
     ReduceJobs jobs{};
     SpecFoldJobs sj{};
     sj.basis = d->spectral; sj.N = N;
@@ -772,7 +779,8 @@ int eeg_dcrnn_pack_cell_spectral(const float* Wg, const float* Wc, const float* 
     return check_launch("pack_cell_spectral");
 }
 int eeg_dcrnn_spectral_ok(const eeg_layer_dims* d, int need_dx) {
-    if (!layer_dims_positive(d) || d->p_batched || d->x_planes_ready) return 0;
+    if (!layer_dims_positive(d) || d->p_batched) return 0;
+    if (d->x_planes_ready && d->Fin != d->H) return 0;           // (a handed-over transformed input is the layer below's U^T h)
     if (check_dims(d->N, d->H, d->Fin, d->M)) return 0;
     return spec_supported(d->T, d->B, d->N, d->H, d->Fin, d->M, need_dx) ? 1 : 0;
 }
@@ -812,19 +820,43 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
     float* XW = ws;
     int rc3 = -1;
     if (d->spectral != nullptr) {
-        // spectral form of 1. + 2. (shared symmetric support): Xh = U^T X (node-major, kept in `planes` for the backward),
-        // Yh_i = Xh_i Wt_i (grouped GEMM, K = Fin), XW = U Yh + bias.  A batch-major X is read in its storage order: the rows of Xh /
-        // Yh are then batch-major too and the second mix restores the time-major order the recurrence wants.
+        // spectral form (shared symmetric support; spec_common.h): Xh = U^T X (node-major, time-major rows; kept in `planes` for the
+        // backward, or handed over by the layer below: x_planes_ready), Yh_i = Xh_i Wt_i + csum_i * bias (grouped GEMM, K = Fin), and
+        // the two-wave recurrent kernel takes Yh as it is (U Yh in its role B) and leaves U^T h / U^T (r*h) behind (Hplanes = Hh
+        // (N, B + Sp, H), RHplanes = RHh (N, Sp, H)).  Where that kernel does not apply: XW = U Yh and the by-products as HBM passes.
         if (!eeg_dcrnn_spectral_ok(d, 0)) return fail("layer_fwd: the spectral form does not cover this shape (eeg_dcrnn_spectral_ok)");
         if (Xtm != nullptr || d->spack == nullptr) return fail("layer_fwd: spectral excludes Xtm and needs spack");
+        if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_fwd: Hplanes/RHplanes must be both NULL or both non-NULL");
         const SpecPack sp = make_spec_pack(Fin, H, M, d->N);
-        const int Sp = spec_rows(S);
+        const int N = d->N, Sp = spec_rows(S), SpE = d->B + Sp;
+        const size_t xgs = d->x_plane_stride > 0 ? (size_t)d->x_plane_stride : (size_t)Sp * Fin;
         float* Yh = ws + (size_t)R * 3 * H;
-        if (launch_spec_mix(1, X, d->spectral, nullptr, d->N, d->T, d->B, Fin, 0, planes, st, "spec_mix_x")) return fail("spec_mix: launch failed");
-        if (launch_nng(planes, Fin, Sp, d->N, d->spack + sp.sxq, sp.sxq_stride, sp.nct_x, Yh, num_cus(), st, "gemm_nn_xw")) return fail("gemm_nng: launch failed");
-        if (launch_spec_mix(0, Yh, d->spectral, pack + p.bias, d->N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, XW, st, "spec_mix_y")) return fail("spec_mix: launch failed");
-        if (check_launch("layer_fwd (spectral x-part)")) return 1;
-        rc3 = 0;
+        if (!d->x_planes_ready && launch_spec_mix(1, X, d->spectral, nullptr, N, d->T, d->B, Fin, d->x_batch_major ? 1 : 0, planes, st, "spec_mix_x"))
+            return fail("spec_mix: launch failed");
+        if (launch_nng(planes, Fin, Sp, N, d->spack + sp.sxq, sp.sxq_stride, sp.nct_x, Yh, num_cus(), st, "gemm_nn_xw", pack + p.bias,
+                       d->spectral + spec_csum_offset(N), xgs)) return fail("gemm_nng: launch failed");
+        int done = 0;
+        SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, nullptr, nullptr,
+                     (size_t)0, d->T, d->B, N, d->act, seq_probe_arg(st)};
+        a.variant = g_tune[12] == 0 ? 1 : 0;
+        // the two-wave kernel in its SPEC instantiation where it applies (dev knob 22 = 1: the mixes as separate passes)
+        if (g_tune[22] == 0 && seq2_spec_ok(H, M, N, d->T, d->B, a.variant, Sp, SpE)) {
+            a.spec_U = d->spectral; a.Yh = Yh; a.Hh = Hplanes; a.RHh = RHplanes; a.spec_Sp = Sp; a.spec_SpE = SpE; a.spec_done = &done;
+            if (seq_fwd(H, M, a, st)) return 1;
+            if (!done) return fail("layer_fwd: the fused spectral recurrent kernel was not selected (internal)");
+        }
+        if (!done) {
+            if (launch_spec_mix(0, Yh, d->spectral, nullptr, N, d->T, d->B, 3 * H, 0, XW, st, "spec_mix_y")) return fail("spec_mix: launch failed");
+            if (seq_fwd(H, M, a, st)) return 1;
+            if (Hplanes != nullptr) {
+                if (launch_spec_mix(1, Hext, d->spectral, nullptr, N, d->T + 1, d->B, H, 0, Hplanes, st, "spec_mix_h", SpE)) return fail("spec_mix: launch failed");
+                if (launch_spec_mix(1, RHs, d->spectral, nullptr, N, d->T, d->B, H, 0, RHplanes, st, "spec_mix_h")) return fail("spec_mix: launch failed");
+            }
+        } else if (Hplanes != nullptr) {
+            if (launch_spec_zero_rows(Hplanes, N, (d->T + 1) * d->B, SpE, H, st)) return fail("spec_zero_rows: launch failed");
+            if (launch_spec_zero_pad(RHplanes, N, S, H, st)) return fail("spec_zero_pad: launch failed");
+        }
+        return check_launch("layer_fwd (spectral)");
     } else if (d->x_planes_ready) {
         if (Xtm != nullptr) return fail("layer_fwd: x_planes_ready excludes a batch-major input");
     } else {
@@ -871,8 +903,8 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
                  dXW, dh0, dbias, d->T, d->B, N, d->act, seq_probe_arg(st)};
     a.variant = g_tune[13] == 0 ? 1 : 0;          // two waves per SIMD where that kernel exists (knob 13 = 1: off)
     int dyh_done = 0;                             // spectral form: the two-wave BPTT kernel writes dYh = U^T dXW itself (dev knob 21 = 1: separate pass)
-    if (d->spectral != nullptr && g_tune[21] == 0) {
-        a.spec_U = d->spectral; a.dYh = ws + w.dyh; a.spec_Sp = spec_rows(S); a.spec_bt = d->x_batch_major ? 1 : 0; a.spec_done = &dyh_done;
+    if (d->spectral != nullptr && g_tune[21] == 0 && seq2_spec_ok(H, M, N, d->T, d->B, a.variant, spec_rows(S), d->B + spec_rows(S))) {
+        a.spec_U = d->spectral; a.dYh = ws + w.dyh; a.spec_Sp = spec_rows(S); a.spec_done = &dyh_done;
     }
     if (seq_bwd(H, M, a, st)) return 1;
     // 2. weight gradients (hoisted, split-K with fixed-order reduction); the bias sums ride in their reduction launch
@@ -883,24 +915,31 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         bt.T = d->T; bt.B = d->B; bt.N = N;
     }
     if (d->spectral != nullptr) {
-        // spectral form: dYh = U^T dXW (node-major, rows in the order of Xh), dWt_i = Xh_i^T dYh_i folded into dW_m by the
-        // reduction, dX = U [dYh_i Wt_i^T]_i
+        // spectral form: dYh = U^T dXW (node-major, time-major rows; written by the two-wave BPTT kernel itself where it runs),
+        // dWt_i = Xh_i^T dYh_i etc. folded into dW_m by the reduction, dX = U [dYh_i Wt_i^T]_i
         if (!eeg_dcrnn_spectral_ok(d, dX != nullptr)) return fail("layer_bwd: the spectral form does not cover this shape (eeg_dcrnn_spectral_ok)");
         if (d->spack == nullptr) return fail("layer_bwd: spectral needs spack");
+        if ((Hplanes != nullptr) != (RHplanes != nullptr)) return fail("layer_bwd: Hplanes/RHplanes must be both NULL or both non-NULL");
         const SpecPack sp = make_spec_pack(Fin, H, M, N);
-        const int Sp = spec_rows(S);
+        const int Sp = spec_rows(S), SpE = d->B + Sp;
         float* dYh = ws + w.dyh;
         if (dyh_done) {
             if (launch_spec_zero_pad(dYh, N, S, 3 * H, st)) return fail("spec_zero_pad: launch failed");
-        } else if (launch_spec_mix(1, dXW, d->spectral, nullptr, N, d->T, d->B, 3 * H, d->x_batch_major ? 1 : 0, dYh, st, "spec_mix_dy")) return fail("spec_mix: launch failed");
-        if (cell_weight_grads_spectral(d, planes, Hext, RHs, dYh, ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w,
-                                       d->x_batch_major ? 1 : 0, dWg, dWc, st, dbias, dbg, dbc)) return 1;
+        } else if (launch_spec_mix(1, dXW, d->spectral, nullptr, N, d->T, d->B, 3 * H, 0, dYh, st, "spec_mix_dy")) return fail("spec_mix: launch failed");
+        const float *hh = Hplanes, *rhh = RHplanes;
+        size_t hh_gs = (size_t)SpE * H;
+        if (hh == nullptr) {                        // no by-products from the forward: U^T h_{t-1}, U^T (r*h_{t-1}) here
+            if (launch_spec_mix(1, Hext, d->spectral, nullptr, N, d->T, d->B, H, 0, ws + w.hplanes, st, "spec_mix_h")) return fail("spec_mix: launch failed");
+            if (launch_spec_mix(1, RHs, d->spectral, nullptr, N, d->T, d->B, H, 0, ws + w.rhplanes, st, "spec_mix_h")) return fail("spec_mix: launch failed");
+            hh = ws + w.hplanes; rhh = ws + w.rhplanes; hh_gs = 0;
+        }
+        if (cell_weight_grads_spectral(d, planes, xs_spec(d), hh, hh_gs, rhh, dYh, ws + w.partial, w, dWg, dWc, st, dbias, dbg, dbc)) return 1;
         if (dX != nullptr) {
             float* dXh = ws + w.z;
             if (launch_nng(dYh, 3 * H, Sp, N, d->spack + sp.sxtq, sp.sxtq_stride, sp.nct_t, dXh, num_cus(), st, "gemm_nn_dx")) return fail("gemm_nng: launch failed");
-            if (launch_spec_mix(0, dXh, d->spectral, nullptr, N, d->T, d->B, Fin, d->x_batch_major ? 1 : 0, dX, st, "spec_mix_dx")) return fail("spec_mix: launch failed");
+            if (launch_spec_mix(0, dXh, d->spectral, nullptr, N, d->T, d->B, Fin, 0, dX, st, "spec_mix_dx")) return fail("spec_mix: launch failed");
         }
-        return check_launch("layer_bwd (spectral x-part)");
+        return check_launch("layer_bwd (spectral)");
     }
     if (cell_weight_grads(d, X, planes, xs, Hext, RHs, dXW, P, Hplanes, RHplanes, (size_t)(d->T + 1) * state,
                           ws + w.hplanes, ws + w.rhplanes, ws + w.partial, w, false, dWg, dWc, st, bt, dbias, dbg, dbc)) return 1;

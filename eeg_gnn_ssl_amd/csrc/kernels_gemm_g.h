@@ -1,7 +1,8 @@
 // Grouped hoisted GEMMs of the spectral form (kernels_spectral.h): one plain GEMM per graph frequency i, all in ONE launch.
 //
-//  gemm_nng_kernel: C[i*Sp + r][:] = A[i*Sp + r][0:F) * W_i for the G row groups of Sp rows (Sp % 16 == 0) of a node-major
-//  (G, Sp, F) tensor -- gemm_nnr_kernel (kernels_gemm_q.h: persistent balanced row ranges, LDS ring filled by
+//  gemm_nng_kernel: C[i*Sp + r][:] = A_i[r][0:F) * W_i for the G row groups of Sp rows (Sp % 16 == 0) of a node-major
+//  (G, Sp, F) tensor (group i of A starts a_gstride floats behind group i-1: the transformed input may be a row window of the
+//  layer below's (N, SpE, H) by-product) -- gemm_nnr_kernel (kernels_gemm_q.h: persistent balanced row ranges, LDS ring filled by
 //  buffer_load ... lds, ds_read_b128 fragments against quad-ordered weights streamed from L2 into registers, transposed MFMA
 //  issue) with the right-hand side selected per 128-row tile.  Differences:
 //   * one A segment (nseg = 1); a tile never straddles a group: the tile walk of a workgroup's row range is cut at the group
@@ -9,7 +10,8 @@
 //     one chunk ahead, the MFMA cursor;
 //   * every row tile is whole (Sp % 16 == 0) and every column block is whole (nct == 4 * NJ): no guards on the stores;
 //   * NJ column tiles per wave: 3 (192 columns: the pre-activations [r|u|c] of a 64-unit cell) or 1 (64 columns: dX of a layer
-//     above the first); no bias (it is added by the node mix that follows).
+//     above the first); the cell's bias enters as the accumulator start gscale[group] * bias[col] (a node-constant row b is
+//     (sum_n U[n][i]) * b in the eigenbasis: the node mix behind this GEMM then needs no bias).
 //  K order: the F / 16 whole chunks, then one tail chunk with the (F / 4) % 4 left-over pieces (zero weights behind them; the
 //  lanes of the padding pieces fetch columns 0..3 of their row: finite values times zero).
 // Reference semantics: model/cell.py:98-117 in the eigenbasis of the support.
@@ -19,9 +21,10 @@
 namespace eeg {
 
 template <int NJ, int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __restrict__ A, int F, int Sp, int G,
+__global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __restrict__ A, unsigned a_gstride, int F, int Sp, int G,
                                                          const float* __restrict__ Wq, unsigned w_group_stride,
-                                                         float* __restrict__ C, int ldc) {
+                                                         float* __restrict__ C, int ldc,
+                                                         const float* __restrict__ bias, const float* __restrict__ gscale) {
     constexpr int NS = 4, ST = 128 * 16, NCT = 4 * NJ;
     EEG_DYN_SMEM(sm);
     const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
         for (int i = 0; i < 2; ++i) {
             int r = cur * 16 + 16 * (w + 4 * i) + (lane >> 2);
             if (r >= Rtot) r = Rtot - 1;
-            a_voff[i] = ((unsigned)r * F + 4 * a_piece) * 4u;
+            const int g = r / Sp;                                             // (rows behind a short tile may belong to the next group)
+            a_voff[i] = ((unsigned)g * a_gstride + (unsigned)(r - g * Sp) * F + 4 * a_piece) * 4u;
         }
     };
     tile_rows(d_cur);
@@ -82,6 +86,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
     const wbuf_t rc = make_wbuf(C);
     const int a_lds = lr * 16 + 4 * (lg ^ nnq_gsw((lr >> 2) & 3));
     f32x4 acc[8][NJ], oa[8], ob[NJ], obn[NJ];
+    // bias (nullable): the tiles of group g start from gscale[g] * bias[col] -- a per-node-constant bias row in the eigenbasis
+    f32x4 bia[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bia[j] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + c_col + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto acc_init = [&](int cur) __attribute__((always_inline)) {
+        const float sc = bias != nullptr ? gscale[cur / RTg] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = bia[j] * sc;
+    };
     int b_cur = rt0, b_c = 0;                                                // weight cursor: (tile start, chunk) requested next
     auto load_b = [&](f32x4 (&dst)[NJ]) __attribute__((always_inline)) {
         const unsigned so = (unsigned)(b_cur / RTg) * w_group_stride + (unsigned)(b_c * NCT) * 256u;
@@ -94,10 +109,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
     for (int p = 0; p < NS - 1; ++p)
         if (p < Q) issue_a();
     __syncthreads();                                                         // the prologue DMAs of all waves
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc_init(rt0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) oa[i] = *reinterpret_cast<const f32x4*>(sm + a_lds + i * 256);
     int r_stage = 1, m_c = 0, m_cur = rt0, nrt = tile_len(rt0);
@@ -133,13 +145,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
                 for (int j = 0; j < NJ; ++j)
                     if (i < nrt) wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
             EEG_SCHED_FENCE();                                               // (a store's data registers must not be rewritten right behind it)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             m_c = 0;
             m_cur += nrt;
             nrt = m_cur < rt1 ? tile_len(m_cur) : 0;
+            acc_init(m_cur < rt1 ? m_cur : rt0);
         }
     }
 }
@@ -150,19 +159,25 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
 template <int KT, int OT, int RC, bool PLANAR>
 __global__ __launch_bounds__(256, 2) void gemm_tnq_grouped_kernel(SegPtrs segs, int F, int Sp, int G, int spg,
                                                                  const float* __restrict__ dY, int ldy, int ycol0, int Ov,
-                                                                 float* __restrict__ partial, int rows_per_split) {
+                                                                 float* __restrict__ partial, int rows_per_split, long long a_gskew) {
     const int y = (int)blockIdx.y, i = y / spg, ls = y - i * spg;
     const int rbeg = i * Sp + ls * rows_per_split;
     int rend = rbeg + rows_per_split;
     if (rend > (i + 1) * Sp) rend = (i + 1) * Sp;
+    // a_gskew = (floats between two groups of A) - Sp * F: all rows of this workgroup lie in group i, so shifting the base makes
+    // the linear row index i*Sp + r address row r of group i
+    segs.p[0] += (long long)i * a_gskew;
     gemm_tnq_rows<KT, OT, RC, false, PLANAR, false>(segs, 1, F, Sp * G, dY, ldy, ycol0, Ov, partial, 0, 0, 0, 0, (int)blockIdx.x, y, rbeg, rend);
 }
 // The two h-part problems of a cell in the eigenbasis -- (U^T h)_i^T dYh_i[:, 0:2H] and (U^T (r*h))_i^T dYh_i[:, 2H:3H] -- as ONE launch
 // whose workgroups alternate between the two over the workgroup slots of a CU (cf. gemm_tnq_pair_kernel).
 template <int KT, int RC, bool PLANAR>
 __global__ __launch_bounds__(256, 2) void gemm_tnq_grouped_pair_kernel(TnqJob ja, TnqJob jb, int F, int Sp, int G, int spg,
-                                                                      const float* __restrict__ dY, int ldy, int rows_per_split) {
+                                                                      const float* __restrict__ dY, int ldy, int rows_per_split,
+                                                                      long long a_gskew, long long b_gskew) {
     const int yy = (int)blockIdx.y, y = yy >> 1, i = y / spg, ls = y - i * spg;
+    ja.segs.p[0] += (long long)i * a_gskew;
+    jb.segs.p[0] += (long long)i * b_gskew;
     const int which = (yy & 1) ^ ((yy >> 8) & 1);
     const int rbeg = i * Sp + ls * rows_per_split;
     int rend = rbeg + rows_per_split;

@@ -285,6 +285,36 @@ __device__ __forceinline__ void spec_mix_tiles_out(const float* const (&tile)[NG
     }
 }
 
+// The 4-node remainder of a one-column-tile GEMM (mfma_nodes32 MODE 2) with the weight fragments read from LDS instead of held in
+// registers: wl = this wave's block [NKS/4 quads][64 lanes][4] (lane-linear 16-byte reads, conflict-free), filled once per launch.
+// Role B of the SPEC forward kernel needs its candidate weights for nothing else, and 48 registers for the spectral mixes.
+template <int NKS>
+__device__ __forceinline__ float mfma_rem4_ldsw(const float* __restrict__ X, int stride, int lane, int lg, const float* __restrict__ wl) {
+    const int s1 = lg ^ sigma4(lane & 3);
+    const float* p1 = X + (16 + (lane & 3)) * stride;
+    auto frag = [&](int q) { return *reinterpret_cast<const float4*>(p1 + 64 * (q >> 2) + 4 * ((4 * (q & 3)) ^ s1)); };
+    f32x4 rem[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rem[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NQ = NKS / 4;
+    float4 a1 = frag(0), w4 = *reinterpret_cast<const float4*>(wl + 4 * lane);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float4 n1 = a1, nw = w4;
+        if (q + 1 < NQ) { n1 = frag(q + 1); nw = *reinterpret_cast<const float4*>(wl + (q + 1) * 256 + 4 * lane); }
+        EEG_SCHED_FENCE();
+        const float x1[4] = {a1.x, a1.y, a1.z, a1.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rem[j] = mfma4(x1[j], ww[j], rem[j]);
+        EEG_SCHED_FENCE();
+        a1 = n1;
+        w4 = nw;
+    }
+    f32x4 t = (rem[0] + rem[1]) + (rem[2] + rem[3]);
+    EEG_PIN(t);
+    return rem4_reduce(t);
+}
+
 // Optional in-kernel phase timer (development aid, eeg_dcrnn_set_seq_probe): lane 0 of every wave
 // accumulates shader-clock cycles per phase.  COMPILE-TIME switch: a run-time "probe != nullptr"
 // branch directly behind an MFMA chain lets the compiler sink the first VALU read of the MFMA
@@ -566,13 +596,20 @@ __global__ __launch_bounds__(256, 1) void seq_fwd_kernel(
 //   phase 1 (after barrier 1: hops(h) complete)   A: r (both node tiles), r*h, hops(r*h)      B: u (nodes 0..15 -> LDS U)
 //   phase 2 (after barrier 2: hops(r*h) complete) A: c, h' of nodes 0..15 (u from LDS U)      B: c, h' of nodes 16..19
 //   phase 3 (after barrier 3: h' complete)        A: hops(h') for the next step              B: -
-template <int H, int M, int NKS, bool PROBE = false>
+// SPEC (spectral form of the hoisted x-part, spec_common.h): the pre-activations arrive in the eigenbasis of the shared support,
+// Yh (N, spec_Sp, 3H) node-major with the bias already inside (row of (t, b) = t*B + b), and role B turns its column tile of every
+// step into [r|u|c] = U Yh itself: 15 dword loads a step ahead, 15 + 15 MFMAs behind barrier (3); r and the 16-node part of c go to
+// role A through two [16][64] LDS tiles (XR, XC; the remainder of r through XRr), u and the remainder of c stay in its registers.
+// The by-products the backward wants leave in the eigenbasis too, from role B: Hh (N, spec_SpE, H) row slot*B + b <- U^T h_slot
+// (slot 0 = the initial state; rows B.. of every frequency ARE the next layer's transformed input) and RHh (N, spec_Sp, H) <-
+// U^T (r * h_{t-1}) -- 10 + 10 MFMAs per step instead of the hop planes.  Three HBM passes (U Yh, U^T h, U^T (r*h)) are gone.
+template <int H, int M, int NKS, bool PROBE = false, bool SPEC = false>
 __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     const float* __restrict__ XW, const float* __restrict__ h0, const float* __restrict__ P, int p_batched,
     const float* __restrict__ bhg, const float* __restrict__ bhc,
     float* __restrict__ Hseq, float* __restrict__ Rs, float* __restrict__ Us, float* __restrict__ Cs,
     float* __restrict__ RHs, float* __restrict__ Hpl, float* __restrict__ RHpl, size_t plane_stride,
-    int T, int B, int N, int act, long long* probe) {
+    int T, int B, int N, int act, long long* probe, const float* __restrict__ spec_U = nullptr, int spec_Sp = 0, int spec_SpE = 0) {
     using G = SeqGeom<H, M>;
     PhaseProbe<PROBE> pp;
     pp.start();
@@ -582,9 +619,15 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     float* Pl = sm;
     float* A = Pl + (M - 1) * kPFloats;     // [32][KAP]  slot 0 = h, slots m = P_m h
     float* A2 = A + 32 * KAP;               // [32][KAP]  slot 0 = r*h
-    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, role = wave8 >> 2, wave = wave8 & 3;
+    // (SPEC: the role is a scalar -- with a per-lane role the two role bodies are linearised one behind the other and what one
+    //  of them keeps in registers for the whole launch stays allocated while the other runs)
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = SPEC ? wave_uniform(tid >> 6) : (tid >> 6), role = wave8 >> 2, wave = wave8 & 3;
     const int lr = lane & 15, lg = lane >> 4;
     float* U = A2 + 32 * KAP;                      // [16][UST] update gate of nodes 0..15 of the current step
+    float* XR = U + 16 * UST;                      // SPEC: [16][UST] r pre-activations of nodes 0..15 of the next step (from role B)
+    float* XC = XR + 16 * UST;                     //       ... of c
+    float* XRr = XC + 16 * UST;                    //       [4 tiles][64 lanes]: r pre-activation of node 16 + lg, column ct*16 + lr
+    float* W1L = XRr + 4 * 64;                     //       [4 tiles][KS/4][64][4]: role B's candidate weights (mfma_rem4_ldsw)
     const bool save = Rs != nullptr;
     const int ct = wave;                               // NCT == 4 == waves per role
     // results leave through buffer descriptors (one VGPR offset per node tile, the step offset in an SGPR): the 64-bit
@@ -593,13 +636,26 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                  bC = make_wbuf(save ? Cs : Hseq), bRH = make_wbuf(save ? RHs : Hseq);
     // (the launcher takes this kernel only while T*B*N*H floats stay below 2 GB: 32-bit buffer offsets)
 
-    float w0[1][KS], w1[1][KS];                        // role A: r and c fragments; role B: u and c fragments
+    float w0[1][KS], w1[1][KS];                        // role A: r and c fragments; role B: u and c fragments (SPEC: see below)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        w0[0][ks] = bhg[((size_t)ks * NGT + (role == 0 ? ct : NCT + ct)) * 64 + lane];
-        w1[0][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
+    for (int ks = 0; ks < KS; ++ks) w0[0][ks] = bhg[((size_t)ks * NGT + (role == 0 ? ct : NCT + ct)) * 64 + lane];
+    if (!SPEC || role == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) w1[0][ks] = bhc[((size_t)ks * NCT + ct) * 64 + lane];
+    } else {                                           // SPEC, role B: its candidate fragments go to LDS once (quad-major, lane-linear)
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = bhc[((size_t)(4 * q + j) * NCT + ct) * 64 + lane];
+            st4(W1L + (ct * (KS / 4) + q) * 256 + 4 * lane, v);
+        }
     }
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // One clip of this workgroup.  ROLE_C >= 0 (SPEC): the role is a compile-time constant of the call and each role walks the clips
+    // in a loop of its own -- inside ONE loop the other role's body is reachable from every point of a role's body through the loop
+    // header, so everything that role keeps in registers for the whole launch (role A's candidate fragments) would stay allocated here.
+    auto clip = [&](const int b, auto ROLE_T) __attribute__((always_inline)) {
+    constexpr int ROLE_C = decltype(ROLE_T)::value;
     __syncthreads();
     for (int e = tid; e < 2 * 32 * KAP; e += 512) A[e] = 0.f;
     lds_load_polys(Pl, P, p_batched ? b : 0, M, N);
@@ -621,19 +677,20 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     const bool valid1 = node1 < N;
     const int oxw1 = (valid1 ? node1 : N - 1) * (3 * H) + col1, oh1 = (valid1 ? node1 : N - 1) * H + col1;
     const int l1 = lds_sw(node1, col1, KAP);           // this lane's element of the h / r*h slot (rows 16..19)
-    if (role == 0) {
+    if (ROLE_C < 0 ? role == 0 : ROLE_C == 0) {
         EEG_SETPRIO(3);         // the r -> r*h -> c chain is the critical path: its instructions issue first
         float pf[poly_slots<M, NKS>()][NKS];
         load_poly_frags<M, NKS, false>(Pl, pf, lr, lg);
         auto diffuse_own = [&](float* buf, float* planes, int t) {
             EEG_WAVE_SYNC();
-            float* g = planes != nullptr ? planes + ((size_t)t * B + b) * N * H : nullptr;
+            float* g = (!SPEC && planes != nullptr) ? planes + ((size_t)t * B + b) * N * H : nullptr;   // (SPEC: Hpl / RHpl are role B's U^T h, U^T (r*h))
             lds_diffuse_tile<M, NKS>(buf, KAP, ct * 16, H, pf, lr, lg, g, plane_stride, N, true);
         };
         diffuse_own(A, Hpl, 0);
-        f32x4 nxr0, nxc;
-        float nxr1;
+        f32x4 nxr0 = zero4, nxc = zero4;
+        float nxr1 = 0.f;
         auto fetch_xw = [&](int t) {                                  // (descriptor on the step's rows: no 64-bit lane addresses)
+            if constexpr (SPEC) return;                               // (role B mixes them out of Yh: XR / XC / XRr)
             const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
             nxr0 = wbuf_ld4(bx, oxw0, 0u);
             nxr1 = wbuf_ld(bx, oxw1, 0u);
@@ -659,6 +716,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             const unsigned so = (unsigned)(s * N * H);
             EEG_LDS_BARRIER();                                        // (1) hops(h) complete
             pp.mark(0);
+            if constexpr (SPEC) {                                     // this step's r pre-activations, mixed by role B in the window before
+                ar[0][0] = ld4(XR + lds_sw(lr, col, UST));
+                ar[0][1][0] = XRr[ct * 64 + lane];
+                if (M > 1 && pre_r) ra += ar[0][0];                   // (the run-ahead hop-0 slot started from zero)
+            }
 
             // all 16x16x4 MFMAs of the r GEMM, then all its 4x4x1 MFMAs (TWOPASS: one change of MFMA shape instead of one per quad;
             // round 4, with the register-reduced remainder: seq_fwd 0.527 -> 0.512 ms; the same order for role B's u GEMM loses)
@@ -691,6 +753,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             EEG_LDS_BARRIER();                                        // (2) hops(r*h) and u of nodes 0..15 complete
             pp.mark(3);
             if (t + 1 < T) fetch_xw(t + 1);
+            if constexpr (SPEC) ac[0][0] = ld4(XC + lds_sw(lr, col, UST));
             mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac);
             pp.mark(4);
             {
@@ -706,10 +769,10 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             }
             pp.mark(5);
             EEG_LDS_BARRIER();                                        // (3) h' complete (rows 16..19 come from role B)
-            if (t + 1 < T || Hpl != nullptr) diffuse_own(A, Hpl, t + 1);
+            if (t + 1 < T || (!SPEC && Hpl != nullptr)) diffuse_own(A, Hpl, t + 1);
             pre_r = M > 1 && t + 1 < T;
             if (pre_r) {      // hop-0 slot of the next step's r GEMM (seq_fwd -2.8 %, profiles/r04_d_*)
-                ra = nxr0;
+                ra = SPEC ? zero4 : nxr0;
                 rc[0] = rc[1] = rc[2] = rc[3] = rc[4] = zero4;
                 f32x4 rr4[4] = {zero4, zero4, zero4, zero4};
                 mfma_tile_quads<KS, 0, QSA>(A, KAP, lane, lr, lg, w0[0], ra, rc[4], rr4);
@@ -720,15 +783,66 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         cs.end(probe, cs_me);
         pp.stamp(2);
     } else {
-        f32x4 nxu0;
-        float nxu1, nxc1;
+        f32x4 nxu0 = zero4;
+        float nxu1 = 0.f, nxc1 = 0.f;
+        // SPEC: this lane's fragments of U (pre-activations: rows of U as the MFMA B operand) and of U^T (by-products), the Yh values of
+        // the next step (node rows 4ks + lg of this column tile of r, u, c), and the two mixes
+        float ux[NKS], ux4[NKS], ut[NKS], ut4[NKS], yv[3][NKS];
+        unsigned vy[NKS];
+        const wbuf_t bY = make_wbuf(XW), bHh = make_wbuf(Hpl != nullptr ? Hpl : Hseq), bRHh = make_wbuf(RHpl != nullptr ? RHpl : Hseq);
+        const unsigned oe0 = (unsigned)lr * (unsigned)spec_SpE * H + col, oe1 = (unsigned)node1 * (unsigned)spec_SpE * H + col1;
+        const unsigned or0 = (unsigned)lr * (unsigned)spec_Sp * H + col, or1 = (unsigned)node1 * (unsigned)spec_Sp * H + col1;
+        if constexpr (SPEC) {
+            load_spec_frags<NKS>(spec_U, N, lane, ut, ut4);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const int i = 4 * ks + lg, j4 = 16 + (lane & 3);
+                ux[ks] = (i < N && lr < N) ? spec_U[lr * N + i] : 0.f;
+                ux4[ks] = (i < N && j4 < N) ? spec_U[j4 * N + i] : 0.f;
+                vy[ks] = (unsigned)(i < N ? i : N - 1) * (unsigned)spec_Sp * (3 * H) + ct * 16 + lr;
+            }
+        }
+        auto fetch_y = [&](int t) {
+            const unsigned so = (unsigned)(((size_t)t * B + b) * (3 * H));
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) yv[g][ks] = wbuf_ld(bY, vy[ks] + g * H, so);
+        };
+        auto xw_mix = [&]() {                                        // yv (step t') -> XR, XC, XRr (LDS, for role A) and nxu0, nxu1, nxc1
+            f32x4 acc[3] = {zero4, zero4, zero4}, rem[3] = {zero4, zero4, zero4};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = mfma16(yv[g][ks], ux[ks], acc[g]);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) rem[g] = mfma4(ux4[ks], yv[g][ks], rem[g]);
+            st4(XR + lds_sw(lr, col, UST), acc[0]);
+            st4(XC + lds_sw(lr, col, UST), acc[2]);
+            XRr[ct * 64 + lane] = rem4_reduce(rem[0]);
+            nxu0 = acc[1];
+            nxu1 = rem4_reduce(rem[1]);
+            nxc1 = rem4_reduce(rem[2]);
+        };
+        auto export_tile = [&](const float* tile, wbuf_t out, unsigned o0, unsigned o1, unsigned row) {
+            const float* const tl[1] = {tile};
+            const int strd[1] = {KAP}, scol[1] = {ct * 16}, gcol[1] = {0};
+            spec_mix_tiles_out<NKS, 1>(tl, strd, scol, gcol, ut, ut4, lr, lg, out, o0, o1, row * H, valid[0], valid1);
+        };
         auto fetch_x = [&](int t) {
+            if constexpr (SPEC) { fetch_y(t); return; }
             const wbuf_t bx = make_wbuf(XW + ((size_t)t * B + b) * N * (3 * H));
             nxu0 = wbuf_ld4(bx, oxw0 + H, 0u);
             nxu1 = wbuf_ld(bx, oxw1 + H, 0u);
             nxc1 = wbuf_ld(bx, oxw1 + 2 * H, 0u);
         };
         fetch_x(0);
+        if constexpr (SPEC) {
+            if (Hpl != nullptr) export_tile(A, bHh, oe0, oe1, (unsigned)b);                       // slot 0: U^T of the initial state
+            xw_mix();                                                                                 // the pre-activations of step 0
+        }
         // The hop-0 slot of the NEXT step's update-gate GEMM (the first K quads: h' itself, complete at barrier 3) runs in the third
         // window, where role A mixes h' and the matrix pipe is otherwise idle; the other hop slots follow behind barrier (1).
         // (Round 3 measured this move as a loss; with the register-reduced remainder it wins: seq_fwd -3..4 %, profiles/r04_d_*.)
@@ -763,7 +877,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             }
             EEG_LDS_BARRIER();                                        // (2)
             // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend, one element per lane
-            mfma_nodes32<1, KS, true, 2, 0, false, false, true>(A2, KAP, lane, lr, lg, w1, ac);
+            if constexpr (SPEC) ac[0][1][0] += mfma_rem4_ldsw<KS>(A2, KAP, lane, lg, W1L + ct * (KS / 4) * 256);
+            else mfma_nodes32<1, KS, true, 2, 0, false, false, true>(A2, KAP, lane, lr, lg, w1, ac);
             {
                 const float h1 = A[l1];
                 const float c1 = act == 0 ? tanhf_(ac[0][1][0]) : fmaxf(ac[0][1][0], 0.f);
@@ -777,8 +892,15 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     }
                 }
             }
+            if constexpr (SPEC) {                                     // U^T (r * h_{t-1}) of this column tile (slot 0 of A2: complete at barrier 2)
+                if (RHpl != nullptr) export_tile(A2, bRHh, or0, or1, (unsigned)s);
+            }
             EEG_LDS_BARRIER();                                        // (3)
             pre = t + 1 < T;
+            if constexpr (SPEC) {
+                if (Hpl != nullptr) export_tile(A, bHh, oe0, oe1, (unsigned)(s + B));                // slot t+1: U^T h_t (h' complete at barrier 3)
+                if (pre) xw_mix();                                                                    // step t+1's pre-activations (Yh requested in phase 1)
+            }
             if (pre) {                                                // hop-0 slot of step t+1's update gate, from h' (slot 0 of A)
                 ua = nxu0; ub = zero4; ux1 = nxu1;
                 urem[0] = urem[1] = urem[2] = urem[3] = zero4;
@@ -787,7 +909,13 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             }
         }
     }
-    }   // clips of this workgroup
+    };   // clip
+    if constexpr (SPEC) {
+        if (role == 0) { for (int b = blockIdx.x; b < B; b += gridDim.x) clip(b, SeqIdx<0>()); }
+        else { for (int b = blockIdx.x; b < B; b += gridDim.x) clip(b, SeqIdx<1>()); }
+    } else {
+        for (int b = blockIdx.x; b < B; b += gridDim.x) clip(b, SeqIdx<-1>());
+    }
     if (role == 0) pp.dump(probe, 0);
 }
 
@@ -1100,7 +1228,7 @@ __global__ __launch_bounds__(256, 1) void seq_bwd_kernel(
 //   window 1 (after barrier 1)               A: GEMM1, dR, P^T dR       B: coefficients(t-1) -> LDS, requests operands(t-2); GEMM2 dU half; sums dC, dU
 //   window 2 (after barrier 2)               A: -                       B: GEMM2 dR half; DP = result + external gradient(t-1)
 // SPEC (spectral form of the hoisted x-part, spec_common.h): the step's [dR|dU|dC] leaves as dYh = U^T dXW in the NODE-major layout
-// (N, Sp, 3H) the grouped weight-gradient / input-gradient GEMMs read (row of (t, b): b*T + t when spec_bt, else t*B + b), instead
+// (N, Sp, 3H) the grouped weight-gradient / input-gradient GEMMs read (row of (t, b) = t*B + b), instead
 // of dXW -- role A mixes its column tile of dC, dU, dR with U^T in window 2, where it has nothing else to do (15 + 15 MFMAs beside
 // role B's dR half), from the slot-0 columns it wrote itself.  A separate HBM pass over dXW (read 3H, write 3H per node row) is gone.
 template <int H, int M, int NKS, bool PROBE = false, bool SPEC = false>
@@ -1110,7 +1238,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
     const float* __restrict__ d_at_end, const float* __restrict__ d_at_len, const long long* __restrict__ lengths,
     const float* __restrict__ P, int p_batched, const float* __restrict__ b1p, const float* __restrict__ b2p,
     float* __restrict__ dXW, float* __restrict__ dh0, float* __restrict__ dbias_part, int T, int B, int N, int act,
-    long long* probe, const float* __restrict__ spec_U = nullptr, float* __restrict__ dYh = nullptr, int spec_Sp = 0, int spec_bt = 0) {
+    long long* probe, const float* __restrict__ spec_U = nullptr, float* __restrict__ dYh = nullptr, int spec_Sp = 0) {
     using G = SeqGeom<H, M>;
     static_assert(G::CT == 1 && NKS == 5, "one column tile per wave, second node tile on the 4x4x1 MFMA");
     constexpr int KAP = G::KAP, KS = G::KS, KGP = G::KGP, KSG = G::KSG, NCT = G::NCT, ROWS = 32, DPS = 20;
@@ -1363,7 +1491,7 @@ __global__ __launch_bounds__(512, 1) void seq_bwd2_kernel(
             // dYh = U^T [dR | dU | dC] of this column tile, from the slot-0 columns this wave wrote itself (complete for all nodes)
             const float* const tl[3] = {EG, EG, EC};
             const int strd[3] = {KGP, KGP, KAP}, scol[3] = {ct * 16, H + ct * 16, ct * 16}, gcol[3] = {0, H, 2 * H};
-            const unsigned row = spec_bt ? (unsigned)b * (unsigned)T + (unsigned)t : (unsigned)t * (unsigned)B + (unsigned)b;
+            const unsigned row = (unsigned)t * (unsigned)B + (unsigned)b;
             EEG_WAVE_SYNC();
             spec_mix_tiles_out<NKS, 3>(tl, strd, scol, gcol, uf, u4, lr, lg, bY, oy0, oy1, row * (3 * H), valid[0], valid1);
         }

@@ -101,6 +101,14 @@ __global__ __launch_bounds__(256) void spectral_basis_kernel(const float* __rest
         }
     }
     if (tid >= 3 && tid < kSpecInfo) out[N * N + kSpecTc + tid] = 0.f;
+    // csum[i] = sum_n U[n][i]: U^T applied to a constant node vector -- a bias b (the same row for every node) is csum[i] * b in
+    // the eigenbasis, which is how the grouped GEMM adds it
+    if (tid < 32) {
+        double c = 0.0;
+        if (tid < N)
+            for (int n = 0; n < N; ++n) c += V[n * 32 + tid];
+        out[N * N + kSpecTc + kSpecInfo + tid] = (float)c;
+    }
 }
 constexpr size_t kSpecBasisLds = (2 * 32 * 32 + 32 + 256) * sizeof(double) + 32 * sizeof(int);
 
@@ -133,11 +141,11 @@ __global__ void pack_spectral_kernel(const float* __restrict__ Wg, const float* 
 }
 
 // ---- node mixes ------------------------------------------------------------------------------------------------------------------
-// row map between the rows r of the node-major side and the sample index s of the sample-major side (in ITS storage order):
-//   map 0: s = r;   map 1: the node-major rows are batch-major (r = b*T + t), the sample-major side is time-major (s = t*B + b).
-// Both mixes walk the NODE-major rows in order (N sequential streams); the sample-major side is touched in whole samples
+// The node-major side is ALWAYS time-major: row r = t*B + b.  map = 1: the sample-major side is the BATCH-major model input
+// (B, T, N, F) as the trainer holds it (model.py:253's transpose is never materialised): sample r lives at storage index b*T + t.
+// Both mixes walk the node-major rows in order (N sequential streams); the sample-major side is touched in whole samples
 // (N * F * 4 contiguous bytes each).
-__device__ __forceinline__ size_t spec_sample(size_t r, int map, int T, int B) { return map ? (r % T) * (size_t)B + r / T : r; }
+__device__ __forceinline__ size_t spec_sample(size_t r, int map, int T, int B) { return map ? (r % B) * (size_t)T + r / B : r; }
 
 // in: sample-major X (S, N, F);  out: node-major Xh (N, Sp, F), Xh[i][r(s)] = sum_n U[n][i] X[s][n];  pad rows [S, Sp) <- 0
 template <int N>

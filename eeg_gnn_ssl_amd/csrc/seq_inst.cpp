@@ -38,14 +38,28 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
                 if (a.probe != nullptr) {
                     EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, true>), lds2);
                     EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
-                                 a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
+                                 a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe,
+                                 nullptr, 0, 0);
                     return hipGetLastError() == hipSuccess ? 0 : 2;
                 }
             }
 #endif
+            if constexpr (M >= 2) {
+                if (a.Yh != nullptr && a.spec_U != nullptr && a.spec_done != nullptr && (double)a.N * a.spec_Sp * 3 * H * sizeof(float) < 2147483648.0 &&
+                    (double)a.N * a.spec_SpE * H * sizeof(float) < 2147483648.0) {
+                    const size_t lds3 = lds2 + (2 * 16 * 64 + 4 * 64 + 4 * (SeqGeom<H, M>::KS / 4) * 256) * sizeof(float);   // + XR, XC [16][64], XRr [4][64], W1L
+                    EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, false, true>), lds3);
+                    EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, false, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds3, st, a.Yh,
+                                 a.h0, a.P, a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hh, a.RHh, (size_t)0, a.T, a.B, a.N, a.act, a.probe,
+                                 a.spec_U, a.spec_Sp, a.spec_SpE);
+                    *a.spec_done = 1;
+                    return hipGetLastError() == hipSuccess ? 0 : 2;
+                }
+            }
             EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS>), lds2);
             EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
-                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe);
+                         a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe,
+                         nullptr, 0, 0);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }
@@ -83,7 +97,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
                     EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, true>), lds2);
                     EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us,
                                  a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe, nullptr, nullptr, 0, 0);
+                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe, nullptr, nullptr, 0);
                     return hipGetLastError() == hipSuccess ? 0 : 2;
                 }
             }
@@ -93,7 +107,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
                     EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, false, true>), lds2);
                     EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, false, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq,
                                  a.h0, a.Rs, a.Us, a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe, a.spec_U, a.dYh, a.spec_Sp, a.spec_bt);
+                                 a.dbias_part, a.T, a.B, a.N, a.act, a.probe, a.spec_U, a.dYh, a.spec_Sp);
                     *a.spec_done = 1;
                     return hipGetLastError() == hipSuccess ? 0 : 2;
                 }
@@ -101,7 +115,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
             EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS>), lds2);
             EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us, a.Cs,
                          a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
-                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe, nullptr, nullptr, 0, 0);
+                         a.dbias_part, a.T, a.B, a.N, a.act, a.probe, nullptr, nullptr, 0);
             return hipGetLastError() == hipSuccess ? 0 : 2;
         }
     }

@@ -16,6 +16,13 @@ struct SeqFwdArgs {
     int T, B, N, act;
     long long* probe;
     int variant = 0;        // 1: two waves per SIMD (seq_fwd2_kernel) where it exists
+    // spectral form (spec_common.h): where the two-wave kernel runs it takes the pre-activations in the eigenbasis, Yh (N, spec_Sp,
+    // 3H) node-major with the bias inside, INSTEAD of XW, writes U^T h_slot to Hh (N, spec_SpE, H) (row slot*B + b, slots 0..T) and
+    // U^T (r*h_{t-1}) to RHh (N, spec_Sp, H) (both nullable) instead of hop planes, and sets *spec_done = 1; else nothing of this
+    const float *spec_U = nullptr, *Yh = nullptr;
+    float *Hh = nullptr, *RHh = nullptr;
+    int spec_Sp = 0, spec_SpE = 0;
+    int* spec_done = nullptr;
 };
 struct SeqBwdArgs {
     const float *Hseq, *h0, *Rs, *Us, *Cs, *dHseq, *d_at_end, *d_at_len;
@@ -28,10 +35,10 @@ struct SeqBwdArgs {
     long long* probe;
     int variant = 0;        // 1: two waves per SIMD (seq_bwd2_kernel) or two workgroups per CU (seq_bwd_stream_kernel) where they apply
     // spectral form (spec_common.h): where the two-wave kernel runs it writes dYh = U^T dXW (node-major (N, spec_Sp, 3H); row of
-    // (t, b) = b*T + t when spec_bt, else t*B + b) INSTEAD of dXW and sets *spec_done = 1; elsewhere dXW is written as usual
+    // (t, b) = t*B + b) INSTEAD of dXW and sets *spec_done = 1; elsewhere dXW is written as usual
     const float* spec_U = nullptr;
     float* dYh = nullptr;
-    int spec_Sp = 0, spec_bt = 0;
+    int spec_Sp = 0;
     int* spec_done = nullptr;
 };
 

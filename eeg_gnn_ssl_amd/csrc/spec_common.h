@@ -25,9 +25,10 @@
 
 namespace eeg {
 
-// ---- the basis block: U (N*N, row n = node, column i = frequency) | tc[kMaxM][32] = T_m(lam_i) | info[32] ---------------------
-constexpr int kSpecTc = kMaxM * 32, kSpecInfo = 32;
-__host__ __device__ constexpr int spec_basis_floats(int N) { return N * N + kSpecTc + kSpecInfo; }
+// ---- the basis block: U (N*N, row n = node, column i = frequency) | tc[kMaxM][32] = T_m(lam_i) | info[32] | csum[32] = sum_n U[n][i]
+constexpr int kSpecTc = kMaxM * 32, kSpecInfo = 32, kSpecCsum = 32;
+__host__ __device__ constexpr int spec_basis_floats(int N) { return N * N + kSpecTc + kSpecInfo + kSpecCsum; }
+__host__ __device__ constexpr int spec_csum_offset(int N) { return N * N + kSpecTc + kSpecInfo; }
 __host__ __device__ constexpr int spec_rows(int S) { return round_up(S, 16); }
 constexpr int kSpecSweeps = 12;
 

@@ -29,35 +29,36 @@ int launch_spec_pack(const float* Wg, const float* Wc, const float* basis, int F
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bt,
-                    float* out, hipStream_t st, const char* tag) {
-    const int S = T * B, Sp = spec_rows(S), F4 = F / 4;
+int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bm,
+                    float* out, hipStream_t st, const char* tag, int node_rows) {
+    const int S = T * B, Sp = node_rows > 0 ? node_rows : spec_rows(S), F4 = F / 4;
     if (N == 19 && F4 <= 128) {
         int threads = 256;
         while (threads > 64 && (threads / 2) >= F4 && (threads / 2) / F4 >= Sp) threads /= 2;
         const int SPW = threads / F4;
         int nb = ceil_div(to_nodes ? Sp : S, SPW);
         if (nb > 1024) nb = 1024;                          // ~4 workgroups per CU, each walking consecutive passes (cf. diffuse_fwd)
-        if (to_nodes) EEG_LAUNCH_P(tag, spec_mix_in_kernel<19>, dim3(nb), dim3(threads), 0, st, in, basis, S, Sp, F, bt, T, B, out);
-        else EEG_LAUNCH_P(tag, spec_mix_out_kernel<19>, dim3(nb), dim3(threads), 0, st, in, basis, bias, S, Sp, F, bt, T, B, out);
+        if (to_nodes) EEG_LAUNCH_P(tag, spec_mix_in_kernel<19>, dim3(nb), dim3(threads), 0, st, in, basis, S, Sp, F, bm, T, B, out);
+        else EEG_LAUNCH_P(tag, spec_mix_out_kernel<19>, dim3(nb), dim3(threads), 0, st, in, basis, bias, S, Sp, F, bm, T, B, out);
     } else {
         const size_t total = (size_t)(to_nodes ? Sp : S) * N * F4;
         int nb = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-        EEG_LAUNCH_P(tag, spec_mix_generic_kernel, dim3(nb), dim3(256), (size_t)N * N * sizeof(float), st, in, basis, bias, N, S, Sp, F, bt,
+        EEG_LAUNCH_P(tag, spec_mix_generic_kernel, dim3(nb), dim3(256), (size_t)N * N * sizeof(float), st, in, basis, bias, N, S, Sp, F, bm,
                      T, B, to_nodes, out);
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int launch_spec_zero_pad(float* Xh, int N, int S, int F, hipStream_t st) {
-    const int Sp = spec_rows(S);
-    if (Sp == S) return 0;
+int launch_spec_zero_rows(float* Xh, int N, int S, int Sp, int F, hipStream_t st) {
+    if (Sp <= S) return 0;
     EEG_LAUNCH_P("zero", spec_zero_pad_kernel, dim3(ceil_div(N * (Sp - S) * F, 256)), dim3(256), 0, st, Xh, N, S, Sp, F);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+int launch_spec_zero_pad(float* Xh, int N, int S, int F, hipStream_t st) { return launch_spec_zero_rows(Xh, N, S, spec_rows(S), F, st); }
 
 int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wstride, int nct, float* C, int num_cus, hipStream_t st,
-               const char* tag) {
+               const char* tag, const float* bias, const float* gscale, size_t a_gstride) {
+    const unsigned ags = (unsigned)(a_gstride != 0 ? a_gstride : (size_t)Sp * F);
     const size_t lds = (size_t)4 * 128 * 16 * sizeof(float);
     const int RT = (Sp / 16) * G;
     int Gw = 2 * (num_cus > 0 ? num_cus : 256);
@@ -65,10 +66,10 @@ int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wst
     if (Gw < 1) Gw = 1;
     if (nct == 12) {
         EEG_SET_MAX_LDS((gemm_nng_kernel<3, 2>), lds);
-        EEG_LAUNCH_P(tag, (gemm_nng_kernel<3, 2>), dim3(Gw), dim3(256), lds, st, A, F, Sp, G, Wq, (unsigned)wstride, C, 16 * nct);
+        EEG_LAUNCH_P(tag, (gemm_nng_kernel<3, 2>), dim3(Gw), dim3(256), lds, st, A, ags, F, Sp, G, Wq, (unsigned)wstride, C, 16 * nct, bias, gscale);
     } else if (nct == 4) {
         EEG_SET_MAX_LDS((gemm_nng_kernel<1, 2>), lds);
-        EEG_LAUNCH_P(tag, (gemm_nng_kernel<1, 2>), dim3(Gw), dim3(256), lds, st, A, F, Sp, G, Wq, (unsigned)wstride, C, 16 * nct);
+        EEG_LAUNCH_P(tag, (gemm_nng_kernel<1, 2>), dim3(Gw), dim3(256), lds, st, A, ags, F, Sp, G, Wq, (unsigned)wstride, C, 16 * nct, bias, gscale);
     } else {
         return 1;
     }
@@ -102,21 +103,23 @@ TngPlan tng_plan(int F, int Sp, int G, int num_cus) {
 
 namespace {
 template <int KT, bool PLANAR>
-int launch_tng_one(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag) {
+int launch_tng_one(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag,
+                   long long skew) {
     constexpr int RC = 16, OT = 6;
     const size_t lds = 3 * (size_t)(RC * 32 * (KT + OT)) * sizeof(float);
     SegPtrs segs;
     for (int m = 0; m < kMaxM; ++m) segs.p[m] = m == 0 ? A : nullptr;
     EEG_SET_MAX_LDS((gemm_tnq_grouped_kernel<KT, OT, RC, PLANAR>), lds);
     EEG_LAUNCH_P(tag, (gemm_tnq_grouped_kernel<KT, OT, RC, PLANAR>), dim3(p.nkb, G * p.spg), dim3(256), lds, st, segs, F, Sp, G, p.spg, dY, 192,
-                 0, 192, partial, p.rps);
+                 0, 192, partial, p.rps, skew);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 }  // namespace
 
 int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp, int G, const float* dY, float* part_g, float* part_c,
-                    hipStream_t st, const char* tag) {
+                    hipStream_t st, const char* tag, size_t ah_gstride) {
     if (!p.ok || !p.planar || p.KT != 2 || p.nkb != 1) return 1;
+    const long long skew = ah_gstride != 0 ? (long long)ah_gstride - (long long)Sp * 64 : 0;
     constexpr int RC = 16, KT = 2;
     const size_t lds = 3 * (size_t)(RC * 32 * (KT + 4)) * sizeof(float);
     TnqJob ja, jb;
@@ -125,15 +128,17 @@ int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp,
     jb.ycol0 = 128; jb.Ov = 64; jb.partial = part_c;
     EEG_SET_MAX_LDS((gemm_tnq_grouped_pair_kernel<KT, RC, true>), lds);
     EEG_LAUNCH_P(tag, (gemm_tnq_grouped_pair_kernel<KT, RC, true>), dim3(1, 2 * G * p.spg), dim3(256), lds, st, ja, jb, 64, Sp, G, p.spg, dY, 192,
-                 p.rps);
+                 p.rps, skew, (long long)0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag) {
+int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag,
+               size_t a_gstride) {
     if (!p.ok) return 1;
-    if (p.planar) return launch_tng_one<2, true>(p, A, F, Sp, G, dY, partial, st, tag);
-    if (p.KT == 4) return launch_tng_one<4, false>(p, A, F, Sp, G, dY, partial, st, tag);
-    return launch_tng_one<5, false>(p, A, F, Sp, G, dY, partial, st, tag);
+    const long long skew = a_gstride != 0 ? (long long)a_gstride - (long long)Sp * F : 0;
+    if (p.planar) return launch_tng_one<2, true>(p, A, F, Sp, G, dY, partial, st, tag, skew);
+    if (p.KT == 4) return launch_tng_one<4, false>(p, A, F, Sp, G, dY, partial, st, tag, skew);
+    return launch_tng_one<5, false>(p, A, F, Sp, G, dY, partial, st, tag, skew);
 }
 
 }  // namespace eeg

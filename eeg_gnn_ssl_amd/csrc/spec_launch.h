@@ -14,23 +14,30 @@ int launch_spec_basis(const float* S, int N, float* basis, hipStream_t st);
 int launch_spec_pack(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N, float* spack, hipStream_t st);
 
 // node mixes: to_nodes = 1: X (S,N,F) -> Xh (N,Sp,F) with U^T (pad rows zeroed); 0: Yh (N,Sp,F) -> Y (S,N,F) with U (+ bias).
-// bt = 1: the node-major rows are batch-major (r = b*T + t) while the sample-major side is time-major
-int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bt,
-                    float* out, hipStream_t st, const char* tag);
+// The node-major rows are time-major (r = t*B + b); bm = 1: the sample-major side is the batch-major (B, T, N, F) model input
+// node_rows: rows per frequency of the node-major side (its group stride; 0 = T*B rounded up to 16); rows [T*B, node_rows) are zeroed
+int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bm,
+                    float* out, hipStream_t st, const char* tag, int node_rows = 0);
 
 // pad rows [S, Sp) of every frequency of a node-major (N, Sp, F) tensor <- 0 (no launch when Sp == S)
 int launch_spec_zero_pad(float* Xh, int N, int S, int F, hipStream_t st);
 
 // grouped NN: C (N*Sp, 16*nct) = A (N*Sp, F) * W_i;  Wq = block 0 of the per-frequency quad packs, wstride floats apart
+// bias (16*nct floats, nullable) + gscale (G floats): the tiles of group g start from gscale[g] * bias
+// a_gstride: floats between two groups of A (0 = Sp * F, contiguous)
 int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wstride, int nct, float* C, int num_cus,
-               hipStream_t st, const char* tag);
+               hipStream_t st, const char* tag, const float* bias = nullptr, const float* gscale = nullptr, size_t a_gstride = 0);
 
 // grouped TN: partial [G*spg][F][192] of A (G*Sp, F)^T dY (G*Sp, 192)
 struct TngPlan { int ok, KT, planar, nkb, spg, rps; };
 TngPlan tng_plan(int F, int Sp, int G, int num_cus);
-int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag);
+int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag,
+               size_t a_gstride = 0);
 // h-part pair (F = 64): part_g [G*spg][64][128] = Ah^T dY[:, 0:128], part_c [G*spg][64][64] = Arh^T dY[:, 128:192]; one launch
+// (ah_gstride: floats between two groups of Ah, 0 = contiguous; Arh is contiguous)
 int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp, int G, const float* dY, float* part_g, float* part_c,
-                    hipStream_t st, const char* tag);
+                    hipStream_t st, const char* tag, size_t ah_gstride = 0);
+// rows [S, Sp) of every group of a (N, Sp, F) node-major tensor <- 0, Sp any row count >= S
+int launch_spec_zero_rows(float* Xh, int N, int S, int Sp, int F, hipStream_t st);
 
 }  // namespace eeg

@@ -453,9 +453,14 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     dims = _layer_dims(t_len, b, n, h, fin, m, act, p_batched, ready)
     if spec:
         _check(lib, basis, "basis")
-        if ready or p_batched or basis.numel() != _spectral_basis_floats(n) or not lib.query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), 0):
-            raise RuntimeError("dcgru_layer: the spectral form needs one shared support (p_batched = 0), no handed-over hop planes and "
-                               "a shape eeg_dcrnn_spectral_ok accepts")
+        sp_rows = int(lib.query("eeg_dcrnn_spectral_rows", t_len * b))
+        if ready:      # x_planes = the layer below's U^T h (N, B + Sp, Fin): rows B.. of every frequency are this layer's transformed input
+            dims.x_plane_stride = (b + sp_rows) * fin
+        if p_batched or basis.numel() != _spectral_basis_floats(n) or not lib.query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), 0):
+            raise RuntimeError("dcgru_layer: the spectral form needs one shared support (p_batched = 0) and a shape "
+                               "eeg_dcrnn_spectral_ok accepts")
+        if ready and tuple(x_planes.shape) != (n, b + sp_rows, fin):
+            raise RuntimeError(f"x_planes has shape {tuple(x_planes.shape)}, expected {(n, b + sp_rows, fin)} (the layer below's U^T h)")
     empty = _new((0,), p)
     # a transposed view of a contiguous batch-major (B,T,N,Fin) tensor (what model.py:253 produces) is consumed
     # as it is: the diffusion kernel emits the time-major copy as a by-product
@@ -489,8 +494,12 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     if spec:
         spack = torch.ops.eeg_dcrnn.pack_cell_spectral(wg, wc, basis, fin, h, m, n)
         dims.spectral, dims.spack = basis.data_ptr(), spack.data_ptr()
-        planes = _new((n, lib.query("eeg_dcrnn_spectral_rows", s), fin), x)
-        planes_ptr = planes.data_ptr()
+        if ready:
+            _check(lib, x_planes, "x_planes")
+            planes, planes_ptr = _new((0,), p), x_planes.data_ptr() + 4 * b * fin
+        else:
+            planes = _new((n, sp_rows, fin), x)
+            planes_ptr = planes.data_ptr()
     elif ready:
         _check(lib, x_planes, "x_planes")
         if tuple(x_planes.shape) != (m - 1, t_len + 1, b, n, fin):
@@ -502,14 +511,15 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
     hext = _new((t_len + 1, b, n * h), x)
     if save:
         rs, us, cs, rhs = (_new((t_len, b, n * h), x) for _ in range(4))
-        # (spectral form: the backward contracts U^T h, not the hop rows P_m h -- the recurrent kernel keeps no by-product planes)
-        hpl, rhpl = (_new((0,) if spec else (m - 1, t_len + 1, b, n, h), x) for _ in range(2))
+        if spec:       # the by-products in the eigenbasis: U^T h_slot (slots 0..T; the next layer's transformed input) and U^T (r*h_{t-1})
+            hpl, rhpl = _new((n, b + sp_rows, h), x), _new((n, sp_rows, h), x)
+        else:
+            hpl, rhpl = (_new((m - 1, t_len + 1, b, n, h), x) for _ in range(2))
     else:
         rs = us = cs = rhs = hpl = rhpl = None
     ws = _new((lib.query("eeg_dcrnn_layer_fwd_ws_floats", ctypes.byref(dims)),), x)
     lib.call("eeg_dcrnn_layer_fwd", ctypes.byref(dims), _p(xsrc if xsrc is not None else xk), _p(xtm) if (xsrc is not None and bm != 2) else None,
-             _p(h0), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), None if spec else _p(hpl),
-             None if spec else _p(rhpl), _p(ws), _stream(x))
+             _p(h0), _p(p), _p(pack), planes_ptr, _p(hext), _p(rs), _p(us), _p(cs), _p(rhs), _p(hpl), _p(rhpl), _p(ws), _stream(x))
     if lengths is not None:
         lengths = lengths.to(device=x.device, dtype=torch.int64).contiguous()
         hsel = _new((b, n * h), x)
@@ -540,12 +550,15 @@ def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_pla
     xtm = ne(t_len, b, n, fin) if (not x.is_contiguous() and not zero_copy) else ne(0)
     planes = ne(0) if x_planes is not None else ne(m - 1, t_len * b, n, fin)
     spack = ne(0)
+    byp = [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)]
     if spec:
         lib = _lib.get_lib()
-        planes = ne(n, int(lib.query("eeg_dcrnn_spectral_rows", t_len * b)), fin)
+        sp_rows = int(lib.query("eeg_dcrnn_spectral_rows", t_len * b))
+        if x_planes is None:
+            planes = ne(n, sp_rows, fin)
         spack = ne(int(lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)))
-    return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + \
-        [(ne(0) if spec else ne(m - 1, t_len + 1, b, n, h)) for _ in range(2)] + [spack]
+        byp = [ne(n, b + sp_rows, h), ne(n, sp_rows, h)]
+    return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + byp + [spack]
 
 
 def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack, planes, x_planes, hext, rs, us, cs, rhs,
@@ -565,7 +578,10 @@ def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack
     planes_ptr = x_planes.data_ptr() + 4 * b * n * fin if ready else planes.data_ptr()
     _set_pack3(dims, pack, fin, h, m)
     if basis is not None:                 # the forward ran the spectral form: `planes` is its node-major transformed input
-        if spack is None or ready or not lib.query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), 1 if need_dx else 0):
+        if ready:                         # ... handed over by the layer below: rows B.. of every frequency of its U^T h (N, B + Sp, Fin)
+            dims.x_plane_stride = x_planes.shape[1] * fin
+            planes_ptr = x_planes.data_ptr() + 4 * b * fin
+        if spack is None or not lib.query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), 1 if need_dx else 0):
             raise RuntimeError("dcgru_layer_bwd: the spectral form does not cover this call (input gradient of a layer whose "
                                "input width is not 64?)")
         dims.spectral, dims.spack = basis.data_ptr(), spack.data_ptr()
@@ -1206,9 +1222,12 @@ def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activati
         if p_batched or not _lib.get_lib().query("eeg_dcrnn_spectral_ok", ctypes.byref(dims), need_dx):
             basis = None
         else:
-            x_planes = None                # the spectral layer transforms its own input: no hop-plane hand-over
+            if x_planes is not None and x_planes.dim() != 3:
+                x_planes = None            # (hop planes of a layer that took the general path)
             global spectral_layer_calls
             spectral_layer_calls += 1
+    if basis is None and x_planes is not None and x_planes.dim() != 5:
+        x_planes = None                    # (the U^T h of a spectral layer is of no use to the general path)
     if x_planes is not None:
         global hop_plane_handovers
         hop_plane_handovers += 1
