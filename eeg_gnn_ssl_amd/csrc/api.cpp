@@ -356,7 +356,7 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
 // the two-wave recurrent kernels exist in a SPEC instantiation (spectral form: seq_launch.h) for exactly these calls -- mirrors the
 // selection inside seq_inst.cpp (64 units, at most 20 nodes, 2 or 3 hop matrices, two-wave variant on, 2 GB buffer descriptors)
 bool seq2_spec_ok(int H, int M, int N, int T, int B, int variant, int Sp, int SpE) {
-    if (H != 64 || N > 20 || M < 2 || M > 3 || variant != 1 || phase_probe_armed()) return false;
+    if (H != 64 || N < 16 || N > 20 || M < 2 || M > 3 || variant != 1 || phase_probe_armed()) return false;
     return (double)T * B * N * 3 * H * sizeof(float) < 2147483648.0 && (double)N * Sp * 3 * H * sizeof(float) < 2147483648.0 &&
            (double)N * SpE * H * sizeof(float) < 2147483648.0;
 }

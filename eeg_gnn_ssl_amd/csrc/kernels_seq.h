@@ -266,20 +266,31 @@ __device__ __forceinline__ void spec_mix_tiles_out(const float* const (&tile)[NG
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) a[g][ks] = tile[g][lds_sw(4 * ks + lg, src_col[g] + lr, stride[g])];
-    f32x4 acc[NG], rem[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = rem[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) acc[g] = mfma16(a[g][ks], uf[ks], acc[g]);
+    f32x4 acc[NG], alt[NG], rem[NG], rem2[NG];                                // (NG == 1: two 16x16x4 chains -- a lone accumulator
+#pragma unroll                                                                //  makes every MFMA wait for the one before it)
+    for (int g = 0; g < NG; ++g) acc[g] = alt[g] = rem[g] = rem2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) rem[g] = mfma4(u4[ks], a[g][ks], rem[g]);
+        for (int g = 0; g < NG; ++g) {
+            if (NG == 1 && (ks & 1)) alt[g] = mfma16(a[g][ks], uf[ks], alt[g]);
+            else acc[g] = mfma16(a[g][ks], uf[ks], acc[g]);
+        }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (ks & 1) rem2[g] = mfma4(u4[ks], a[g][ks], rem2[g]);
+            else rem[g] = mfma4(u4[ks], a[g][ks], rem[g]);
+        }
+    if (NG == 1) acc[0] += alt[0];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const float r1 = rem4_reduce(rem[g]);
+        // (the register swaps of rem4_reduce are inline asm, which the compiler's hazard recognizer does not look into: they must not be
+        //  the first readers of an MFMA result -- the two-chain sum is an ordinary VALU instruction and gets the matrix-write wait states)
+        f32x4 tr = rem[g] + rem2[g];
+        EEG_PIN(tr);
+        const float r1 = rem4_reduce(tr);
         if (valid0) wbuf_st4(out, voff0 + (unsigned)gcol[g], soff, acc[g]);
         if (valid1) wbuf_st1(out, voff1 + (unsigned)gcol[g], soff, r1);
     }
@@ -296,19 +307,25 @@ __device__ __forceinline__ float mfma_rem4_ldsw(const float* __restrict__ X, int
     f32x4 rem[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rem[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int NQ = NKS / 4;
-    float4 a1 = frag(0), w4 = *reinterpret_cast<const float4*>(wl + 4 * lane);
+    constexpr int NQ = NKS / 4, D = 2;                       // fragments D quads ahead: a quad is only 4 x 8 cycles of MFMAs
+    float4 xa[D], wa[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xa[d] = frag(d < NQ ? d : NQ - 1);
+        wa[d] = *reinterpret_cast<const float4*>(wl + (d < NQ ? d : NQ - 1) * 256 + 4 * lane);
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        float4 n1 = a1, nw = w4;
-        if (q + 1 < NQ) { n1 = frag(q + 1); nw = *reinterpret_cast<const float4*>(wl + (q + 1) * 256 + 4 * lane); }
+        const float4 a1 = xa[q % D], w4 = wa[q % D];
+        if (q + D < NQ) {
+            xa[q % D] = frag(q + D);
+            wa[q % D] = *reinterpret_cast<const float4*>(wl + (q + D) * 256 + 4 * lane);
+        }
         EEG_SCHED_FENCE();
         const float x1[4] = {a1.x, a1.y, a1.z, a1.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) rem[j] = mfma4(x1[j], ww[j], rem[j]);
         EEG_SCHED_FENCE();
-        a1 = n1;
-        w4 = nw;
     }
     f32x4 t = (rem[0] + rem[1]) + (rem[2] + rem[3]);
     EEG_PIN(t);
@@ -625,8 +642,8 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
     const int lr = lane & 15, lg = lane >> 4;
     float* U = A2 + 32 * KAP;                      // [16][UST] update gate of nodes 0..15 of the current step
     float* XR = U + 16 * UST;                      // SPEC: [16][UST] r pre-activations of nodes 0..15 of the next step (from role B)
-    float* XC = XR + 16 * UST;                     //       ... of c
-    float* XRr = XC + 16 * UST;                    //       [4 tiles][64 lanes]: r pre-activation of node 16 + lg, column ct*16 + lr
+    float* XC = XR + 16 * UST;                     //       ... of c, two buffers (step parity: written one phase after the other is read)
+    float* XRr = XC + 2 * 16 * UST;                //       [4 tiles][64 lanes]: r pre-activation of node 16 + lg, column ct*16 + lr
     float* W1L = XRr + 4 * 64;                     //       [4 tiles][KS/4][64][4]: role B's candidate weights (mfma_rem4_ldsw)
     const bool save = Rs != nullptr;
     const int ct = wave;                               // NCT == 4 == waves per role
@@ -753,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
             EEG_LDS_BARRIER();                                        // (2) hops(r*h) and u of nodes 0..15 complete
             pp.mark(3);
             if (t + 1 < T) fetch_xw(t + 1);
-            if constexpr (SPEC) ac[0][0] = ld4(XC + lds_sw(lr, col, UST));
+            if constexpr (SPEC) ac[0][0] = ld4(XC + (t & 1) * (16 * UST) + lds_sw(lr, col, UST));
             mfma_nodes32<1, KS, true, 1>(A2, KAP, lane, lr, lg, w1, ac);
             pp.mark(4);
             {
@@ -788,7 +805,10 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         // SPEC: this lane's fragments of U (pre-activations: rows of U as the MFMA B operand) and of U^T (by-products), the Yh values of
         // the next step (node rows 4ks + lg of this column tile of r, u, c), and the two mixes
         float ux[NKS], ux4[NKS], ut[NKS], ut4[NKS], yv[3][NKS];
-        unsigned vy[NKS];
+        // (16 <= N <= 20 here: node rows 4ks + lg of the first four k-steps exist for every lane -- one lane offset + a scalar per k-step;
+        //  the rows 16 + lg of the last one are clamped to N - 1 where they do not exist: ux / ux4 are zero there)
+        const unsigned vyb = (unsigned)lg * (unsigned)spec_Sp * (3 * H) + ct * 16 + lr;
+        const unsigned vy4 = (unsigned)(16 + lg < N ? 16 + lg : N - 1) * (unsigned)spec_Sp * (3 * H) + ct * 16 + lr;
         const wbuf_t bY = make_wbuf(XW), bHh = make_wbuf(Hpl != nullptr ? Hpl : Hseq), bRHh = make_wbuf(RHpl != nullptr ? RHpl : Hseq);
         const unsigned oe0 = (unsigned)lr * (unsigned)spec_SpE * H + col, oe1 = (unsigned)node1 * (unsigned)spec_SpE * H + col1;
         const unsigned or0 = (unsigned)lr * (unsigned)spec_Sp * H + col, or1 = (unsigned)node1 * (unsigned)spec_Sp * H + col1;
@@ -799,7 +819,6 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 const int i = 4 * ks + lg, j4 = 16 + (lane & 3);
                 ux[ks] = (i < N && lr < N) ? spec_U[lr * N + i] : 0.f;
                 ux4[ks] = (i < N && j4 < N) ? spec_U[j4 * N + i] : 0.f;
-                vy[ks] = (unsigned)(i < N ? i : N - 1) * (unsigned)spec_Sp * (3 * H) + ct * 16 + lr;
             }
         }
         auto fetch_y = [&](int t) {
@@ -807,10 +826,11 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) yv[g][ks] = wbuf_ld(bY, vy[ks] + g * H, so);
+                for (int ks = 0; ks < NKS; ++ks)
+                    yv[g][ks] = ks < 4 ? wbuf_ld(bY, vyb + g * H, so + (unsigned)(4 * ks) * (unsigned)spec_Sp * (3 * H)) : wbuf_ld(bY, vy4 + g * H, so);
         };
-        auto xw_mix = [&]() {                                        // yv (step t') -> XR, XC, XRr (LDS, for role A) and nxu0, nxu1, nxc1
-            f32x4 acc[3] = {zero4, zero4, zero4}, rem[3] = {zero4, zero4, zero4};
+        auto xw_mix = [&](int tn) {                                  // yv (step tn) -> XR, XC[tn & 1], XRr (LDS, for role A) and nxu0, nxu1, nxc1
+            f32x4 acc[3] = {zero4, zero4, zero4}, rem[3] = {zero4, zero4, zero4}, rem2[3] = {zero4, zero4, zero4};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -818,13 +838,19 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) rem[g] = mfma4(ux4[ks], yv[g][ks], rem[g]);
+                for (int g = 0; g < 3; ++g) {
+                    if (ks & 1) rem2[g] = mfma4(ux4[ks], yv[g][ks], rem2[g]);
+                    else rem[g] = mfma4(ux4[ks], yv[g][ks], rem[g]);
+                }
+            // (rem4_reduce's register swaps are inline asm: never the first readers of an MFMA result -- see spec_mix_tiles_out)
+            f32x4 t0 = rem[0] + rem2[0], t1 = rem[1] + rem2[1], t2 = rem[2] + rem2[2];
+            EEG_PIN(t0); EEG_PIN(t1); EEG_PIN(t2);
             st4(XR + lds_sw(lr, col, UST), acc[0]);
-            st4(XC + lds_sw(lr, col, UST), acc[2]);
-            XRr[ct * 64 + lane] = rem4_reduce(rem[0]);
+            st4(XC + (tn & 1) * (16 * UST) + lds_sw(lr, col, UST), acc[2]);
+            XRr[ct * 64 + lane] = rem4_reduce(t0);
             nxu0 = acc[1];
-            nxu1 = rem4_reduce(rem[1]);
-            nxc1 = rem4_reduce(rem[2]);
+            nxu1 = rem4_reduce(t1);
+            nxc1 = rem4_reduce(t2);
         };
         auto export_tile = [&](const float* tile, wbuf_t out, unsigned o0, unsigned o1, unsigned row) {
             const float* const tl[1] = {tile};
@@ -840,8 +866,7 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
         };
         fetch_x(0);
         if constexpr (SPEC) {
-            if (Hpl != nullptr) export_tile(A, bHh, oe0, oe1, (unsigned)b);                       // slot 0: U^T of the initial state
-            xw_mix();                                                                                 // the pre-activations of step 0
+            xw_mix(0);                                                // the pre-activations of step 0
         }
         // The hop-0 slot of the NEXT step's update-gate GEMM (the first K quads: h' itself, complete at barrier 3) runs in the third
         // window, where role A mixes h' and the matrix pipe is otherwise idle; the other hop slots follow behind barrier (1).
@@ -875,6 +900,9 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 st4(U + lds_sw(lr, col, UST), u0);                        // nodes >= N: finite, never used
                 if (save && valid[0]) wbuf_st4(bU, oh0, so, u0);
             }
+            if constexpr (SPEC) {                                     // slot t of Hh: U^T h_{t-1} (slot 0 of A: complete since barrier 3, rewritten in phase 2)
+                if (Hpl != nullptr) export_tile(A, bHh, oe0, oe1, (unsigned)s);
+            }
             EEG_LDS_BARRIER();                                        // (2)
             // remainder nodes 16..19 of this column tile: c (from hops(r*h)) and the blend, one element per lane
             if constexpr (SPEC) ac[0][1][0] += mfma_rem4_ldsw<KS>(A2, KAP, lane, lg, W1L + ct * (KS / 4) * 256);
@@ -892,21 +920,27 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                     }
                 }
             }
-            if constexpr (SPEC) {                                     // U^T (r * h_{t-1}) of this column tile (slot 0 of A2: complete at barrier 2)
+            if constexpr (SPEC) {
+                // U^T (r * h_{t-1}) of this column tile (slot 0 of A2: complete at barrier 2), then the pre-activations of step t+1 (Yh
+                // requested in phase 1): role A reads XR / XRr behind barrier (1) and the other XC buffer behind barrier (2) of step t+1
                 if (RHpl != nullptr) export_tile(A2, bRHh, or0, or1, (unsigned)s);
             }
             EEG_LDS_BARRIER();                                        // (3)
             pre = t + 1 < T;
-            if constexpr (SPEC) {
-                if (Hpl != nullptr) export_tile(A, bHh, oe0, oe1, (unsigned)(s + B));                // slot t+1: U^T h_t (h' complete at barrier 3)
-                if (pre) xw_mix();                                                                    // step t+1's pre-activations (Yh requested in phase 1)
-            }
             if (pre) {                                                // hop-0 slot of step t+1's update gate, from h' (slot 0 of A)
-                ua = nxu0; ub = zero4; ux1 = nxu1;
+                ua = SPEC ? zero4 : nxu0; ub = zero4; ux1 = SPEC ? 0.f : nxu1;
                 urem[0] = urem[1] = urem[2] = urem[3] = zero4;
                 // (nxc1 of step t+1 stays in its register until the top of the next iteration; the registers of nxu are free now)
                 mfma_tile_quads<KS, 0, QS>(A, KAP, lane, lr, lg, w0[0], ua, ub, urem);
+                if constexpr (SPEC) {                                 // the pre-activations of step t+1 (their chains start from zero above)
+                    xw_mix(t + 1);
+                    ua += nxu0;
+                    ux1 = nxu1;
+                }
             }
+        }
+        if constexpr (SPEC) {                                         // slot T: U^T h_{T-1} (the next layer's last input row block)
+            if (Hpl != nullptr) export_tile(A, bHh, oe0, oe1, (unsigned)((size_t)T * B + b));
         }
     }
     };   // clip

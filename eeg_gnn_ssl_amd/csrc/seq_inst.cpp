@@ -47,7 +47,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
             if constexpr (M >= 2) {
                 if (a.Yh != nullptr && a.spec_U != nullptr && a.spec_done != nullptr && (double)a.N * a.spec_Sp * 3 * H * sizeof(float) < 2147483648.0 &&
                     (double)a.N * a.spec_SpE * H * sizeof(float) < 2147483648.0) {
-                    const size_t lds3 = lds2 + (2 * 16 * 64 + 4 * 64 + 4 * (SeqGeom<H, M>::KS / 4) * 256) * sizeof(float);   // + XR, XC [16][64], XRr [4][64], W1L
+                    const size_t lds3 = lds2 + (3 * 16 * 64 + 4 * 64 + 4 * (SeqGeom<H, M>::KS / 4) * 256) * sizeof(float);   // + XR, 2 x XC [16][64], XRr [4][64], W1L
                     EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, false, true>), lds3);
                     EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, false, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds3, st, a.Yh,
                                  a.h0, a.P, a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hh, a.RHh, (size_t)0, a.T, a.B, a.N, a.act, a.probe,
