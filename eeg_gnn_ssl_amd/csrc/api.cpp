@@ -356,7 +356,7 @@ int diffuse_adj(const float* Z, const float* P, int p_batched, int S, int B, int
 // the two-wave recurrent kernels exist in a SPEC instantiation (spectral form: seq_launch.h) for exactly these calls -- mirrors the
 // selection inside seq_inst.cpp (64 units, at most 20 nodes, 2 or 3 hop matrices, two-wave variant on, 2 GB buffer descriptors)
 bool seq2_spec_ok(int H, int M, int N, int T, int B, int variant, int Sp, int SpE) {
-    if (H != 64 || N < 16 || N > 20 || M < 2 || M > 3 || variant != 1 || phase_probe_armed()) return false;
+    if (H != 64 || N < 16 || N > 20 || M < 2 || M > 3 || variant != 1 || (phase_probe_armed() && M != 3)) return false;   // (probe instantiations: M = 3)
     return (double)T * B * N * 3 * H * sizeof(float) < 2147483648.0 && (double)N * Sp * 3 * H * sizeof(float) < 2147483648.0 &&
            (double)N * SpE * H * sizeof(float) < 2147483648.0;
 }
@@ -529,7 +529,10 @@ int cell_weight_grads_spectral(const eeg_layer_dims* d, const float* Xh, size_t 
     int nblocks = sj.j[0].nblocks + sj.j[1].nblocks + sj.j[2].nblocks;
     jobs.bias_part = bias_part; jobs.bias_B = d->B; jobs.dbg = dbg; jobs.dbc = dbc;
     if (bias_part != nullptr) nblocks += ceil_div(3 * H, 16);
-    EEG_LAUNCH_P("reduce_unpack", reduce_unpack3s_kernel, dim3(nblocks), dim3(256), 256 * sizeof(float4), st, jobs, sj, 0, Fin, H, M, dWg, dWc);
+    const int ns_max = N * (w.gx.spg > w.gh.spg ? w.gx.spg : w.gh.spg);
+    const size_t fold_lds = spec_fold_lds_bytes(M, ns_max);
+    EEG_SET_MAX_LDS(reduce_unpack3s_kernel, fold_lds);
+    EEG_LAUNCH_P("reduce_unpack", reduce_unpack3s_kernel, dim3(nblocks), dim3(256), fold_lds, st, jobs, sj, 0, Fin, H, M, dWg, dWc);
     return check_launch("reduce_unpack (spectral)");
 }
 

@@ -926,7 +926,14 @@ __global__ __launch_bounds__(512, 1) void seq_fwd2_kernel(
                 if (RHpl != nullptr) export_tile(A2, bRHh, or0, or1, (unsigned)s);
             }
             EEG_LDS_BARRIER();                                        // (3)
+#ifdef EEG_X_BPRE
             pre = t + 1 < T;
+#else
+            pre = !SPEC && t + 1 < T;                                 // (SPEC: the third window belongs to the mix of the next step's pre-activations)
+#endif
+            if constexpr (SPEC) {
+                if (!pre && t + 1 < T) xw_mix(t + 1);
+            }
             if (pre) {                                                // hop-0 slot of step t+1's update gate, from h' (slot 0 of A)
                 ua = SPEC ? zero4 : nxu0; ub = zero4; ux1 = SPEC ? 0.f : nxu1;
                 urem[0] = urem[1] = urem[2] = urem[3] = zero4;

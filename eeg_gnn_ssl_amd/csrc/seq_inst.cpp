@@ -35,7 +35,7 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
             const size_t lds2 = lds + 16 * 64 * sizeof(float);      // + the update-gate tile U [16][64]
 #if defined(EEG_DEV)
             if constexpr (M == 3) {
-                if (a.probe != nullptr) {
+                if (a.probe != nullptr && a.Yh == nullptr) {
                     EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, true>), lds2);
                     EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.XW, a.h0, a.P,
                                  a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hpl, a.RHpl, a.plane_stride, a.T, a.B, a.N, a.act, a.probe,
@@ -47,6 +47,19 @@ int fwd_nks(const SeqFwdArgs& a, hipStream_t st) {
             if constexpr (M >= 2) {
                 if (a.Yh != nullptr && a.spec_U != nullptr && a.spec_done != nullptr && (double)a.N * a.spec_Sp * 3 * H * sizeof(float) < 2147483648.0 &&
                     (double)a.N * a.spec_SpE * H * sizeof(float) < 2147483648.0) {
+#if defined(EEG_DEV)
+                    if constexpr (M == 3) {
+                        if (a.probe != nullptr) {
+                            const size_t ldsp = lds2 + (3 * 16 * 64 + 4 * 64 + 4 * (SeqGeom<H, M>::KS / 4) * 256) * sizeof(float);
+                            EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, true, true>), ldsp);
+                            EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, true, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), ldsp, st,
+                                         a.Yh, a.h0, a.P, a.p_batched, a.bhg, a.bhc, a.Hseq, a.Rs, a.Us, a.Cs, a.RHs, a.Hh, a.RHh, (size_t)0, a.T, a.B, a.N,
+                                         a.act, a.probe, a.spec_U, a.spec_Sp, a.spec_SpE);
+                            *a.spec_done = 1;
+                            return hipGetLastError() == hipSuccess ? 0 : 2;
+                        }
+                    }
+#endif
                     const size_t lds3 = lds2 + (3 * 16 * 64 + 4 * 64 + 4 * (SeqGeom<H, M>::KS / 4) * 256) * sizeof(float);   // + XR, 2 x XC [16][64], XRr [4][64], W1L
                     EEG_SET_MAX_LDS((seq_fwd2_kernel<H, M, NKS, false, true>), lds3);
                     EEG_LAUNCH_P("seq_fwd", (seq_fwd2_kernel<H, M, NKS, false, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds3, st, a.Yh,
@@ -93,7 +106,7 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
             const size_t lds2 = ((size_t)(M - 1) * kPFloats + 32 * (SeqGeom<H, M>::KAP + SeqGeom<H, M>::KGP) + 4 * 20 * 20 + 2 * 4 * (5 * 256 + 256 + 64)) * sizeof(float);
 #if defined(EEG_DEV)
             if constexpr (M == 3) {
-                if (a.probe != nullptr) {
+                if (a.probe != nullptr && a.dYh == nullptr) {
                     EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, true>), lds2);
                     EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq, a.h0, a.Rs, a.Us,
                                  a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,
@@ -104,6 +117,18 @@ int bwd_nks(const SeqBwdArgs& a, hipStream_t st) {
 #endif
             if constexpr (M >= 2) {
                 if (a.dYh != nullptr && a.spec_U != nullptr && a.spec_done != nullptr && (double)a.N * a.spec_Sp * 3 * H * sizeof(float) < 2147483648.0) {
+#if defined(EEG_DEV)
+                    if constexpr (M == 3) {
+                        if (a.probe != nullptr) {
+                            EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, true, true>), lds2);
+                            EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, true, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st,
+                                         a.Hseq, a.h0, a.Rs, a.Us, a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW,
+                                         a.dh0, a.dbias_part, a.T, a.B, a.N, a.act, a.probe, a.spec_U, a.dYh, a.spec_Sp);
+                            *a.spec_done = 1;
+                            return hipGetLastError() == hipSuccess ? 0 : 2;
+                        }
+                    }
+#endif
                     EEG_SET_MAX_LDS((seq_bwd2_kernel<H, M, NKS, false, true>), lds2);
                     EEG_LAUNCH_P("seq_bwd", (seq_bwd2_kernel<H, M, NKS, false, true>), dim3(a.B < kSeqMaxGrid ? a.B : kSeqMaxGrid), dim3(512), lds2, st, a.Hseq,
                                  a.h0, a.Rs, a.Us, a.Cs, a.dHseq, a.d_at_end, a.d_at_len, a.lengths, a.P, a.p_batched, a.b1, a.b2, a.dXW, a.dh0,

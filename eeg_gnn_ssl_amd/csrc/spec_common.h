@@ -69,30 +69,48 @@ struct SpecFoldJobs {
     const float* basis;
     int N;
 };
+// LDS: [16][16] float4 reduction tile, then the coefficient table tcl[m][sp] = T_m(lam_{sp / spg}) of this job (M * N * spg floats;
+// spec_fold_lds_bytes): the split loop then is loads + multiply-adds only, eight loads in flight per thread.
+__host__ __device__ inline size_t spec_fold_lds_bytes(int M, int nsplit_max) { return 256 * 16 + (size_t)M * nsplit_max * sizeof(float); }
 template <int MM>
 __device__ __forceinline__ void spec_fold_block_m(int block, const SpecFoldJob& jb, int kind, const float* __restrict__ basis, int N,
                                                    int acc_flag, int Fin, int H, int M, float* __restrict__ dWg, float* __restrict__ dWc) {
     EEG_DYN_SMEM(sm);
     float4 (*red)[16] = reinterpret_cast<float4 (*)[16]>(sm);
+    float* tcl = sm + 256 * 4;
     const int O = jb.O;
     const size_t total = (size_t)jb.K * O;
     const int g = threadIdx.x >> 4, q = threadIdx.x & 15;
     const size_t idx4 = ((size_t)block * 16 + q) * 4;
     const float* tc = basis + N * N;
+    const int nsplit = N * jb.spg;
+    for (int e = threadIdx.x; e < M * nsplit; e += 256) {
+        const int m = e / nsplit, sp = e - m * nsplit;
+        tcl[e] = tc[m * 32 + sp / jb.spg];
+    }
+    __syncthreads();
     float4 a[MM];
 #pragma unroll
     for (int m = 0; m < MM; ++m) a[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nsplit = N * jb.spg;
     if (idx4 < total) {
-        for (int sp = g; sp < nsplit; sp += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(jb.part + (size_t)sp * total + idx4);
-            const int i = sp / jb.spg;
+        constexpr int UN = 8;
+        for (int base = g; base < nsplit; base += 16 * UN) {
+            float4 v[UN];
 #pragma unroll
-            for (int m = 0; m < MM; ++m) {
-                if (m < M) {
-                    const float t = tc[m * 32 + i];
-                    a[m].x = fmaf(t, v.x, a[m].x); a[m].y = fmaf(t, v.y, a[m].y);
-                    a[m].z = fmaf(t, v.z, a[m].z); a[m].w = fmaf(t, v.w, a[m].w);
+            for (int u = 0; u < UN; ++u) {
+                const int sp = base + 16 * u;
+                v[u] = sp < nsplit ? *reinterpret_cast<const float4*>(jb.part + (size_t)sp * total + idx4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int sp = base + 16 * u < nsplit ? base + 16 * u : 0;      // (beyond the end: v = 0)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    if (m < M) {
+                        const float t = tcl[m * nsplit + sp];
+                        a[m].x = fmaf(t, v[u].x, a[m].x); a[m].y = fmaf(t, v[u].y, a[m].y);
+                        a[m].z = fmaf(t, v[u].z, a[m].z); a[m].w = fmaf(t, v[u].w, a[m].w);
+                    }
                 }
             }
         }

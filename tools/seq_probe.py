@@ -18,6 +18,9 @@ dev = torch.device("cuda", 0)
 x, y, lengths, sup = bench.synthetic_batch(task, filt, t_len, batch, classes, seed=123)
 model = DCRNNModel_classification(bench.make_args(filt), classes, device=dev).to(dev).train()
 x, y, lengths, sup = x.to(dev), y.to(dev), lengths.to(dev), [s.to(dev) for s in sup]
+if os.environ.get("EEG_PROBE_SHARED", "1") != "0":       # the distance graph in its shared form: the spectral kernels (as TrainStep runs them)
+    from eeg_gnn_ssl_amd import ops
+    sup = ops.collapse_shared_supports(sup)
 _lib._LIB = _lib.EegDcrnnLib(os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else _lib.DEV_LIB_PATH, strict=False)   # cycle probe: dev build only
 lib = _lib.get_lib()
 
