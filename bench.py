@@ -417,7 +417,36 @@ class Ctx:
     def sync_all(self):
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        self.sync()
+
+    # --emulator (TEST INFRASTRUCTURE, tests/test_ddp_gloo.py): the same measure() code on host tensors through the SIMT-emulator
+    # build of the kernel sources, gloo instead of RCCL -- what exercises the world > 1 branch on a machine without a GPU
+    @property
+    def on_gpu(self):
+        return self.dev.type == "cuda"
+
+    def sync(self):
+        if self.on_gpu:
+            torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True) if self.on_gpu else _HostEvent()
+
+    def stream(self):
+        return torch.cuda.current_stream() if self.on_gpu else None
+
+
+class _HostEvent:
+    """stands in for torch.cuda.Event in --emulator runs (host clock; nothing is asynchronous there)"""
+
+    def __init__(self):
+        self.t = 0.0
+
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
 
 
 def parse_prof_report(text):
@@ -538,7 +567,7 @@ def measure(ctx, workload, steps, warmup, primary):
             graphed, whole_graph = True, bool(args.graph_update)
         except Exception as e:                                   # noqa: BLE001 -- fall back to eager launches
             log(f"HIP graph capture failed ({type(e).__name__}: {e}); launching eagerly")
-            torch.cuda.synchronize()
+            ctx.sync()
     one_step = stepper.replay_step if graphed else (lambda: stepper.step(x, y, lengths, supports))
 
     clock_buf = torch.zeros(3, dtype=torch.int64, device=dev)
@@ -550,7 +579,7 @@ def measure(ctx, workload, steps, warmup, primary):
         for _ in range(warmup):
             step_fn()
         ctx.sync_all()
-        cur = torch.cuda.current_stream()
+        cur = ctx.stream()
         t0 = time.perf_counter()
         for k in range(steps):
             if marks is not None:
@@ -561,13 +590,13 @@ def measure(ctx, workload, steps, warmup, primary):
         ctx.sync_all()
         dt = time.perf_counter() - t0
         # shader clock under sustained fp32-MFMA load right behind the timed steps (200 us on every SIMD, outside the timed region)
-        if marks is not None and hasattr(lib._dll, "eeg_dcrnn_prof_clock_probe"):
+        if marks is not None and ctx.on_gpu and hasattr(lib._dll, "eeg_dcrnn_prof_clock_probe"):
             clock_buf.zero_()
             lib.call("eeg_dcrnn_prof_clock_probe", ctypes.c_void_p(clock_buf.data_ptr()), ctypes.c_void_p(cur.cuda_stream))
             torch.cuda.synchronize()
         return dt, loss
 
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks = [ctx.event() for _ in range(steps + 1)]
     elapsed, loss = timed(one_step, marks)
     step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(steps)]
     cyc, ticks = (int(v) for v in clock_buf.tolist()[:2])
@@ -648,7 +677,7 @@ def measure(ctx, workload, steps, warmup, primary):
         lib.query("eeg_dcrnn_prof_enable", 1)
         for _ in range(steps):
             stepper.step(x, y, lengths, supports)
-        torch.cuda.synchronize()
+        ctx.sync()
         lib.query("eeg_dcrnn_prof_enable", 0)
         if has_clk:
             lib.call("eeg_dcrnn_prof_clock_samples", None)
@@ -666,14 +695,14 @@ def measure(ctx, workload, steps, warmup, primary):
     if primary:
         snap = stepper.snapshot()
         keep_grad = stepper.fp.flat_grad.clone()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = ctx.event(), ctx.event()
         tail_ms = 0.0
         for _ in range(steps):
             stepper.fp.flat_grad.copy_(keep_grad)
             e0.record()
             stepper.reduce_and_update()
             e1.record()
-            torch.cuda.synchronize()
+            ctx.sync()
             tail_ms += e0.elapsed_time(e1) / steps
         stepper.restore(snap)
         stepper.fp.flat_grad.copy_(keep_grad)
@@ -685,6 +714,8 @@ def measure(ctx, workload, steps, warmup, primary):
         elapsed = max(float(t.item()) for t in allr)             # MAX over ranks
         backend = dist.get_backend()
         world_seen = dist.get_world_size()
+        # the line's n_gpus / global batch are WORLD_SIZE's: the process group must have exactly that many ranks, all of them here
+        assert world_seen == world and len(per_rank_ms) == world, (world_seen, world, per_rank_ms)
     else:
         per_rank_ms = [round(elapsed / steps * 1e3, 3)]
         backend = dist.get_backend() if dist.is_initialized() else None
@@ -693,7 +724,8 @@ def measure(ctx, workload, steps, warmup, primary):
     n_grad = stepper.fp.flat_grad.numel()
     reduce_issued = bool(stepper.reduce)
     del stepper, model, x, y, supports
-    torch.cuda.empty_cache()
+    if ctx.on_gpu:
+        torch.cuda.empty_cache()
     if rank != 0:
         return None
 
@@ -943,10 +975,15 @@ def main():
                     "the DEV build libeeg_dcrnn_hip_dev.so instead of the product library")
     ap.add_argument("--lib", default=None, help="development A/B runs only: load this build of the C ABI (e.g. a library built "
                     "from an older commit, kept under build/ab/) instead of the product library; named in config.library")
+    ap.add_argument("--emulator", action="store_true", help="TEST INFRASTRUCTURE, never a measurement: run measure() on host "
+                    "tensors through the SIMT-emulator build of the kernel sources (tests/emu) with the gloo backend, eager launches, "
+                    "no profiler / baselines -- tests/test_ddp_gloo.py drives the world > 1 branch of this file that way")
     args = ap.parse_args()
 
     ctx = Ctx(args)
     world, rank = ctx.world, ctx.rank
+    if args.emulator:
+        return main_emulator(ctx)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (HIP) device: eeg_gnn_ssl_amd has no CPU path")
     torch.cuda.set_device(ctx.local_rank)
@@ -1050,6 +1087,34 @@ def main():
     if world == 1 and args.split_bf16_experiment:
         out["experimental_split_bf16"] = split_bf16_experiment()
     print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def main_emulator(ctx):
+    """--emulator: the contract's protocol (per-rank shards, barrier + MAX over ranks, ONE line from rank 0) on the CPU.  The figures
+    it prints are emulator times: meaningless as measurements, and the line says so."""
+    args, world, rank = ctx.args, ctx.world, ctx.rank
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_support
+    emu_support.install_emulator()
+    ctx.dev = torch.device("cpu")
+    ctx.copy_stream = None
+    args.no_prof = args.no_stream_inputs = args.no_cpu_baseline = True
+    # (no graph capture on the host.  With --graph-update the capture attempt is left in: it raises, and the fall-back of measure()
+    #  -- eager launches, exchange and update behind them -- is what runs; tests/test_ddp_gloo.py checks exactly that path)
+    args.no_graph = not args.graph_update
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.set_num_threads(1)
+    out = measure(ctx, args.workload, args.steps, args.warmup, primary=True)
+    if rank == 0:
+        out["data"] = "synthetic; EMULATOR RUN (host, SIMT emulator of the kernel sources, gloo): protocol test, not a measurement"
+        out["roofline"] = None
+        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

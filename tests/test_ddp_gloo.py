@@ -313,3 +313,57 @@ def test_a_rank_without_evaluation_batches_joins_the_collectives(tmp_path):
         predict(torch.nn.Linear(1, 1), [])
     with pytest.raises(ValueError, match="no batches"):
         evaluate_ssl(torch.nn.Linear(1, 1), [])
+
+
+def _run_bench_emulator(world, extra, port):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per "GPU"), on the host: --emulator = the SIMT
+    emulator of the kernel sources + gloo.  Returns (the JSON lines rank 0 printed on stdout, stderr)."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_support
+    emu_support.install_emulator()          # builds the emulator library once, before the ranks start
+    emu_support.uninstall()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--emulator", "--workload", "cfg1", "--batch", "2", "--secondary", "none"] + list(extra)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    return lines, r.stderr
+
+
+def test_bench_world_size_2_branch_end_to_end():
+    """The `world > 1` code of bench.py -- per-rank shards with different seeds, barrier + MAX over ranks of the timed region, the
+    all_gather of the per-rank times, ONE JSON line from rank 0 -- had never executed anywhere (no multi-GPU node).
+    Here it runs end to end with two gloo ranks on the emulator: the protocol is checked, the figures are not measurements."""
+    lines, err = _run_bench_emulator(2, [], 29631)
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    dd = d["distributed"]
+    assert dd["world_size"] == 2 and dd["backend"] == "gloo" and dd["all_reduce_issued"] is True
+    assert len(dd["per_rank_ms_per_step"]) == 2
+    # value = clips of ALL ranks over the MAX of the ranks' timed regions
+    slowest = max(dd["per_rank_ms_per_step"])
+    assert abs(d["ms_per_step"] - slowest) <= 1e-3 * slowest + 1e-3
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) <= 0.06 * d["value"] + 0.1
+    assert "EMULATOR RUN" in d["data"] and d["config"]["launch"] == "eager"
+    assert "[bench" in err and err.count("timed 2 steps") == 1, "only rank 0 logs"
+
+
+def test_bench_world_size_2_graph_update_falls_back_to_eager_exchange():
+    """--graph-update asks for the whole step (exchange + update included) as one captured graph.  Where capture is not possible (here:
+    no HIP device at all) measure() must fall back to eager launches with the all-reduce and the fused update issued behind them,
+    on every rank alike -- the run completes, the line says `eager`, the exchange was issued."""
+    lines, err = _run_bench_emulator(2, ["--graph-update"], 29633)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["distributed"]["world_size"] == 2 and d["distributed"]["all_reduce_issued"] is True
+    assert d["config"]["launch"] == "eager"
+    assert "graph capture failed" in err
+    assert d["config"]["final_loss"] == d["config"]["final_loss"] and d["config"]["final_loss"] > 0      # finite
