@@ -126,7 +126,7 @@ def is_hbm_role(name):
     return "diffuse" in name or "spec_mix" in name or name in HBM_ROLES
 
 
-def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS, raw=False, spectral=False):
+def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS, raw=False, spectral=False, fused=True):
     """Per-step algorithmic FLOPs / bytes of every profiled kernel role.  Roles = the names the
     library's event recorder uses; at the benchmark shapes each role is ONE kernel symbol per layer
     (reported by the library's recorder with every launch), so `roofline.kernels` carries the symbols and `roofline.by_symbol`
@@ -150,13 +150,20 @@ def algorithmic_work(filter_type, t_len, batch, task="detection", layers=LAYERS,
         w["gemm_tn_hg"] += 2.0 * r * (m * h) * 2 * h
         w["gemm_tn_hc"] += 2.0 * r * (m * h) * h
         if spectral:
+            # fused: the two-wave recurrent kernels do the spectral node mixes themselves (csrc/kernels_seq.h SPEC): forward U Yh (3H
+            # wide) + U^T h, U^T (r*h) (H wide each), backward U^T [dR|dU|dC] -- executed MFMA work on top of the cell's; the layers
+            # above the first take their transformed input from the layer below.  Not fused: the same mixes as HBM-bound passes
+            if fused:
+                w["seq_fwd"] += s * (2.0 * n * n * 3 * h + 2 * 2.0 * n * n * h)
+                w["seq_bwd"] += s * (2.0 * n * n * 3 * h)
             # spectral form of the hoisted x-part (shared symmetric support; csrc/spec_common.h): the GEMMs contract over Fin, not
             # M * Fin (EXECUTED FLOPs), framed by HBM-bound node mixes (bytes = every operand read once + every result written once)
             w["gemm_nn_xw"] += 2.0 * r * fin * 3 * h - 2.0 * r * (m * fin) * 3 * h
             w["gemm_tn_x"] += 2.0 * r * fin * 3 * h - 2.0 * r * (m * fin) * 3 * h
             w["gemm_tn_hg"] += 2.0 * r * h * 2 * h - 2.0 * r * (m * h) * 2 * h
             w["gemm_tn_hc"] += 2.0 * r * h * h - 2.0 * r * (m * h) * h
-            for k_, wd in (("spec_mix_x", fin), ("spec_mix_y", 3 * h), ("spec_mix_dy", 3 * h), ("spec_mix_h", 2 * h)):
+            for k_, wd in (("spec_mix_x", fin if (l == 0 or not fused) else 0), ("spec_mix_y", 0 if fused else 3 * h),
+                           ("spec_mix_dy", 0 if fused else 3 * h), ("spec_mix_h", 0 if fused else 2 * h)):
                 w[k_] = w.get(k_, 0.0) + 2 * 4.0 * r * wd
             if l > 0:
                 w["gemm_nn_dx"] += 2.0 * r * 3 * h * fin
@@ -210,7 +217,7 @@ def synthetic_raw_signals(batch, t_len, seed):
     return torch.from_numpy((20.0 * np.einsum("bnk,bkt->bnt", mix, src) + 5.0 * noise).astype(np.float32))
 
 
-def per_launch_work(filter_type, t_len, batch, layers=LAYERS, spectral=False):
+def per_launch_work(filter_type, t_len, batch, layers=LAYERS, spectral=False, fused=True):
     """Encoder roles: the algorithmic work of every launch of a step IN LAUNCH ORDER (forward roles bottom-up, backward roles
     top-down), so that a role whose layers run different kernel instantiations (e.g. `gemm_tn_x`: batch-major layer 0, planar
     above) can be priced per SYMBOL.  Sums equal algorithmic_work()."""
@@ -229,12 +236,15 @@ def per_launch_work(filter_type, t_len, batch, layers=LAYERS, spectral=False):
            "gemm_nn_dx": [2.0 * r * 3 * h * (m * fin) for fin in fins[1:]],
            "diffuse_adj": [4.0 * s * n * fin * (m + 1) for fin in fins[1:]]}
     if spectral:
-        fwd = {"seq_fwd": fwd["seq_fwd"], "gemm_nn_xw": [2.0 * r * fin * 3 * h for fin in fins],
-               "spec_mix_x": [8.0 * r * fin for fin in fins], "spec_mix_y": [8.0 * r * 3 * h for _ in fins]}
+        fwd = {"seq_fwd": [v + (s * (2.0 * n * n * 3 * h + 2 * 2.0 * n * n * h) if fused else 0.0) for v in fwd["seq_fwd"]],
+               "gemm_nn_xw": [2.0 * r * fin * 3 * h for fin in fins],
+               "spec_mix_x": [8.0 * r * fin for fin in (fins[:1] if fused else fins)],
+               "spec_mix_y": [] if fused else [8.0 * r * 3 * h for _ in fins]}
+        bwd["seq_bwd"] = [v + (s * (2.0 * n * n * 3 * h) if fused else 0.0) for v in bwd["seq_bwd"]]
         bwd.update({"gemm_tn_x": [2.0 * r * fin * 3 * h for fin in fins], "gemm_nn_dx": [2.0 * r * 3 * h * fin for fin in fins[1:]],
                     "gemm_tn_hg": [2.0 * r * h * 2 * h for _ in fins], "gemm_tn_hc": [2.0 * r * h * h for _ in fins],
-                    "spec_mix_h": [8.0 * r * h for _ in fins for _ in (0, 1)],
-                    "spec_mix_dy": [8.0 * r * 3 * h for _ in fins], "spec_mix_dx": [8.0 * r * fin for fin in fins[1:]]})
+                    "spec_mix_h": [] if fused else [8.0 * r * h for _ in fins for _ in (0, 1)],
+                    "spec_mix_dy": [] if fused else [8.0 * r * 3 * h for _ in fins], "spec_mix_dx": [8.0 * r * fin for fin in fins[1:]]})
         bwd.pop("diffuse_adj")
     out = dict(fwd)
     out.update({k: v[::-1] for k, v in bwd.items()})
@@ -732,8 +742,9 @@ def measure(ctx, workload, steps, warmup, primary):
     ms_per_step = elapsed / steps * 1e3
     clips_per_s = batch * world / (elapsed / steps)
     spectral = any(k.startswith("spec_mix") for k in prof)      # the encoder ran the spectral form of its hoisted x-part
-    work = algorithmic_work(filt, t_len, batch, task, layers, raw=raw_in, spectral=spectral)
-    launch_work = per_launch_work(filt, t_len, batch, layers, spectral=spectral)
+    fused = spectral and "spec_mix_y" not in prof                 # ... and its recurrent kernels did the 3H-wide node mixes themselves
+    work = algorithmic_work(filt, t_len, batch, task, layers, raw=raw_in, spectral=spectral, fused=fused)
+    launch_work = per_launch_work(filt, t_len, batch, layers, spectral=spectral, fused=fused)
     merge_paired_roles(work, launch_work, prof)
 
     def rate(w, ms, hbm):
