@@ -81,6 +81,7 @@ _SIGNATURES = {
                                       POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                       _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_teacher_flags": (c_int, [_FP, _FP, c_int64, ctypes.c_double, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_augment_draw": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _FP, c_void_p]),
     "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_rng_take": (c_int, [_FP, ctypes.c_uint64, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, _FP, _FP, _FP, c_void_p]),

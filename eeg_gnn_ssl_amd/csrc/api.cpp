@@ -997,6 +997,19 @@ static int corr_nsplit(int B, int T) {
     if (ns > cap) ns = cap;
     return ns < 1 ? 1 : ns;
 }
+int eeg_dcrnn_augment_draw(const uint64_t* rng_used, int B, int N, const int32_t* swap_perm, int32_t* flags, int32_t* perm,
+                           float* log_scale, const float* S_plain, const float* S_reflected, int n_supports, float* S_out, void* stream) {
+    if (rng_used == nullptr || swap_perm == nullptr || flags == nullptr || perm == nullptr || log_scale == nullptr)
+        return fail("augment_draw: null generator pair / swap table / output");
+    if (B < 1 || N < 1 || N > kMaxNodes) return fail("augment_draw: B=%d clips, num_nodes=%d unsupported (B >= 1, 1 <= N <= %d)", B, N, kMaxNodes);
+    if (S_out != nullptr && (S_plain == nullptr || S_reflected == nullptr || n_supports < 1))
+        return fail("augment_draw: per-clip supports need the plain and the reflected set (n_supports=%d)", n_supports);
+    EEG_LAUNCH_P("augment_draw", augment_draw_kernel, dim3(B), dim3(128), 0, S_(stream), reinterpret_cast<const unsigned long long*>(rng_used), N,
+                 reinterpret_cast<const int*>(swap_perm), reinterpret_cast<int*>(flags), reinterpret_cast<int*>(perm), log_scale, S_plain,
+                 S_reflected, n_supports, S_out);
+    return check_launch("augment_draw");
+}
+
 size_t eeg_dcrnn_corr_graph_ws_floats(int B, int T) { return (B >= 1 && T >= 1) ? (size_t)B * corr_nsplit(B, T) * kGramFloats : 0; }
 int eeg_dcrnn_corr_graph(const float* X, int B, int T, int N, int D, int top_k, float* adj, float* S1, float* S2,
                          float* ws, void* stream) {

@@ -231,4 +231,37 @@ __global__ __launch_bounds__(256, EEG_FFT_MINW) void fft200_features_kernel(cons
     }
 }
 
+// Data augmentation drawn on the device (dataloader_detection.py:384-389: `_random_reflect` then `_random_scale` per sample, in the
+// DataLoader workers): clip b takes Philox counter used[1] + b of the {seed, offset} pair `used` (eeg_dcrnn_rng_take): word 0 is the
+// fair coin of `np.random.choice([True, False])` (top bit), word 1 the uniform of `np.random.uniform(0.8, 1.2)`.  Outputs, all
+// read by later launches of the same step: flags[b]; perm[b][n] = the source channel of node n (swap_perm[n] if reflected, else n)
+// and log_scale[b] = log(scale) -- the `perm` / `log_scale` operands of the featurisation kernels above; and, for the distance
+// graph (`_get_combined_graph(swap_nodes)`, :405-409), the per-clip supports S_out[s][b] = flags[b] ? S_refl[s] : S_plain[s].
+__global__ __launch_bounds__(128) void augment_draw_kernel(const unsigned long long* __restrict__ used, int N, const int* __restrict__ swap_perm,
+                                                            int* __restrict__ flags, int* __restrict__ perm, float* __restrict__ log_scale,
+                                                            const float* __restrict__ S_plain, const float* __restrict__ S_refl, int nsup,
+                                                            float* __restrict__ S_out) {
+    const int b = blockIdx.x, B = gridDim.x;
+    const unsigned long long seed = used[0], c = used[1] + (unsigned long long)b;
+    unsigned w[4];
+    philox4x32_10((unsigned)c, (unsigned)(c >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+    const int reflect = (int)(w[0] >> 31);
+    if (threadIdx.x == 0) {
+        flags[b] = reflect;
+        const double scale = 0.8 + 0.4 * ((double)w[1] * (1.0 / 4294967296.0));
+        log_scale[b] = (float)log(scale);
+    }
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const int s = swap_perm[n];
+        perm[b * N + n] = (reflect && (unsigned)s < (unsigned)N) ? s : n;
+    }
+    if (S_out != nullptr) {
+        const int NN = N * N;
+        for (int e = threadIdx.x; e < nsup * NN; e += blockDim.x) {
+            const int s = e / NN, r = e - s * NN;
+            S_out[((size_t)s * B + b) * NN + r] = reflect ? S_refl[e] : S_plain[e];
+        }
+    }
+}
+
 }  // namespace eeg

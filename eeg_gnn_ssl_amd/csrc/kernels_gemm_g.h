@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
+    #ifndef EEG_X_NNG_NOMFMA
                     for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(ob[j][s], oa[i][s], acc[i][j]);   // transposed issue
+#else
+                    for (int j = 0; j < NJ; ++j) acc[i][j][s] += ob[j][s] * oa[i][s][0];
+#endif
             }
             oa[i] = *reinterpret_cast<const f32x4*>(st + a_lds + i * 256);  // refilled in place from chunk q+1
         }
@@ -143,7 +147,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
+#if defined(EEG_X_NNG_NOSTORE)
+                    { if (i < nrt && acc[i][j][0] == 1.2345e-33f) wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]); }
+#elif defined(EEG_X_NNG_TILEMAJOR)
+                    { if (i < nrt) wbuf_st4(rc, (unsigned)(lane * 4), (unsigned)(((m_cur + i) * NCT + NJ * w + j) * 256), acc[i][j]); }
+#else
                     if (i < nrt) wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+#endif
             EEG_SCHED_FENCE();                                               // (a store's data registers must not be rewritten right behind it)
             m_c = 0;
             m_cur += nrt;

@@ -52,6 +52,8 @@ __device__ __forceinline__ unsigned pk_bf16(float lo, float hi) {
 // counted wait on the vector-memory queue (it retires in order), alone or in front of a raw workgroup barrier
 #define EEG_VM_WAIT_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
 #define EEG_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N> __device__ __forceinline__ void vm_wait_barrier_n() { asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void vm_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // EEG_PIN: the value is (re)defined here as far as the optimizer knows (blocks hoisting / sinking of what computes it);
 // EEG_USE: the value is needed here (keeps accumulators of ablated code paths alive).  No instructions.
 #define EEG_PIN(v) asm volatile("" : "+v"(v))

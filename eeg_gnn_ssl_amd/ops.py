@@ -11,7 +11,7 @@ dispatcher's "no kernel for the CPU backend" error, and the C-ABI stub refuses n
 Operators (namespace `eeg_dcrnn`):
     hop_polys, pack_cell, diffusion_hops, dconv (+ dconv_bwd), dcgru_layer (+ dcgru_layer_bwd),
     dcgru_decoder (+ dcgru_decoder_bwd), cls_head (+ cls_head_bwd), rng_take_, dropout_mask, gather_last, corr_graph,
-    fft_features, bce_logits, ce_logits, masked_loss, clip_adam_, clip_adam_dev_, teacher_flags_.
+    fft_features, bce_logits, ce_logits, masked_loss, clip_adam_, clip_adam_dev_, teacher_flags_, augment_draw_.
 The functions below them are the Python conveniences the modules in model/ and train_step.py call.
 """
 from __future__ import annotations
@@ -1103,6 +1103,46 @@ _define("teacher_flags_", "(Tensor(a!) rng_state, Tensor(b!) samples_seen, int i
         _teacher_flags_impl, lambda rng_state, samples_seen, increment, cl_decay_steps, t_len: rng_state.new_empty((t_len,), dtype=torch.int32))
 
 
+def _augment_draw_impl(rng_state, batch: int, swap_perm, plain_supports, reflected_supports):
+    lib = _lib.get_lib()
+    _check_rng(lib, rng_state, "rng_state")
+    _check(lib, swap_perm, "swap_perm", torch.int32)
+    n = swap_perm.numel()
+    if batch < 1 or n < 1:
+        raise RuntimeError(f"augment_draw: batch={batch}, num_nodes={n}")
+    used = _rng_take_impl(rng_state, int(batch))
+    flags = _new((batch,), rng_state, torch.int32)
+    perm = _new((batch, n), rng_state, torch.int32)
+    log_scale = _new((batch,), rng_state, torch.float32)
+    nsup, s_out = 0, _new((0,), rng_state, torch.float32)
+    if plain_supports is not None or reflected_supports is not None:
+        if plain_supports is None or reflected_supports is None:
+            raise RuntimeError("augment_draw: the per-clip supports need BOTH the plain and the reflected set")
+        plain_supports, reflected_supports = plain_supports.contiguous(), reflected_supports.contiguous()
+        _check(lib, plain_supports, "plain_supports")
+        _check(lib, reflected_supports, "reflected_supports")
+        if plain_supports.dim() != 3 or tuple(plain_supports.shape[1:]) != (n, n) or plain_supports.shape != reflected_supports.shape:
+            raise RuntimeError(f"augment_draw: supports must be two (n_supports, {n}, {n}) tensors, got {tuple(plain_supports.shape)} and "
+                               f"{tuple(reflected_supports.shape)}")
+        nsup = plain_supports.shape[0]
+        s_out = _new((nsup, batch, n, n), rng_state, torch.float32)
+    lib.call("eeg_dcrnn_augment_draw", _p(used), int(batch), int(n), _p(swap_perm), _p(flags), _p(perm), _p(log_scale),
+             _p(plain_supports) if nsup else None, _p(reflected_supports) if nsup else None, int(nsup), _p(s_out) if nsup else None,
+             _stream(rng_state))
+    return flags, perm, log_scale, s_out
+
+
+def _augment_draw_fake(rng_state, batch, swap_perm, plain_supports, reflected_supports):
+    n = swap_perm.numel()
+    so = (0,) if plain_supports is None else (plain_supports.shape[0], batch, n, n)
+    return (rng_state.new_empty((batch,), dtype=torch.int32), rng_state.new_empty((batch, n), dtype=torch.int32),
+            rng_state.new_empty((batch,), dtype=torch.float32), rng_state.new_empty(so, dtype=torch.float32))
+
+
+_define("augment_draw_", "(Tensor(a!) rng_state, int batch, Tensor swap_perm, Tensor? plain_supports, Tensor? reflected_supports) -> "
+        "(Tensor, Tensor, Tensor, Tensor)", _augment_draw_impl, _augment_draw_fake)
+
+
 # =============================================================================================
 # Python conveniences used by model/, utils.py and train_step.py
 # =============================================================================================
@@ -1347,6 +1387,23 @@ def teacher_flags(rng_state, samples_seen, increment, cl_decay_steps, t_len):
     """Scheduled-sampling flags of one decoder forward drawn ON THE DEVICE (model.py:194-200, utils.py:385-390): int32[t_len],
     flag t = u_t < k / (k + exp(samples_seen / k)); advances the generator and adds `increment` to samples_seen on the stream."""
     return torch.ops.eeg_dcrnn.teacher_flags_(rng_state, samples_seen, int(increment), float(cl_decay_steps), int(t_len))
+
+
+def draw_augmentation(rng_state, batch, swap_perm, plain_supports=None, reflected_supports=None):
+    """The reference's per-sample augmentation draws (dataloader_detection.py:233-256,384-389), ON THE DEVICE from a Philox
+    generator state (`make_rng_state`; advanced on the stream: a captured step draws afresh at every replay): per clip a fair coin
+    -- reflect along the midline or not -- and a scale factor uniform in [0.8, 1.2).
+    swap_perm: int32 (N,) source channel of every node of a reflected clip (`utils.swap_permutation`).
+    plain_supports / reflected_supports: lists (or stacked tensors) of the (N,N) supports of the distance graph and of its reflected
+    partner (`utils.compute_supports` / `utils.reflected_supports`); given, the per-clip supports are returned as well.
+    Returns (flags int32 (B,), perm int32 (B,N), log_scale float32 (B,), supports: list of (B,N,N) tensors or None) -- `perm` and
+    `log_scale` are the operands of `fft_features`."""
+    stack = lambda t: None if t is None else (t if torch.is_tensor(t) else torch.stack(list(t)))   # noqa: E731
+    ps, rs = stack(plain_supports), stack(reflected_supports)
+    if ps is not None and ps.dim() == 2:
+        ps, rs = ps[None], rs[None]
+    flags, perm, log_scale, s_out = torch.ops.eeg_dcrnn.augment_draw_(rng_state, int(batch), swap_perm, ps, rs)
+    return flags, perm, log_scale, (None if ps is None else [s_out[i] for i in range(s_out.shape[0])])
 
 
 def clip_adam_step_dev(params, grads, exp_avg, exp_avg_sq, step_dev, lr_dev, betas, eps, weight_decay, max_norm, grad_scale, ws,

@@ -57,7 +57,8 @@ class TrainStep:
                  weight_decay: float = 5e-4, max_grad_norm: float = 5.0,
                  scaler_mean: Optional[float] = None, scaler_std: Optional[float] = None,
                  always_reduce: bool = False, raw_window: Optional[int] = None, raw_mean: float = 0.0, raw_std: float = 1.0,
-                 shared_graph: bool = True):
+                 shared_graph: bool = True, data_augment: bool = False, swap_perm=None, reflected_supports=None,
+                 feature_std: Optional[float] = None):
         """shared_graph: batched supports whose clips all carry one and the same graph (the reference's trainers pass the distance
         graph that way) are handed to the model in their 2-D form, which lets the encoder run its hoisted GEMMs in the
         eigenbasis of that graph (`ops.collapse_shared_supports`: one comparison + one flag read per supports TENSOR, cached; a
@@ -65,6 +66,16 @@ class TrainStep:
         re-capturing, or pass shared_graph=False).
         always_reduce: issue the gradient all-reduce whenever a process group exists, also at world size 1 (exercises
         the RCCL path on a single GPU; a sum over one rank is the identity).
+        data_augment: the reference's training-set augmentation (`--data_augment`; dataloader_detection.py:233-256,384-389: per
+        sample a fair coin -- reflect the electrodes along the midline or not -- and an amplitude factor uniform in [0.8, 1.2), which
+        under use_fft is `+= log(factor)` before standardisation), drawn ON THE DEVICE every step (`ops.draw_augmentation`, a Philox
+        state of this object: a captured step draws afresh at every replay).  With raw_window the draws are operands of the
+        featurisation kernel; for feature inputs (already standardised) the step applies x[b, :, perm[b]] + log(factor_b) /
+        feature_std, which is the same value (feature_std = the scaler's std, required then).  Graph side as in the reference:
+        supports=None (correlation graph) is built from the UN-reflected, un-scaled clip (`_get_indiv_graphs` never reads its
+        swapped name table); for the distance graph pass `reflected_supports` (`utils.reflected_supports`: the graph of
+        `_get_combined_graph(swap_nodes)`) -- every clip then carries the plain or the reflected supports according to its coin
+        (per-clip graphs: the general path, not the spectral form).  swap_perm: `utils.swap_permutation(num_nodes)` by default.
         raw_window: the step takes RAW resampled signals (B, N, T*raw_window) instead of features and runs the reference's
         DataLoader-side chain on the device in front of the model (dataloader_detection.py:57-71,346-354,384-393): log|FFT| of every
         raw_window-sample step (`eeg_dcrnn_fft_features`) -> z-score with (raw_mean, raw_std) = the model input; with
@@ -94,6 +105,22 @@ class TrainStep:
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
         self.raw_window, self.raw_mean, self.raw_std = raw_window, float(raw_mean), float(raw_std)
         self.shared_graph = bool(shared_graph)
+        self.data_augment = bool(data_augment)
+        self.feature_std = None if feature_std is None else float(feature_std)
+        self.swap_perm, self.reflected_supports, self._augment_rng = None, None, None
+        if self.data_augment:
+            from . import utils
+            if raw_window is None and feature_std is None:
+                raise ValueError("TrainStep: data_augment on feature inputs needs feature_std (the StandardScaler's std: the reference "
+                                 "adds log(scale) BEFORE it standardises)")
+            sp = utils.swap_permutation(model.num_nodes) if swap_perm is None else torch.as_tensor(swap_perm)
+            if sp.numel() != model.num_nodes:
+                raise ValueError(f"TrainStep: swap_perm has {sp.numel()} entries for {model.num_nodes} nodes")
+            self.swap_perm = sp.to(device=dev, dtype=torch.int32).contiguous()
+            if reflected_supports is not None:
+                self.reflected_supports = torch.stack([torch.as_tensor(r, dtype=torch.float32) for r in reflected_supports]).to(dev).contiguous()
+            self._augment_rng = ops.make_rng_state(dev, stream_id=2)
+        self.last_augmentation = None     # (flags, perm, log_scale) of the latest step (tests / logging)
         self._graphs = {}
         # curriculum learning (SSL, model.py:194-200): where the persistent decoder kernels apply, the teacher-forcing flags are
         # drawn on the device (`eeg_dcrnn_teacher_flags`) -- in eager steps and graph replays alike; elsewhere on the host
@@ -179,10 +206,19 @@ class TrainStep:
         """supports=None: build the per-clip correlation graph and its dual random-walk supports from
         the clips on the device (the DataLoader-side `_get_indiv_graphs` of the reference)."""
         self.fp.zero_grad()
+        perm, log_scale = None, None
+        if self.data_augment and self.model.training:
+            supports, perm, log_scale = self._draw_augmentation(x.shape[0], supports)
         if self.raw_window is not None:              # raw signals in: featurise on the device (x becomes the standardised log|FFT|)
-            feat_raw, x = ops.fft_features(x, window=self.raw_window, mean=self.raw_mean, std=self.raw_std)
+            feat_raw, x = ops.fft_features(x, window=self.raw_window, mean=self.raw_mean, std=self.raw_std, perm=perm, log_scale=log_scale)
             if supports is None:
-                supports = ops.correlation_supports(feat_raw, top_k=3)
+                supports = ops.correlation_supports(feat_raw, top_k=3)       # (feat_raw: un-reflected, un-scaled, un-standardised)
+        elif perm is not None:
+            plain = x
+            idx = perm.to(torch.int64)[:, None, :, None].expand(-1, x.shape[1], -1, x.shape[3])
+            x = x.gather(2, idx) + (log_scale / self.feature_std)[:, None, None, None]
+            if supports is None:
+                supports = ops.correlation_supports(plain, top_k=3)
         if supports is None:
             supports = ops.correlation_supports(x, top_k=3)
         elif self.shared_graph:
@@ -202,6 +238,22 @@ class TrainStep:
         with self.fp.sink:                       # backward operators write into the flat gradient bucket
             out.backward(seed.view_as(out))
         return loss.detach()
+
+    def _draw_augmentation(self, batch, supports):
+        """this step's draws; with a distance graph and its reflected partner, the per-clip supports"""
+        plain = None
+        if supports is not None and self.reflected_supports is not None:
+            shared = ops.collapse_shared_supports(supports) if self.shared_graph else supports
+            if any(s_.dim() != 2 for s_ in shared):
+                raise RuntimeError("TrainStep(data_augment, reflected_supports): the supports of the step must be ONE graph shared by all "
+                                   "clips (2-D tensors, or batched copies of it): the reflected partner is chosen per clip")
+            if len(shared) != self.reflected_supports.shape[0]:
+                raise RuntimeError(f"TrainStep: {len(shared)} supports, {self.reflected_supports.shape[0]} reflected partners")
+            plain = torch.stack([s_.to(torch.float32) for s_ in shared])
+        flags, perm, log_scale, sel = ops.draw_augmentation(self._augment_rng, batch, self.swap_perm, plain,
+                                                            None if plain is None else self.reflected_supports)
+        self.last_augmentation = (flags, perm, log_scale)
+        return (supports if sel is None else sel), perm, log_scale
 
     # -- HIP-graph replay of forward + loss + backward -------------------------------------------
     def capture(self, x, y, seq_lengths, supports, warmup: int = 2, slot: int = 0, include_update: bool = False):

@@ -86,6 +86,51 @@ def correlation_graph(clip, top_k=3):
     return keep_topk(np.abs(adj), top_k=top_k, directed=True)
 
 
+# ---- reflection augmentation: the graph side (host, once per run) --------------------------------------------
+# the 19-electrode montage in the reference's channel order (constants.py:2-21)
+INCLUDED_CHANNELS = ["EEG FP1", "EEG FP2", "EEG F3", "EEG F4", "EEG C3", "EEG C4", "EEG P3", "EEG P4", "EEG O1", "EEG O2",
+                     "EEG F7", "EEG F8", "EEG T3", "EEG T4", "EEG T5", "EEG T6", "EEG FZ", "EEG CZ", "EEG PZ"]
+_MIDLINE_PAIRS = (("EEG FP1", "EEG FP2"), ("EEG Fp1", "EEG Fp2"), ("EEG F3", "EEG F4"), ("EEG F7", "EEG F8"),
+                  ("EEG C3", "EEG C4"), ("EEG T3", "EEG T4"), ("EEG T5", "EEG T6"), ("EEG O1", "EEG O2"))
+
+
+def get_swap_pairs(channels=None):
+    """data_utils.py:37-62: index pairs mirrored along the midline by `_random_reflect`, in the reference's order (P3 / P4 are
+    NOT among them -- kept as is)."""
+    channels = INCLUDED_CHANNELS if channels is None else list(channels)
+    return [(channels.index(a), channels.index(b)) for a, b in _MIDLINE_PAIRS if a in channels and b in channels]
+
+
+def swap_permutation(num_nodes, swap_pairs=None):
+    """source channel of every node of a reflected clip (`EEG_seq_reflect[:, [a, b]] = EEG_seq[:, [b, a]]`,
+    dataloader_detection.py:233-246) as an int32 (N,) tensor -- the `swap_perm` of `ops.draw_augmentation`."""
+    perm = np.arange(num_nodes, dtype=np.int32)
+    for a, b in (get_swap_pairs() if swap_pairs is None else swap_pairs):
+        perm[a], perm[b] = b, a
+    return torch.from_numpy(perm)
+
+
+def reflected_adjacency(adj_mat, swap_pairs=None):
+    """`_get_combined_graph(swap_nodes)` (dataloader_detection.py:309-333): the distance-graph adjacency a REFLECTED clip is
+    paired with.  Every assignment of the reference's loop reads the ORIGINAL matrix, so a position touched by two pairs keeps
+    the later pair's value only: entry (a, c) of pairs (a, b), (c, d) ends as adj[a, d], not adj[b, d] -- the result is symmetric
+    but NOT the permutation similarity P A P^T (its spectrum differs from the plain graph's).  Reproduced as is."""
+    adj = np.asarray(adj_mat)
+    new = adj.copy()
+    for a, b in (get_swap_pairs() if swap_pairs is None else swap_pairs):
+        new[[a, b], :] = adj[[b, a], :]
+        new[:, [a, b]] = adj[:, [b, a]]
+        np.fill_diagonal(new, 1)
+        new[a, b], new[b, a] = adj[b, a], adj[a, b]
+    return new
+
+
+def reflected_supports(adj_mat, filter_type, swap_pairs=None):
+    """supports of the reflected distance graph (`_compute_supports(_get_combined_graph(swap_nodes))`,
+    dataloader_detection.py:405-409): list of float32 (N,N) tensors, the partner of `compute_supports(adj_mat, filter_type)`."""
+    return compute_supports(reflected_adjacency(adj_mat, swap_pairs), filter_type)
+
+
 # ---- sequence helpers -----------------------------------------------------------------------
 def last_relevant_pytorch(output, lengths, batch_first=True):
     """Gather `output` at t = lengths-1 (reference utils.py:346-357).  Stays on the device (the

@@ -238,6 +238,18 @@ int eeg_dcrnn_decoder_bwd(const eeg_decoder_dims* d, const int32_t* teacher, con
 int eeg_dcrnn_teacher_flags(uint64_t* rng_state, int64_t* samples_seen, int64_t increment, double cl_decay_steps, int T,
                             int32_t* flags, void* stream);
 
+/* Data augmentation drawn on the device (data/dataloader_detection.py:233-256 `_random_reflect`, `_random_scale`, applied per
+ * sample at :384-389 in the DataLoader workers).  rng_used = the {seed, offset} pair eeg_dcrnn_rng_take handed out for B
+ * counters; clip b uses counter offset + b: word 0's top bit = the reflection coin, word 1 / 2^32 = u, scale = 0.8 + 0.4 u.
+ * swap_perm: DEVICE int32[N], the source channel of every node of a reflected clip (data_utils.py:37-62 `get_swap_pairs`).
+ * Outputs (DEVICE): flags int32[B]; perm int32[B][N] (swap_perm where flags[b], else the identity) and log_scale float[B]
+ * (= log(scale), float) -- the operands of eeg_dcrnn_fft_features; and, when S_out != NULL, the per-clip supports of the
+ * distance graph (`_get_combined_graph(swap_nodes)`, :309-333,405-409): S_out[s][b] = flags[b] ? S_reflected[s] : S_plain[s]
+ * (S_plain / S_reflected: n_supports x N x N, S_out: n_supports x B x N x N). */
+int eeg_dcrnn_augment_draw(const uint64_t* rng_used, int B, int N, const int32_t* swap_perm, int32_t* flags, int32_t* perm,
+                           float* log_scale, const float* S_plain, const float* S_reflected, int n_supports, float* S_out,
+                           void* stream);
+
 /* utils.last_relevant_pytorch (utils.py:346-357): last[b] = Htop[lengths[b]-1, b]. Htop (T,B,NH). */
 int eeg_dcrnn_gather_last(const float* Htop, const int64_t* lengths, int T, int B, int NH,
                           float* last, void* stream);

@@ -27,6 +27,8 @@ __device__ __forceinline__ void permlane16_swap(float& a, float& b) { emu::perml
 #define EEG_LDS_WAIT() ((void)0)
 #define EEG_VM_WAIT_BARRIER(n) __syncthreads()
 #define EEG_VM_WAIT(n) ((void)0)
+template <int N> inline void vm_wait_barrier_n() { __syncthreads(); }
+template <int N> inline void vm_wait_n() {}
 #define EEG_PIN(v) ((void)0)
 #define EEG_USE(v) ((void)0)
 #define EEG_PIN_S(v) ((void)0)

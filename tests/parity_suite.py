@@ -958,6 +958,107 @@ def check_raw_input_chain(device, b=4, t_len=3):
         assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"raw chain/d_{k}", tol=1e-4)
 
 
+def expected_augmentation(seed, offset, batch, swap_perm):
+    """the documented function of the generator pair (include/eeg_dcrnn.h eeg_dcrnn_augment_draw): clip b takes Philox counter
+    offset + b; reflection coin = top bit of word 0, scale = 0.8 + 0.4 * word 1 / 2^32"""
+    words = philox4x32_10_numpy(np.uint64(offset) + np.arange(batch, dtype=np.uint64), int(seed))
+    flags = (words[:, 0] >> np.uint32(31)).astype(np.int32)
+    scale = 0.8 + 0.4 * (words[:, 1].astype(np.float64) / 4294967296.0)
+    ident = np.arange(len(swap_perm), dtype=np.int32)
+    perm = np.where(flags[:, None] == 1, np.asarray(swap_perm, dtype=np.int32)[None, :], ident[None, :])
+    return flags, perm, np.log(scale).astype(np.float32)
+
+
+def check_augmentation_draws(device, adj3d):
+    """known-answer test of the device-side augmentation draws (dataloader_detection.py:233-256): flags / perm / log_scale are the
+    documented function of the generator pair, the generator advances by one counter per clip on the stream, the per-clip supports
+    are the plain or the reflected set, the coin is fair and the scale uniform in [0.8, 1.2)."""
+    from eeg_gnn_ssl_amd import ops, utils
+    sp = utils.swap_permutation(19)
+    assert sorted(sp.tolist()) == list(range(19)) and sp[sp.long()].tolist() == list(range(19))      # an involution
+    st = torch.tensor([123456789123, 7], dtype=torch.int64, device=device)
+    plain = utils.compute_supports(adj3d, "dual_random_walk")
+    refl = utils.reflected_supports(adj3d, "dual_random_walk")
+    flags, perm, ls, sel = ops.draw_augmentation(st, 10, sp.to(device), [t.to(device) for t in plain], [t.to(device) for t in refl])
+    ef, ep, el = expected_augmentation(123456789123, 7, 10, sp.numpy())
+    assert flags.dtype == torch.int32 and flags.tolist() == ef.tolist() and perm.cpu().numpy().tolist() == ep.tolist()
+    np.testing.assert_allclose(ls.cpu().numpy(), el, rtol=0, atol=2e-7)
+    assert st.tolist() == [123456789123, 17]
+    assert len(sel) == 2 and tuple(sel[0].shape) == (10, 19, 19)
+    for i in range(2):
+        for b in range(10):
+            want = refl[i] if ef[b] else plain[i]
+            assert torch.equal(sel[i][b].cpu(), want), (i, b)
+    f2, p2, l2, none = ops.draw_augmentation(st, 4096, sp.to(device))
+    assert none is None and st.tolist() == [123456789123, 17 + 4096]
+    ef2, _, el2 = expected_augmentation(123456789123, 17, 4096, sp.numpy())
+    assert f2.tolist() == ef2.tolist()
+    rate = float(f2.float().mean().item())
+    assert abs(rate - 0.5) < 3 * 0.5 / np.sqrt(4096.0), rate
+    sc = torch.exp(l2.double()).cpu().numpy()
+    assert sc.min() >= 0.8 - 1e-6 and sc.max() < 1.2 + 1e-6 and abs(sc.mean() - 1.0) < 0.01, (sc.min(), sc.max(), sc.mean())
+    try:
+        ops.draw_augmentation(st, 4, sp.to(device), [plain[0].to(device)], None)
+    except RuntimeError as e:
+        assert "BOTH" in str(e)
+    else:
+        raise AssertionError("a plain set without its reflected partner must be refused")
+
+
+def check_augmented_step(device, adj3d, graph="distance", raw=True, b=6, t_len=2):
+    """TrainStep(data_augment=True): the reference's per-sample augmentation (dataloader_detection.py:384-393: `_random_reflect`,
+    `_random_scale`, then the scaler) with the draws made on the device, and its graph side (:402-409): the distance graph of a
+    reflected clip is `_get_combined_graph(swap_nodes)` (pinned by golden_reflect_v1.npz), the correlation graph is built from the
+    UN-reflected, un-scaled clip (Q10).  The draws are read back and handed to the oracle chain (numpy FFT -> reflect -> + log
+    scale -> z-score -> host graph builders -> oracle model): loss and every parameter gradient agree.  raw=False: the same on
+    already standardised features (x[b, :, perm[b]] + log(scale) / std)."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification, utils
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    g = torch.Generator().manual_seed(57)
+    raw_sig = 20.0 * torch.randn(b, 19, t_len * 200, generator=g)
+    y = (torch.rand(b, generator=g) > 0.5).float()
+    lengths = torch.full((b,), t_len, dtype=torch.int64)
+    mean, std = 5.53, 0.65
+    filt = "laplacian" if graph == "distance" else "dual_random_walk"
+    cfg = orc.DCRNNConfig(filter_type=filt, num_classes=1)
+    params = orc.init_params(cfg, "classification", seed=3)
+    model = DCRNNModel_classification(make_args(cfg), 1, device=device)
+    load(model, params, device)
+    model.train()
+    feats = np.stack([orc.fft_features(raw_sig[i].numpy().astype(np.float64), window=200) for i in range(b)])      # (B, T, N, 100)
+    plain = utils.compute_supports(adj3d, filt)
+    refl = utils.reflected_supports(adj3d, filt)
+    kw = dict(raw_window=200, raw_mean=mean, raw_std=std) if raw else dict(feature_std=std)
+    st = TrainStep(model, task="detection", data_augment=True, reflected_supports=refl if graph == "distance" else None, **kw)
+    sup_in = [p_.unsqueeze(0).repeat(b, 1, 1).to(device) for p_ in plain] if graph == "distance" else None      # batched copies, as the trainers pass them
+    x_in = raw_sig if raw else torch.from_numpy(((feats - mean) / std).astype(np.float32))
+    draws = []
+    for _ in range(2):                                           # two steps: the generator advanced, the draws differ
+        loss = st.forward_backward(x_in.to(device), y.to(device), lengths.to(device), sup_in)
+        flags, perm, ls = (t.cpu() for t in st.last_augmentation)
+        draws.append(flags.tolist() + ls.tolist())
+        fa = np.stack([feats[i][:, perm[i].numpy(), :] + float(ls[i]) for i in range(b)])
+        x = torch.from_numpy(((fa - mean) / std).astype(np.float32))
+        if graph == "distance":
+            sups = [torch.stack([(refl[k] if flags[i] else plain[k]) for i in range(b)]) for k in range(len(plain))]
+        else:
+            src = feats if raw else (feats - mean) / std            # (feature inputs: the graph of the un-augmented INPUT)
+            per = [utils.compute_supports(utils.correlation_graph(src[i], top_k=3), filt) for i in range(b)]
+            sups = [torch.stack([per[i][k] for i in range(b)]) for k in range(2)]
+        po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        lo = orc.bce_with_logits(orc.classification_forward(po, cfg, x, lengths, sups), y)
+        lo.backward()
+        assert abs(float(loss.item()) - float(lo.item())) < 2e-5, (float(loss.item()), float(lo.item()))
+        for k, q in model.named_parameters():
+            assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"augmented step {graph}/d_{k}", tol=1e-4)
+    assert draws[0] != draws[1]
+    assert 0 < sum(draws[0][:b]) + sum(draws[1][:b]) < 2 * b       # both outcomes of the coin were exercised
+    model.eval()                                                 # no augmentation outside training
+    st.last_augmentation = None
+    st.forward_backward(x_in.to(device), y.to(device), lengths.to(device), sup_in)
+    assert st.last_augmentation is None
+
+
 def check_split_bf16(device, adj3d, filt="laplacian", din=100, layers=2, t_len=3, b=3, seed=4):
     """The OPT-IN three-term bf16 split of the hoisted NN GEMMs (ops.set_gemm_mode(1); include/eeg_dcrnn.h eeg_layer_dims.pack3):
     logits and every parameter gradient of the classification model against the oracle at the suite's tolerance -- the split keeps

@@ -59,7 +59,7 @@ def test_operators_are_registered_with_the_dispatcher():
     import eeg_gnn_ssl_amd  # noqa: F401  (registers the library)
     for name in ("hop_polys", "pack_cell", "diffusion_hops", "dconv", "dconv_bwd", "dcgru_layer", "dcgru_layer_bwd",
                  "dcgru_decoder", "dcgru_decoder_bwd", "spectral_basis", "pack_cell_spectral", "cls_head", "cls_head_bwd", "rng_take_", "dropout_mask", "gather_last", "corr_graph", "fft_features",
-                 "bce_logits", "ce_logits", "masked_loss", "clip_adam_", "clip_adam_dev_", "teacher_flags_"):
+                 "bce_logits", "ce_logits", "masked_loss", "clip_adam_", "clip_adam_dev_", "teacher_flags_", "augment_draw_"):
         op = getattr(torch.ops.eeg_dcrnn, name)
         assert op.default._schema.name == f"eeg_dcrnn::{name}"
     assert torch.ops.eeg_dcrnn.clip_adam_.default._schema.is_mutable

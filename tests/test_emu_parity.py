@@ -246,6 +246,15 @@ def test_raw_signals_to_step_chain_vs_oracle():
     ps.check_raw_input_chain("cpu", b=2, t_len=2)
 
 
+def test_augmentation_draws_known_answer(adj3d):
+    ps.check_augmentation_draws("cpu", adj3d)
+
+
+@pytest.mark.parametrize("graph,raw", [("distance", True), ("correlation", True), ("distance", False)])
+def test_augmented_step_vs_oracle(graph, raw, adj3d):
+    ps.check_augmented_step("cpu", adj3d, graph=graph, raw=raw, b=4, t_len=2)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features("cpu", golden_fft)
 

@@ -969,6 +969,17 @@ def test_raw_signals_to_step_chain_vs_oracle():
     ps.check_raw_input_chain(DEV, b=9, t_len=7)
 
 
+def test_augmentation_draws_known_answer(adj3d):
+    """device-side reflection coin / amplitude factor / per-clip distance-graph supports: known answers of the generator pair"""
+    ps.check_augmentation_draws(DEV, adj3d)
+
+
+@pytest.mark.parametrize("graph,raw", [("distance", True), ("correlation", True), ("distance", False), ("correlation", False)])
+def test_augmented_step_vs_oracle(graph, raw, adj3d):
+    """TrainStep(data_augment=True) against the oracle chain with the SAME draws (dataloader_detection.py:384-409)"""
+    ps.check_augmented_step(DEV, adj3d, graph=graph, raw=raw, b=9, t_len=5)
+
+
 def test_fft_features(golden_fft):
     ps.check_fft_features(DEV, golden_fft)
 

@@ -49,3 +49,31 @@ def test_keep_topk_semantics():
         assert np.array_equal(d[i, top], a[i, top])
     u = utils.keep_topk(a, top_k=3, directed=False)
     assert ((u != 0) == ((d != 0) | (d != 0).T)).all()
+
+
+def test_reflection_helpers_against_the_reference():
+    """get_swap_pairs / _random_reflect / _random_scale / _get_combined_graph(swap_nodes) / _compute_supports of the reflected graph
+    (data_utils.py:37-62, dataloader_detection.py:233-256,309-354): goldens produced by the genuine reference
+    (tests/golden/make_golden_reflect.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_reflect_v1.npz"))
+    pairs = [tuple(p) for p in g["pairs"].tolist()]
+    assert utils.get_swap_pairs() == pairs and (6, 7) not in pairs            # (P3 / P4 are not mirrored by the reference)
+    perm = utils.swap_permutation(19).numpy()
+    assert np.array_equal(g["clip"][:, perm, :], g["clip_reflected"])         # EEG_seq_reflect[:, [a, b]] = EEG_seq[:, [b, a]]
+    assert np.allclose(g["clip_reflected"] + np.log(g["scale"][0]), g["clip_reflected_scaled"], rtol=0, atol=1e-12)
+    adj_r = utils.reflected_adjacency(g["adj"])
+    assert np.array_equal(adj_r, g["adj_reflected"]) and np.array_equal(adj_r, adj_r.T)
+    # the loop of the reference reads the ORIGINAL matrix at every assignment: the result is NOT P A P^T
+    P = np.eye(19)[perm]
+    assert not np.allclose(P @ g["adj"] @ P.T, adj_r)
+    assert not np.allclose(np.linalg.eigvalsh(g["adj"].astype(np.float64)), np.linalg.eigvalsh(adj_r.astype(np.float64)), atol=1e-4)
+    for ft, n in (("laplacian", 1), ("dual_random_walk", 2)):
+        for tag, a in (("plain", g["adj"]), ("reflected", None)):
+            sup = utils.compute_supports(a, ft) if a is not None else utils.reflected_supports(g["adj"], ft)
+            assert len(sup) == n
+            for i, s_ in enumerate(sup):
+                np.testing.assert_allclose(s_.numpy(), g[f"supports/{ft}/{tag}/{i}"], rtol=0, atol=2e-7)
+    # `_get_indiv_graphs(eeg_clip, swap_nodes)` ignores its swapped name table (SURVEY Q10): one graph either way
+    assert np.array_equal(g["indiv_adj_plain"], g["indiv_adj_swapped"])
+    np.testing.assert_allclose(utils.correlation_graph(g["clip"], top_k=3), g["indiv_adj_plain"], rtol=0, atol=2e-6)
