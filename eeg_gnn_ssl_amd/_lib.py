@@ -82,6 +82,11 @@ _SIGNATURES = {
                                       _FP, _FP, _FP, c_void_p]),
     "eeg_dcrnn_teacher_flags": (c_int, [_FP, _FP, c_int64, ctypes.c_double, c_int, _FP, c_void_p]),
     "eeg_dcrnn_augment_draw": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, _FP, c_void_p]),
+    "eeg_dcrnn_pack_cells": (c_int, [c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(ctypes.c_int32),
+                             c_int, c_int, POINTER(c_void_p), _FP, c_int, POINTER(c_void_p), c_void_p]),
+    "eeg_dcrnn_cls_head_loss_ws_floats": (c_size_t, [c_int, c_int, c_int]),
+    "eeg_dcrnn_cls_head_loss": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_int, c_float, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
+                                c_void_p]),
     "eeg_dcrnn_gather_last": (c_int, [_FP, _FP, c_int, c_int, c_int, _FP, c_void_p]),
     "eeg_dcrnn_rng_take": (c_int, [_FP, ctypes.c_uint64, _FP, c_void_p]),
     "eeg_dcrnn_cls_head_fwd": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_float, _FP, _FP, _FP, c_void_p]),

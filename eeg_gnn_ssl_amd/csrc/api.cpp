@@ -781,6 +781,26 @@ int eeg_dcrnn_pack_cell_spectral(const float* Wg, const float* Wc, const float* 
     if (launch_spec_pack(Wg, Wc, basis, Fin, H, M, N, spack, S_(stream))) return fail("pack_cell_spectral: launch failed");
     return check_launch("pack_cell_spectral");
 }
+int eeg_dcrnn_pack_cells(int n_cells, const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
+                         const int32_t* Fin, int H, int M, float* const* packs, const float* basis, int N, float* const* spacks,
+                         void* stream) {
+    if (n_cells < 1 || n_cells > 4) return fail("pack_cells: %d cells (1..4 per launch)", n_cells);
+    if (Wg == nullptr || bg == nullptr || Wc == nullptr || bc == nullptr || Fin == nullptr || packs == nullptr) return fail("pack_cells: null pointer table");
+    if (!h_supported(H)) return fail("pack_cells: rnn_units=%d unsupported", H);
+    if (!m_supported(M)) return fail("pack_cells: num hop matrices M=%d unsupported (1,2,3,4,5,7)", M);
+    if ((basis == nullptr) != (spacks == nullptr)) return fail("pack_cells: the per-frequency packs need the basis block and their output table");
+    int fin[4];
+    for (int c = 0; c < n_cells; ++c) {
+        fin[c] = Fin[c];
+        if (fin[c] < 4 || fin[c] % 4 != 0) return fail("pack_cells: input dim %d of cell %d must be a positive multiple of 4", fin[c], c);
+        if (Wg[c] == nullptr || bg[c] == nullptr || Wc[c] == nullptr || bc[c] == nullptr || packs[c] == nullptr || (spacks != nullptr && spacks[c] == nullptr))
+            return fail("pack_cells: null pointer in the tables of cell %d", c);
+        if (spacks != nullptr && eeg_dcrnn_spectral_pack_floats(fin[c], H, M, N) == 0)
+            return fail("pack_cells: input_dim=%d rnn_units=%d hop matrices=%d nodes=%d: the spectral form exists for 64 units", fin[c], H, M, N);
+    }
+    if (launch_pack_cells(n_cells, Wg, bg, Wc, bc, fin, H, M, packs, basis, N, spacks, S_(stream))) return fail("pack_cells: launch failed");
+    return check_launch("pack_cells");
+}
 int eeg_dcrnn_spectral_ok(const eeg_layer_dims* d, int need_dx) {
     if (!layer_dims_positive(d) || d->p_batched) return 0;
     if (d->x_planes_ready && d->Fin != d->H) return 0;           // (a handed-over transformed input is the layer below's U^T h)
@@ -1338,6 +1358,33 @@ int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits,
     return check_launch("cls_head_bwd_w");
 }
 
+size_t eeg_dcrnn_cls_head_loss_ws_floats(int B, int H, int C) {
+    return (B >= 1 && H >= 1 && C >= 1) ? (size_t)ceil_div(B, 4) * ((size_t)C * H + C + 1) : 0;
+}
+int eeg_dcrnn_cls_head_loss(const float* z, const float* W, const float* bias, const void* targets, int kind, int B, int N, int H, int C,
+                            float dropout_p, const uint64_t* rng_used, float* logits, int32_t* arg, float* dlogits, float* dz,
+                            float* dW, float* dbias, float* loss, float* ws, void* stream) {
+    if (B < 1 || N < 1 || H < 1 || C < 1) return fail("cls_head_loss: empty input (B=%d, N=%d, H=%d, C=%d)", B, N, H, C);
+    if (N > 64) return fail("cls_head_loss: num_nodes=%d unsupported (<= 64)", N);
+    if (H % 4 != 0) return fail("cls_head_loss: rnn_units=%d must be a multiple of 4", H);
+    if (kind != 0 && kind != 1) return fail("cls_head_loss: kind=%d (0 = BCE-with-logits, 1 = cross-entropy)", kind);
+    if (kind == 0 && C != 1) return fail("cls_head_loss: BCE-with-logits takes one logit per clip (num_classes=%d)", C);
+    if (check_dropout_p("cls_head_loss", dropout_p)) return 1;
+    const DropCfg drop = make_drop_cfg(dropout_p);
+    if (drop.on && rng_used == nullptr) return fail("cls_head_loss: dropout_p > 0 needs the {seed, offset} pair of eeg_dcrnn_rng_take");
+    if (z == nullptr || W == nullptr || bias == nullptr || targets == nullptr || logits == nullptr || arg == nullptr || dlogits == nullptr ||
+        dz == nullptr || dW == nullptr || dbias == nullptr || loss == nullptr || ws == nullptr)
+        return fail("cls_head_loss: null pointer");
+    const int O = C * H + C, nblk = ceil_div(B, 4);
+    const size_t lds = (size_t)(4 * cls_tail_wave_floats(N, H, C) + 4 * (O + 1)) * sizeof(float);
+    if (lds > kMaxLdsBytes) return fail("cls_head_loss: N=%d x (classes=%d + rnn_units=%d) floats of four clips do not fit the %zu-byte LDS", N, C, H, (size_t)kMaxLdsBytes);
+    EEG_SET_MAX_LDS(cls_head_loss_kernel, lds);
+    EEG_LAUNCH_P("cls_head_loss", cls_head_loss_kernel, dim3(nblk), dim3(256), lds, S_(stream), z, W, bias, targets, kind, B, N, H, C, drop,
+                 reinterpret_cast<const unsigned long long*>(rng_used), logits, reinterpret_cast<int*>(arg), dlogits, dz, ws);
+    if (check_launch("cls_head_loss")) return 1;
+    EEG_LAUNCH_P("cls_head_loss", cls_head_loss_finish_kernel, dim3(1), dim3(256), 0, S_(stream), ws, nblk, B, H, C, dW, dbias, loss);
+    return check_launch("cls_head_loss_finish");
+}
 size_t eeg_dcrnn_dconv_fwd_ws_floats(int B, int N, int F, int M, int O) {
     if (B < 1 || N < 1 || F < 1 || M < 1 || O < 1) return 0;
     return (size_t)(M - 1) * B * N * F + (size_t)F * M * O;

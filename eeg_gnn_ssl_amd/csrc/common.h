@@ -157,4 +157,11 @@ __host__ __device__ inline float dropout_mask1(unsigned long long seed, unsigned
     const unsigned word = k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
     return (scale != 0.f && word >= thr) ? scale : 0.f;
 }
+// 16-byte global accesses of four consecutive floats
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return (f32x4){v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
 }  // namespace eeg

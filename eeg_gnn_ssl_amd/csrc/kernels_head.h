@@ -115,6 +115,133 @@ __global__ void cls_head_bwd_w_kernel(const float* __restrict__ z, const float* 
     }
 }
 
+// ---- head + criterion + their backward in one launch (train.py:266-272 of an optimisation step) ------------------------------------
+// cls_head_fwd_kernel -> bce_logits_kernel / ce_logits_kernel (kernels_tail.h) -> cls_head_bwd_dz_kernel -> cls_head_bwd_w_kernel,
+// fused for the training step: one WAVE per clip (4 clips per workgroup) stages mask * relu(z) of its clip in LDS once and derives
+// everything from it -- logits / arg (kept: evaluation metrics and the parity tests read them), the clip's loss term, dlogits
+// (mean reduction: 1/B folded in), dz (the seed of the BPTT kernels; rows of nodes that are not an arg-max are zero) and the clip's
+// contribution to dW / dbias.  The contributions and loss terms of a workgroup's clips are summed in LDS in clip order and written
+// as partial[blk][O + 1] (O = C*H + C); cls_head_loss_finish_kernel adds the partials in block order (fixed order: bit-reproducible).
+// kind 0: nn.BCEWithLogitsLoss on logits (B,1), float targets; kind 1: nn.CrossEntropyLoss on (B,C), int64 targets (a label outside
+// 0..C-1 makes the LOSS NaN, see ce_logits_kernel).  LDS per wave: [N][C] node logits | [N][H] masked relu(z) | [C] dlogits | [C] arg.
+__host__ __device__ inline int cls_tail_wave_floats(int N, int H, int C) { return N * C + N * H + 2 * C; }
+__global__ __launch_bounds__(256) void cls_head_loss_kernel(const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ bias,
+                                                            const void* __restrict__ targets, int kind, int B, int N, int H, int C, DropCfg drop,
+                                                            const unsigned long long* __restrict__ used, float* __restrict__ logits,
+                                                            int* __restrict__ arg, float* __restrict__ dlogits, float* __restrict__ dz,
+                                                            float* __restrict__ partial) {
+    EEG_DYN_SMEM(sm);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, b = blockIdx.x * 4 + w, O = C * H + C;
+    float* nl = sm + w * cls_tail_wave_floats(N, H, C);       // [N][C]
+    float* zs = nl + N * C;                                   // [N][H]
+    float* dl = zs + N * H;                                   // [C]
+    int* ag = reinterpret_cast<int*>(dl + C);                 // [C]
+    float* contrib = sm + 4 * cls_tail_wave_floats(N, H, C);  // [4][O + 1]
+    const bool live = b < B;
+    const int groups = N * H / 4;
+    if (live) {
+        const unsigned long long seed = drop.on ? used[0] : 0ull, off = drop.on ? used[1] : 0ull;
+        for (int g = lane; g < groups; g += 64) {
+            const size_t gg = (size_t)b * groups + g;
+            const f32x4 v = ld4g(z + 4 * gg);
+            f32x4 m = {1.f, 1.f, 1.f, 1.f};
+            if (drop.on) m = dropout_mask4(seed, off, gg, drop.thr, drop.scale);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zs[4 * g + j] = fmaxf(v[j], 0.f) * m[j];
+        }
+        EEG_WAVE_SYNC();
+        if (lane < N) {
+            for (int c = 0; c < C; ++c) {
+                float s = bias[c];
+                for (int h = 0; h < H; ++h) s = fmaf(zs[lane * H + h], W[c * H + h], s);
+                nl[lane * C + c] = s;
+            }
+        }
+        EEG_WAVE_SYNC();
+        for (int c = lane; c < C; c += 64) {
+            float best = nl[c];
+            int bi = 0;
+            for (int q = 1; q < N; ++q)
+                if (nl[q * C + c] > best) { best = nl[q * C + c]; bi = q; }
+            logits[(size_t)b * C + c] = best;
+            arg[(size_t)b * C + c] = bi;
+            dl[c] = best;                                      // (the logit for now)
+            ag[c] = bi;
+        }
+        EEG_WAVE_SYNC();
+        if (lane == 0) {                                       // the clip's loss term and d loss / d logits (C is a handful)
+            float term;
+            if (kind == 0) {
+                const float v = dl[0], t = reinterpret_cast<const float*>(targets)[b];
+                term = fmaxf(v, 0.f) - v * t + log1pf(expf(-fabsf(v)));
+                dl[0] = (1.f / (1.f + expf(-v)) - t) / (float)B;
+            } else {
+                float mx = dl[0];
+                for (int c = 1; c < C; ++c) mx = fmaxf(mx, dl[c]);
+                float se = 0.f;
+                for (int c = 0; c < C; ++c) se += expf(dl[c] - mx);
+                const float lse = mx + logf(se);
+                const long long tl = reinterpret_cast<const long long*>(targets)[b];
+                const bool t_ok = tl >= 0 && tl < (long long)C;
+                const int t = t_ok ? (int)tl : -1;
+                term = lse - (t_ok ? dl[t] : __builtin_nanf(""));
+                for (int c = 0; c < C; ++c) dl[c] = (expf(dl[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
+            }
+            contrib[w * (O + 1) + O] = term;
+            for (int c = 0; c < C; ++c) dlogits[(size_t)b * C + c] = dl[c];
+        }
+        EEG_WAVE_SYNC();
+        // dz[b][n][h] = sum_c [arg_c == n] dl_c W[c][h] * (z > 0) * mask; zs > 0 <=> z > 0 and kept, and the mask value is then drop.scale
+        const float keep = drop.on ? drop.scale : 1.f;
+        for (int g = lane; g < groups; g += 64) {
+            const int n = (4 * g) / H, h0 = (4 * g) % H;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < C; ++c)
+                if (ag[c] == n) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaf(dl[c], W[c * H + h0 + j], o[j]);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = zs[4 * g + j] > 0.f ? o[j] * keep : 0.f;
+            *reinterpret_cast<float4*>(dz + ((size_t)b * groups + g) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        // this clip's dW[c][h] = dl_c * mask relu(z)[arg_c][h], dbias[c] = dl_c
+        for (int i = lane; i < O; i += 64) {
+            float v;
+            if (i < C * H) { const int c = i / H, h = i % H; v = dl[c] * zs[ag[c] * H + h]; }
+            else v = dl[i - C * H];
+            contrib[w * (O + 1) + i] = v;
+        }
+    }
+    __syncthreads();
+    const int nlive = B - blockIdx.x * 4 < 4 ? B - blockIdx.x * 4 : 4;
+    for (int i = threadIdx.x; i <= O; i += blockDim.x) {
+        float s = 0.f;
+        for (int q = 0; q < nlive; ++q) s += contrib[q * (O + 1) + i];
+        partial[(size_t)blockIdx.x * (O + 1) + i] = s;
+    }
+}
+// dW / dbias / loss from the per-workgroup partials, in block order
+__global__ __launch_bounds__(256) void cls_head_loss_finish_kernel(const float* __restrict__ partial, int nblk, int B, int H, int C,
+                                                                   float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ loss) {
+    const int O = C * H + C;
+    for (int i = threadIdx.x; i <= O; i += blockDim.x) {
+        float s = 0.f;
+        int q = 0;
+        for (; q + 8 <= nblk; q += 8) {                        // eight loads in flight, added in order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(q + u) * (O + 1) + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; q < nblk; ++q) s += partial[(size_t)q * (O + 1) + i];
+        if (i < C * H) dW[i] = s;
+        else if (i < O) dbias[i - C * H] = s;
+        else loss[0] = s / (float)B;
+    }
+}
+
 // ---- dropout generator plumbing (common.h: Philox4x32-10 keep masks) --------------------------------------------------------
 // first launch of a forward entry point that drops: hands the {seed, offset} pair of this call to `used` and advances the
 // generator state by the counters the call will draw.  The compute kernels behind it on the stream only read `used`.

@@ -46,11 +46,6 @@ struct SeqGeom {
     static constexpr int bwd_rows(int nks) { return (nks == 5 && bwd_lds_floats(32) * sizeof(float) > kMaxLdsBytes) ? 20 : 32; }
 };
 
-__device__ __forceinline__ f32x4 ld4(const float* p) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    return (f32x4){v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 
 // acc[i][nt] += W-frag[i][.] x X(32 nodes x 4*NKS, LDS, stride)^T for NT column tiles; the node
 // fragments are read as float4 (k = 16q + 4*(lane>>4) + j) one quad ahead of their use.

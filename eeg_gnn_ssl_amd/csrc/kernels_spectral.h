@@ -112,13 +112,13 @@ __global__ __launch_bounds__(256) void spectral_basis_kernel(const float* __rest
 }
 constexpr size_t kSpecBasisLds = (2 * 32 * 32 + 32 + 256) * sizeof(double) + 32 * sizeof(int);
 
-__global__ void pack_spectral_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, const float* __restrict__ basis,
-                                     float* __restrict__ out, SpecPack p) {
+__device__ __forceinline__ void pack_spectral_body(const float* __restrict__ Wg, const float* __restrict__ Wc, const float* __restrict__ basis,
+                                                   float* __restrict__ out, const SpecPack& p, int bid, int nb) {
     const int Fin = p.Fin, H = p.H, M = p.M, N = p.N;
     const float* tc = basis + N * N;
     const NnqOrder ox = make_nnq_order(1, Fin), ot = make_nnq_order(1, 3 * H);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < p.total; idx += stride) {
+    const size_t stride = (size_t)nb * blockDim.x;
+    for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < p.total; idx += stride) {
         const bool tr = idx >= p.sxtq;
         const size_t bs = tr ? p.sxtq_stride : p.sxq_stride, e0 = idx - (tr ? p.sxtq : p.sxq);
         const int i = (int)(e0 / bs);
@@ -138,6 +138,10 @@ __global__ void pack_spectral_kernel(const float* __restrict__ Wg, const float* 
         }
         out[idx] = v;
     }
+}
+__global__ void pack_spectral_kernel(const float* __restrict__ Wg, const float* __restrict__ Wc, const float* __restrict__ basis,
+                                     float* __restrict__ out, SpecPack p) {
+    pack_spectral_body(Wg, Wc, basis, out, p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- node mixes ------------------------------------------------------------------------------------------------------------------

@@ -1,10 +1,29 @@
 // Instantiations + launch logic of the spectral form of the hoisted x-part, in their own translation unit.
 #include "kernels_gemm_g.h"
 #include "kernels_spectral.h"
+#include "pack_cell.h"
 #include "spec_launch.h"
 #include "prof.h"
 
 namespace eeg {
+
+// The packs of ALL cells of an encoder in one launch (their weights change with every optimisation step): blockIdx.y = job
+// (a cell's fragment packs, kernels_pack.h, or its per-frequency packs above), blockIdx.x strides over the job's elements.
+constexpr int kMaxPackJobs = 8;
+struct PackJob {
+    const float *Wg, *bg, *Wc, *bc, *basis;
+    float* out;
+    int spectral;          // 0: pack_cell_body (cp), 1: pack_spectral_body (sp)
+    CellPack cp;
+    SpecPack sp;
+};
+struct PackJobs { PackJob j[kMaxPackJobs]; };
+__global__ void pack_cells_kernel(PackJobs jobs) {
+    const PackJob& jb = jobs.j[blockIdx.y];
+    if (jb.spectral) pack_spectral_body(jb.Wg, jb.Wc, jb.basis, jb.out, jb.sp, (int)blockIdx.x, (int)gridDim.x);
+    else pack_cell_body(jb.Wg, jb.bg, jb.Wc, jb.bc, jb.out, jb.cp, (int)blockIdx.x, (int)gridDim.x);
+}
+
 
 bool spec_supported(int T, int B, int N, int H, int Fin, int M, int need_dx) {
     if (T < 1 || B < 1 || N < 2 || N > kMaxNodes || H != 64 || Fin < 4 || Fin % 4 != 0 || M < 2 || M > kMaxM) return false;
@@ -26,6 +45,25 @@ int launch_spec_basis(const float* S, int N, float* basis, hipStream_t st) {
 int launch_spec_pack(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N, float* spack, hipStream_t st) {
     const SpecPack p = make_spec_pack(Fin, H, M, N);
     EEG_LAUNCH_P("pack_cell", pack_spectral_kernel, dim3(1024), dim3(256), 0, st, Wg, Wc, basis, spack, p);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int launch_pack_cells(int n_cells, const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
+                      const int* Fin, int H, int M, float* const* packs, const float* basis, int N, float* const* spacks, hipStream_t st) {
+    PackJobs jobs{};
+    int n = 0;
+    for (int c = 0; c < n_cells; ++c) {
+        if (n + (spacks != nullptr ? 2 : 1) > kMaxPackJobs) return 1;
+        PackJob& a = jobs.j[n++];
+        a.Wg = Wg[c]; a.bg = bg[c]; a.Wc = Wc[c]; a.bc = bc[c]; a.basis = nullptr; a.out = packs[c]; a.spectral = 0;
+        a.cp = make_cell_pack(Fin[c], H, M);
+        if (spacks != nullptr) {
+            PackJob& b = jobs.j[n++];
+            b.Wg = Wg[c]; b.bg = nullptr; b.Wc = Wc[c]; b.bc = nullptr; b.basis = basis; b.out = spacks[c]; b.spectral = 1;
+            b.sp = make_spec_pack(Fin[c], H, M, N);
+        }
+    }
+    EEG_LAUNCH_P("pack_cell", pack_cells_kernel, dim3(256, n), dim3(256), 0, st, jobs);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -59,7 +97,7 @@ int launch_spec_zero_pad(float* Xh, int N, int S, int F, hipStream_t st) { retur
 int launch_nng(const float* A, int F, int Sp, int G, const float* Wq, size_t wstride, int nct, float* C, int num_cus, hipStream_t st,
                const char* tag, const float* bias, const float* gscale, size_t a_gstride) {
     const unsigned ags = (unsigned)(a_gstride != 0 ? a_gstride : (size_t)Sp * F);
-    const size_t lds = (size_t)4 * 128 * 16 * sizeof(float);
+    const size_t lds = nng_lds_bytes(nct / 4);
     const int RT = (Sp / 16) * G;
     int Gw = 2 * (num_cus > 0 ? num_cus : 256);
     if (Gw > ceil_div(RT, 8)) Gw = ceil_div(RT, 8);

@@ -13,6 +13,10 @@ size_t spec_pack_floats(int Fin, int H, int M, int N);
 int launch_spec_basis(const float* S, int N, float* basis, hipStream_t st);
 int launch_spec_pack(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N, float* spack, hipStream_t st);
 
+// the fragment packs (and, with a basis, the per-frequency packs) of n_cells cells in ONE launch; spacks / basis nullable together
+int launch_pack_cells(int n_cells, const float* const* Wg, const float* const* bg, const float* const* Wc, const float* const* bc,
+                      const int* Fin, int H, int M, float* const* packs, const float* basis, int N, float* const* spacks, hipStream_t st);
+
 // node mixes: to_nodes = 1: X (S,N,F) -> Xh (N,Sp,F) with U^T (pad rows zeroed); 0: Yh (N,Sp,F) -> Y (S,N,F) with U (+ bias).
 // The node-major rows are time-major (r = t*B + b); bm = 1: the sample-major side is the batch-major (B, T, N, F) model input
 // node_rows: rows per frequency of the node-major side (its group stride; 0 = T*B rounded up to 16); rows [T*B, node_rows) are zeroed

@@ -97,14 +97,15 @@ class DCGRUCell(nn.Module):
             if s.dim() not in (2, 3) or s.shape[-1] != n or s.shape[-2] != n:
                 raise RuntimeError(f"supports[{i}] has shape {tuple(s.shape)}, expected ({n}, {n}) or (B, {n}, {n})")
 
-    def run_sequence(self, x, h0, p, p_batched, lengths=None, x_off=0, x_planes=None, want_hsel=True, basis=None):
+    def run_sequence(self, x, h0, p, p_batched, lengths=None, x_off=0, x_planes=None, want_hsel=True, basis=None, pack=None, spack=None):
         """x (T + x_off, B, N, Din) -> ops.LayerOut (hext (T+1,B,N*H), hsel (B,N*H), hpl); used by the encoder /
         decoder loops.  x_off = 1 with x_planes: x is the `hext` of the layer below and x_planes its `hpl`.
-        basis: `ops.shared_spectral_basis` of the one symmetric support all clips share (or None)."""
+        basis: `ops.shared_spectral_basis` of the one symmetric support all clips share (or None).
+        pack / spack: this cell's packs when the caller made them ahead (`ops.pack_cells`: all layers in one launch)."""
         return ops.dcgru_layer_ex(x, x_off, h0, p, p_batched, self.dconv_gate.weight, self.dconv_gate.biases,
                                   self.dconv_candidate.weight, self.dconv_candidate.biases,
                                   self._num_nodes, self._num_units, self.num_matrices,
-                                  self._activation_name, lengths, x_planes, want_hsel, basis)
+                                  self._activation_name, lengths, x_planes, want_hsel, basis, pack, spack)
 
     def forward(self, supports, inputs, state):
         self._check_supports(supports)

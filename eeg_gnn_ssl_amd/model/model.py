@@ -92,13 +92,16 @@ class DCRNNEncoder(nn.Module):
         basis = ops.shared_spectral_basis(supports, self.max_diffusion_step)
         cur, x_off, planes = inputs.reshape(t_len, b, self.num_nodes, -1), 0, None
         finals, top_sel, out = [], None, None
+        # the weight packs of ALL layers in one launch (they change with every optimisation step); None: each layer packs its own
+        packs = ops.pack_encoder_cells(self.encoding_cells, basis, self.num_nodes)
         for layer, cell in enumerate(self.encoding_cells):
             h0 = None if initial_hidden_state is None else initial_hidden_state[layer]
             is_top = layer == self.num_rnn_layers - 1
             # layers >= 1 read the `hext` of the layer below (slots 1..T) and take its hop planes as their own
             # (a layer's final state is only copied out when somebody reads it: `finals`, or the top state at len-1)
             out = cell.run_sequence(cur, h0, p, p_batched, lengths if is_top else None, x_off, planes,
-                                    want_hsel=want_finals or (is_top and lengths is not None), basis=basis)
+                                    want_hsel=want_finals or (is_top and lengths is not None), basis=basis,
+                                    pack=None if packs is None else packs[0][layer], spack=None if packs is None else packs[1][layer])
             if is_top and lengths is not None:
                 top_sel = out.hsel
                 finals.append(out.hext[t_len] if want_finals else None)
@@ -193,12 +196,18 @@ class DCRNNModel_classification(_FusedDropout, nn.Module):
         self.relu = nn.ReLU()
         self._init_dropout_rng(0)
 
-    def forward(self, input_seq, seq_lengths, supports):
+    def encode_last(self, input_seq, seq_lengths, supports):
+        """model.py:253-265: the top layer's state at t = seq_lengths-1 as (B, num_nodes, rnn_units) -- the input of the head"""
         b = input_seq.shape[0]
         if self.strict_lengths:
             utils.check_seq_lengths(seq_lengths, input_seq.shape[1])
         x = input_seq.transpose(0, 1)                         # (T,B,N,Din); made contiguous by the op
         _, _, last = self.encoder.run(x, None, supports, lengths=seq_lengths, want_finals=False)
+        return last.view(b, self.num_nodes, self.rnn_units)
+
+    def forward(self, input_seq, seq_lengths, supports):
+        b = input_seq.shape[0]
+        last = self.encode_last(input_seq, seq_lengths, supports)
         drop_p = self._drop_p()
         # dropout -> relu -> fc -> max over nodes in ONE launch (the mask is generated in the kernel, recomputed in its backward)
         return ops.cls_head(last.view(b, self.num_nodes, self.rnn_units), self.fc.weight, self.fc.bias, drop_p,

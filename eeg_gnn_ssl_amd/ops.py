@@ -11,7 +11,8 @@ dispatcher's "no kernel for the CPU backend" error, and the C-ABI stub refuses n
 Operators (namespace `eeg_dcrnn`):
     hop_polys, pack_cell, diffusion_hops, dconv (+ dconv_bwd), dcgru_layer (+ dcgru_layer_bwd),
     dcgru_decoder (+ dcgru_decoder_bwd), cls_head (+ cls_head_bwd), rng_take_, dropout_mask, gather_last, corr_graph,
-    fft_features, bce_logits, ce_logits, masked_loss, clip_adam_, clip_adam_dev_, teacher_flags_, augment_draw_.
+    fft_features, bce_logits, ce_logits, masked_loss, cls_head_loss, pack_cells, clip_adam_, clip_adam_dev_, teacher_flags_,
+    augment_draw_.
 The functions below them are the Python conveniences the modules in model/ and train_step.py call.
 """
 from __future__ import annotations
@@ -293,6 +294,55 @@ _define("pack_cell_spectral", "(Tensor wg, Tensor wc, Tensor basis, int fin, int
         lambda wg, wc, basis, fin, h, m, n: wg.new_empty((int(_lib.get_lib().query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)),)))
 
 
+def _pack_cells_impl(wgs, bgs, wcs, bcs, h: int, m: int, basis, n: int):
+    """the packs of all cells of an encoder in ONE launch: [pack_0 .. pack_{L-1}] + (with a basis) [spack_0 .. spack_{L-1}]"""
+    lib = _lib.get_lib()
+    cells = len(wgs)
+    if not (cells == len(bgs) == len(wcs) == len(bcs)) or cells < 1 or cells > 4:
+        raise RuntimeError(f"pack_cells: {cells} cells (1..4, one weight / bias tensor of each kind per cell)")
+    wgs, bgs, wcs, bcs = ([t.detach() for t in ts] for ts in (wgs, bgs, wcs, bcs))
+    fins, packs, spacks = [], [], []
+    for c in range(cells):
+        fin = wgs[c].shape[0] // m - h
+        rows = (fin + h) * m
+        for t, nm in ((wgs[c], "dconv_gate.weight"), (bgs[c], "dconv_gate.biases"), (wcs[c], "dconv_candidate.weight"), (bcs[c], "dconv_candidate.biases")):
+            _check(lib, t, nm)
+        if fin < 4 or tuple(wgs[c].shape) != (rows, 2 * h) or tuple(wcs[c].shape) != (rows, h) or tuple(bgs[c].shape) != (2 * h,) \
+                or tuple(bcs[c].shape) != (h,):
+            raise RuntimeError(f"pack_cells: cell {c} parameter shapes {tuple(wgs[c].shape)}, {tuple(bgs[c].shape)}, {tuple(wcs[c].shape)}, "
+                               f"{tuple(bcs[c].shape)} do not match num_units={h}, num_matrices={m}")
+        if _pack3_halves(fin, h, m) > 0:
+            raise RuntimeError("pack_cells: the opt-in bf16 split packs its cells one by one (ops.pack_cell)")
+        fins.append(fin)
+        packs.append(_new((_pack_base_floats(fin, h, m),), wgs[c]))
+        if basis is not None:
+            size = lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)
+            if size == 0:
+                raise RuntimeError(f"pack_cells: the spectral form exists for 64 units (got num_units={h}, input_dim={fin})")
+            spacks.append(_new((size,), wgs[c]))
+    if basis is not None:
+        _check(lib, basis, "basis")
+        if basis.numel() != _spectral_basis_floats(n):
+            raise RuntimeError(f"pack_cells: basis {tuple(basis.shape)} is not the block of a {n}-node support")
+    tab = lambda ts: (ctypes.c_void_p * cells)(*[t.data_ptr() for t in ts])      # noqa: E731
+    fin_arr = (ctypes.c_int32 * cells)(*fins)
+    lib.call("eeg_dcrnn_pack_cells", cells, tab(wgs), tab(bgs), tab(wcs), tab(bcs), fin_arr, h, m, tab(packs), _p(basis), n,
+             tab(spacks) if basis is not None else None, _stream(packs[0]))
+    return packs + spacks
+
+
+def _pack_cells_fake(wgs, bgs, wcs, bcs, h, m, basis, n):
+    fins = [w.shape[0] // m - h for w in wgs]
+    out = [wgs[0].new_empty((_pack_floats(f, h, m),)) for f in fins]
+    if basis is not None:
+        out += [wgs[0].new_empty((int(_lib.get_lib().query("eeg_dcrnn_spectral_pack_floats", f, h, m, n)),)) for f in fins]
+    return out
+
+
+_define("pack_cells", "(Tensor[] wg, Tensor[] bg, Tensor[] wc, Tensor[] bc, int h, int m, Tensor? basis, int n) -> Tensor[]",
+        _pack_cells_impl, _pack_cells_fake)
+
+
 def _diffusion_hops_impl(x, p, p_batched: int, batch: int) -> torch.Tensor:
     lib = _lib.get_lib()
     _check(lib, x, "x")
@@ -430,13 +480,14 @@ def _layer_dims(t_len, b, n, h, fin, m, act, p_batched, planes_ready):
 
 
 def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, lengths, x_planes, n: int, h: int, m: int,
-                      act: int, save: bool, want_hsel: bool, basis=None):
+                      act: int, save: bool, want_hsel: bool, basis=None, pack=None, spack=None):
     """x: (T + x_off, B, N, Fin) — x_off = 1 when x is the `hext` of the layer below (its slot 0 is that layer's
     initial state), whose `hpl` output is then passed as x_planes.  Returns hext (T+1, B, N*H) (slot 0 = initial
     state, slot t+1 = h_t), hsel (B, N*H) = h at t = lengths-1 (T-1 without lengths) and the tensors the backward
     needs: [xtm, pack, planes, rs, us, cs, rhs, hpl, rhpl, spack] (numel-0 placeholders where nothing is kept).
     basis (`spectral_basis` of the ONE symmetric support all clips share; p_batched must be 0): the hoisted x-part runs in the
-    eigenbasis of the support; `planes` is then the node-major transformed input (N, Sp, Fin) and spack the per-frequency packs."""
+    eigenbasis of the support; `planes` is then the node-major transformed input (N, Sp, Fin) and spack the per-frequency packs.
+    pack / spack: the packs of this cell made ahead (`pack_cells`: all layers in one launch); None: packed here."""
     lib = _lib.get_lib()
     if x.dim() != 4 or x.shape[2] != n:
         raise RuntimeError(f"inputs have shape {tuple(x.shape)}, expected (T, B, num_nodes={n}, input_dim)")
@@ -487,12 +538,19 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
         h0 = h0.contiguous()
         _check(lib, h0, "initial_hidden_state")
     _check(lib, p, "P")
-    pack = torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
+    pack_given, spack_given = pack is not None, spack is not None
+    if pack is None:
+        pack = torch.ops.eeg_dcrnn.pack_cell(wg, bg, wc, bc, fin, h, m)
+    elif pack.numel() < _pack_base_floats(fin, h, m):
+        raise RuntimeError(f"dcgru_layer: pack has {pack.numel()} floats, a cell of input_dim={fin}, num_units={h}, num_matrices={m} needs "
+                           f"{_pack_base_floats(fin, h, m)}")
     _set_pack3(dims, pack, fin, h, m)
     s = t_len * b
-    spack = _new((0,), p)            # (its own placeholder: outputs must not alias)
     if spec:
-        spack = torch.ops.eeg_dcrnn.pack_cell_spectral(wg, wc, basis, fin, h, m, n)
+        if spack is None:
+            spack = torch.ops.eeg_dcrnn.pack_cell_spectral(wg, wc, basis, fin, h, m, n)
+        elif spack.numel() != lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n):
+            raise RuntimeError(f"dcgru_layer: spack has {spack.numel()} floats, expected {lib.query('eeg_dcrnn_spectral_pack_floats', fin, h, m, n)}")
         dims.spectral, dims.spack = basis.data_ptr(), spack.data_ptr()
         if ready:
             _check(lib, x_planes, "x_planes")
@@ -530,10 +588,13 @@ def _dcgru_layer_impl(x, x_off: int, h0, p, p_batched: int, wg, bg, wc, bc, leng
         hsel = _new((0,), x)           # nobody reads the final state of this layer (a lower layer of the classification model)
     if not save:
         return hext, hsel, []
-    return hext, hsel, [xtm if xtm is not None else empty, pack, planes, rs, us, cs, rhs, hpl, rhpl, spack]
+    # outputs must not alias each other or an input: packs handed in are kept by the autograd context from the INPUTS
+    return hext, hsel, [xtm if xtm is not None else empty, _new((0,), p) if pack_given else pack, planes, rs, us, cs, rhs, hpl, rhpl,
+                        _new((0,), p) if (spack_given or not spec) else spack]
 
 
-def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel, basis=None):
+def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel, basis=None,
+                      pack=None, spack=None):
     t_len, b, fin = x.shape[0] - x_off, x.shape[1], x.shape[3]
     ne = lambda *shape: x.new_empty(shape)   # noqa: E731
     hext, hsel = ne(t_len + 1, b, n * h), (ne(b, n * h) if (want_hsel or lengths is not None) else ne(0))
@@ -549,16 +610,17 @@ def _dcgru_layer_fake(x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_pla
         zero_copy = spec or _lib.get_lib().query("eeg_dcrnn_batch_major_ok", ctypes.byref(dims)) == 2
     xtm = ne(t_len, b, n, fin) if (not x.is_contiguous() and not zero_copy) else ne(0)
     planes = ne(0) if x_planes is not None else ne(m - 1, t_len * b, n, fin)
-    spack = ne(0)
+    spack_in, spack = spack, ne(0)
     byp = [ne(m - 1, t_len + 1, b, n, h) for _ in range(2)]
     if spec:
         lib = _lib.get_lib()
         sp_rows = int(lib.query("eeg_dcrnn_spectral_rows", t_len * b))
         if x_planes is None:
             planes = ne(n, sp_rows, fin)
-        spack = ne(int(lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)))
+        if spack_in is None:
+            spack = ne(int(lib.query("eeg_dcrnn_spectral_pack_floats", fin, h, m, n)))
         byp = [ne(n, b + sp_rows, h), ne(n, sp_rows, h)]
-    return hext, hsel, [xtm, ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + byp + [spack]
+    return hext, hsel, [xtm, ne(0) if pack is not None else ne(_pack_floats(fin, h, m)), planes] + [ne(t_len, b, n * h) for _ in range(4)] + byp + [spack]
 
 
 def _dcgru_layer_bwd_impl(d_hext, d_hsel, x, x_off: int, p, p_batched: int, pack, planes, x_planes, hext, rs, us, cs, rhs,
@@ -619,7 +681,7 @@ def _dcgru_layer_bwd_fake(d_hext, d_hsel, x, x_off, p, p_batched, pack, planes, 
 
 _define("dcgru_layer",
         "(Tensor x, int x_off, Tensor? h0, Tensor P, int p_batched, Tensor wg, Tensor bg, Tensor wc, Tensor bc, Tensor? lengths, "
-        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel, Tensor? basis) -> "
+        "Tensor? x_planes, int n, int h, int m, int act, bool save, bool want_hsel, Tensor? basis, Tensor? pack=None, Tensor? spack=None) -> "
         "(Tensor hext, Tensor hsel, Tensor[] saved)",
         _dcgru_layer_impl, _dcgru_layer_fake)
 _define("dcgru_layer_bwd",
@@ -631,7 +693,7 @@ _define("dcgru_layer_bwd",
 
 
 def _dcgru_layer_setup(ctx, inputs, output):
-    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel, basis) = inputs
+    (x, x_off, h0, p, p_batched, wg, bg, wc, bc, lengths, x_planes, n, h, m, act, save, want_hsel, basis, _pack, _spack) = inputs
     hext, _, saved = output
     ctx.set_materialize_grads(False)
     ctx.saved_ok = bool(save) and len(saved) == 10
@@ -640,7 +702,12 @@ def _dcgru_layer_setup(ctx, inputs, output):
     if ctx.saved_ok:
         xtm = saved[0]
         lens = None if lengths is None else lengths.to(device=x.device, dtype=torch.int64).contiguous()
-        ctx.save_for_backward(xtm if xtm.numel() else x, p, x_planes, lens, basis, hext, *saved[1:])
+        kept = list(saved[1:])
+        if _pack is not None:
+            kept[0] = _pack
+        if _spack is not None and basis is not None:
+            kept[8] = _spack
+        ctx.save_for_backward(xtm if xtm.numel() else x, p, x_planes, lens, basis, hext, *kept)
 
 
 def _dcgru_layer_backward(ctx, d_hext, d_hsel, d_saved):
@@ -658,8 +725,10 @@ def _dcgru_layer_backward(ctx, d_hext, d_hsel, d_saved):
                                                   rs, us, cs, rhs, hpl, rhpl, lens, has_h0, n, h, m, act, need_dx, need_dh0, *bufs,
                                                   basis, spack if basis is not None else None)
     ret = [None if t is not None else g for t, g in zip(sunk, bufs)]
-    return (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None, None,
-            None)
+    grads = (dx if need_dx else None, None, dh0 if need_dh0 else None, None, None, *ret, None, None, None, None, None, None, None, None,
+             None, None, None)
+    # trailing arguments a caller left at their defaults (pack, spack) are not inputs of THIS call: one gradient slot per given input
+    return grads[:len(ctx.needs_input_grad)]
 
 
 torch.library.register_autograd(f"{NS}::dcgru_layer", _dcgru_layer_backward, setup_context=_dcgru_layer_setup, lib=_libdef)
@@ -921,6 +990,50 @@ def _cls_head_backward(ctx, dlogits, _darg):
 torch.library.register_autograd(f"{NS}::cls_head", _cls_head_backward, setup_context=_cls_head_setup, lib=_libdef)
 
 
+def _cls_head_loss_impl(z, w, bias, targets, kind: int, dropout_p: float, rng_used, dw, db):
+    """head forward + criterion + the head's backward for one optimisation step (eeg_dcrnn_cls_head_loss): returns
+    (loss (1,), logits (B,C), arg (B,C) int32, dlogits (B,C), dz (B,N,H)); dw (C,H) / db (C) are overwritten."""
+    lib = _lib.get_lib()
+    z, w, bias = z.contiguous(), w.detach().contiguous(), bias.detach().contiguous()
+    for t, nm in ((z, "head input"), (w, "fc.weight"), (bias, "fc.bias"), (dw, "fc.weight gradient"), (db, "fc.bias gradient")):
+        _check(lib, t, nm)
+    if z.dim() != 3:
+        raise RuntimeError(f"cls_head_loss: head input has shape {tuple(z.shape)}, expected (B, num_nodes, rnn_units)")
+    b, n, h = z.shape
+    c = w.shape[0]
+    if tuple(w.shape) != (c, h) or bias.numel() != c or tuple(dw.shape) != (c, h) or db.numel() != c or not dw.is_contiguous() or not db.is_contiguous():
+        raise RuntimeError(f"cls_head_loss: fc operands {tuple(w.shape)}, {tuple(bias.shape)}, gradients {tuple(dw.shape)}, {tuple(db.shape)} do not "
+                           f"fit a head input of {h} units")
+    if kind == 0:
+        tg = targets.to(torch.float32).contiguous().view(-1)
+        _check(lib, tg, "targets")
+    else:
+        tg = targets.to(torch.int64).contiguous().view(-1)
+        _check(lib, tg, "targets", torch.int64)
+    if tg.numel() != b:
+        raise RuntimeError(f"cls_head_loss: {tg.numel()} targets for {b} clips")
+    drop = dropout_p > 0
+    if drop:
+        if rng_used is None:
+            raise RuntimeError("cls_head_loss: dropout_p > 0 needs rng_used (ops.rng_take)")
+        _check_rng(lib, rng_used, "rng_used")
+    loss, logits, arg = _new((1,), z), _new((b, c), z), _new((b, c), z, torch.int32)
+    dlogits, dz = _new((b, c), z), torch.empty_like(z)
+    ws = _new((lib.query("eeg_dcrnn_cls_head_loss_ws_floats", b, h, c),), z)
+    lib.call("eeg_dcrnn_cls_head_loss", _p(z), _p(w), _p(bias), _p(tg), int(kind), b, n, h, c, float(dropout_p), _p(rng_used) if drop else None,
+             _p(logits), _p(arg), _p(dlogits), _p(dz), _p(dw), _p(db), _p(loss), _p(ws), _stream(z))
+    return loss, logits, arg, dlogits, dz
+
+
+def _cls_head_loss_fake(z, w, bias, targets, kind, dropout_p, rng_used, dw, db):
+    b, c = z.shape[0], w.shape[0]
+    return (z.new_empty((1,)), z.new_empty((b, c)), z.new_empty((b, c), dtype=torch.int32), z.new_empty((b, c)), torch.empty_like(z))
+
+
+_define("cls_head_loss", "(Tensor z, Tensor w, Tensor bias, Tensor targets, int kind, float dropout_p, Tensor? rng_used, Tensor(a!) dw, Tensor(b!) db) "
+        "-> (Tensor, Tensor, Tensor, Tensor, Tensor)", _cls_head_loss_impl, _cls_head_loss_fake)
+
+
 def _gather_last_impl(htop, lengths):
     lib = _lib.get_lib()
     htop = htop.contiguous()
@@ -1161,7 +1274,26 @@ def hop_polys(supports: Sequence[torch.Tensor], max_diffusion_step: int, batch: 
     if len(sups) == 0:
         raise RuntimeError("hop_polys: empty supports list")
     flag = 1 if any(s.dim() == 3 for s in sups) else 0
-    return torch.ops.eeg_dcrnn.hop_polys(sups, int(max_diffusion_step), int(batch)), flag
+    if flag or any(s.requires_grad for s in sups):
+        return torch.ops.eeg_dcrnn.hop_polys(sups, int(max_diffusion_step), int(batch)), flag
+    # graphs shared by all clips (2-D supports: the distance graph, one constant tensor for a whole run): the polynomials are a pure
+    # function of the supports -- built once per supports tensors (identity + version), not once per forward
+    import weakref
+    key = (int(max_diffusion_step),) + tuple((s.data_ptr(), s._version, str(s.device), tuple(s.shape), s.dtype) for s in sups)
+    hit = _polys_cache.get(key)
+    if hit is not None and all(r() is s for r, s in zip(hit[0], sups)):
+        return hit[1], 0
+    out = torch.ops.eeg_dcrnn.hop_polys(sups, int(max_diffusion_step), int(batch))
+    if not (out.is_cuda and torch.cuda.is_current_stream_capturing()):      # (a tensor born inside a capture lives in the graph's pool)
+        if len(_polys_cache) > 64:
+            for k in [k for k, v in _polys_cache.items() if any(r() is None for r in v[0])]:
+                del _polys_cache[k]
+        _polys_cache[key] = ([weakref.ref(s) for s in sups], out)
+    return out, 0
+
+
+# (max_diffusion_step, identity + version of every support) -> (weakrefs, P): see hop_polys
+_polys_cache = {}
 
 
 # id of a batched supports tensor -> (weakref, its 2-D form or None)
@@ -1248,8 +1380,26 @@ class LayerOut:
         return self.hext[1:]
 
 
+def pack_encoder_cells(cells, basis, num_nodes):
+    """(packs, spacks) of the cells of an encoder from ONE launch (`pack_cells`), or None where the cells pack themselves (a single
+    layer, more than four, the opt-in bf16 split).  spacks is a list of None without a basis."""
+    cells = list(cells)
+    if len(cells) < 2 or len(cells) > 4 or GEMM_MODE != 0:
+        return None
+    h, m = cells[0]._num_units, cells[0].num_matrices
+    if basis is not None and h != 64:
+        basis = None
+    # (detached: the packs are a re-layout the layer operators consume next to the parameters themselves, whose gradients come from
+    #  the layer operators' backward)
+    out = torch.ops.eeg_dcrnn.pack_cells([c.dconv_gate.weight.detach() for c in cells], [c.dconv_gate.biases.detach() for c in cells],
+                                         [c.dconv_candidate.weight.detach() for c in cells], [c.dconv_candidate.biases.detach() for c in cells],
+                                         h, m, basis, int(num_nodes))
+    k = len(cells)
+    return out[:k], (out[k:] if basis is not None else [None] * k)
+
+
 def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activation="tanh", lengths=None, x_planes=None,
-                   want_hsel=True, basis=None) -> LayerOut:
+                   want_hsel=True, basis=None, pack=None, spack=None) -> LayerOut:
     """One DCGRU layer over x (T + x_off, B, N, Fin).  x_off = 1 / x_planes: x is the `hext` of the layer below and
     x_planes its `hpl` (the layer then skips its own diffusion pass).  want_hsel=False: the caller does not read the layer's
     final state (hsel comes back empty; saves one copy per step).  basis (`shared_spectral_basis`): the hoisted x-part of the
@@ -1272,7 +1422,8 @@ def dcgru_layer_ex(x, x_off, h0, p, p_batched, wg, bg, wc, bc, n, h, m, activati
         global hop_plane_handovers
         hop_plane_handovers += 1
     hext, hsel, saved = torch.ops.eeg_dcrnn.dcgru_layer(x, int(x_off), h0, p, int(p_batched), wg, bg, wc, bc, lengths, x_planes,
-                                                        n, h, m, act, save, bool(want_hsel), basis)
+                                                        n, h, m, act, save, bool(want_hsel), basis, pack,
+                                                        spack if basis is not None else None)
     return LayerOut(hext, hsel, saved[7].detach() if (save and saved[7].numel()) else None)
 
 
@@ -1339,6 +1490,24 @@ def cls_head(z, w, bias, dropout_p=0.0, rng_state=None, return_rng_used=False):
     used = rng_take(rng_state, z.numel() // 4) if dropout_p > 0 else None
     logits, _ = torch.ops.eeg_dcrnn.cls_head(z, w, bias, float(dropout_p), used)
     return (logits, used) if return_rng_used else logits
+
+
+def cls_head_loss(z, fc_weight, fc_bias, targets, task="detection", dropout_p=0.0, rng_state=None):
+    """The tail of a supervised optimisation step behind the encoder (model.py:267-270 + train.py:203-206,266-272) in two launches:
+    dropout -> relu -> fc -> max over nodes, the criterion (task "detection": BCE-with-logits, "classification": cross-entropy) and
+    their backward.  z (B,N,H) = the top layer's state at len-1, DETACHED from autograd: the gradients of fc go straight into
+    `fc_weight.grad` / `fc_bias.grad` (written in place inside `with GradSink`, else accumulated), and the caller seeds the encoder's
+    backward with the returned dz (`last.backward(dz)`).  Returns (loss (), logits (B,C), dz (B,N,H))."""
+    used = rng_take(rng_state, z.numel() // 4) if dropout_p > 0 else None
+    sunk = [GradSink.take(q) for q in (fc_weight, fc_bias)]
+    dw = sunk[0] if sunk[0] is not None else torch.empty_like(fc_weight)
+    db = sunk[1] if sunk[1] is not None else torch.empty_like(fc_bias)
+    loss, logits, _arg, _dl, dz = torch.ops.eeg_dcrnn.cls_head_loss(z.detach(), fc_weight.detach(), fc_bias.detach(), targets,
+                                                                    0 if task == "detection" else 1, float(dropout_p), used, dw, db)
+    for q, buf, sk in ((fc_weight, dw, sunk[0]), (fc_bias, db, sunk[1])):
+        if sk is None and q.requires_grad:
+            q.grad = buf if q.grad is None else q.grad + buf
+    return loss[0], logits, dz
 
 
 def rng_take(rng_state, groups):

@@ -105,6 +105,10 @@ class TrainStep:
         self.scaler_mean, self.scaler_std = scaler_mean, scaler_std
         self.raw_window, self.raw_mean, self.raw_std = raw_window, float(raw_mean), float(raw_std)
         self.shared_graph = bool(shared_graph)
+        # detection / classification: head + criterion + head backward as ONE operator behind the encoder (ops.cls_head_loss) instead
+        # of model.forward -> loss kernel -> autograd through the head (same values; False: that public path, launch by launch)
+        self.fused_head = True
+        self.last_logits = None
         self.data_augment = bool(data_augment)
         self.feature_std = None if feature_std is None else float(feature_std)
         self.swap_perm, self.reflected_supports, self._augment_rng = None, None, None
@@ -229,6 +233,16 @@ class TrainStep:
                 out = self.model(x, y, supports, batches_seen=self.samples_seen_dev)
             else:
                 out = self.model(x, y, supports, batches_seen=self.samples_seen)    # train_ssl.py:163
+        elif self.fused_head and hasattr(self.model, "encode_last"):
+            # encoder -> [head, criterion and the head's backward: two launches] -> encoder backward seeded with d loss / d last
+            m = self.model
+            last = m.encode_last(x, seq_lengths, supports)
+            drop_p = m._drop_p()
+            with self.fp.sink:
+                loss, self.last_logits, dz = ops.cls_head_loss(last, m.fc.weight, m.fc.bias, y, self.task, drop_p,
+                                                               m._rng_state(last.device) if drop_p > 0 else None)
+                last.backward(dz)
+            return loss.detach()
         else:
             out = self.model(x, seq_lengths, supports)
         # The loss kernels return value AND gradient (d loss / d out) from one pass: backward is seeded with that gradient

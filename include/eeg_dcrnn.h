@@ -139,6 +139,13 @@ int eeg_dcrnn_spectral_basis(const float* support, int N, float* basis, void* st
 size_t eeg_dcrnn_spectral_pack_floats(int Fin, int H, int M, int N);
 int eeg_dcrnn_pack_cell_spectral(const float* Wg, const float* Wc, const float* basis, int Fin, int H, int M, int N,
                                  float* spack, void* stream);
+/* The packs of ALL cells of an encoder in ONE launch (their weights change with every optimisation step, cell.py:40-46):
+ * cell c: eeg_dcrnn_pack_cell(Wg[c], bg[c], Wc[c], bc[c], Fin[c], H, M, packs[c]) and, when basis / spacks are given,
+ * eeg_dcrnn_pack_cell_spectral(Wg[c], Wc[c], basis, Fin[c], H, M, N, spacks[c]).  The pointer TABLES are host arrays of
+ * device pointers (n_cells <= 4); basis and spacks are NULL together. */
+int eeg_dcrnn_pack_cells(int n_cells, const float* const* Wg, const float* const* bg, const float* const* Wc,
+                         const float* const* bc, const int32_t* Fin, int H, int M, float* const* packs, const float* basis,
+                         int N, float* const* spacks, void* stream);
 int eeg_dcrnn_spectral_ok(const eeg_layer_dims* d, int need_dx);
 size_t eeg_dcrnn_spectral_rows(size_t S);
 
@@ -268,6 +275,17 @@ int eeg_dcrnn_cls_head_fwd(const float* z, const float* W, const float* bias, in
 int eeg_dcrnn_cls_head_bwd(const float* z, const float* W, const float* dlogits, const int32_t* arg,
                            int B, int N, int H, int C, float dropout_p, const uint64_t* rng_used,
                            float* dz, float* dW, float* dbias, void* stream);
+
+/* Head + criterion + their backward for the optimisation step (model.py:260-270 forward, train.py:203-206,266-272 loss and the
+ * head's share of `loss.backward()`), two launches: logits (B,C), arg (B,C) as eeg_dcrnn_cls_head_fwd; loss[0] = mean criterion,
+ * kind 0 = nn.BCEWithLogitsLoss (C == 1, targets float[B]), kind 1 = nn.CrossEntropyLoss (targets int64[B]; a label outside
+ * 0..C-1 makes the loss NaN); dlogits (B,C) = d loss / d logits; dz (B,N,H) = d loss / d z (the seed of the encoder's backward);
+ * dW (C,H), dbias (C) = the gradients of the fc layer (overwritten).  Sums over the batch run in a fixed order.
+ * ws: eeg_dcrnn_cls_head_loss_ws_floats(B, H, C) floats. */
+size_t eeg_dcrnn_cls_head_loss_ws_floats(int B, int H, int C);
+int eeg_dcrnn_cls_head_loss(const float* z, const float* W, const float* bias, const void* targets, int kind, int B, int N,
+                            int H, int C, float dropout_p, const uint64_t* rng_used, float* logits, int32_t* arg,
+                            float* dlogits, float* dz, float* dW, float* dbias, float* loss, float* ws, void* stream);
 /* mask[e] = keep(e) / (1 - p) for e < n: the factors the fused kernels apply for the {seed, offset} pair in rng_used (a forward
  * call's output), materialised -- the parity tests hand them to the oracle. */
 int eeg_dcrnn_dropout_mask(const uint64_t* rng_used, size_t n, float dropout_p, float* mask, void* stream);

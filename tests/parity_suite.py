@@ -958,6 +958,90 @@ def check_raw_input_chain(device, b=4, t_len=3):
         assert_close_scaled(q.grad.cpu().numpy(), po[k].grad.numpy(), f"raw chain/d_{k}", tol=1e-4)
 
 
+def check_cls_head_loss(device, shapes=((1, 19, 64, 1), (5, 19, 64, 4), (256, 19, 64, 1), (37, 21, 32, 3))):
+    """`ops.cls_head_loss` (head + criterion + the head's backward, two launches) against the launch-by-launch public path --
+    `ops.cls_head` -> `bce_logits` / `ce_logits` -> autograd through the head: logits, dlogits and dz are the SAME arithmetic
+    (bit-equal), loss / dW / dbias are sums over the batch in another fixed order (rounding-level agreement), with and without
+    dropout (same generator pair), for batches that do not fill the last workgroup; gradients land in the GradSink buffers or
+    accumulate into .grad; twice the same call is bit-identical."""
+    from eeg_gnn_ssl_amd import ops
+    g = torch.Generator().manual_seed(77)
+    for (b, n, h, c) in shapes:
+        for p_drop in (0.0, 0.5):
+            z = torch.randn(b, n, h, generator=g).to(device)
+            w = (0.3 * torch.randn(c, h, generator=g)).to(device).requires_grad_(True)
+            bias = (0.1 * torch.randn(c, generator=g)).to(device).requires_grad_(True)
+            task = "detection" if c == 1 else "classification"
+            y = ((torch.rand(b, generator=g) > 0.5).float() if c == 1 else torch.randint(0, c, (b,), generator=g)).to(device)
+            st1 = torch.tensor([4242, 11], dtype=torch.int64, device=device)
+            st2 = st1.clone()
+            # launch by launch
+            zr = z.clone().requires_grad_(True)
+            logits, used = ops.cls_head(zr, w, bias, p_drop, st1, return_rng_used=True)
+            loss_ref, seed = (torch.ops.eeg_dcrnn.bce_logits(logits.detach().view(-1), y) if c == 1
+                              else torch.ops.eeg_dcrnn.ce_logits(logits.detach(), y))
+            logits.backward(seed.view_as(logits))
+            # fused
+            w2, b2 = w.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+            loss, lg, dz = ops.cls_head_loss(z, w2, b2, y, task, p_drop, st2)
+            assert st1.tolist() == st2.tolist()
+            assert torch.equal(lg, logits.detach()), (b, c, p_drop)
+            assert torch.equal(dz, zr.grad), (b, c, p_drop, float((dz - zr.grad).abs().max()))
+            assert abs(float(loss) - float(loss_ref)) <= 2e-6 * max(1.0, abs(float(loss_ref)))
+            for got, want, nm in ((w2.grad, w.grad, "dW"), (b2.grad, bias.grad, "db")):
+                assert float((got - want).abs().max()) <= 2e-6 * max(1e-3, float(want.abs().max())), (nm, b, c, p_drop)
+            # again into .grad: accumulates; bit-identical contribution
+            st3 = torch.tensor([4242, 11], dtype=torch.int64, device=device)
+            first = w2.grad.clone()
+            loss_b, _, dz_b = ops.cls_head_loss(z, w2, b2, y, task, p_drop, st3)
+            assert torch.equal(dz_b, dz) and float(loss_b) == float(loss) and torch.equal(w2.grad, first + first)
+    # refusals
+    z = torch.randn(2, 19, 64).to(device)
+    w = torch.randn(4, 64).to(device)
+    for bad, msg in ((lambda: ops.cls_head_loss(z, w, torch.zeros(4).to(device), torch.zeros(3, dtype=torch.int64).to(device), "classification"), "targets"),
+                     (lambda: ops.cls_head_loss(z, w, torch.zeros(4).to(device), torch.zeros(2).to(device), "detection"), "one logit"),
+                     (lambda: ops.cls_head_loss(z, w, torch.zeros(4).to(device), torch.zeros(2, dtype=torch.int64).to(device), "classification", 0.5), "generator")):
+        try:
+            bad()
+        except RuntimeError as e:
+            assert msg in str(e), (msg, str(e))
+        else:
+            raise AssertionError(f"cls_head_loss accepted operands that do not fit ({msg})")
+    lo, _, _ = ops.cls_head_loss(z, w, torch.zeros(4).to(device), torch.tensor([0, 7]).to(device), "classification")
+    assert bool(torch.isnan(lo))                               # a label outside 0..C-1: NaN loss, no out-of-bounds read
+
+
+def check_fused_head_step_equals_public_path(device, adj3d, task="detection"):
+    """TrainStep with the fused head (default) against the same step through model.forward -> loss kernel -> autograd
+    (fused_head = False): loss and the whole flat gradient agree at rounding level; with dropout the same masks are drawn."""
+    from eeg_gnn_ssl_amd import DCRNNModel_classification
+    from eeg_gnn_ssl_amd.train_step import TrainStep
+    nc = 1 if task == "detection" else 4
+    cfg = orc.DCRNNConfig(filter_type="laplacian", num_classes=nc, input_dim=8, rnn_units=32)
+    g = torch.Generator().manual_seed(5)
+    b, t_len = 7, 3
+    x = torch.randn(b, t_len, 19, 8, generator=g)
+    y = (torch.rand(b, generator=g) > 0.5).float() if nc == 1 else torch.randint(0, nc, (b,), generator=g)
+    lengths = torch.randint(1, t_len + 1, (b,), generator=g)
+    sup = [t.to(device) for t in cases.supports_for("laplacian", adj3d, b)]
+    grads, losses = [], []
+    for fused in (True, False):
+        params = orc.init_params(cfg, "classification", seed=9)
+        args = make_args(cfg)
+        args.dropout = 0.4
+        model = DCRNNModel_classification(args, nc, device=device)
+        load(model, params, device)
+        model.train()
+        model.set_dropout_seed(99, 0)
+        st = TrainStep(model, task=task)
+        st.fused_head = fused
+        losses.append(float(st.forward_backward(x.to(device), y.to(device), lengths.to(device), sup)))
+        grads.append(st.fp.flat_grad.clone())
+        assert model.dropout_rng_state() == (99, b * 19 * 32 // 4)
+    assert abs(losses[0] - losses[1]) <= 2e-6 * max(1.0, abs(losses[1])), losses
+    assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * float(grads[1].abs().max())
+
+
 def expected_augmentation(seed, offset, batch, swap_perm):
     """the documented function of the generator pair (include/eeg_dcrnn.h eeg_dcrnn_augment_draw): clip b takes Philox counter
     offset + b; reflection coin = top bit of word 0, scale = 0.8 + 0.4 * word 1 / 2^32"""

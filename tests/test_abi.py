@@ -184,7 +184,7 @@ def test_split_bf16_report_parser():
     """bench.py --split-bf16-experiment: the lab binary's report (a committed run: profiles/r03_bf16x3_lab.txt) becomes the
     `experimental_split_bf16` object; the 6-product split is no less accurate than the fp32 matrix pipe."""
     import bench
-    e = bench.parse_split_bf16_report(open(os.path.join(ROOT, "profiles", "r03_bf16x3_lab.txt")).read())
+    e = bench.parse_split_bf16_report(open(os.path.join(ROOT, "profiles", "archive", "r03_bf16x3_lab.txt")).read())
     assert e["six_products"]["ms"] > 0 and e["three_products"]["ms"] > 0 and e["fp32_mfma_ms"] > 0
     assert e["six_products"]["ms"] > e["three_products"]["ms"]
     assert e["six_products"]["max_abs_err_vs_fp64"] <= 1.5 * e["fp32_mfma_max_abs_err_vs_fp64"] < 2e-5

@@ -236,8 +236,9 @@ def _worker_ssl64(rank, world, port, out_dir):
 
 
 def test_two_ranks_ssl_device_curriculum_and_evaluation(tmp_path):
-    """Curriculum learning with the flags drawn on the device (eeg_dcrnn_teacher_flags): both ranks draw the SAME flags (same
-    generator seed, same global sample counter, which advances by the GLOBAL batch), end with identical parameters, and
+    """Curriculum learning with the flags drawn on the device (eeg_dcrnn_teacher_flags): each rank flips the coins of ITS shard (the
+    generator seed mixes the rank in, like the dropout masks it also serves: ops.make_rng_state) against the SAME threshold -- the
+    global sample counter advances by the GLOBAL batch on every rank --, the ranks end with identical parameters, and
     `evaluate_ssl` returns on every rank the batch-size-weighted masked MAE of the union of the shards."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import emu_support
@@ -246,7 +247,9 @@ def test_two_ranks_ssl_device_curriculum_and_evaluation(tmp_path):
     mp.spawn(_worker_ssl64, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(tmp_path / f"s{r}.pt") for r in range(2))
     assert r0["device_curriculum"] is True and r1["device_curriculum"] is True
-    assert r0["flags"] == r1["flags"] and [f[2] for f in r0["flags"]] == [0, 6, 12]      # (seed, offset, samples seen) per step
+    # (seed, offset, samples seen) per step: per-rank seeds, equal offsets and counters
+    assert [f[1:] for f in r0["flags"]] == [f[1:] for f in r1["flags"]] and [f[2] for f in r0["flags"]] == [0, 6, 12]
+    assert r0["flags"][0][0] != r1["flags"][0][0] and len({f[0] for f in r0["flags"]}) == 1
     assert r0["seen_dev"] == r1["seen_dev"] == r0["seen"] == r1["seen"] == 18
     assert torch.equal(r0["param"], r1["param"])
     assert r0["eval"] == r1["eval"]

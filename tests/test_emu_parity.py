@@ -246,6 +246,15 @@ def test_raw_signals_to_step_chain_vs_oracle():
     ps.check_raw_input_chain("cpu", b=2, t_len=2)
 
 
+def test_fused_head_and_criterion_operator():
+    ps.check_cls_head_loss("cpu", shapes=((1, 19, 64, 1), (5, 19, 64, 4), (37, 21, 32, 3)))
+
+
+@pytest.mark.parametrize("task", ["detection", "classification"])
+def test_fused_head_step_equals_public_path(task, adj3d):
+    ps.check_fused_head_step_equals_public_path("cpu", adj3d, task)
+
+
 def test_augmentation_draws_known_answer(adj3d):
     ps.check_augmentation_draws("cpu", adj3d)
 

@@ -245,8 +245,12 @@ def test_full_size_gradients_vs_oracle(workload, adj3d):
         from eeg_gnn_ssl_amd.train_step import TrainStep
         st = TrainStep(model, task=task)
         st.forward_backward(xd, y.to(DEV), lengths.to(DEV), None)
+        # TrainStep's fused head (ops.cls_head_loss) seeds the encoder with the same bits; the fc gradients are batch sums in another fixed order
         for k, p in model.named_parameters():
-            assert torch.equal(p.grad, grads[k]), k
+            if k.startswith("fc."):
+                assert (p.grad - grads[k]).abs().max().item() <= 2e-6 * grads[k].abs().max().item(), k
+            else:
+                assert torch.equal(p.grad, grads[k]), k
 
 
 SPECTRAL_CASES = [dict(din=100, layers=2, t_len=3, b=4, classes=1),
@@ -967,6 +971,16 @@ def test_evaluation_driver(adj3d):
 
 def test_raw_signals_to_step_chain_vs_oracle():
     ps.check_raw_input_chain(DEV, b=9, t_len=7)
+
+
+def test_fused_head_and_criterion_operator():
+    """head + criterion + head backward in two launches vs the launch-by-launch chain (bit-equal logits / dz)"""
+    ps.check_cls_head_loss(DEV)
+
+
+@pytest.mark.parametrize("task", ["detection", "classification"])
+def test_fused_head_step_equals_public_path(task, adj3d):
+    ps.check_fused_head_step_equals_public_path(DEV, adj3d, task)
 
 
 def test_augmentation_draws_known_answer(adj3d):
