@@ -261,6 +261,13 @@ def merge_paired_roles(work, launch_work, roles):
             work[pair] = work.pop(a) + work.pop(b)
             if a in launch_work and b in launch_work:
                 launch_work[pair] = [x + y for x, y in zip(launch_work.pop(a), launch_work.pop(b))]
+    # Round 6: under the spectral form the x-part and both h-part weight-gradient problems of a cell are ONE launch (role
+    # `gemm_tn_f`, csrc/kernels_gemm_f.h): priced with the sum of the three
+    fused, parts = "gemm_tn_f", ("gemm_tn_x", "gemm_tn_hg", "gemm_tn_hc")
+    if fused in roles and not any(r in roles for r in parts + ("gemm_tn_h",)) and all(r in work for r in parts):
+        work[fused] = sum(work.pop(r) for r in parts)
+        if all(r in launch_work for r in parts):
+            launch_work[fused] = [sum(v) for v in zip(*(launch_work.pop(r) for r in parts))]
     return work, launch_work
 
 

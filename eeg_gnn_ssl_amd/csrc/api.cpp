@@ -395,6 +395,7 @@ struct BwdWs {
     // part_g / part_c = the grouped TNs' [N*spg][K][O]; z = dXh (N, Sp, Fin)
     size_t dyh;
     TngPlan gx, gh;
+    TnfPlan gf;                // the three problems in one pass (kernels_gemm_f.h); ok: gx.spg = gh.spg = gf.spg
 };
 // dev knob 2 bit 1 = 2: the round-2 TN kernels everywhere
 TnqPlan tn_plan_q(int nseg, int F, int R, int O, bool bt) {
@@ -414,6 +415,9 @@ BwdWs bwd_ws(const eeg_layer_dims* d, int need_dx) {
     w.dyh = o;      o += spec ? Rp * 3 * d->H : 0;
     w.gx = spec ? tng_plan(d->Fin, spec_rows(d->T * d->B), d->N, num_cus()) : TngPlan{};
     w.gh = spec ? tng_plan(d->H, spec_rows(d->T * d->B), d->N, num_cus()) : TngPlan{};
+    // dev knob 23 = 1: the three separate grouped launches
+    w.gf = spec && g_tune[23] == 0 ? tnf_plan(d->Fin, d->H, spec_rows(d->T * d->B), d->N, num_cus()) : TnfPlan{};
+    if (w.gf.ok) { w.gx.spg = w.gh.spg = w.gf.spg; w.gx.rps = w.gh.rps = w.gf.rps; }
     w.nsplit_x = tn_split(d->M, d->Fin, (int)R, 3 * d->H, &w.rps_x);
     w.nsplit_hg = tn_split(d->M, d->H, (int)R, 2 * d->H, &w.rps_hg);
     w.nsplit_hc = tn_split(d->M, d->H, (int)R, d->H, &w.rps_hc);
@@ -518,8 +522,12 @@ int cell_weight_grads_spectral(const eeg_layer_dims* d, const float* Xh, size_t 
     const int S = d->T * d->B, H = d->H, M = d->M, Fin = d->Fin, N = d->N, Sp = spec_rows(S);
     float* part_g = part + (w.part_g - w.partial);
     float* part_c = part + (w.part_c - w.partial);
-    if (launch_tng(w.gx, Xh, Fin, Sp, N, dYh, part, st, "gemm_tn_x", x_gs)) return fail("gemm_tng: launch failed");
-    if (launch_tng_pair(w.gh, hh, rhh, Sp, N, dYh, part_g, part_c, st, "gemm_tn_h", hh_gs)) return fail("gemm_tng_pair: launch failed");
+    if (w.gf.ok) {
+        if (launch_tnf(w.gf, Xh, x_gs, Fin, hh, hh_gs, rhh, dYh, Sp, N, part, part_g, part_c, st, "gemm_tn_f")) return fail("gemm_tnf: launch failed");
+    } else {
+        if (launch_tng(w.gx, Xh, Fin, Sp, N, dYh, part, st, "gemm_tn_x", x_gs)) return fail("gemm_tng: launch failed");
+        if (launch_tng_pair(w.gh, hh, rhh, Sp, N, dYh, part_g, part_c, st, "gemm_tn_h", hh_gs)) return fail("gemm_tng_pair: launch failed");
+    }
     ReduceJobs jobs{};
     SpecFoldJobs sj{};
     sj.basis = d->spectral; sj.N = N;

@@ -1,0 +1,216 @@
+// Fused weight-gradient GEMM of one cell in the eigenbasis of a shared symmetric support (spec_common.h): the three hoisted
+// contractions over the rows of ONE graph frequency i
+//     dWt^x_i = Xh_i^T dYh_i            (Fin x 3H)      Xh  = U^T x          (N, Sp, Fin)
+//     dWt^g_i = Hh_i^T dYh_i[:, 0:2H]   (H   x 2H)      Hh  = U^T h_{t-1}    (N, Sp, H)
+//     dWt^c_i = RHh_i^T dYh_i[:, 2H:3H] (H   x H)       RHh = U^T (r*h_{t-1})
+// in ONE pass over dYh = U^T dXW (N, Sp, 3H): the three kernels this replaces (gemm_tnq_grouped_kernel + the two jobs of
+// gemm_tnq_grouped_pair_kernel) read the 3H-wide operand twice.  Model side: the parameter gradients of
+// DCGRUCell's two DiffusionGraphConv (reference model/cell.py:76-117, autograd of `torch.matmul(x, self.weight)`).
+//
+// Shape of the thing (H = 64): per row the operands are Fin + 64 + 64 + 192 floats and the work is 2 * 192 * (Fin + 64) FLOP --
+// 24..29 FLOP/B, where the MFMA and the HBM roof of this part meet.  Construction:
+//   * v_mfma_f32_32x32x2_f32: a fragment = 32 consecutive floats of an operand row per half-wave, so the LDS images are the plain
+//     row-major chunks as they lie in HBM (every chunk of every operand is CONTIGUOUS there: 1-KB LDS-DMA pieces, no row maps, no
+//     swizzle) and every fragment read is a conflict-free ds_read_b32 (its two 32-lane groups read one row each);
+//   * a workgroup (4 waves) owns ALL output tiles of its row range: wave (e, s) = (A column half, dYh column role) accumulates
+//     Xh tiles {e, e+2} x dYh tiles {3s..3s+2}, Hh tile e x gate tiles {2s, 2s+1}, RHh tile e x candidate tile 4+s: 3*NXT + 3
+//     MFMAs per k-step of two rows against NXT + 6 fragment dwords -- all four waves carry the same MFMA count;
+//   * ring of kTnfNS stages of kTnfRC rows, requests kTnfNS-1 chunks ahead with counted waits on the vector-memory queue, one
+//     workgroup barrier per chunk; two workgroups per CU;
+//   * partials in the layout of the kernels it replaces ([N*spg][K][O] per problem): the fold launch is unchanged.
+// Features beyond Fin in the last Xh tile are whatever follows in the image (never stored: an MFMA output row depends on its own
+// A row only).  Pad rows [S, Sp) of dYh are zeros (spec_common.h), so they add nothing.
+#pragma once
+#include "common.h"
+
+namespace eeg {
+
+#ifndef EEG_X_TNF_RC
+#define EEG_X_TNF_RC 8
+#endif
+#ifndef EEG_X_TNF_NS
+#define EEG_X_TNF_NS 5
+#endif
+#ifndef EEG_X_TNF_MINW
+#define EEG_X_TNF_MINW 2
+#endif
+constexpr int kTnfRC = EEG_X_TNF_RC, kTnfNS = EEG_X_TNF_NS, kTnfWgsPerCu = EEG_X_TNF_MINW;
+// floats of one stage: Xh image (FXT pieces of 256 floats) | Hh (8 x 64) | RHh (8 x 64) | dYh (8 x 192)
+__host__ __device__ constexpr int tnf_stage_floats(int FXT) { return (kTnfRC / 8) * (FXT * 256 + 512 + 512 + 1536); }
+__host__ __device__ constexpr size_t tnf_lds_bytes(int FXT) { return (size_t)kTnfNS * tnf_stage_floats(FXT) * sizeof(float); }
+
+// 1-KB requests per chunk: [Xh: FXT | Hh: 2 | RHh: 2 | dYh: 6] per 8 rows; per wave a quarter of them, rounded up
+__host__ __device__ constexpr int tnf_ndma(int FXT) { return (kTnfRC / 8) * (FXT + 10); }
+__host__ __device__ constexpr int tnf_per(int FXT) { return (tnf_ndma(FXT) + 3) / 4; }
+
+template <int FXT, int S>
+__device__ __forceinline__ void tnf_role(float* sm, const int Q, const int Fin, const int e, const int lane,
+                                         const wbuf_t (&dsc)[tnf_per(FXT)], const int (&lofs)[tnf_per(FXT)],
+                                         const unsigned (&vof)[tnf_per(FXT)], unsigned (&soff)[tnf_per(FXT)],
+                                         const unsigned (&cstep)[tnf_per(FXT)],
+                                         float* __restrict__ px, float* __restrict__ pg, float* __restrict__ pc) {
+    constexpr int RC = kTnfRC, NS = kTnfNS, KS = RC / 2, NXT = (FXT + 1) / 2, PER = tnf_per(FXT);
+    constexpr int RM = RC / 8, HI = RM * FXT * 256, RI = HI + RM * 512, YI = RI + RM * 512, ST = tnf_stage_floats(FXT);
+    // dYh tiles of this role: x-part {3S, 3S+1, 3S+2}; gate {2S, 2S+1}; candidate 4 + S.  Loaded: the three x tiles + one more
+    // (S = 0: tile 4, the candidate's; S = 1: tile 2, the first gate tile) -- the others coincide with x tiles.
+    constexpr int YX = 3 * S, YE = S == 0 ? 4 : 2;
+    const int hh = lane >> 5, l32 = lane & 31;
+    f32x16 ax[NXT][3], ah[2], ar;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+#pragma unroll
+        for (int a = 0; a < NXT; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ax[a][c][v] = 0.f;
+        ah[0][v] = 0.f; ah[1][v] = 0.f; ar[v] = 0.f;
+    }
+    int d_stage = 0;
+    auto issue = [&]() __attribute__((always_inline)) {
+        float* base = sm + d_stage * ST;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            wbuf_dma16(dsc[j], base + lofs[j], vof[j], soff[j]);
+            soff[j] += cstep[j];
+        }
+        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+    };
+    // fragment offsets (floats) of k-step 0 inside a stage
+    const int ox = hh * Fin + 32 * e + l32, oh = HI + hh * 64 + 32 * e + l32, orr = RI + hh * 64 + 32 * e + l32, oy = YI + hh * 192 + l32;
+    float fx[2][NXT], fh[2], fr[2], fy[2][4];
+    auto load = [&](auto PAR, const float* st, int ks) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+#pragma unroll
+        for (int a = 0; a < NXT; ++a) fx[p][a] = st[ox + 2 * ks * Fin + 64 * a];
+        fh[p] = st[oh + 2 * ks * 64];
+        fr[p] = st[orr + 2 * ks * 64];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fy[p][c] = st[oy + 2 * ks * 192 + 32 * (YX + c)];
+        fy[p][3] = st[oy + 2 * ks * 192 + 32 * YE];
+    };
+    auto mma = [&](auto PAR) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+#pragma unroll
+        for (int a = 0; a < NXT; ++a)
+#pragma unroll
+#ifndef EEG_X_TNF_NOMFMA
+            for (int c = 0; c < 3; ++c) ax[a][c] = mfma32(fx[p][a], fy[p][c], ax[a][c]);
+#else
+            for (int c = 0; c < 3; ++c) ax[a][c][0] += fx[p][a] * fy[p][c];
+#endif
+        // gate tiles 2S, 2S+1: S = 0 -> x tiles 0, 1; S = 1 -> the extra tile (2) and x tile 0 (3)
+#ifndef EEG_X_TNF_NOMFMA
+        ah[0] = mfma32(fh[p], S == 0 ? fy[p][0] : fy[p][3], ah[0]);
+        ah[1] = mfma32(fh[p], S == 0 ? fy[p][1] : fy[p][0], ah[1]);
+#else
+        ah[0][0] += fh[p] * (S == 0 ? fy[p][0] : fy[p][3]);
+        ah[1][0] += fh[p] * (S == 0 ? fy[p][1] : fy[p][0]);
+#endif
+        // candidate tile 4 + S: S = 0 -> the extra tile (4); S = 1 -> x tile 2 (5)
+#ifndef EEG_X_TNF_NOMFMA
+        ar = mfma32(fr[p], S == 0 ? fy[p][3] : fy[p][2], ar);
+#else
+        ar[0] += fr[p] * (S == 0 ? fy[p][3] : fy[p][2]);
+#endif
+    };
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < Q) issue();
+    int r_stage = 0;
+    for (int q = 0; q < Q; ++q) {
+        // chunk q landed (this wave's pieces: counted wait; every wave's: the barrier), and every wave is past its reads of chunk
+        // q-1, whose stage takes chunk q + NS - 1
+        if (q + NS - 1 <= Q) vm_wait_barrier_n<(NS - 2) * PER>();
+        else EEG_VM_WAIT_BARRIER(0);
+#ifndef EEG_X_TNF_NODMA
+        if (q + NS - 1 < Q) issue();
+#endif
+        const float* st = sm + r_stage * ST;
+        load(IntC<0>(), st, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks & 1) {
+                if (ks + 1 < KS) load(IntC<0>(), st, ks + 1);
+                EEG_SCHED_FENCE();
+                mma(IntC<1>());
+            } else {
+                if (ks + 1 < KS) load(IntC<1>(), st, ks + 1);
+                EEG_SCHED_FENCE();
+                mma(IntC<0>());
+            }
+            EEG_SCHED_FENCE();
+        }
+        r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+    }
+    // ---- epilogue: D tile register v of lane (hh, l32) = (feature 8*(v>>2) + 4*hh + (v&3), column l32) ------------------------------
+#pragma unroll
+    for (int a = 0; a < NXT; ++a) {
+        const int xe = e + 2 * a;
+        if (xe >= FXT) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int f = 32 * xe + 8 * (v >> 2) + 4 * hh + (v & 3);
+                if (f < Fin) px[(size_t)f * 192 + 32 * (YX + c) + l32] = ax[a][c][v];
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int f = 32 * e + 8 * (v >> 2) + 4 * hh + (v & 3);
+        pg[(size_t)f * 128 + 32 * (2 * S) + l32] = ah[0][v];
+        pg[(size_t)f * 128 + 32 * (2 * S + 1) + l32] = ah[1][v];
+        pc[(size_t)f * 64 + 32 * S + l32] = ar[v];
+    }
+}
+
+// grid = G * spg workgroups: workgroup y = i * spg + ls takes rows [ls * rps, min((ls+1) * rps, Sp)) of frequency i
+// (rps % kTnfRC == 0, Sp % 16 == 0).  x_gstride / h_gstride: floats between two frequencies of Xh / Hh (RHh, dYh: contiguous).
+template <int FXT>
+__global__ __launch_bounds__(256, kTnfWgsPerCu) void gemm_tnf_kernel(const float* __restrict__ Xh, long long x_gstride, int Fin,
+                                                         const float* __restrict__ Hh, long long h_gstride,
+                                                         const float* __restrict__ RHh, const float* __restrict__ dY, int Sp, int spg, int rps,
+                                                         float* __restrict__ part_x, float* __restrict__ part_g, float* __restrict__ part_c) {
+    constexpr int RC = kTnfRC, RM = RC / 8, NDMA = tnf_ndma(FXT), PER = tnf_per(FXT), NX = RM * FXT, NH = RM * 2;
+    constexpr int HI = NX * 256, RI = HI + NH * 256, YI = RI + NH * 256;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), e = w & 1, s = w >> 1;
+    const int y = (int)blockIdx.x, i = y / spg, ls = y - i * spg;
+    const int rbeg = ls * rps;
+    int rend = rbeg + rps;
+    if (rend > Sp) rend = Sp;
+    const int Q = rend > rbeg ? (rend - rbeg) / RC : 0;
+    // this wave's PER requests per chunk: piece d = w + 4j of the list [Xh: FXT | Hh: 2 | RHh: 2 | dYh: 6] (a wave without a piece
+    // of its own repeats the last one: same bytes to the same place)
+    wbuf_t dsc[PER];
+    int lofs[PER];
+    unsigned vof[PER], soff[PER], cstep[PER];
+    const wbuf_t rx = make_wbuf(Xh + (size_t)i * x_gstride), rh = make_wbuf(Hh + (size_t)i * h_gstride);
+    const wbuf_t rr = make_wbuf(RHh + (size_t)i * Sp * 64), ry = make_wbuf(dY + (size_t)i * Sp * 192);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int d = w + 4 * j;
+        if (d >= NDMA) d = NDMA - 1;
+        // (the piece offset rides in the per-lane part, so that a lane past the end of the Xh chunk can fall back to the chunk's start)
+        if (d < NX) {                                      // the chunk is RC * Fin floats
+            dsc[j] = rx; lofs[j] = d * 256; cstep[j] = (unsigned)(RC * Fin) * 4u;
+            soff[j] = (unsigned)(rbeg * Fin) * 4u;
+            vof[j] = d * 1024 + lane * 16 < RC * Fin * 4 ? (unsigned)(d * 1024 + lane * 16) : 0u;
+        } else if (d < NX + NH) {
+            dsc[j] = rh; lofs[j] = HI + (d - NX) * 256; cstep[j] = RC * 64 * 4u;
+            soff[j] = (unsigned)(rbeg * 64) * 4u; vof[j] = (unsigned)((d - NX) * 1024 + lane * 16);
+        } else if (d < NX + 2 * NH) {
+            dsc[j] = rr; lofs[j] = RI + (d - NX - NH) * 256; cstep[j] = RC * 64 * 4u;
+            soff[j] = (unsigned)(rbeg * 64) * 4u; vof[j] = (unsigned)((d - NX - NH) * 1024 + lane * 16);
+        } else {
+            dsc[j] = ry; lofs[j] = YI + (d - NX - 2 * NH) * 256; cstep[j] = RC * 192 * 4u;
+            soff[j] = (unsigned)(rbeg * 192) * 4u; vof[j] = (unsigned)((d - NX - 2 * NH) * 1024 + lane * 16);
+        }
+    }
+    float* px = part_x + (size_t)y * Fin * 192;
+    float* pg = part_g + (size_t)y * 64 * 128;
+    float* pc = part_c + (size_t)y * 64 * 64;
+    if (s == 0) tnf_role<FXT, 0>(sm, Q, Fin, e, lane, dsc, lofs, vof, soff, cstep, px, pg, pc);
+    else tnf_role<FXT, 1>(sm, Q, Fin, e, lane, dsc, lofs, vof, soff, cstep, px, pg, pc);
+}
+
+}  // namespace eeg

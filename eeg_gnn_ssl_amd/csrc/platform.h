@@ -19,6 +19,14 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x2_f32: A: lane l -> A[i = l & 31][k = l >> 5]; B: lane l -> B[k = l >> 5][j = l & 31]; D: lane l, register v ->
+// (row 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), column l & 31).  Same rate as the 16x16x4 form (64 FLOP / cycle and SIMD) with HALF the
+// fragment dwords per FLOP; a fragment is 32 consecutive floats of one operand row per half-wave (conflict-free ds_read_b32 on a
+// plain row-major image of any row stride).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
 // bf16 matrix pipe (opt-in three-term split of the hoisted NN GEMMs, kernels_gemm_bf.h): a fragment of v_mfma_f32_16x16x32_bf16 is
 // 8 bf16 = 4 VGPRs per lane (A: row lane&15, k = 8*(lane>>4) + i; B: k = 8*(lane>>4) + i, column lane&15; D as the fp32 16x16 tile)
 typedef short bf16x8 __attribute__((ext_vector_type(8)));

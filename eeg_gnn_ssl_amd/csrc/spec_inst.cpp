@@ -1,5 +1,6 @@
 // Instantiations + launch logic of the spectral form of the hoisted x-part, in their own translation unit.
 #include "kernels_gemm_g.h"
+#include "kernels_gemm_f.h"
 #include "kernels_spectral.h"
 #include "pack_cell.h"
 #include "spec_launch.h"
@@ -168,6 +169,46 @@ int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp,
     EEG_LAUNCH_P(tag, (gemm_tnq_grouped_pair_kernel<KT, RC, true>), dim3(1, 2 * G * p.spg), dim3(256), lds, st, ja, jb, 64, Sp, G, p.spg, dY, 192,
                  p.rps, skew, (long long)0);
     return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// Row splits of the fused kernel: every workgroup of the launch resident at once (2 per CU), rows per split a multiple of 16.
+TnfPlan tnf_plan(int Fin, int H, int Sp, int G, int num_cus) {
+    TnfPlan p{};
+    if (H != 64 || Fin < 4 || Fin % 4 != 0 || Fin > 128 || Sp < 16 || Sp % 16 != 0 || G < 1) return p;
+    p.fxt = ceil_div(Fin, 32);
+    const int target = kTnfWgsPerCu * (num_cus > 0 ? num_cus : 256);
+    int spg = target / G;
+    if (spg < 1) spg = 1;
+    int rps = round_up(ceil_div(Sp, spg), 16);
+    if (rps < 64) rps = 64;
+    if (rps > Sp) rps = Sp;
+    p.rps = rps;
+    p.spg = ceil_div(Sp, rps);
+    p.ok = 1;
+    return p;
+}
+namespace {
+template <int FXT>
+int launch_tnf_one(const TnfPlan& p, const float* Xh, size_t xgs, int Fin, const float* Hh, size_t hgs, const float* RHh, const float* dY,
+                   int Sp, int G, float* part_x, float* part_g, float* part_c, hipStream_t st, const char* tag) {
+    const size_t lds = tnf_lds_bytes(FXT);
+    EEG_SET_MAX_LDS((gemm_tnf_kernel<FXT>), lds);
+    EEG_LAUNCH_P(tag, (gemm_tnf_kernel<FXT>), dim3(G * p.spg), dim3(256), lds, st, Xh, (long long)xgs, Fin, Hh, (long long)hgs, RHh, dY, Sp,
+                 p.spg, p.rps, part_x, part_g, part_c);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+}  // namespace
+int launch_tnf(const TnfPlan& p, const float* Xh, size_t x_gstride, int Fin, const float* Hh, size_t h_gstride, const float* RHh,
+               const float* dY, int Sp, int G, float* part_x, float* part_g, float* part_c, hipStream_t st, const char* tag) {
+    if (!p.ok) return 1;
+    const size_t xgs = x_gstride != 0 ? x_gstride : (size_t)Sp * Fin, hgs = h_gstride != 0 ? h_gstride : (size_t)Sp * 64;
+    switch (p.fxt) {
+        case 1: return launch_tnf_one<1>(p, Xh, xgs, Fin, Hh, hgs, RHh, dY, Sp, G, part_x, part_g, part_c, st, tag);
+        case 2: return launch_tnf_one<2>(p, Xh, xgs, Fin, Hh, hgs, RHh, dY, Sp, G, part_x, part_g, part_c, st, tag);
+        case 3: return launch_tnf_one<3>(p, Xh, xgs, Fin, Hh, hgs, RHh, dY, Sp, G, part_x, part_g, part_c, st, tag);
+        case 4: return launch_tnf_one<4>(p, Xh, xgs, Fin, Hh, hgs, RHh, dY, Sp, G, part_x, part_g, part_c, st, tag);
+    }
+    return 1;
 }
 
 int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const float* dY, float* partial, hipStream_t st, const char* tag,

@@ -41,6 +41,12 @@ int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const flo
 // (ah_gstride: floats between two groups of Ah, 0 = contiguous; Arh is contiguous)
 int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp, int G, const float* dY, float* part_g, float* part_c,
                     hipStream_t st, const char* tag, size_t ah_gstride = 0);
+// fused weight-gradient GEMM of a 64-unit cell (kernels_gemm_f.h): the x-part and both h-part problems in one pass over dY;
+// partials in the layouts above with ONE split count (spg) for the three.  ok = 0: shape not covered (Fin > 128, H != 64)
+struct TnfPlan { int ok, fxt, spg, rps; };
+TnfPlan tnf_plan(int Fin, int H, int Sp, int G, int num_cus);
+int launch_tnf(const TnfPlan& p, const float* Xh, size_t x_gstride, int Fin, const float* Hh, size_t h_gstride, const float* RHh,
+               const float* dY, int Sp, int G, float* part_x, float* part_g, float* part_c, hipStream_t st, const char* tag);
 // rows [S, Sp) of every group of a (N, Sp, F) node-major tensor <- 0, Sp any row count >= S
 int launch_spec_zero_rows(float* Xh, int N, int S, int Sp, int F, hipStream_t st);
 

@@ -11,6 +11,8 @@ struct f32x2 { float v[2]; float& operator[](int i) { return v[i]; } const float
 #define EEG_SET_MAX_LDS(kern, bytes) ((void)0)
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return emu::mfma16(a, b, c); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return emu::mfma4(a, b, c); }
+using emu::f32x16;
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return emu::mfma32(a, b, c); }
 using emu::bf16x8;
 using emu::u32x4;
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) { return emu::mfma_bf16(a, b, c); }

@@ -43,6 +43,8 @@ struct Fiber {
     f32x4 mc, md;
     bool sync_only = false;
     bool mfma4 = false;          // this rendezvous is a v_mfma_f32_4x4x1_16B_f32
+    bool mfma32 = false;         // this rendezvous is a v_mfma_f32_32x32x2_f32 of (ma, mb) on the 16-register accumulator mc16
+    float mc16[16] = {0}, md16[16] = {0};
     bool mfma_bf = false;        // this rendezvous is a v_mfma_f32_16x16x32_bf16 of (bfa, bfb): 8 bf16 per lane and operand, as floats
     float bfa[8] = {0}, bfb[8] = {0};
     int shfl_mask = -1;          // >= 0: this rendezvous is a __shfl_xor with that lane mask
@@ -83,6 +85,20 @@ inline f32x4 mfma4(float a, float b, f32x4 c) {
     yield_to_sched();
     cur->mfma4 = false;
     return cur->md;
+}
+// v_mfma_f32_32x32x2_f32: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31], D: lane l, register v -> (8*(v>>2) + 4*(l>>5) + (v&3), l & 31)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+inline f32x16 mfma32(float a, float b, f32x16 c) {
+    cur->ma = a;
+    cur->mb = b;
+    for (int v = 0; v < 16; ++v) cur->mc16[v] = c[v];
+    cur->mfma32 = true;
+    cur->st = WAIT_WAVE;
+    yield_to_sched();
+    cur->mfma32 = false;
+    f32x16 d;
+    for (int v = 0; v < 16; ++v) d[v] = cur->md16[v];
+    return d;
 }
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -260,6 +276,30 @@ static void run_mfma(std::vector<Fiber>& f, unsigned w0) {
     }
     if (nbf != 0) {
         fprintf(stderr, "emu: wave mixes bf16 and fp32 mfma at one rendezvous\n");
+        abort();
+    }
+    unsigned n32 = 0;
+    for (unsigned l = 0; l < 64; ++l) n32 += f[w0 + l].mfma32;
+    if (n32 == 64) {
+        float A[32][2], B[2][32];
+        for (unsigned l = 0; l < 64; ++l) {
+            A[l & 31][l >> 5] = f[w0 + l].ma;
+            B[l >> 5][l & 31] = f[w0 + l].mb;
+        }
+        for (unsigned l = 0; l < 64; ++l) {
+            Fiber& x = f[w0 + l];
+            for (int v = 0; v < 16; ++v) {
+                const int row = 8 * (v >> 2) + 4 * (l >> 5) + (v & 3), col = l & 31;
+                float acc = x.mc16[v];
+                for (int k = 0; k < 2; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+                x.md16[v] = acc;
+            }
+            x.st = RUNNABLE;
+        }
+        return;
+    }
+    if (n32 != 0) {
+        fprintf(stderr, "emu: wave mixes 32x32x2 and other mfma at one rendezvous\n");
         abort();
     }
     unsigned n4 = 0;

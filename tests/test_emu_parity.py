@@ -58,7 +58,11 @@ def test_opt_in_split_bf16_gemms(filt, din, layers, adj3d):
 SPECTRAL_CASES = [dict(din=100, layers=2, t_len=3, b=4, classes=1),
                   dict(din=8, layers=2, t_len=5, b=7, classes=4, k=3, seed=3, lengths=[5, 4, 3, 2, 1, 5, 5]),
                   dict(din=36, layers=3, t_len=2, b=3, classes=1, k=1, seed=5, n=20, act="relu"),
-                  dict(din=12, layers=2, t_len=2, b=40, classes=1, seed=6, n=7)]
+                  dict(din=12, layers=2, t_len=2, b=40, classes=1, seed=6, n=7),
+                  # fused weight-gradient GEMM (kernels_gemm_f.h): three Xh tiles (the odd one rides on a junk tile), the widest input,
+                  # and a ring that wraps (80 rows per frequency = 10 chunks through 5 stages)
+                  dict(din=68, layers=2, t_len=3, b=3, classes=1, seed=8, n=5),
+                  dict(din=128, layers=1, t_len=4, b=20, classes=1, seed=9, n=3)]
 
 
 @pytest.mark.parametrize("case", SPECTRAL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k in ("din", "layers", "n", "b", "k")))
@@ -138,6 +142,19 @@ def test_streamed_weight_bptt_kernel(emulator, adj3d, filt, k, lengths, act):
         ps.check_vs_oracle_random("cpu", filt, 8, 64, 2, 3, 3, 4, adj3d, seed=5, lengths=lengths, act=act, k=k)
     finally:
         emulator.call("eeg_dcrnn_set_tuning", 3, 0)
+
+
+def test_spectral_weight_gradients_fused_and_as_three_grouped_launches(emulator, adj3d):
+    """Round 6: gemm_tnf_kernel computes the x-part and both h-part weight gradients of a cell in one pass over dYh; dev knob 23 = 1
+    keeps the three grouped launches it replaces (still the path of input widths beyond 128).  Both against the oracle."""
+    for separate in (0, 1):
+        emulator.call("eeg_dcrnn_set_tuning", 23, separate)
+        try:
+            ps.check_spectral_form("cpu", adj3d, din=100, layers=2, t_len=3, b=6, classes=1, seed=11)
+        finally:
+            emulator.call("eeg_dcrnn_set_tuning", 23, 0)
+    # beyond 128 input features the fused kernel has no instantiation: the grouped launches take the layer
+    ps.check_spectral_form("cpu", adj3d, din=132, layers=1, t_len=2, b=3, classes=1, seed=12, n=4)
 
 
 @pytest.mark.parametrize("filt,k", [("laplacian", 2), ("dual_random_walk", 2)])

@@ -258,7 +258,11 @@ SPECTRAL_CASES = [dict(din=100, layers=2, t_len=3, b=4, classes=1),
                   dict(din=36, layers=3, t_len=2, b=3, classes=1, k=1, seed=5, n=20, act="relu"),
                   dict(din=12, layers=2, t_len=2, b=40, classes=1, seed=6, n=7),
                   dict(din=100, layers=2, t_len=12, b=300, classes=1, seed=8),          # more row tiles than workgroups, S % 128 != 0
-                  dict(din=64, layers=3, t_len=7, b=33, classes=4, seed=9, n=32)]       # S = 231: pad rows in every frequency
+                  dict(din=64, layers=3, t_len=7, b=33, classes=4, seed=9, n=32),       # S = 231: pad rows in every frequency
+                  # fused weight-gradient GEMM (kernels_gemm_f.h): three Xh tiles, the widest input it takes, one past it (grouped launches)
+                  dict(din=68, layers=2, t_len=9, b=50, classes=1, seed=10, n=5),
+                  dict(din=128, layers=2, t_len=6, b=130, classes=1, seed=11),
+                  dict(din=132, layers=1, t_len=5, b=40, classes=1, seed=12, n=4)]
 
 
 @pytest.mark.parametrize("case", SPECTRAL_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items() if k in ("din", "layers", "n", "b", "k")))
