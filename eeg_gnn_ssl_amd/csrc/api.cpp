@@ -864,8 +864,11 @@ int eeg_dcrnn_layer_fwd(const eeg_layer_dims* d, const float* X, float* Xtm, con
         float* Yh = ws + (size_t)R * 3 * H;
         if (!d->x_planes_ready && launch_spec_mix(1, X, d->spectral, nullptr, N, d->T, d->B, Fin, d->x_batch_major ? 1 : 0, planes, st, "spec_mix_x"))
             return fail("spec_mix: launch failed");
-        if (launch_nng(planes, Fin, Sp, N, d->spack + sp.sxq, sp.sxq_stride, sp.nct_x, Yh, num_cus(), st, "gemm_nn_xw", pack + p.bias,
-                       d->spectral + spec_csum_offset(N), xgs)) return fail("gemm_nng: launch failed");
+        int nnf = g_tune[20] == 0 ? launch_nnf(planes, xgs, Fin, Sp, N, d->spack + sp.sxr, sp.sxr_stride, Yh, num_cus(), st, "gemm_nn_xw", pack + p.bias,
+                                               d->spectral + spec_csum_offset(N)) : -1;
+        if (nnf > 0) return fail("gemm_nnf: launch failed");
+        if (nnf < 0 && launch_nng(planes, Fin, Sp, N, d->spack + sp.sxq, sp.sxq_stride, sp.nct_x, Yh, num_cus(), st, "gemm_nn_xw", pack + p.bias,
+                                  d->spectral + spec_csum_offset(N), xgs)) return fail("gemm_nng: launch failed");
         int done = 0;
         SeqFwdArgs a{XW, h0 != nullptr ? Hext : nullptr, P, d->p_batched, pack + p.bhg, pack + p.bhc, Hext + state, Rs, Us, Cs, RHs, nullptr, nullptr,
                      (size_t)0, d->T, d->B, N, d->act, seq_probe_arg(st)};

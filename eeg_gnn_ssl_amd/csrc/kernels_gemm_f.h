@@ -15,8 +15,8 @@
 //   * a workgroup (4 waves) owns ALL output tiles of its row range: wave (e, s) = (A column half, dYh column role) accumulates
 //     Xh tiles {e, e+2} x dYh tiles {3s..3s+2}, Hh tile e x gate tiles {2s, 2s+1}, RHh tile e x candidate tile 4+s: 3*NXT + 3
 //     MFMAs per k-step of two rows against NXT + 6 fragment dwords -- all four waves carry the same MFMA count;
-//   * ring of kTnfNS stages of kTnfRC rows, requests kTnfNS-1 chunks ahead with counted waits on the vector-memory queue, one
-//     workgroup barrier per chunk; two workgroups per CU;
+//   * ring of tnf_ns() stages of kTnfRC rows, requests one less than that many chunks ahead with counted waits on the vector-memory queue, one
+//     workgroup barrier per chunk; two workgroups per CU (three for Fin <= 64);
 //   * partials in the layout of the kernels it replaces ([N*spg][K][O] per problem): the fold launch is unchanged.
 // Features beyond Fin in the last Xh tile are whatever follows in the image (never stored: an MFMA output row depends on its own
 // A row only).  Pad rows [S, Sp) of dYh are zeros (spec_common.h), so they add nothing.
@@ -34,10 +34,19 @@ namespace eeg {
 #ifndef EEG_X_TNF_MINW
 #define EEG_X_TNF_MINW 2
 #endif
-constexpr int kTnfRC = EEG_X_TNF_RC, kTnfNS = EEG_X_TNF_NS, kTnfWgsPerCu = EEG_X_TNF_MINW;
+// narrow inputs (FXT <= 2: 96 accumulator registers) run three workgroups per CU on a three-stage ring (measured: -3 % against 2 x 5)
+#ifndef EEG_X_TNF_NS2
+#define EEG_X_TNF_NS2 3
+#endif
+#ifndef EEG_X_TNF_MINW2
+#define EEG_X_TNF_MINW2 3
+#endif
+constexpr int kTnfRC = EEG_X_TNF_RC;
+__host__ __device__ constexpr int tnf_ns(int FXT) { return FXT <= 2 ? EEG_X_TNF_NS2 : EEG_X_TNF_NS; }
+__host__ __device__ constexpr int tnf_wgs_per_cu(int FXT) { return FXT <= 2 ? EEG_X_TNF_MINW2 : EEG_X_TNF_MINW; }
 // floats of one stage: Xh image (FXT pieces of 256 floats) | Hh (8 x 64) | RHh (8 x 64) | dYh (8 x 192)
 __host__ __device__ constexpr int tnf_stage_floats(int FXT) { return (kTnfRC / 8) * (FXT * 256 + 512 + 512 + 1536); }
-__host__ __device__ constexpr size_t tnf_lds_bytes(int FXT) { return (size_t)kTnfNS * tnf_stage_floats(FXT) * sizeof(float); }
+__host__ __device__ constexpr size_t tnf_lds_bytes(int FXT) { return (size_t)tnf_ns(FXT) * tnf_stage_floats(FXT) * sizeof(float); }
 
 // 1-KB requests per chunk: [Xh: FXT | Hh: 2 | RHh: 2 | dYh: 6] per 8 rows; per wave a quarter of them, rounded up
 __host__ __device__ constexpr int tnf_ndma(int FXT) { return (kTnfRC / 8) * (FXT + 10); }
@@ -49,7 +58,7 @@ __device__ __forceinline__ void tnf_role(float* sm, const int Q, const int Fin, 
                                          const unsigned (&vof)[tnf_per(FXT)], unsigned (&soff)[tnf_per(FXT)],
                                          const unsigned (&cstep)[tnf_per(FXT)],
                                          float* __restrict__ px, float* __restrict__ pg, float* __restrict__ pc) {
-    constexpr int RC = kTnfRC, NS = kTnfNS, KS = RC / 2, NXT = (FXT + 1) / 2, PER = tnf_per(FXT);
+    constexpr int RC = kTnfRC, NS = tnf_ns(FXT), KS = RC / 2, NXT = (FXT + 1) / 2, PER = tnf_per(FXT);
     constexpr int RM = RC / 8, HI = RM * FXT * 256, RI = HI + RM * 512, YI = RI + RM * 512, ST = tnf_stage_floats(FXT);
     // dYh tiles of this role: x-part {3S, 3S+1, 3S+2}; gate {2S, 2S+1}; candidate 4 + S.  Loaded: the three x tiles + one more
     // (S = 0: tile 4, the candidate's; S = 1: tile 2, the first gate tile) -- the others coincide with x tiles.
@@ -166,7 +175,7 @@ __device__ __forceinline__ void tnf_role(float* sm, const int Q, const int Fin, 
 // grid = G * spg workgroups: workgroup y = i * spg + ls takes rows [ls * rps, min((ls+1) * rps, Sp)) of frequency i
 // (rps % kTnfRC == 0, Sp % 16 == 0).  x_gstride / h_gstride: floats between two frequencies of Xh / Hh (RHh, dYh: contiguous).
 template <int FXT>
-__global__ __launch_bounds__(256, kTnfWgsPerCu) void gemm_tnf_kernel(const float* __restrict__ Xh, long long x_gstride, int Fin,
+__global__ __launch_bounds__(256, tnf_wgs_per_cu(FXT)) void gemm_tnf_kernel(const float* __restrict__ Xh, long long x_gstride, int Fin,
                                                          const float* __restrict__ Hh, long long h_gstride,
                                                          const float* __restrict__ RHh, const float* __restrict__ dY, int Sp, int spg, int rps,
                                                          float* __restrict__ part_x, float* __restrict__ part_g, float* __restrict__ part_c) {
@@ -211,6 +220,147 @@ __global__ __launch_bounds__(256, kTnfWgsPerCu) void gemm_tnf_kernel(const float
     float* pc = part_c + (size_t)y * 64 * 64;
     if (s == 0) tnf_role<FXT, 0>(sm, Q, Fin, e, lane, dsc, lofs, vof, soff, cstep, px, pg, pc);
     else tnf_role<FXT, 1>(sm, Q, Fin, e, lane, dsc, lofs, vof, soff, cstep, px, pg, pc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Grouped NN GEMM of the hoisted x-part in the eigenbasis, same construction: Yh_i = Xh_i Wt_i + gscale[i] * bias for every graph
+// frequency i (model side: `torch.matmul(x, self.weight) + biases` of DiffusionGraphConv.forward, reference model/cell.py:113-117,
+// with K = Fin instead of M * Fin, spec_common.h).  K is small (64 / 100) and the output wide (3H = 192): per 64 rows 16..26 KB come
+// in, 48 KB go out, 1.6..2.5 MFLOP are spent -- the HBM roof of the part is the tighter one.  Construction:
+//   * the weights of a frequency live in REGISTERS (wave (rw, cw): row tile rw of the 64-row chunk x column tiles 3cw..3cw+2; its
+//     fragments W[8q + 4hh + s][32(3cw+t) + c] are 12 * KQ dwords, loaded once per frequency a workgroup visits): the loop has no
+//     weight traffic at all, LDS holds only the ring of activation chunks;
+//   * an activation fragment is ONE ds_read_b128 per 4 k-steps (lane (row, hh): the 16 bytes k = 8q + 4hh .. +3 of its row).  A row of
+//     K = 100 floats is 25 sixteen-byte units -- odd, so the 16 rows of a ds_read_b128 lane group fall on 16 different slots of the
+//     plain row-major image (contiguous 1-KB LDS-DMA pieces); K = 64 (16 units) is XOR-swizzled in the SOURCE addresses of the DMA;
+//   * non-transposed issue: lane (c, hh) holds column c of 16 rows, every store instruction writes two whole 128-byte lines;
+//   * persistent workgroups (2 per CU) over a balanced contiguous range of 64-row chunks; a range may cross into the next frequency
+//     (weights reloaded there); ragged ends (Sp % 64) through bounded descriptors: no per-lane guards anywhere.
+// KQ = ceil(K / 8); SWZ: K == 64.  A: (G, Sp, K) with a_gstride floats between frequencies; Wr: SpecPack::sxr; C: (G, Sp, 192).
+#ifndef EEG_X_NNF_NS
+#define EEG_X_NNF_NS 3
+#endif
+constexpr int kNnfNS = EEG_X_NNF_NS;
+__host__ __device__ constexpr int nnf_stage_floats(int K) { return 64 * K + 4; }          // + one zeroed 16-byte unit behind the last row
+__host__ __device__ constexpr size_t nnf_lds_bytes(int K) { return (size_t)kNnfNS * nnf_stage_floats(K) * sizeof(float); }
+
+template <int KQ, bool SWZ>
+__global__ __launch_bounds__(256, 2) void gemm_nnf_kernel(const float* __restrict__ A, long long a_gstride, int K, int Sp, int G,
+                                                         const float* __restrict__ Wr, unsigned w_gstride, float* __restrict__ C,
+                                                         const float* __restrict__ bias, const float* __restrict__ gscale) {
+    constexpr int NS = kNnfNS;
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), rw = w & 1, cw = w >> 1, hh = lane >> 5, l32 = lane & 31;
+    const int ST = nnf_stage_floats(K), CPG = ceil_div(Sp, 64), total = G * CPG;
+    const int NPC = ceil_div(64 * K, 256), PER = ceil_div(NPC, 4);        // 1-KB pieces of a chunk; per wave (the last one repeated)
+    const int g0 = (int)(((long long)blockIdx.x * total) / gridDim.x), g1 = (int)(((long long)(blockIdx.x + 1) * total) / gridDim.x);
+    const int Q = g1 - g0;
+    if (tid < 4 * NS) sm[(tid >> 2) * ST + 64 * K + (tid & 3)] = 0.f;     // the unit behind the last row of every stage
+    // ---- request side -------------------------------------------------------------------------------------------------------------
+    // piece p = w + 4j covers bytes [1024 p, 1024 p + 1024) of the chunk image; lane part of the source: SWZ: row (l >> 4) of the
+    // piece's 4 rows, unit (l & 15) ^ ((4w + (l >> 4)) & 15) (the row index mod 16 is the same for every j); else the image is the chunk
+    const unsigned lane_src = SWZ ? (unsigned)((lane >> 4) * 256 + (((lane & 15) ^ ((4 * w + (lane >> 4)) & 15)) << 4)) : (unsigned)lane * 16u;
+    int d_g = g0, d_stage = 0, d_grp = -1;
+    wbuf_t ra = make_wbuf_n(A, 0u);
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int grp = d_g / CPG, lc = d_g - grp * CPG;
+        if (grp != d_grp) { d_grp = grp; ra = make_wbuf_n(A + (size_t)grp * a_gstride, (unsigned)(Sp * K) * 4u); }
+        float* base = sm + d_stage * ST;
+        const unsigned cb = (unsigned)(lc * 64 * K) * 4u;
+        for (int j = 0; j < PER; ++j) {
+            int p = w + 4 * j;
+            if (p >= NPC) p = NPC - 1;
+            wbuf_dma16(ra, base + p * 256, cb + (unsigned)p * 1024u + lane_src, 0u);
+        }
+        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+        ++d_g;
+    };
+    // ---- compute side -------------------------------------------------------------------------------------------------------------
+    float wr[KQ][4][3];
+    f32x16 acc[3];
+    float binit[3] = {0.f, 0.f, 0.f};
+    int c_grp = -1;
+    wbuf_t rc = make_wbuf_n(C, 0u);
+    const int row = 32 * rw + l32;                                        // this lane's activation row inside a chunk
+    const int a_row = row * K;
+    const int ccol = 32 * 3 * cw + l32;                                   // first of this lane's three output columns
+#pragma unroll 1
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < Q) issue();
+    int r_stage = 0;
+#pragma unroll 1
+    for (int q = 0; q < Q; ++q) {
+        const int g = g0 + q, grp = g / CPG, lc = g - grp * CPG;
+        if (grp != c_grp) {                                               // a new frequency: its weights, bias scale and output window
+            c_grp = grp;
+            const wbuf_t rwt = make_wbuf(Wr + (size_t)grp * w_gstride);
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) wr[kq][s][t] = wbuf_ld(rwt, (unsigned)(4 * hh * 192 + ccol), (unsigned)((8 * kq + s) * 192 + 32 * t));
+            const float gs = bias != nullptr ? gscale[grp] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) binit[t] = bias != nullptr ? gs * bias[ccol + 32 * t] : 0.f;
+            rc = make_wbuf_n(C + (size_t)grp * Sp * 192, (unsigned)(Sp * 192) * 4u);
+        }
+        // Queue discipline (it retires in order, stores included): behind the requests of chunk q the queue holds the requests of the
+        // chunks q+1 .. q+NS-2 that exist (PER each) and the 48-store bursts of the chunks q-NS+1 .. q-1 that exist: a counted wait for
+        // the largest supported count not above that (the counter has 6 bits).
+        {
+            int nd = Q - 1 - q;
+            if (nd > NS - 2) nd = NS - 2;
+            const int n = 48 * (q < NS - 1 ? q : NS - 1) + PER * nd;
+            if (n >= 63) vm_wait_n<63>(); else if (n >= 55) vm_wait_n<55>(); else if (n >= 52) vm_wait_n<52>(); else if (n >= 48) vm_wait_n<48>();
+            else if (n >= 14) vm_wait_n<14>(); else if (n >= 8) vm_wait_n<8>(); else if (n >= 7) vm_wait_n<7>(); else if (n >= 4) vm_wait_n<4>();
+            else vm_wait_n<0>();
+        }
+#ifndef EEG_X_NNF_NOBAR
+        EEG_LDS_BARRIER();                                                // chunk q landed in every wave; all are past their reads of chunk q-1
+#endif
+#ifndef EEG_X_NNF_NODMA
+        if (q + NS - 1 < Q) issue();
+#endif
+        const float* st = sm + r_stage * ST;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = binit[t];
+        f32x4 a4 = *reinterpret_cast<const f32x4*>(st + a_row + (SWZ ? ((hh ^ (row & 15)) << 2) : 4 * hh));
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            f32x4 an = a4;
+#ifndef EEG_X_NNF_NOLDS
+            if (kq + 1 < KQ) an = *reinterpret_cast<const f32x4*>(st + a_row + (SWZ ? (((2 * (kq + 1) + hh) ^ (row & 15)) << 2) : 4 * (2 * (kq + 1) + hh)));
+#endif
+            EEG_SCHED_FENCE();
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t] = mfma32(a4[s], wr[kq][s][t], acc[t]);
+            EEG_SCHED_FENCE();
+            a4 = an;
+        }
+        // D tile register v of lane (hh, c) = (row 8*(v>>2) + 4*hh + (v&3), column c)
+        // (one per-lane offset per 8-row band; the rest of a store's address fits the instruction's 12-bit offset)
+        unsigned ob[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            ob[b] = (unsigned)((lc * 64 + 32 * rw + 4 * hh + 8 * b) * 192 + ccol);
+            EEG_PIN(ob[b]);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+#ifndef EEG_X_NNF_NOSTORE
+            for (int v = 0; v < 16; ++v) wbuf_st1(rc, ob[v >> 2] + (unsigned)((v & 3) * 192 + 32 * t), 0u, acc[t][v]);
+#else
+            for (int v = 0; v < 16; ++v) { EEG_USE(acc[t][v]); (void)rc; }
+#endif
+        EEG_SCHED_FENCE();                                                // (a store's data registers must not be rewritten right behind it)
+        r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+    }
 }
 
 }  // namespace eeg

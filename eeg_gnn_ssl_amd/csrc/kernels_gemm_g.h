@@ -23,6 +23,9 @@
 
 namespace eeg {
 
+#ifndef EEG_X_NNG_STAUX
+#define EEG_X_NNG_STAUX 0
+#endif
 constexpr int kNngStages = 4;
 // LDS of one workgroup: the ring of kNngStages stages, each 128 rows x 16 floats of activations + 4 NJ column tiles of weights
 __host__ __device__ constexpr size_t nng_lds_bytes(int NJ) { return (size_t)kNngStages * (128 * 16 + 4 * NJ * 256) * sizeof(float); }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nng_kernel(const float* __rest
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #ifndef EEG_X_NNG_NOSTORE
-                    if (i < nrt) wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
+                    if (i < nrt) wbuf_st4_aux<EEG_X_NNG_STAUX>(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
 #else
                     if (i < nrt && acc[i][j][0] == 1.2345e-33f) wbuf_st4(rc, (unsigned)(lr * ldc + c_col + 16 * j), (unsigned)(row0 + 16 * i) * (unsigned)ldc, acc[i][j]);
 #endif

@@ -119,6 +119,18 @@ __device__ __forceinline__ void pack_spectral_body(const float* __restrict__ Wg,
     const NnqOrder ox = make_nnq_order(1, Fin), ot = make_nnq_order(1, 3 * H);
     const size_t stride = (size_t)nb * blockDim.x;
     for (size_t idx = (size_t)bid * blockDim.x + threadIdx.x; idx < p.total; idx += stride) {
+        if (idx >= p.sxr) {                                    // row-major Wt_i[f][o], zero rows beyond Fin
+            const size_t e0 = idx - p.sxr;
+            const int i = (int)(e0 / p.sxr_stride), e = (int)(e0 - (size_t)i * p.sxr_stride), f = e / (3 * H), o = e - f * 3 * H;
+            float v = 0.f;
+            if (f < Fin)
+                for (int m = 0; m < M; ++m) {
+                    const float w = o < 2 * H ? Wg[((size_t)f * M + m) * (2 * H) + o] : Wc[((size_t)f * M + m) * H + (o - 2 * H)];
+                    v = fmaf(tc[m * 32 + i], w, v);
+                }
+            out[idx] = v;
+            continue;
+        }
         const bool tr = idx >= p.sxtq;
         const size_t bs = tr ? p.sxtq_stride : p.sxq_stride, e0 = idx - (tr ? p.sxtq : p.sxq);
         const int i = (int)(e0 / bs);

@@ -102,6 +102,14 @@ __device__ __forceinline__ wbuf_t make_wbuf(const float* p) {              // p 
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
+// Descriptor over exactly `nbytes` bytes: accesses whose per-lane offset (voff; keep the scalar offset 0 with these) reaches past the
+// end are dropped (stores) / return nothing useful (loads) instead of touching memory -- ragged last tiles without per-lane guards.
+__device__ __forceinline__ wbuf_t make_wbuf_n(const float* p, unsigned nbytes) {   // p, nbytes must be wave-uniform
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(nbytes), 0x00020000);
+}
 __device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4u * voff, 4u * soff, 0));
 }
@@ -112,6 +120,12 @@ __device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff
 __device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
     typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), b, 4u * voff, 4u * soff, 0);
+}
+// the same with a cache-policy operand (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__device__ __forceinline__ void wbuf_st4_aux(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), b, 4u * voff, 4u * soff, AUX);
 }
 __device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {
     typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));

@@ -35,10 +35,11 @@ constexpr int kSpecSweeps = 12;
 // ---- per-frequency weight packs of one cell ------------------------------------------------------------------------------------
 // sxq : N blocks, block i = Wt_i  (K = Fin) x (3H) in the quad order of gemm_nng_kernel (nnq order over one segment of width Fin)
 // sxtq: N blocks, block i = Wt_i^T (K = 3H)  x round_up(Fin, 16) columns (zero beyond Fin), same order over one segment of width 3H
+// sxr : N blocks, block i = Wt_i row-major, round_up(Fin, 8) rows (zero beyond Fin) x 3H columns: gemm_nnf_kernel (kernels_gemm_f.h)
 struct SpecPack {
     int Fin, H, M, N;
     int nch_x, nct_x, nch_t, nct_t;
-    size_t sxq, sxq_stride, sxtq, sxtq_stride, total;
+    size_t sxq, sxq_stride, sxtq, sxtq_stride, sxr, sxr_stride, total;
 };
 __host__ __device__ inline SpecPack make_spec_pack(int Fin, int H, int M, int N) {
     SpecPack p;
@@ -49,7 +50,9 @@ __host__ __device__ inline SpecPack make_spec_pack(int Fin, int H, int M, int N)
     p.sxtq_stride = (size_t)p.nch_t * p.nct_t * 256;
     p.sxq = 0;
     p.sxtq = p.sxq + p.sxq_stride * N;
-    p.total = p.sxtq + p.sxtq_stride * N;
+    p.sxr = p.sxtq + p.sxtq_stride * N;
+    p.sxr_stride = (size_t)round_up(Fin, 8) * 3 * H;
+    p.total = p.sxr + p.sxr_stride * N;
     return p;
 }
 // ---- weight-gradient fold ------------------------------------------------------------------------------------------------------------

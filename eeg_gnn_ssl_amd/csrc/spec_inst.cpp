@@ -171,12 +171,41 @@ int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp,
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+namespace {
+template <int KQ, bool SWZ>
+int launch_nnf_one(const float* A, size_t ags, int K, int Sp, int G, const float* Wr, size_t wstride, float* C, int num_cus, hipStream_t st,
+                   const char* tag, const float* bias, const float* gscale) {
+    const size_t lds = nnf_lds_bytes(K);
+    const int total = G * ceil_div(Sp, 64);
+    int nb = 2 * (num_cus > 0 ? num_cus : 256);
+    if (nb > total) nb = total;
+    EEG_SET_MAX_LDS((gemm_nnf_kernel<KQ, SWZ>), lds);
+    EEG_LAUNCH_P(tag, (gemm_nnf_kernel<KQ, SWZ>), dim3(nb), dim3(256), lds, st, A, (long long)ags, K, Sp, G, Wr, (unsigned)wstride, C, bias, gscale);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+}  // namespace
+int launch_nnf(const float* A, size_t a_gstride, int K, int Sp, int G, const float* Wr, size_t wstride, float* C, int num_cus, hipStream_t st,
+               const char* tag, const float* bias, const float* gscale) {
+    if (K < 4 || K % 4 != 0 || Sp < 16 || G < 1 || (double)Sp * 192 * 4 >= 2.0e9) return -1;
+    const size_t ags = a_gstride != 0 ? a_gstride : (size_t)Sp * K;
+    const int kq = ceil_div(K, 8);
+    const bool odd = ((K / 4) & 1) != 0;         // an odd number of 16-byte units per row: the plain row-major image is conflict-free
+#define EEG_NNF(KQ, SWZ) return launch_nnf_one<KQ, SWZ>(A, ags, K, Sp, G, Wr, wstride, C, num_cus, st, tag, bias, gscale)
+    if (K == 64) EEG_NNF(8, true);
+    if (odd && kq == 13) EEG_NNF(13, false);
+    if (odd && kq == 9) EEG_NNF(9, false);
+    if (odd && kq == 5) EEG_NNF(5, false);
+    if (odd && kq == 2) EEG_NNF(2, false);
+#undef EEG_NNF
+    return -1;
+}
+
 // Row splits of the fused kernel: every workgroup of the launch resident at once (2 per CU), rows per split a multiple of 16.
 TnfPlan tnf_plan(int Fin, int H, int Sp, int G, int num_cus) {
     TnfPlan p{};
     if (H != 64 || Fin < 4 || Fin % 4 != 0 || Fin > 128 || Sp < 16 || Sp % 16 != 0 || G < 1) return p;
     p.fxt = ceil_div(Fin, 32);
-    const int target = kTnfWgsPerCu * (num_cus > 0 ? num_cus : 256);
+    const int target = tnf_wgs_per_cu(p.fxt) * (num_cus > 0 ? num_cus : 256);
     int spg = target / G;
     if (spg < 1) spg = 1;
     int rps = round_up(ceil_div(Sp, spg), 16);

@@ -41,6 +41,11 @@ int launch_tng(const TngPlan& p, const float* A, int F, int Sp, int G, const flo
 // (ah_gstride: floats between two groups of Ah, 0 = contiguous; Arh is contiguous)
 int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp, int G, const float* dY, float* part_g, float* part_c,
                     hipStream_t st, const char* tag, size_t ah_gstride = 0);
+// grouped NN with register-resident weights (kernels_gemm_f.h): C (G, Sp, 192) = A (G, Sp, K) * Wr_i + gscale[i] * bias; Wr = SpecPack::sxr
+// block 0, wstride floats apart.  Returns -1 when the width has no instantiation (the caller takes launch_nng), 0 ok, 2 launch error.
+// dev knob 20 = 1: never
+int launch_nnf(const float* A, size_t a_gstride, int K, int Sp, int G, const float* Wr, size_t wstride, float* C, int num_cus, hipStream_t st,
+               const char* tag, const float* bias, const float* gscale);
 // fused weight-gradient GEMM of a 64-unit cell (kernels_gemm_f.h): the x-part and both h-part problems in one pass over dY;
 // partials in the layouts above with ONE split count (spg) for the three.  ok = 0: shape not covered (Fin > 128, H != 64)
 struct TnfPlan { int ok, fxt, spg, rps; };

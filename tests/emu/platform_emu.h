@@ -42,9 +42,12 @@ __device__ __forceinline__ void lds_dma16(float* lds_wave_base, const float* g) 
 }
 __device__ __forceinline__ int wave_uniform(int v) { return v; }
 
-struct wbuf_t { const float* p; };
+struct wbuf_t { const float* p; size_t n = ~(size_t)0; };          // n: bytes covered (make_wbuf_n); accesses past it are dropped
 __device__ __forceinline__ wbuf_t make_wbuf(const float* p) { return wbuf_t{p}; }
-__device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) { return b.p[(size_t)voff + soff]; }
+__device__ __forceinline__ wbuf_t make_wbuf_n(const float* p, unsigned nbytes) { return wbuf_t{p, nbytes}; }
+__device__ __forceinline__ float wbuf_ld(wbuf_t b, unsigned voff, unsigned soff) {
+    return 4 * ((size_t)voff + soff) + 4 <= b.n ? b.p[(size_t)voff + soff] : 0.f;
+}
 __device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff) {
     const float* q = b.p + (size_t)voff + soff;
     return f32x4{q[0], q[1], q[2], q[3]};
@@ -53,12 +56,17 @@ __device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff,
     float* q = const_cast<float*>(b.p) + (size_t)voff + soff;
     q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
 }
+template <int AUX>
+__device__ __forceinline__ void wbuf_st4_aux(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) { wbuf_st4(b, voff, soff, v); }
 __device__ __forceinline__ void wbuf_st2(wbuf_t b, unsigned voff, unsigned soff, float x, float y) {
     float* q = const_cast<float*>(b.p) + (size_t)voff + soff; q[0] = x; q[1] = y;
 }
-__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) { const_cast<float*>(b.p)[(size_t)voff + soff] = x; }
+__device__ __forceinline__ void wbuf_st1(wbuf_t b, unsigned voff, unsigned soff, float x) {
+    if (4 * ((size_t)voff + soff) + 4 <= b.n) const_cast<float*>(b.p)[(size_t)voff + soff] = x;
+}
 __device__ __forceinline__ void wbuf_dma16(wbuf_t b, float* lds_wave_base, unsigned voff_bytes, unsigned soff_bytes) {
-    memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
+    if ((size_t)voff_bytes + soff_bytes + 16 <= b.n) memcpy(lds_wave_base + 4 * (threadIdx.x & 63), reinterpret_cast<const char*>(b.p) + voff_bytes + soff_bytes, 16);
+    else memset(lds_wave_base + 4 * (threadIdx.x & 63), 0, 16);
 }
 
 __device__ __forceinline__ unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) {
