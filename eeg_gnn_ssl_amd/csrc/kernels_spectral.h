@@ -233,6 +233,58 @@ __global__ __launch_bounds__(256) void spec_mix_out_kernel(const float* __restri
     }
 }
 
+// Both mixes on the matrix pipe (round 6): per unit (row r, 32-column tile) the mix is a (N x N) x (N x 32) product -- A = the
+// basis (zero-padded to 32 x 2*KS, in registers), B = 2*KS rows of 32 consecutive floats (one 128-byte line per half-wave and
+// k-step, straight from HBM into registers, no LDS), D = 32 x 32 of which the first N rows are stored (128-byte lines again).
+// The VALU form above spends 4 N^2 FMAs per 16-byte column (18 us of VALU per 150 MB pass at N = 19, scalar loads of the 361
+// coefficients in the loop); here a unit is KS MFMAs.  DIR 0: to nodes (X -> Xh = U^T X, pad rows written as zeros); DIR 1: from
+// nodes (Yh -> Y = U Yh + bias).  Row maps as above.
+template <int DIR, int KS>
+__global__ __launch_bounds__(256) void spec_mix_mfma_kernel(const float* __restrict__ in, const float* __restrict__ basis,
+                                                           const float* __restrict__ bias, int N, int S, int Sp, int F, int map, int T,
+                                                           int B, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, hh = lane >> 5, l32 = lane & 31;
+    const int gw = (int)blockIdx.x * 4 + wave_uniform((int)threadIdx.x >> 6), nw = (int)gridDim.x * 4;
+    // A[o][k] (o = output node / frequency = l32, k = 2 ks + hh): DIR 0: U[k][o]; DIR 1: U[o][k]
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 2 * ks + hh;
+        a[ks] = (k < N && l32 < N) ? (DIR == 0 ? basis[k * N + l32] : basis[l32 * N + k]) : 0.f;
+    }
+    const int NFT = ceil_div(F, 32), rows = DIR == 0 ? Sp : S, units = rows * NFT;
+    for (int u = gw; u < units; u += nw) {
+        const int r = u / NFT, ft = u - r * NFT, f = 32 * ft + l32, fc = f < F ? f : F - 1;
+        const size_t s = r < S ? spec_sample((size_t)r, map, T, B) : 0;
+        f32x16 acc;
+        const float bv = (DIR == 1 && bias != nullptr) ? bias[fc] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = bv;
+        if (r < S) {
+            float b[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int k = 2 * ks + hh;
+                if (k >= N) k = N - 1;                    // (its A column is zero: any finite in-bounds value)
+                b[ks] = DIR == 0 ? in[(s * N + k) * F + fc] : in[((size_t)k * Sp + r) * F + fc];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acc = mfma32(a[ks], b[ks], acc);
+        }
+        if (f < F) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int o = 8 * (v >> 2) + 4 * hh + (v & 3);
+                if (2 * KS <= 8 * (v >> 2)) continue;     // (output rows beyond the padded node count: never any)
+                if (o < N) {
+                    if (DIR == 0) out[((size_t)o * Sp + r) * F + f] = acc[v];
+                    else out[(s * N + o) * F + f] = acc[v];
+                }
+            }
+        }
+    }
+}
+
 // rows [S, Sp) of every frequency of a node-major (N, Sp, F) tensor <- 0 (a producer that writes the S real rows only)
 __global__ void spec_zero_pad_kernel(float* __restrict__ Xh, int N, int S, int Sp, int F) {
     const int per = (Sp - S) * F, total = N * per;

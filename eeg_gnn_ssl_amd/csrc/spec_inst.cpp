@@ -71,6 +71,23 @@ int launch_pack_cells(int n_cells, const float* const* Wg, const float* const* b
 int launch_spec_mix(int to_nodes, const float* in, const float* basis, const float* bias, int N, int T, int B, int F, int bm,
                     float* out, hipStream_t st, const char* tag, int node_rows) {
     const int S = T * B, Sp = node_rows > 0 ? node_rows : spec_rows(S), F4 = F / 4;
+#ifndef EEG_X_MIX_VALU
+    // the mixes on the matrix pipe where a row is whole 128-byte tiles (measured at cfg2: F = 64 from nodes 0.046 -> 0.037 ms; F = 100
+    // to nodes 0.045 -> 0.070: a fourth tile with 4 of 32 columns and rows that straddle lines -- that one keeps the VALU form)
+    if (N <= 32 && F % 32 == 0 && (double)(to_nodes ? Sp : S) * (F / 32) < 2.0e9) {
+        const int units = (to_nodes ? Sp : S) * ceil_div(F, 32);
+        int nb = ceil_div(units, 4);
+        if (nb > 2048) nb = 2048;
+        if (N <= 20) {
+            if (to_nodes) EEG_LAUNCH_P(tag, (spec_mix_mfma_kernel<0, 10>), dim3(nb), dim3(256), 0, st, in, basis, bias, N, S, Sp, F, bm, T, B, out);
+            else EEG_LAUNCH_P(tag, (spec_mix_mfma_kernel<1, 10>), dim3(nb), dim3(256), 0, st, in, basis, bias, N, S, Sp, F, bm, T, B, out);
+        } else {
+            if (to_nodes) EEG_LAUNCH_P(tag, (spec_mix_mfma_kernel<0, 16>), dim3(nb), dim3(256), 0, st, in, basis, bias, N, S, Sp, F, bm, T, B, out);
+            else EEG_LAUNCH_P(tag, (spec_mix_mfma_kernel<1, 16>), dim3(nb), dim3(256), 0, st, in, basis, bias, N, S, Sp, F, bm, T, B, out);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : 2;
+    }
+#endif
     if (N == 19 && F4 <= 128) {
         int threads = 256;
         while (threads > 64 && (threads / 2) >= F4 && (threads / 2) / F4 >= Sp) threads /= 2;
