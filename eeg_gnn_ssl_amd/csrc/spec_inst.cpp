@@ -222,7 +222,11 @@ TnfPlan tnf_plan(int Fin, int H, int Sp, int G, int num_cus) {
     TnfPlan p{};
     if (H != 64 || Fin < 4 || Fin % 4 != 0 || Fin > 128 || Sp < 16 || Sp % 16 != 0 || G < 1) return p;
     p.fxt = ceil_div(Fin, 32);
+#ifdef EEG_X_TNF_TARGET1
+    const int target = 1 * (num_cus > 0 ? num_cus : 256);
+#else
     const int target = tnf_wgs_per_cu(p.fxt) * (num_cus > 0 ? num_cus : 256);
+#endif
     int spg = target / G;
     if (spg < 1) spg = 1;
     int rps = round_up(ceil_div(Sp, spg), 16);

@@ -1080,6 +1080,12 @@ def _fft_features_impl(raw, window: int, mean: float, std: float, standardise: b
     if perm is not None:
         if perm.numel() != b * n:
             raise RuntimeError(f"fft_features: perm has shape {tuple(perm.shape)}, expected ({b}, {n}) source channels")
+        # Every row must be a permutation of 0..N-1 (feat_raw is written at the SOURCE slot: a row that is not one would leave slots
+        # of the torch.empty allocation unwritten).  A host tensor is checked here (no device sync involved); a device tensor is the
+        # output of eeg_dcrnn_augment_draw (a permutation by construction) or the caller's responsibility.
+        if lib.is_device_build and perm.device.type == "cpu" and not bool((torch.sort(perm.reshape(b, n).to(torch.int64), dim=1).values
+                                                    == torch.arange(n, dtype=torch.int64)).all()):
+            raise RuntimeError("fft_features: every row of perm must be a permutation of 0..N-1")
         perm = perm.to(device=raw.device, dtype=torch.int32).contiguous()
     if log_scale is not None and log_scale.numel() != b:
         raise RuntimeError(f"fft_features: log_scale has {log_scale.numel()} entries for {b} clips")

@@ -1036,3 +1036,16 @@ def test_randomized_shapes_vs_oracle():
     import fuzz_gpu
     done, refused, kinks = fuzz_gpu.run(cases=150, seed=4)
     assert done["model"] + done["decoder"] == 150 and kinks <= 3
+
+
+def test_fft_features_refuses_a_host_perm_that_is_not_a_permutation():
+    """advisor (round 5): feat_raw is written at the source slot, so a perm row that repeats a channel would leave a slot of the
+    torch.empty allocation unwritten; a host-side perm is checked before it is copied to the device (no sync involved)"""
+    from eeg_gnn_ssl_amd import ops
+    raw = torch.randn(2, 19, 400, device=DEV)
+    ident = torch.arange(19, dtype=torch.int32).repeat(2, 1)
+    ops.fft_features(raw, window=200, mean=0.0, std=1.0, perm=ident)
+    bad = ident.clone()
+    bad[1, 4] = 5
+    with pytest.raises(RuntimeError, match="permutation"):
+        ops.fft_features(raw, window=200, mean=0.0, std=1.0, perm=bad)
