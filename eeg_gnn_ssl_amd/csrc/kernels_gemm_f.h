@@ -52,74 +52,29 @@ __host__ __device__ constexpr size_t tnf_lds_bytes(int FXT) { return (size_t)tnf
 __host__ __device__ constexpr int tnf_ndma(int FXT) { return (kTnfRC / 8) * (FXT + 10); }
 __host__ __device__ constexpr int tnf_per(int FXT) { return (tnf_ndma(FXT) + 3) / 4; }
 
-template <int FXT, int S>
-__device__ __forceinline__ void tnf_role(float* sm, const int Q, const int Fin, const int e, const int lane,
-                                         const wbuf_t (&dsc)[tnf_per(FXT)], const int (&lofs)[tnf_per(FXT)],
-                                         const unsigned (&vof)[tnf_per(FXT)], unsigned (&soff)[tnf_per(FXT)],
-                                         const unsigned (&cstep)[tnf_per(FXT)],
-                                         float* __restrict__ px, float* __restrict__ pg, float* __restrict__ pc) {
-    constexpr int RC = kTnfRC, NS = tnf_ns(FXT), KS = RC / 2, NXT = (FXT + 1) / 2, PER = tnf_per(FXT);
-    constexpr int RM = RC / 8, HI = RM * FXT * 256, RI = HI + RM * 512, YI = RI + RM * 512, ST = tnf_stage_floats(FXT);
-    // dYh tiles of this role: x-part {3S, 3S+1, 3S+2}; gate {2S, 2S+1}; candidate 4 + S.  Loaded: the three x tiles + one more
-    // (S = 0: tile 4, the candidate's; S = 1: tile 2, the first gate tile) -- the others coincide with x tiles.
-    constexpr int YX = 3 * S, YE = S == 0 ? 4 : 2;
-    const int hh = lane >> 5, l32 = lane & 31;
-    f32x16 ax[NXT][3], ah[2], ar;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-#pragma unroll
-        for (int a = 0; a < NXT; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) ax[a][c][v] = 0.f;
-        ah[0][v] = 0.f; ah[1][v] = 0.f; ar[v] = 0.f;
-    }
+// The request ring + chunk loop shared by the wave roles: `load(IntC<p>, stage, ks)` fills fragment set p for k-step ks of the stage,
+// `mma(IntC<p>)` issues the role's MFMAs on fragment set p.
+template <int FXT>
+struct TnfRing {
+    static constexpr int PER = tnf_per(FXT);
+    const wbuf_t (&dsc)[PER];
+    const int (&lofs)[PER];
+    const unsigned (&vof)[PER];
+    unsigned (&soff)[PER];
+    const unsigned (&cstep)[PER];
+};
+template <int FXT, class LoadF, class MmaF>
+__device__ __forceinline__ void tnf_ring(float* sm, const int Q, const TnfRing<FXT>& rg, LoadF load, MmaF mma) {
+    constexpr int RC = kTnfRC, NS = tnf_ns(FXT), KS = RC / 2, PER = tnf_per(FXT), ST = tnf_stage_floats(FXT);
     int d_stage = 0;
     auto issue = [&]() __attribute__((always_inline)) {
         float* base = sm + d_stage * ST;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            wbuf_dma16(dsc[j], base + lofs[j], vof[j], soff[j]);
-            soff[j] += cstep[j];
+            wbuf_dma16(rg.dsc[j], base + rg.lofs[j], rg.vof[j], rg.soff[j]);
+            rg.soff[j] += rg.cstep[j];
         }
         d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
-    };
-    // fragment offsets (floats) of k-step 0 inside a stage
-    const int ox = hh * Fin + 32 * e + l32, oh = HI + hh * 64 + 32 * e + l32, orr = RI + hh * 64 + 32 * e + l32, oy = YI + hh * 192 + l32;
-    float fx[2][NXT], fh[2], fr[2], fy[2][4];
-    auto load = [&](auto PAR, const float* st, int ks) __attribute__((always_inline)) {
-        constexpr int p = decltype(PAR)::value;
-#pragma unroll
-        for (int a = 0; a < NXT; ++a) fx[p][a] = st[ox + 2 * ks * Fin + 64 * a];
-        fh[p] = st[oh + 2 * ks * 64];
-        fr[p] = st[orr + 2 * ks * 64];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) fy[p][c] = st[oy + 2 * ks * 192 + 32 * (YX + c)];
-        fy[p][3] = st[oy + 2 * ks * 192 + 32 * YE];
-    };
-    auto mma = [&](auto PAR) __attribute__((always_inline)) {
-        constexpr int p = decltype(PAR)::value;
-#pragma unroll
-        for (int a = 0; a < NXT; ++a)
-#pragma unroll
-#ifndef EEG_X_TNF_NOMFMA
-            for (int c = 0; c < 3; ++c) ax[a][c] = mfma32(fx[p][a], fy[p][c], ax[a][c]);
-#else
-            for (int c = 0; c < 3; ++c) ax[a][c][0] += fx[p][a] * fy[p][c];
-#endif
-        // gate tiles 2S, 2S+1: S = 0 -> x tiles 0, 1; S = 1 -> the extra tile (2) and x tile 0 (3)
-#ifndef EEG_X_TNF_NOMFMA
-        ah[0] = mfma32(fh[p], S == 0 ? fy[p][0] : fy[p][3], ah[0]);
-        ah[1] = mfma32(fh[p], S == 0 ? fy[p][1] : fy[p][0], ah[1]);
-#else
-        ah[0][0] += fh[p] * (S == 0 ? fy[p][0] : fy[p][3]);
-        ah[1][0] += fh[p] * (S == 0 ? fy[p][1] : fy[p][0]);
-#endif
-        // candidate tile 4 + S: S = 0 -> the extra tile (4); S = 1 -> x tile 2 (5)
-#ifndef EEG_X_TNF_NOMFMA
-        ar = mfma32(fr[p], S == 0 ? fy[p][3] : fy[p][2], ar);
-#else
-        ar[0] += fr[p] * (S == 0 ? fy[p][3] : fy[p][2]);
-#endif
     };
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p)
@@ -150,25 +105,168 @@ __device__ __forceinline__ void tnf_role(float* sm, const int Q, const int Fin, 
         }
         r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
     }
-    // ---- epilogue: D tile register v of lane (hh, l32) = (feature 8*(v>>2) + 4*hh + (v&3), column l32) ------------------------------
+}
+// D tile register v of lane (hh, l32) = (row 8*(v>>2) + 4*hh + (v&3), column l32): store a 32 x 32 tile at out[(f0 + row) * ld + c0 + col]
+__device__ __forceinline__ void tnf_store_tile(float* __restrict__ out, int ld, int f0, int c0, int fmax, int lane, const f32x16& t) {
+    const int hh = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int f = f0 + 8 * (v >> 2) + 4 * hh + (v & 3);
+        if (f < fmax) out[(size_t)f * ld + c0 + l32] = t[v];
+    }
+}
+
+template <int FXT, int S>
+__device__ __forceinline__ void tnf_role(float* sm, const int Q, const int Fin, const int e, const int lane, const TnfRing<FXT>& rg,
+                                         float* __restrict__ px, float* __restrict__ pg, float* __restrict__ pc) {
+    constexpr int RC = kTnfRC, NXT = (FXT + 1) / 2;
+    constexpr int RM = RC / 8, HI = RM * FXT * 256, RI = HI + RM * 512, YI = RI + RM * 512;
+    // dYh tiles of this role: x-part {3S, 3S+1, 3S+2}; gate {2S, 2S+1}; candidate 4 + S.  Loaded: the three x tiles + one more
+    // (S = 0: tile 4, the candidate's; S = 1: tile 2, the first gate tile) -- the others coincide with x tiles.
+    constexpr int YX = 3 * S, YE = S == 0 ? 4 : 2;
+    const int hh = lane >> 5, l32 = lane & 31;
+    f32x16 ax[NXT][3], ah[2], ar;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+#pragma unroll
+        for (int a = 0; a < NXT; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ax[a][c][v] = 0.f;
+        ah[0][v] = 0.f; ah[1][v] = 0.f; ar[v] = 0.f;
+    }
+    // fragment offsets (floats) of k-step 0 inside a stage
+    const int ox = hh * Fin + 32 * e + l32, oh = HI + hh * 64 + 32 * e + l32, orr = RI + hh * 64 + 32 * e + l32, oy = YI + hh * 192 + l32;
+    float fx[2][NXT], fh[2], fr[2], fy[2][4];
+    auto load = [&](auto PAR, const float* st, int ks) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+#pragma unroll
+        for (int a = 0; a < NXT; ++a) fx[p][a] = st[ox + 2 * ks * Fin + 64 * a];
+        fh[p] = st[oh + 2 * ks * 64];
+        fr[p] = st[orr + 2 * ks * 64];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fy[p][c] = st[oy + 2 * ks * 192 + 32 * (YX + c)];
+        fy[p][3] = st[oy + 2 * ks * 192 + 32 * YE];
+    };
+    auto mma = [&](auto PAR) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+#pragma unroll
+        for (int a = 0; a < NXT; ++a)
+#pragma unroll
+#ifndef EEG_X_TNF_NOMFMA
+            for (int c = 0; c < 3; ++c) ax[a][c] = mfma32(fx[p][a], fy[p][c], ax[a][c]);
+#else
+            for (int c = 0; c < 3; ++c) ax[a][c][0] += fx[p][a] * fy[p][c];
+#endif
+        // gate tiles 2S, 2S+1: S = 0 -> x tiles 0, 1; S = 1 -> the extra tile (2) and x tile 0 (3)
+#ifndef EEG_X_TNF_NOMFMA
+        ah[0] = mfma32(fh[p], S == 0 ? fy[p][0] : fy[p][3], ah[0]);
+        ah[1] = mfma32(fh[p], S == 0 ? fy[p][1] : fy[p][0], ah[1]);
+        // candidate tile 4 + S: S = 0 -> the extra tile (4); S = 1 -> x tile 2 (5)
+        ar = mfma32(fr[p], S == 0 ? fy[p][3] : fy[p][2], ar);
+#else
+        ah[0][0] += fh[p] * (S == 0 ? fy[p][0] : fy[p][3]);
+        ah[1][0] += fh[p] * (S == 0 ? fy[p][1] : fy[p][0]);
+        ar[0] += fr[p] * (S == 0 ? fy[p][3] : fy[p][2]);
+#endif
+    };
+    tnf_ring<FXT>(sm, Q, rg, load, mma);
 #pragma unroll
     for (int a = 0; a < NXT; ++a) {
         const int xe = e + 2 * a;
         if (xe >= FXT) continue;
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int f = 32 * xe + 8 * (v >> 2) + 4 * hh + (v & 3);
-                if (f < Fin) px[(size_t)f * 192 + 32 * (YX + c) + l32] = ax[a][c][v];
-            }
+        for (int c = 0; c < 3; ++c) tnf_store_tile(px, 192, 32 * xe, 32 * (YX + c), Fin, lane, ax[a][c]);
     }
+    tnf_store_tile(pg, 128, 32 * e, 32 * (2 * S), 64, lane, ah[0]);
+    tnf_store_tile(pg, 128, 32 * e, 32 * (2 * S + 1), 64, lane, ah[1]);
+    tnf_store_tile(pc, 64, 32 * e, 32 * S, 64, lane, ar);
+}
+
+// Fin = 100 (the FFT features of a 1-s window, BASELINE's input width): three whole Xh tiles + FOUR features.  A fourth 32-wide
+// tile would spend 6 of 36 MFMAs per k-step on 28 junk rows; here features 96..99 run on v_mfma_f32_4x4x1 (16 independent 4 x 4
+// outer products per instruction: block b of lane group 4b..4b+3 = features 96..99 x columns 64c + 4b .. + 3, one operand ROW per
+// instruction) and the whole-tile work is re-dealt so that the four waves stay level:
+//   E = 0: Xh tiles 0, 2 x dYh {3S..3S+2}, Hh tile 0 x gate {2S, 2S+1}                                   8 MFMAs per k-step
+//   E = 1: Xh tile 1 x dYh {3S..3S+2}, Hh tile 1 x gate {2S, 2S+1}, RHh tiles 0, 1 x candidate 4+S,     7 MFMAs
+//          + the remainder of columns 0..127 (S = 0: 4 small ones per k-step) / 128..191 (S = 1: 2)
+template <int S, int E>
+__device__ __forceinline__ void tnf_role_r4(float* sm, const int Q, const int lane, const TnfRing<4>& rg,
+                                            float* __restrict__ px, float* __restrict__ pg, float* __restrict__ pc) {
+    constexpr int FXT = 4, Fin = 100, RC = kTnfRC, RM = RC / 8, HI = RM * FXT * 256, RI = HI + RM * 512, YI = RI + RM * 512;
+    constexpr int YX = 3 * S, YE = S == 0 ? 4 : 2, NG = S == 0 ? 2 : 1, G0 = S == 0 ? 0 : 2;   // remainder column groups G0 .. G0+NG-1
+    const int hh = lane >> 5, l32 = lane & 31;
+    f32x16 t[8];                       // E = 0: [0..2] Xh0, [3..5] Xh2, [6..7] Hh0;  E = 1: [0..2] Xh1, [3..4] Hh1, [5] RHh0, [6] RHh1
+    f32x4 rem[2];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int f = 32 * e + 8 * (v >> 2) + 4 * hh + (v & 3);
-        pg[(size_t)f * 128 + 32 * (2 * S) + l32] = ah[0][v];
-        pg[(size_t)f * 128 + 32 * (2 * S + 1) + l32] = ah[1][v];
-        pc[(size_t)f * 64 + 32 * S + l32] = ar[v];
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) t[i][v] = 0.f;
+    rem[0] = rem[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int oxa = hh * Fin + (E == 0 ? 0 : 32) + l32, oxb = hh * Fin + 64 + l32;
+    const int oh = HI + hh * 64 + 32 * E + l32, or0 = RI + hh * 64 + l32, oy = YI + hh * 192 + l32;
+    const int oxr = 96 + (lane & 3), oyr = YI + lane;                 // remainder operands: one row per instruction
+    float fa[2][4], fy[2][4], ra[2][2], rb[2][2][2];
+    auto load = [&](auto PAR, const float* st, int ks) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+        fa[p][0] = st[oxa + 2 * ks * Fin];
+        fa[p][1] = st[E == 0 ? oxb + 2 * ks * Fin : oh + 2 * ks * 64];           // E = 0: Xh2; E = 1: Hh1
+        if (E == 0) fa[p][2] = st[oh + 2 * ks * 64];                              // Hh0
+        else { fa[p][2] = st[or0 + 2 * ks * 64]; fa[p][3] = st[or0 + 32 + 2 * ks * 64]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fy[p][c] = st[oy + 2 * ks * 192 + 32 * (YX + c)];
+        if (E == 1 || S == 1) fy[p][3] = st[oy + 2 * ks * 192 + 32 * YE];
+        if (E == 1) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                ra[p][r] = st[(2 * ks + r) * Fin + oxr];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) rb[p][r][g] = st[oyr + (2 * ks + r) * 192 + 64 * (G0 + g)];
+            }
+        }
+    };
+    auto mma = [&](auto PAR) __attribute__((always_inline)) {
+        constexpr int p = decltype(PAR)::value;
+        const float g0 = S == 0 ? fy[p][0] : fy[p][3], g1 = S == 0 ? fy[p][1] : fy[p][0];   // gate tiles 2S, 2S+1
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[c] = mfma32(fa[p][0], fy[p][c], t[c]);
+        if (E == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[3 + c] = mfma32(fa[p][1], fy[p][c], t[3 + c]);
+            t[6] = mfma32(fa[p][2], g0, t[6]);
+            t[7] = mfma32(fa[p][2], g1, t[7]);
+        } else {
+            const float cd = S == 0 ? fy[p][3] : fy[p][2];                         // candidate tile 4 + S
+            t[3] = mfma32(fa[p][1], g0, t[3]);
+            t[4] = mfma32(fa[p][1], g1, t[4]);
+            t[5] = mfma32(fa[p][2], cd, t[5]);
+            t[6] = mfma32(fa[p][3], cd, t[6]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) rem[g] = mfma4(ra[p][r], rb[p][r][g], rem[g]);
+        }
+    };
+    tnf_ring<4>(sm, Q, rg, load, mma);
+    if (E == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            tnf_store_tile(px, 192, 0, 32 * (YX + c), Fin, lane, t[c]);
+            tnf_store_tile(px, 192, 64, 32 * (YX + c), Fin, lane, t[3 + c]);
+        }
+        tnf_store_tile(pg, 128, 0, 32 * (2 * S), 64, lane, t[6]);
+        tnf_store_tile(pg, 128, 0, 32 * (2 * S + 1), 64, lane, t[7]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tnf_store_tile(px, 192, 32, 32 * (YX + c), Fin, lane, t[c]);
+        tnf_store_tile(pg, 128, 32, 32 * (2 * S), 64, lane, t[3]);
+        tnf_store_tile(pg, 128, 32, 32 * (2 * S + 1), 64, lane, t[4]);
+        tnf_store_tile(pc, 64, 0, 32 * S, 64, lane, t[5]);
+        tnf_store_tile(pc, 64, 32, 32 * S, 64, lane, t[6]);
+        // remainder: register r of lane l = (feature 96 + r, column 64 (G0 + g) + l)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) px[(size_t)(96 + r) * 192 + 64 * (G0 + g) + lane] = rem[g][r];
     }
 }
 
@@ -218,8 +316,18 @@ __global__ __launch_bounds__(256, tnf_wgs_per_cu(FXT)) void gemm_tnf_kernel(cons
     float* px = part_x + (size_t)y * Fin * 192;
     float* pg = part_g + (size_t)y * 64 * 128;
     float* pc = part_c + (size_t)y * 64 * 64;
-    if (s == 0) tnf_role<FXT, 0>(sm, Q, Fin, e, lane, dsc, lofs, vof, soff, cstep, px, pg, pc);
-    else tnf_role<FXT, 1>(sm, Q, Fin, e, lane, dsc, lofs, vof, soff, cstep, px, pg, pc);
+    const TnfRing<FXT> rg{dsc, lofs, vof, soff, cstep};
+#ifndef EEG_X_TNF_NOR4
+    if constexpr (FXT == 4) {
+        if (Fin == 100) {                                  // three whole Xh tiles + four features (tnf_role_r4)
+            if (s == 0) { if (e == 0) tnf_role_r4<0, 0>(sm, Q, lane, rg, px, pg, pc); else tnf_role_r4<0, 1>(sm, Q, lane, rg, px, pg, pc); }
+            else { if (e == 0) tnf_role_r4<1, 0>(sm, Q, lane, rg, px, pg, pc); else tnf_role_r4<1, 1>(sm, Q, lane, rg, px, pg, pc); }
+            return;
+        }
+    }
+#endif
+    if (s == 0) tnf_role<FXT, 0>(sm, Q, Fin, e, lane, rg, px, pg, pc);
+    else tnf_role<FXT, 1>(sm, Q, Fin, e, lane, rg, px, pg, pc);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
