@@ -40,8 +40,8 @@ def test_committed_pmc_traffic_files_carry_per_symbol_traffic_of_the_current_sou
     """profiles/pmc_traffic_<workload>.json: stamped with the hash of the kernel sources they were collected on; bench.py uses them only
     when the stamp matches, and the by-symbol table must name the kernels the bench line ranks"""
     sha = bench.kernel_sources_sha256()
-    for w, must in (("cfg2", ("gemm_nng_kernel<3,2>", "seq_bwd2_kernel<64,3,5,false,true>", "seq_fwd2_kernel<64,3,5,false,true>",
-                               "gemm_tnq_grouped_pair_kernel<2,16,true>")),
+    for w, must in (("cfg2", ("gemm_nnf_kernel<13>", "gemm_nnf_kernel<8,true>", "seq_bwd2_kernel<64,3,5,false,true>",
+                               "seq_fwd2_kernel<64,3,5,false,true>", "gemm_tnf_kernel<2>", "gemm_tnf_kernel<4>")),
                     ("cfg3", ("seq_fwd_kernel<64,5,5>", "corr_gram_kernel<7,true>")), ("cfg5", ("dec_fwd_persist_kernel<64,5>",)),
                     ("raw", ("fft200_features_kernel",))):
         d = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{w}.json")))
