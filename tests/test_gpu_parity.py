@@ -1049,3 +1049,24 @@ def test_fft_features_refuses_a_host_perm_that_is_not_a_permutation():
     bad[1, 4] = 5
     with pytest.raises(RuntimeError, match="permutation"):
         ops.fft_features(raw, window=200, mean=0.0, std=1.0, perm=bad)
+
+
+def test_randomized_shapes_through_the_spectral_form(adj3d):
+    """40 seeded draws over node counts, input widths (every instantiation of gemm_tnf_kernel / gemm_nnf_kernel, the widths that fall back
+    to the round-5 grouped kernels, the MFMA and the VALU node mixes), layer counts, diffusion orders and batch x time extents with ragged
+    row counts per frequency: logits and every gradient against the oracle and against the general path (parity_suite.check_spectral_form)"""
+    import random
+    rng = random.Random(20261001)
+    for case in range(40):
+        n = rng.choice([2, 3, 5, 7, 12, 16, 19, 19, 19, 20, 24, 32])
+        p = dict(n=n, din=rng.choice([4, 8, 12, 20, 36, 60, 64, 68, 96, 100, 100, 104, 128, 132]), layers=rng.choice([1, 2, 2, 3]),
+                 t_len=rng.choice([1, 2, 3, 5, 9]), b=rng.choice([1, 2, 3, 5, 17, 40, 130, 300]), classes=rng.choice([1, 4]),
+                 k=rng.choice([1, 2, 2, 3]), seed=rng.randrange(1 << 20))      # (tanh: a ReLU kink between two correct paths is fuzz_gpu's business)
+        if p["b"] * p["t_len"] > 1200:
+            p["t_len"] = 3
+        if rng.random() < 0.5:
+            p["lengths"] = [rng.randint(1, p["t_len"]) for _ in range(p["b"])]
+        try:
+            ps.check_spectral_form(DEV, adj3d, **p)
+        except Exception as e:
+            raise AssertionError(f"case {case}: {p}: {e}") from e
