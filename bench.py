@@ -268,6 +268,14 @@ def merge_paired_roles(work, launch_work, roles):
         work[fused] = sum(work.pop(r) for r in parts)
         if all(r in launch_work for r in parts):
             launch_work[fused] = [sum(v) for v in zip(*(launch_work.pop(r) for r in parts))]
+    # ... and the input gradient of a spectral layer is one kernel (role `gemm_dx_f`: the K = 3H GEMM + the node mix back): priced with
+    # the GEMM's FLOPs; the mix pass it replaces (`spec_mix_dx`) is no longer launched
+    if "gemm_dx_f" in roles and "gemm_nn_dx" not in roles and "gemm_nn_dx" in work:
+        work["gemm_dx_f"] = work.pop("gemm_nn_dx")
+        if "gemm_nn_dx" in launch_work:
+            launch_work["gemm_dx_f"] = launch_work.pop("gemm_nn_dx")
+        work.pop("spec_mix_dx", None)
+        launch_work.pop("spec_mix_dx", None)
     return work, launch_work
 
 

@@ -969,9 +969,14 @@ int eeg_dcrnn_layer_bwd(const eeg_layer_dims* d, const float* X, const float* P,
         }
         if (cell_weight_grads_spectral(d, planes, xs_spec(d), hh, hh_gs, rhh, dYh, ws + w.partial, w, dWg, dWc, st, dbias, dbg, dbc)) return 1;
         if (dX != nullptr) {
-            float* dXh = ws + w.z;
-            if (launch_nng(dYh, 3 * H, Sp, N, d->spack + sp.sxtq, sp.sxtq_stride, sp.nct_t, dXh, num_cus(), st, "gemm_nn_dx")) return fail("gemm_nng: launch failed");
-            if (launch_spec_mix(0, dXh, d->spectral, nullptr, N, d->T, d->B, Fin, 0, dX, st, "spec_mix_dx")) return fail("spec_mix: launch failed");
+            // one kernel (GEMM over K = 3H + the node mix back) where it applies; dev knob 17 = 1: the grouped GEMM and the mix as passes
+            const int dxf = g_tune[17] == 0 ? launch_dxf(dYh, Sp, S, N, Fin, d->spack + sp.sxtq, sp.sxtq_stride, d->spectral, dX, st, "gemm_dx_f") : -1;
+            if (dxf > 0) return fail("gemm_dxf: launch failed");
+            if (dxf < 0) {
+                float* dXh = ws + w.z;
+                if (launch_nng(dYh, 3 * H, Sp, N, d->spack + sp.sxtq, sp.sxtq_stride, sp.nct_t, dXh, num_cus(), st, "gemm_nn_dx")) return fail("gemm_nng: launch failed");
+                if (launch_spec_mix(0, dXh, d->spectral, nullptr, N, d->T, d->B, Fin, 0, dX, st, "spec_mix_dx")) return fail("spec_mix: launch failed");
+            }
         }
         return check_launch("layer_bwd (spectral)");
     }

@@ -471,4 +471,128 @@ __global__ __launch_bounds__(256, 2) void gemm_nnf_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Input gradient of a spectral layer in ONE kernel: dX[s][j] = sum_i U[j][i] (dYh_i[s] Wt_i^T) -- the grouped NN GEMM over K = 3H
+// (gemm_nng_kernel<1>: dXh, node-major) and the node mix back (spec_mix: dX, sample-major) without the round trip of dXh through
+// HBM.  Model side: autograd's gradient of `torch.matmul(x, self.weight)` w.r.t. x and of the diffusion in front of it (reference
+// model/cell.py:76-117) for layers above the first.  A workgroup takes 32 rows (samples) and walks ALL N frequencies:
+//   * wave w = column tile w of the 64 output features, two 16-row tiles; per frequency 12 chunks of 16 k: activation fragments by
+//     ds_read_b128 from a ring of [32 rows x 192] images (XOR-swizzled in the SOURCE addresses of the LDS-DMA: a 768-byte row is 48
+//     sixteen-byte units -- even -- so the plain image would put the 16 rows of a lane group on one slot), weight fragments as the
+//     lane's own float4 of the quad pack (SpecPack::sxtq) straight from L2 into registers, re-requested for the NEXT frequency
+//     right behind their last use (one register set);
+//   * transposed issue: a lane ends up with 4 consecutive features of one row; the frequency's tile T is folded into the N node
+//     accumulators on the VALU (acc_j += U[j][i] * T: 8 N FMAs per 96 MFMAs), so nothing but dX leaves the kernel;
+//   * rows past S / Sp through bounded descriptors (dropped stores / zero-filled requests).
+// N <= kDxfMaxN (accumulators: 8 N registers).
+constexpr int kDxfMaxN = 20, kDxfNS = 3, kDxfRows = 32, kDxfStage = kDxfRows * 192;
+__host__ __device__ constexpr size_t dxf_lds_bytes() { return (size_t)kDxfNS * kDxfStage * sizeof(float); }
+
+// NT: the node count as a literal (19: the EEG montage -- no branches in the fold), 0 = the runtime argument.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void gemm_dxf_kernel(const float* __restrict__ dYh, int Sp, int S, int Nrt, const float* __restrict__ Wtq,
+                                                         unsigned w_gstride, const float* __restrict__ basis, float* __restrict__ dX) {
+    const int N = NT > 0 ? NT : Nrt;
+    constexpr int NS = kDxfNS, ST = kDxfStage, RB = kDxfRows, PER = 6;        // 24 one-KB pieces per image, 6 per wave
+    EEG_DYN_SMEM(sm);
+    const int tid = threadIdx.x, lane = tid & 63, w = wave_uniform(tid >> 6), lr = lane & 15, lg = lane >> 4;
+    const int r0 = (int)blockIdx.x * RB;
+    // ---- request side: piece p = w + 4j, image position P = 64 p + lane (16-byte units): row P / 48, slot P % 48 holds unit
+    //      (slot & ~15) | ((slot & 15) ^ (row & 15)) of that row
+    unsigned src[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int P = 64 * (w + 4 * j) + lane, row = P / 48, slot = P - row * 48;
+        const int unit = (slot & ~15) | ((slot & 15) ^ (row & 15));
+        src[j] = (unsigned)((r0 + row) * 768 + unit * 16);
+    }
+    // Every vector-memory operation of the frequency loop is UNCONDITIONAL (past the last frequency the last image / weight set is
+    // requested again): with a fixed sequence per iteration the compiler's counted waits in front of the weight registers come out
+    // exact (vmcnt(17)); with conditional requests it drained the queue -- the image requested a moment earlier included -- in every
+    // iteration (measured: 0.098 ms against 0.0xx).
+    int d_i = 0, d_stage = 0;
+    auto issue = [&]() __attribute__((always_inline)) {
+        const wbuf_t ra = make_wbuf_n(dYh + (size_t)d_i * Sp * 192, (unsigned)(Sp * 192) * 4u);
+        float* base = sm + d_stage * ST;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) wbuf_dma16(ra, base + (w + 4 * j) * 256, src[j], 0u);
+        d_stage = d_stage + 1 == NS ? 0 : d_stage + 1;
+        if (d_i + 1 < N) ++d_i;
+    };
+    // ---- compute side -----------------------------------------------------------------------------------------------------------
+    f32x4 acc[kDxfMaxN][2];
+#pragma unroll
+    for (int j = 0; j < kDxfMaxN; ++j) acc[j][0] = acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 wq[12];
+    const unsigned wl = (unsigned)(w * 64 + lane) * 4u;                          // this lane's float4 of column tile w inside a chunk
+    static_assert(kDxfNS == 3, "the queue discipline below is written for two images in flight");
+    issue();
+    issue();
+    {
+        const wbuf_t rw0 = make_wbuf(Wtq);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) wq[c] = wbuf_ld4(rw0, wl, (unsigned)(c * 4 * 256));
+    }
+    // queue, oldest first: image 0 | image 1 | the 12 weight requests of frequency 0.  From here on image i has landed by the time
+    // the weights of frequency i-1 were consumed (the queue retires in order and they were requested behind it): no wait in the loop.
+    vm_wait_n<PER + 12>();
+    int r_stage = 0;
+    const int a_row = lr * 192;                            // fragments: unit 4c + lg of row 16t + lr, swizzled
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+        EEG_LDS_BARRIER();                                 // image i landed in every wave; all are past their reads of image i-1
+#ifndef EEG_X_DXF_NODMA
+        issue();                                           // image i + 2 into the stage of image i - 1
+#endif
+        const wbuf_t rwn = make_wbuf(Wtq + (size_t)(i + 1 < N ? i + 1 : i) * w_gstride);
+        const float* st = sm + r_stage * ST;
+        // U[j][i], j = 0 .. N-1: scalar loads issued here, consumed behind the MFMAs
+        float uu[kDxfMaxN];
+#pragma unroll
+        for (int j = 0; j < kDxfMaxN; ++j) uu[j] = (NT > 0 ? j < NT : j < N) ? basis[j * N + i] : 0.f;
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+        auto frag_off = [&](int c) __attribute__((always_inline)) {
+            const int u = 4 * c + lg;
+            return a_row + (((u & ~15) | ((u & 15) ^ lr)) << 2);
+        };
+        f32x4 fa[2][2];
+        fa[0][0] = *reinterpret_cast<const f32x4*>(st + frag_off(0));
+        fa[0][1] = *reinterpret_cast<const f32x4*>(st + 16 * 192 + frag_off(0));
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            if (c + 1 < 12) {                              // the next chunk's fragments ahead of this chunk's MFMAs
+                fa[(c + 1) & 1][0] = *reinterpret_cast<const f32x4*>(st + frag_off(c + 1));
+                fa[(c + 1) & 1][1] = *reinterpret_cast<const f32x4*>(st + 16 * 192 + frag_off(c + 1));
+            }
+            EEG_SCHED_FENCE();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                  // transposed issue: D[feature 4 lg + v][row lr]
+                t0 = mfma16(wq[c][e], fa[c & 1][0][e], t0);
+                t1 = mfma16(wq[c][e], fa[c & 1][1][e], t1);
+            }
+            EEG_SCHED_FENCE();
+#ifndef EEG_X_DXF_NOW
+            wq[c] = wbuf_ld4(rwn, wl, (unsigned)(c * 4 * 256));   // the next frequency's fragments into the registers just consumed
+#endif
+            EEG_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int j = 0; j < kDxfMaxN; ++j)
+            if (NT > 0 ? j < NT : j < N) {
+                acc[j][0] += t0 * uu[j];
+                acc[j][1] += t1 * uu[j];
+            }
+        r_stage = r_stage + 1 == NS ? 0 : r_stage + 1;
+    }
+    // ---- dX[(r * N + j) * 64 + 16 w + 4 lg .. + 3], r = r0 + 16 t + lr; rows >= S fall off the end of the descriptor
+    const wbuf_t rx = make_wbuf_n(dX, (unsigned)(S * N * 64) * 4u);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const unsigned rb = (unsigned)((r0 + 16 * t + lr) * N * 64 + 16 * w + 4 * lg);
+#pragma unroll
+        for (int j = 0; j < kDxfMaxN; ++j)
+            if (j < N) wbuf_st4(rx, rb + (unsigned)(j * 64), 0u, acc[j][t]);
+    }
+}
+
 }  // namespace eeg

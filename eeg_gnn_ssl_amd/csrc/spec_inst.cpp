@@ -217,10 +217,26 @@ int launch_nnf(const float* A, size_t a_gstride, int K, int Sp, int G, const flo
     return -1;
 }
 
+int launch_dxf(const float* dYh, int Sp, int S, int N, int Fin, const float* Wtq, size_t wstride, const float* basis, float* dX,
+               hipStream_t st, const char* tag) {
+    if (Fin != 64 || N < 1 || N > kDxfMaxN || Sp < 16 || S < 1 || S > Sp) return -1;
+    if ((double)Sp * 192 * 4 >= 2147483648.0 || (double)S * N * 64 * 4 >= 2147483648.0) return -1;
+    const size_t lds = dxf_lds_bytes();
+    if (N == 19) {
+        EEG_SET_MAX_LDS(gemm_dxf_kernel<19>, lds);
+        EEG_LAUNCH_P(tag, gemm_dxf_kernel<19>, dim3(ceil_div(Sp, kDxfRows)), dim3(256), lds, st, dYh, Sp, S, N, Wtq, (unsigned)wstride, basis, dX);
+    } else {
+        EEG_SET_MAX_LDS(gemm_dxf_kernel<0>, lds);
+        EEG_LAUNCH_P(tag, gemm_dxf_kernel<0>, dim3(ceil_div(Sp, kDxfRows)), dim3(256), lds, st, dYh, Sp, S, N, Wtq, (unsigned)wstride, basis, dX);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 // Row splits of the fused kernel: every workgroup of the launch resident at once (2 per CU), rows per split a multiple of 16.
 TnfPlan tnf_plan(int Fin, int H, int Sp, int G, int num_cus) {
     TnfPlan p{};
     if (H != 64 || Fin < 4 || Fin % 4 != 0 || Fin > 128 || Sp < 16 || Sp % 16 != 0 || G < 1) return p;
+    if ((double)Sp * 192 * 4 >= 2147483648.0) return p;      // a frequency's rows go through 2-GB buffer descriptors (platform.h make_wbuf)
     p.fxt = ceil_div(Fin, 32);
 #ifdef EEG_X_TNF_TARGET1
     const int target = 1 * (num_cus > 0 ? num_cus : 256);

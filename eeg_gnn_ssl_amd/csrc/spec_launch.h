@@ -46,6 +46,10 @@ int launch_tng_pair(const TngPlan& p, const float* Ah, const float* Arh, int Sp,
 // dev knob 20 = 1: never
 int launch_nnf(const float* A, size_t a_gstride, int K, int Sp, int G, const float* Wr, size_t wstride, float* C, int num_cus, hipStream_t st,
                const char* tag, const float* bias, const float* gscale);
+// input gradient of a spectral layer in one kernel (kernels_gemm_f.h gemm_dxf_kernel): dX (S, N, 64) = U [dYh_i Wt_i^T]_i; Wtq = SpecPack::sxtq
+// block 0.  -1: shape not covered (N > 20 or Fin != 64: the caller runs the grouped GEMM + the node mix), 0 ok, 2 launch error
+int launch_dxf(const float* dYh, int Sp, int S, int N, int Fin, const float* Wtq, size_t wstride, const float* basis, float* dX,
+               hipStream_t st, const char* tag);
 // fused weight-gradient GEMM of a 64-unit cell (kernels_gemm_f.h): the x-part and both h-part problems in one pass over dY;
 // partials in the layouts above with ONE split count (spg) for the three.  ok = 0: shape not covered (Fin > 128, H != 64)
 struct TnfPlan { int ok, fxt, spg, rps; };

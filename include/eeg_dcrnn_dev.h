@@ -28,6 +28,7 @@ int eeg_dcrnn_set_seq_probe(int64_t* probe);
  * key 18 = 1: the round-4
  * adjoint diffusion (hop planes consumed one at a time) instead of the row-streaming one;
  * key 19 = 1: the two h-part weight-gradient GEMMs of a cell as two launches instead of the paired one;
+ * key 17 = 1: the input gradient of a spectral layer as grouped GEMM + node-mix pass instead of gemm_dxf_kernel;
  * key 20 = 1: the round-5 grouped NN GEMM for the spectral x-part instead of gemm_nnf_kernel (kernels_gemm_f.h);
  * key 21 = 1 / 22 = 1: the general-path BPTT / forward recurrent kernels under the spectral form; key 23 = 1: the three grouped
  * weight-gradient launches instead of the fused one (kernels_gemm_f.h);

@@ -53,6 +53,7 @@ __device__ __forceinline__ f32x4 wbuf_ld4(wbuf_t b, unsigned voff, unsigned soff
     return f32x4{q[0], q[1], q[2], q[3]};
 }
 __device__ __forceinline__ void wbuf_st4(wbuf_t b, unsigned voff, unsigned soff, f32x4 v) {
+    if (4 * ((size_t)voff + soff) + 16 > b.n) return;
     float* q = const_cast<float*>(b.p) + (size_t)voff + soff;
     q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
 }

@@ -150,11 +150,13 @@ def test_spectral_weight_gradients_fused_and_as_three_grouped_launches(emulator,
     for separate in (0, 1):
         emulator.call("eeg_dcrnn_set_tuning", 23, separate)
         emulator.call("eeg_dcrnn_set_tuning", 20, separate)      # and gemm_nnf_kernel (weights in registers) / the round-5 grouped NN kernel
+        emulator.call("eeg_dcrnn_set_tuning", 17, separate)      # and gemm_dxf_kernel (input gradient in one kernel) / grouped GEMM + node mix
         try:
             ps.check_spectral_form("cpu", adj3d, din=100, layers=2, t_len=3, b=6, classes=1, seed=11)
         finally:
             emulator.call("eeg_dcrnn_set_tuning", 23, 0)
             emulator.call("eeg_dcrnn_set_tuning", 20, 0)
+            emulator.call("eeg_dcrnn_set_tuning", 17, 0)
     # gemm_nnf_kernel: a chunk range that crosses into the next frequency (weights reloaded), a ragged last chunk (80 rows = 64 + 16)
     ps.check_spectral_form("cpu", adj3d, din=100, layers=2, t_len=2, b=40, classes=1, seed=13, n=6)
     # beyond 128 input features the fused kernel has no instantiation: the grouped launches take the layer

@@ -11,6 +11,6 @@ import sys,json
 for l in sys.stdin:
     if not l.startswith('{'): continue
     d=json.loads(l); k=d['roofline']['kernels']
-    print('$t'.ljust(28), d['value'], d['ms_per_step'], 'p50', d.get('ms_per_step_p50'), ' '.join(f\"{n}={k[n]['ms_per_step']:.4f}\" for n in ('reduce_unpack','spec_mix_dx','seq_fwd','seq_bwd','gemm_nn_xw','gemm_nn_dx','gemm_tn_f','gemm_tn_x','gemm_tn_h','gemm_tn_hg','gemm_tn_hc','dec_fwd_persist','dec_bwd_persist','diffuse_fwd','diffuse_adj','corr_gram') if n in k), ' '.join(f\"{a.split('<')[-1]}={b['ms_per_step']:.4f}\" for a,b in [x for r in ('gemm_tn_f','gemm_nn_xw') for x in (k.get(r,{}).get('by_symbol') or {}).items()]))"
+    print('$t'.ljust(28), d['value'], d['ms_per_step'], 'p50', d.get('ms_per_step_p50'), ' '.join(f\"{n}={k[n]['ms_per_step']:.4f}\" for n in ('gemm_dx_f','spec_mix_dx','seq_fwd','seq_bwd','gemm_nn_xw','gemm_nn_dx','gemm_tn_f','gemm_tn_x','gemm_tn_h','gemm_tn_hg','gemm_tn_hc','dec_fwd_persist','dec_bwd_persist','diffuse_fwd','diffuse_adj','corr_gram') if n in k), ' '.join(f\"{a.split('<')[-1]}={b['ms_per_step']:.4f}\" for a,b in [x for r in ('gemm_tn_f','gemm_nn_xw') for x in (k.get(r,{}).get('by_symbol') or {}).items()]))"
   done
 done
