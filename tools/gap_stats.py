@@ -11,9 +11,11 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
 rows.sort()
-# a step is cut at a kernel that runs exactly once per step: the gradient-norm partials of the training-step tail (the window
-# [marker k, marker k+1) holds the launches of one step in steady state)
-starts = [i for i, r in enumerate(rows) if "sqnorm_partial" in r[2]]
+# a step is cut at a kernel that runs exactly once per step: the weight packs of the encoder (the window [marker k, marker k+1)
+# holds the launches of one step in steady state)
+starts = [i for i, r in enumerate(rows) if "pack_cells_kernel" in r[2]]
+if len(starts) < 3:      # (workloads that pack cell by cell: the gradient-norm partials of the update, once per step without --graph-update's extra loops)
+    starts = [i for i, r in enumerate(rows) if "sqnorm_partial" in r[2]]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 starts = starts[skip:]
 if len(starts) < 3:
