@@ -1,3 +1,8 @@
+// The hoisted GEMMs of the spectral form (spec_common.h) on v_mfma_f32_32x32x2_f32, round 6:
+//   gemm_tnf_kernel  the three weight-gradient contractions of a cell in one pass over dYh          (this comment)
+//   gemm_nnf_kernel  Yh_i = Xh_i Wt_i + bias with the weights of a frequency in registers            (further down)
+//   gemm_dxf_kernel  dX = U [dYh_i Wt_i^T]_i: the K = 3H GEMM and the node mix back in one kernel     (16x16x4; further down)
+//
 // Fused weight-gradient GEMM of one cell in the eigenbasis of a shared symmetric support (spec_common.h): the three hoisted
 // contractions over the rows of ONE graph frequency i
 //     dWt^x_i = Xh_i^T dYh_i            (Fin x 3H)      Xh  = U^T x          (N, Sp, Fin)
@@ -22,6 +27,7 @@
 // A row only).  Pad rows [S, Sp) of dYh are zeros (spec_common.h), so they add nothing.
 #pragma once
 #include "common.h"
+#include "kernels_gemm_q.h"      // IntC
 
 namespace eeg {
 
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dxf_kernel(const float* __restric
     static_assert(kDxfNS == 3, "the queue discipline below is written for two images in flight");
     issue();
     issue();
+    EEG_SCHED_FENCE();                                     // (the queue order below is what the counted wait is written for)
     {
         const wbuf_t rw0 = make_wbuf(Wtq);
 #pragma unroll

@@ -19,6 +19,10 @@
 //  * spec_mix_in_kernel / spec_mix_out_kernel: the HBM-bound node mixes (one thread = one 16-byte feature column of one sample,
 //    coefficients wave-uniform scalars -- the construction of diffuse_fwd_stream_kernel).
 //  * spec_fold_block: dW_m = sum_i T_m(lam_i) (sum over the row splits of frequency i), fixed order.
+//  * kernels_gemm_f.h (second half of round 6): gemm_nnf_kernel (Yh_i = Xh_i Wt_i, weights in registers), gemm_tnf_kernel (the three
+//    weight-gradient contractions in one pass over dYh), gemm_dxf_kernel (dX = U [dYh_i Wt_i^T]_i in one kernel); the grouped round-5
+//    kernels of kernels_gemm_g.h stay as the path of the widths those do not instantiate.  The 3H-wide mixes (U Yh, U^T dXW) and
+//    U^T h / U^T (r*h) run inside the recurrent kernels (kernels_seq.h, SPEC instantiations).
 #pragma once
 #include "common.h"
 #include "nnq_order.h"

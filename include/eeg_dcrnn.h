@@ -55,8 +55,9 @@ typedef struct eeg_layer_dims {
                                 cell's per-frequency weight packs (eeg_dcrnn_pack_cell_spectral).  The hoisted x-part of the layer
                                 then runs in the eigenbasis of the support: all hop matrices are Chebyshev polynomials of one
                                 symmetric S = U diag(lam) U^T (cell.py:83-93), so sum_m P_m X W_m = U [ (U^T X)_i Wt_i ]_i with
-                                Wt_i = sum_m T_m(lam_i) W_m -- the GEMMs contract over Fin instead of M*Fin, framed by two HBM-bound
-                                node mixes; backward likewise.  Exact up to re-association (~1e-6); the recurrence is unchanged.
+                                Wt_i = sum_m T_m(lam_i) W_m -- the GEMMs contract over Fin instead of M*Fin; the node mixes with U / U^T
+                                run inside the recurrent kernels and the input-gradient GEMM (one pass is left: U^T of the layer-0
+                                input); backward likewise.  Exact up to re-association (~1e-6); the recurrence is unchanged.
                                 Only where eeg_dcrnn_spectral_ok() says so.  `planes` of layer_fwd / layer_bwd is then the
                                 node-major transformed input Xh (N, eeg_dcrnn_spectral_rows(T*B), Fin) (written by layer_fwd, read
                                 by layer_bwd) and x_planes_ready must be 0. */
