@@ -324,3 +324,10 @@ def test_randomized_small_shapes_vs_oracle(emulator):
     import fuzz_gpu
     done, refused, kinks = fuzz_gpu.run(cases=40, seed=11, dev="cpu", small=True)
     assert done["model"] + done["decoder"] == 40 and kinks <= 1
+
+
+def test_randomized_small_shapes_through_the_spectral_form(emulator):
+    """the spectral-form generator of tests/fuzz_gpu.py (--spectral on the GPU box) on the emulator, small shapes: every case against the oracle
+    and against the general path of the same sources"""
+    import fuzz_gpu
+    assert fuzz_gpu.run_spectral(cases=8, seed=4, dev="cpu", small=True) == 8
